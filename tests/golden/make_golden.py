@@ -1,0 +1,119 @@
+"""Generates tests/golden/*.npz FROM THE REFERENCE (run in the build container only):
+
+    python tests/golden/make_golden.py
+
+Imports the reference's own model files from /root/reference via oracle/refload.py, fills the
+weights with the name-keyed deterministic fill (oracle.deterministic_state -- a formula, so the
+20 M weights need not be stored), runs one G-step, one D-step (each from the fresh state) and an
+eval forward, and records inputs + expected outputs.  The files are data only.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import mixstage_oracle as O   # noqa: E402
+from oracle import refload                # noqa: E402
+
+CONFIGS = {
+    # name: (B, T, M, S, dtype)
+    'c1_fp32': (4, 64, 1, 2, torch.float32),     # BASELINE configs[0] (S=2: S=1 crashes, SURVEY s.0 item 4)
+    'c1_fp64': (4, 64, 1, 2, torch.float64),
+    'c2r_fp32': (4, 64, 4, 4, torch.float32),    # BASELINE configs[1] at reduced batch
+    'c3r_fp32': (2, 64, 8, 8, torch.float32),    # headline M=S=8 at reduced batch
+}
+BN_PROBES = ['G.decoder.0.norm', 'G.audio_encoder.conv.7.norm', 'D.conv3.norm']
+
+
+def grad_probe(model):
+  out = {}
+  for n, p in model.named_parameters():
+    if p.grad is None:
+      continue
+    g = p.grad.detach().double().reshape(-1)
+    stride = max(1, g.numel() // 16)
+    out['gnorm/' + n] = np.float64(g.norm().item())
+    out['gsamp/' + n] = g[::stride][:16].numpy()
+  return out
+
+
+def param_probe(model, which):
+  out = {}
+  mod = model.G if which == 'G' else model.D
+  for n, p in mod.named_parameters():
+    v = p.detach().double().reshape(-1)
+    out['psum/%s.%s' % (which, n)] = np.float64(v.sum().item())
+    out['pnorm/%s.%s' % (which, n)] = np.float64(v.norm().item())
+  return out
+
+
+def run(name, B, T, M, S, dtype):
+  audio, pose, labels, style = O.synthetic_batch(B, T=T, M=M, S=S, dtype=dtype)
+  rec = dict(audio=audio.numpy(), pose=pose.numpy(), labels=labels.numpy(), style=style.numpy(),
+             meta=np.array([B, T, M, S], dtype=np.int64))
+  for kind in ('G', 'D'):
+    ref = refload.build_ref_gan(M=M, S=S, T=T, dtype=None)
+    ref.load_state_dict(O.deterministic_state(ref.state_dict()))
+    ref.to(dtype)
+    caps = {}
+    dcalls = []
+
+    def pse_hook(m, i, o):          # hooks must return None (a value would replace the output)
+      caps.setdefault('pse', o.detach().clone())
+
+    def d_hook(m, i, o):
+      dcalls.append(o[0].detach().clone())
+
+    h1 = ref.G.pose_style_encoder.register_forward_hook(pse_hook)
+    h2 = ref.D.register_forward_hook(d_hook)
+    og = torch.optim.Adam(ref.G.parameters(), lr=1e-4)
+    od = torch.optim.Adam(ref.D.parameters(), lr=1e-4)
+    torch.manual_seed(7)
+    # forward/backward/clip/Adam through the trainer-step contract (model-agnostic driver)
+    fake, losses, gnorm = O.oracle_train_step(ref, og, od, audio, pose, labels, style, kind, T=T)
+    h1.remove(); h2.remove()
+    k = kind + '/'
+    rec[k + 'pose'] = fake.numpy()
+    rec[k + 'losses'] = np.array(losses, dtype=np.float64)
+    rec[k + 'total_grad_norm'] = np.float64(gnorm)
+    rec[k + 'labels_cap_soft'] = ref.G.labels_cap_soft.detach().numpy()
+    rec[k + 'dscores'] = np.stack([d.numpy() for d in dcalls])
+    if 'pse' in caps:
+      sc = caps['pse'].double()
+      top2 = sc.topk(2, dim=-1).values
+      rec[k + 'pse_score'] = sc.numpy()
+      rec[k + 'pse_argmax'] = sc.argmax(-1).numpy()
+      rec[k + 'pse_margin'] = (top2[:, 0] - top2[:, 1]).numpy()
+    # note: clip_grad_norm_ rescaled the grads in place before we probe them
+    for kk, v in grad_probe(ref).items():
+      rec[k + kk] = v
+    for kk, v in param_probe(ref, kind).items():
+      rec[k + kk] = v
+    sd = ref.state_dict()
+    for b in BN_PROBES:
+      rec[k + 'bn/' + b + '.running_mean'] = sd[b + '.running_mean'].double().numpy()
+      rec[k + 'bn/' + b + '.running_var'] = sd[b + '.running_var'].double().numpy()
+  # eval forward (running statistics, no update)
+  ref = refload.build_ref_gan(M=M, S=S, T=T, dtype=None)
+  ref.load_state_dict(O.deterministic_state(ref.state_dict()))
+  ref.to(dtype).eval()
+  with torch.no_grad():
+    fake, losses, _ = ref([audio, labels], pose, **O.model_kwargs(style, T))
+  rec['E/pose'] = fake.numpy()
+  rec['E/losses'] = np.array([float(l) for l in losses], dtype=np.float64)
+  # inference branch: sample_flag=1 takes the style ids from kwargs (line 168-174)
+  kw = O.model_kwargs(style, T); kw['sample_flag'] = 1
+  with torch.no_grad():
+    fake, losses, _ = ref([audio, labels], pose, **kw)
+  rec['S/pose'] = fake.numpy()
+  np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + '.npz'), **rec)
+  print(name, 'ok', {k: (v.shape if hasattr(v, 'shape') else v) for k, v in list(rec.items())[:6]})
+
+
+if __name__ == '__main__':
+  assert refload.available(), 'needs /root/reference'
+  for name, cfg in CONFIGS.items():
+    run(name, *cfg)
