@@ -1,0 +1,153 @@
+/* mixstage.h -- C-ABI of libmixstage_hip.so: the MI355X (gfx950) kernels under the
+ * Mix-StAGE audio->pose GAN path.
+ *
+ * The reference (chahuja/mix-stage) has no FFI layer: its path is pure Python on torch.nn
+ * (SURVEY.md section 8b).  The entry points below are therefore what a binding of the reference's
+ * nn.Module calls would bind; each cites the reference lines it replaces
+ * (paths relative to /root/reference/src/model).
+ *
+ * Conventions
+ *   - plain C: device pointers (HBM), sizes, one POD descriptor; no torch types.
+ *   - all tensors are dense row-major fp32 in the reference's (B, C, T) / (B, C, H, W) layout:
+ *     the time (or frequency) axis is contiguous.
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued, never synchronised;
+ *     nothing is allocated inside (callers pass outputs and workspace) -> graph-capturable.
+ *   - return 0 on success, negative on error; ms_last_error() gives the text (thread-local).
+ */
+#ifndef MIXSTAGE_H_
+#define MIXSTAGE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MS_ABI_VERSION 1
+
+/* epilogue of a conv block */
+enum ms_block_mode {
+  MS_BARE = 0,     /* conv + bias                        (nn.Conv1d: JL:83 logits, layers.py:459, S2G:63) */
+  MS_LRELU = 1,    /* conv + bias + LeakyReLU            (S2G:50-51 D.conv1)                              */
+  MS_BN_TRAIN = 2, /* conv + bias + BatchNorm(batch stats, running update) + LeakyReLU  (layers.py:78)    */
+  MS_BN_EVAL = 3   /* conv + bias + BatchNorm(running stats) + LeakyReLU                (layers.py:78)    */
+};
+
+/* how the block reads its input */
+enum ms_input_mode {
+  MS_IN_PLAIN = 0,
+  MS_IN_BCAST = 1, /* every group reads the same Cin/groups... channels: replaces torch.cat([x]*M,1) JL:190 */
+  MS_IN_UP2ADD = 2 /* 1-D only: x = nearest_up2(a) + r, replaces layers.py:151 upconv(x)+residual        */
+};
+
+/* Geometry of one conv block (1-D convs use H = KH = SH = 1, PH = 0). */
+typedef struct ms_conv_desc {
+  int32_t B;          /* batch                                                   */
+  int32_t Cin;        /* input channels PER GROUP                                */
+  int32_t H, W;       /* input spatial size (H = 1 for Conv1d; W = time)         */
+  int32_t Cout;       /* output channels PER GROUP                               */
+  int32_t groups;
+  int32_t KH, KW, SH, SW, PH, PW;
+  int32_t OH, OW;     /* output spatial size                                     */
+  int32_t mode;       /* ms_block_mode                                           */
+  int32_t in_mode;    /* ms_input_mode                                           */
+  float slope;        /* LeakyReLU negative slope (0.2 on the path, 0 = ReLU)    */
+  float eps;          /* BatchNorm eps                                           */
+  float momentum;     /* BatchNorm momentum                                      */
+  int32_t reserved;
+} ms_conv_desc;
+
+const char* ms_last_error(void);
+int ms_abi_version(void);
+
+/* Bytes of scratch the forward / backward of this block needs. */
+size_t ms_conv_block_fwd_workspace(const ms_conv_desc* d);
+size_t ms_conv_block_bwd_workspace(const ms_conv_desc* d);
+
+/* ConvNormRelu.forward (layers.py:77-78), nn.Conv1d.forward, D.conv1 (S2G:50-51,68).
+ *   x        in_mode PLAIN: (B, groups*Cin, H, W); BCAST: (B, Cin, H, W); UP2ADD: a = (B, groups*Cin, W/2)
+ *   x2       UP2ADD only: residual r (B, groups*Cin, W); else NULL
+ *   w        (groups*Cout, Cin, KH, KW)   bias (groups*Cout)
+ *   gamma,beta,running_mean,running_var   (groups*Cout)   BN modes only; running_* updated in BN_TRAIN
+ *   y_raw    BN_TRAIN only: conv+bias output kept for backward, same shape as y
+ *   y        (B, groups*Cout, OH, OW) block output
+ *   save     BN_TRAIN only: 4*groups*Cout floats = mean | invstd | scale | shift
+ */
+int ms_conv_block_fwd(const ms_conv_desc* d, const float* x, const float* x2, const float* w,
+                      const float* bias, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, float* y_raw, float* y, float* save, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* Backward of the same block (what autograd derives for layers.py:78 in the reference).
+ *   dy       grad wrt y.
+ *   y_raw/save as produced by the forward (BN_TRAIN); y (LRELU mode mask); BN_EVAL uses running stats.
+ *   dyr      scratch, same shape as y: grad wrt the raw conv output (returned for inspection)
+ *   dx       grad wrt x  (UP2ADD: grad wrt a, (B, groups*Cin, W/2)); NULL = skip
+ *   dx2      UP2ADD: grad wrt r; else NULL
+ *   dw,dbias,dgamma,dbeta   NULL = skip (dw/dbias together, dgamma/dbeta together)
+ */
+int ms_conv_block_bwd(const ms_conv_desc* d, const float* x, const float* x2, const float* w,
+                      const float* gamma, const float* running_mean, const float* running_var,
+                      const float* y_raw, const float* y, const float* save, const float* dy, float* dyr,
+                      float* dx, float* dx2, float* dw, float* dbias, float* dgamma, float* dbeta,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* AudioEncoder resize (layers.py:197): bilinear to (T,1), align_corners=False, == 1-D lerp in time
+ * of frequency column F/2.   x (B,C,Tin,F) -> y (B,C,Tout). */
+int ms_lerp_time_fwd(const float* x, float* y, int B, int C, int Tin, int F, int Tout, void* stream);
+int ms_lerp_time_bwd(const float* dy, float* dx, int B, int C, int Tin, int F, int Tout, void* stream);
+
+/* Mixture of the M sub-generators (JL:106-115,186-187,194) fused with the softmax of the cluster
+ * scores:  soft = softmax_m(score[b,:,t]);  out[b,t,f] = sum_m soft[b,t,m] * z[b, m*P+f, t].
+ *   z (B, M*P, T)   score (B, M, T)   soft (B, T, M)   out (B, T, P) */
+int ms_softmax_mix_fwd(const float* z, const float* score, float* soft, float* out, int B, int M, int P,
+                       int T, void* stream);
+/* dout (B,T,P), dsoft_extra (B,T,M) or NULL (extra grad flowing into soft, e.g. none on the path)
+ * -> dz (B,M*P,T), dscore (B,M,T) (overwritten) */
+int ms_softmax_mix_bwd(const float* z, const float* soft, const float* dout, float* dz, float* dscore,
+                       int B, int M, int P, int T, void* stream);
+
+/* Cross entropy with mean reduction (JL:159,184,203): score addressed as
+ * score[n_outer*stride_outer + c*stride_c + n_inner*stride_inner], rows = n_outer*n_inner.
+ * loss[0] = mean_rows( logsumexp - score[target] ).  dscore (same addressing) = gscale[0] *
+ * (softmax - onehot)/rows, ADDED to dscore when accumulate != 0. */
+int ms_cross_entropy_fwd(const float* score, const int64_t* target, float* loss, float* row_scratch,
+                         int n_outer, int n_inner, int C, int stride_outer, int stride_c,
+                         int stride_inner, void* stream);
+int ms_cross_entropy_bwd(const float* score, const int64_t* target, const float* gscale, float* dscore,
+                         int n_outer, int n_inner, int C, int stride_outer, int stride_c,
+                         int stride_inner, int accumulate, void* stream);
+
+/* GAN.get_velocity (gan.py:47-52) fused with the (B,T,P)->(B,P,T) transpose D.forward does (S2G:67):
+ * v[b,p,0] = 0, v[b,p,t] = x[b,t,p] - x[b,t-1,p]. */
+int ms_velocity_fwd(const float* x, float* v, int B, int T, int P, void* stream);
+int ms_velocity_bwd(const float* dv, float* dx, int B, int T, int P, void* stream);
+
+/* (B,T,C) <-> (B,C,T) transposes (layers.py:229,280, JL:151,180). */
+int ms_transpose_btc(const float* x, float* y, int B, int T, int C, void* stream); /* (B,T,C)->(B,C,T) */
+int ms_transpose_bct(const float* x, float* y, int B, int C, int T, void* stream); /* (B,C,T)->(B,T,C) */
+
+/* mean |a-b| (or target constant) -> loss[0]  (gan.py:64-75 with criterion L1Loss), and its backward
+ * da = gscale[0] * sign(a-b)/n.  b may be NULL with `target` used instead. */
+int ms_l1_mean_fwd(const float* a, const float* b, float target, float* loss, float* partials, size_t n,
+                   void* stream);
+int ms_l1_mean_bwd(const float* a, const float* b, float target, const float* gscale, float* da, size_t n,
+                   void* stream);
+
+/* Trainer step tail (trainer.py:1138-1146): global L2 norm of a flat gradient buffer, then
+ * clip_grad_norm_(., max_norm) folded into a fused Adam step (torch.optim.Adam defaults).
+ *   norm_out[0] = ||g||_2 ; coef = min(1, max_norm/(norm+1e-6)) applied to g inside ms_adam_step. */
+int ms_sqnorm(const float* g, size_t n, float* norm_out, float* partials, void* stream);
+/* step_state: 4 int32 words on the device, word 0 = step count (starts at 0), words 1..3 scratch. */
+int ms_adam_step(float* p, const float* g, float* m, float* v, size_t n, const float* norm, float max_norm,
+                 float lr, float beta1, float beta2, float eps, int32_t* step_state, void* stream);
+size_t ms_reduce_partials_count(size_t n); /* floats needed in `partials` of ms_sqnorm / ms_l1_mean_fwd */
+
+/* Self-test kernel: C(32x32) = A(32xK) * B(Kx32) through the fp32 MFMA path (checks fragment maps). */
+int ms_selftest_mfma(const float* A, const float* B, float* C, int K, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIXSTAGE_H_ */

@@ -1,0 +1,79 @@
+"""ctypes binding of libmixstage_hip.so (the C-ABI declared in include/mixstage.h).
+
+There is NO CPU fallback: if the shared library is missing or does not load, importing the ops
+raises -- the product path must fail loudly (build it with `python -c "import __graft_entry__ as g;
+g.build()"` or `make -C mix_stage_amd/csrc`).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmixstage_hip.so')
+
+c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+
+class ConvDesc(ctypes.Structure):
+  """struct ms_conv_desc"""
+  _fields_ = [(n, ctypes.c_int32) for n in
+              ('B', 'Cin', 'H', 'W', 'Cout', 'groups', 'KH', 'KW', 'SH', 'SW', 'PH', 'PW', 'OH', 'OW',
+               'mode', 'in_mode')] + \
+             [('slope', c_float), ('eps', c_float), ('momentum', c_float), ('reserved', ctypes.c_int32)]
+
+
+MS_BARE, MS_LRELU, MS_BN_TRAIN, MS_BN_EVAL = 0, 1, 2, 3
+MS_IN_PLAIN, MS_IN_BCAST, MS_IN_UP2ADD = 0, 1, 2
+
+_P = c_void_p
+_DESC = ctypes.POINTER(ConvDesc)
+
+# name -> (restype, argtypes): every symbol include/mixstage.h declares
+SIGNATURES = {
+    'ms_last_error': (ctypes.c_char_p, []),
+    'ms_abi_version': (c_int, []),
+    'ms_conv_block_fwd_workspace': (c_size_t, [_DESC]),
+    'ms_conv_block_bwd_workspace': (c_size_t, [_DESC]),
+    'ms_conv_block_fwd': (c_int, [_DESC] + [_P] * 11 + [_P, c_size_t, _P]),
+    'ms_conv_block_bwd': (c_int, [_DESC] + [_P] * 17 + [_P, c_size_t, _P]),
+    'ms_lerp_time_fwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    'ms_lerp_time_bwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    'ms_softmax_mix_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    'ms_softmax_mix_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    'ms_cross_entropy_fwd': (c_int, [_P, _P, _P, _P] + [c_int] * 6 + [_P]),
+    'ms_cross_entropy_bwd': (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [_P]),
+    'ms_velocity_fwd': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    'ms_velocity_bwd': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    'ms_transpose_btc': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    'ms_transpose_bct': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    'ms_l1_mean_fwd': (c_int, [_P, _P, c_float, _P, _P, c_size_t, _P]),
+    'ms_l1_mean_bwd': (c_int, [_P, _P, c_float, _P, _P, c_size_t, _P]),
+    'ms_sqnorm': (c_int, [_P, c_size_t, _P, _P, _P]),
+    'ms_adam_step': (c_int, [_P, _P, _P, _P, c_size_t, _P, c_float, c_float, c_float, c_float, c_float, _P, _P]),
+    'ms_reduce_partials_count': (c_size_t, [c_size_t]),
+    'ms_selftest_mfma': (c_int, [_P, _P, _P, c_int, _P]),
+}
+
+_lib = None
+
+
+class MixStageLibError(RuntimeError):
+  pass
+
+
+def lib():
+  global _lib
+  if _lib is None:
+    if not os.path.isfile(LIB_PATH):
+      raise MixStageLibError('%s not built: run `make -C mix_stage_amd/csrc` (or __graft_entry__.build()); '
+                             'there is no CPU fallback' % LIB_PATH)
+    handle = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+      fn = getattr(handle, name)          # AttributeError here = header/library drift
+      fn.restype, fn.argtypes = res, args
+    _lib = handle
+  return _lib
+
+
+def check(rc, what):
+  if rc != 0:
+    raise MixStageLibError('%s failed: %s' % (what, lib().ms_last_error().decode()))

@@ -1,0 +1,171 @@
+// Block-level C-ABI entry points: one conv block (conv [+BN] [+LeakyReLU]) forward / backward.
+// Orchestrates the kernels of conv_igemm.hip and elementwise.hip on the caller's stream.
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace ms {
+
+static int validate(const ms_conv_desc* d, const char* who) {
+  if (!d) return set_error("%s: null descriptor", who);
+  if (d->B < 1 || d->Cin < 1 || d->Cout < 1 || d->groups < 1 || d->H < 1 || d->W < 1 || d->KH < 1 || d->KW < 1 ||
+      d->SH < 1 || d->SW < 1 || d->PH < 0 || d->PW < 0)
+    return set_error("%s: bad geometry", who);
+  const int oh = (d->H + 2 * d->PH - d->KH) / d->SH + 1, ow = (d->W + 2 * d->PW - d->KW) / d->SW + 1;
+  if (d->H + 2 * d->PH < d->KH || d->W + 2 * d->PW < d->KW || oh != d->OH || ow != d->OW)
+    return set_error("%s: output size (%d,%d) does not match geometry (expected %d,%d)", who, d->OH, d->OW, oh, ow);
+  if (d->mode < MS_BARE || d->mode > MS_BN_EVAL) return set_error("%s: bad mode %d", who, d->mode);
+  if (d->in_mode < MS_IN_PLAIN || d->in_mode > MS_IN_UP2ADD) return set_error("%s: bad in_mode %d", who, d->in_mode);
+  if (d->in_mode == MS_IN_UP2ADD && (d->H != 1 || d->KH != 1 || (d->W & 1)))
+    return set_error("%s: UP2ADD needs a 1-D block with even W", who);
+  const double out_elems = (double)d->B * d->groups * d->Cout * d->OH * d->OW;
+  const double in_elems = (double)d->B * d->groups * d->Cin * d->H * d->W;
+  if (out_elems >= 2147483648.0 || in_elems >= 2147483648.0) return set_error("%s: tensor exceeds 2^31 elements", who);
+  return 0;
+}
+
+static inline int ctot_of(const ms_conv_desc* d) { return d->groups * d->Cout; }
+static inline size_t wsize_of(const ms_conv_desc* d) { return (size_t)d->groups * d->Cout * d->Cin * d->KH * d->KW; }
+
+}  // namespace ms
+
+using namespace ms;
+
+extern "C" {
+
+size_t ms_conv_block_fwd_workspace(const ms_conv_desc* d) {
+  if (!d || d->mode != MS_BN_TRAIN) return 256;
+  const int npix = d->B * d->OH * d->OW;
+  return align_up((size_t)gather_n_tiles(d->Cout, npix, d->groups) * ctot_of(d) * 2 * sizeof(float), 256) + 256;
+}
+
+size_t ms_conv_block_bwd_workspace(const ms_conv_desc* d) {
+  if (!d) return 256;
+  int bpc;
+  const int nchunk = bwd_chunks(d->B, ctot_of(d), &bpc);
+  const int npix = d->B * d->OH * d->OW;
+  const int splits = wgrad_splits(d->Cout, d->Cin * d->KH * d->KW, d->groups, npix);
+  size_t bytes = 0;
+  bytes += align_up((size_t)ctot_of(d) * nchunk * 2 * sizeof(float), 256);  // bn partials
+  bytes += align_up((size_t)ctot_of(d) * nchunk * sizeof(float), 256);      // colsum partials
+  bytes += align_up(wsize_of(d) * sizeof(float), 256);                      // transposed weights
+  bytes += align_up(wsize_of(d) * sizeof(float) * (splits > 1 ? splits : 0), 256);
+  return bytes + 256;
+}
+
+int ms_conv_block_fwd(const ms_conv_desc* d, const float* x, const float* x2, const float* w, const float* bias,
+                      const float* gamma, const float* beta, float* running_mean, float* running_var, float* y_raw,
+                      float* y, float* save, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = validate(d, "ms_conv_block_fwd");
+  if (rc) return rc;
+  if (!x || !w || !y) return set_error("ms_conv_block_fwd: null tensor");
+  const bool bn = d->mode == MS_BN_TRAIN || d->mode == MS_BN_EVAL;
+  if (bn && (!gamma || !beta || !running_mean || !running_var)) return set_error("ms_conv_block_fwd: BN tensors missing");
+  if (d->mode == MS_BN_TRAIN && (!y_raw || !save || !workspace)) return set_error("ms_conv_block_fwd: y_raw/save/workspace missing");
+  if (d->in_mode == MS_IN_UP2ADD && !x2) return set_error("ms_conv_block_fwd: UP2ADD needs x2");
+  if (workspace_bytes < ms_conv_block_fwd_workspace(d)) return set_error("ms_conv_block_fwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int C = ctot_of(d), npix = d->B * d->OH * d->OW, hw = d->OH * d->OW;
+
+  GatherArgs a = {};
+  a.A = w; a.src = x; a.src2 = x2;
+  a.out = d->mode == MS_BN_TRAIN ? y_raw : y;
+  a.bias = bias; a.bn_g = gamma; a.bn_b = beta; a.bn_m = running_mean; a.bn_v = running_var;
+  a.stats = (float*)workspace;
+  a.Mg = d->Cout; a.Kg = d->Cin * d->KH * d->KW; a.groups = d->groups; a.Kc = d->Cin;
+  a.bcast = d->in_mode == MS_IN_BCAST;
+  a.src_ctotal = a.bcast ? d->Cin : d->groups * d->Cin;
+  a.SRCH = d->H; a.SRCW = d->W; a.OUTH = d->OH; a.OUTW = d->OW; a.Npix = npix;
+  a.KH = d->KH; a.KW = d->KW; a.SH = d->SH; a.SW = d->SW; a.PH = d->PH; a.PW = d->PW;
+  a.a_vec = (a.Kg % 4 == 0) && (((uintptr_t)w & 15) == 0);
+  a.ep = d->mode == MS_BARE ? EP_BARE : d->mode == MS_LRELU ? EP_LRELU : d->mode == MS_BN_EVAL ? EP_BN_EVAL : EP_RAW_STATS;
+  a.slope = d->slope; a.eps = d->eps;
+  int n_tiles = 0;
+  rc = launch_gather(a, false, d->in_mode == MS_IN_UP2ADD, &n_tiles, s);
+  if (rc) return rc;
+  if (d->mode == MS_BN_TRAIN) {
+    rc = launch_bn_finalize(a.stats, n_tiles, gather_tile_n(d->Cout, npix, d->groups), npix, C, gamma, beta, running_mean,
+                            running_var, save, d->eps, d->momentum, s);
+    if (rc) return rc;
+    rc = launch_bn_apply(y_raw, y, save, C, hw, (size_t)npix * C, d->slope, s);
+  }
+  return rc;
+}
+
+int ms_conv_block_bwd(const ms_conv_desc* d, const float* x, const float* x2, const float* w, const float* gamma,
+                      const float* running_mean, const float* running_var, const float* y_raw, const float* y,
+                      const float* save, const float* dy, float* dyr, float* dx, float* dx2, float* dw, float* dbias,
+                      float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
+  (void)running_mean; (void)running_var;
+  int rc = validate(d, "ms_conv_block_bwd");
+  if (rc) return rc;
+  if (d->mode == MS_BN_EVAL) return set_error("ms_conv_block_bwd: BN_EVAL blocks are never differentiated on the path");
+  if (!dy || !w || !workspace) return set_error("ms_conv_block_bwd: null tensor");
+  if (d->mode == MS_BN_TRAIN && (!y_raw || !save || !gamma || !dyr)) return set_error("ms_conv_block_bwd: BN_TRAIN needs y_raw/save/gamma/dyr");
+  if (d->mode == MS_LRELU && (!y || !dyr)) return set_error("ms_conv_block_bwd: LRELU needs y/dyr");
+  if (dw && !x) return set_error("ms_conv_block_bwd: dw needs x");
+  if (d->in_mode == MS_IN_UP2ADD && ((dw && !x2) || (dx && !dx2))) return set_error("ms_conv_block_bwd: UP2ADD needs x2/dx2");
+  if (workspace_bytes < ms_conv_block_bwd_workspace(d)) return set_error("ms_conv_block_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int C = ctot_of(d), npix = d->B * d->OH * d->OW, hw = d->OH * d->OW;
+  const int khw = d->KH * d->KW;
+  const bool up2 = d->in_mode == MS_IN_UP2ADD, bcast = d->in_mode == MS_IN_BCAST;
+
+  int bpc;
+  const int nchunk = bwd_chunks(d->B, C, &bpc);
+  char* wsp = (char*)workspace;
+  float* bn_part = (float*)wsp; wsp += align_up((size_t)C * nchunk * 2 * sizeof(float), 256);
+  float* colpart = (float*)wsp; wsp += align_up((size_t)C * nchunk * sizeof(float), 256);
+  float* wt = (float*)wsp; wsp += align_up(wsize_of(d) * sizeof(float), 256);
+  float* wg_part = (float*)wsp;
+
+  // 1. gradient wrt the raw conv output (+ per-channel column sums = bias gradient)
+  const float* g = dy;
+  if (d->mode == MS_BN_TRAIN) {
+    rc = launch_bn_bwd(dy, y_raw, save, gamma, bn_part, dyr, colpart, dgamma, dbeta, d->B, C, hw, d->slope, s);
+    g = dyr;
+  } else if (d->mode == MS_LRELU) {
+    rc = launch_act_bwd(dy, y, dyr, colpart, d->B, C, hw, 1, d->slope, s);
+    g = dyr;
+  } else if (dbias) {
+    rc = launch_act_bwd(dy, nullptr, nullptr, colpart, d->B, C, hw, 0, 0.f, s);
+  }
+  if (rc) return rc;
+  if (dbias) {
+    rc = launch_colsum_finalize(colpart, dbias, d->B, C, s);
+    if (rc) return rc;
+  }
+
+  // 2. data gradient: transposed gather over dyr with wt[g][ci][co][khw]
+  if (dx) {
+    const int tg = bcast ? 1 : d->groups;          // broadcast input: all groups sum into the same channels
+    const int tcog = bcast ? C : d->Cout;
+    rc = launch_transpose_weight(w, wt, tg, tcog, d->Cin, khw, s);
+    if (rc) return rc;
+    GatherArgs a = {};
+    a.A = wt; a.src = g; a.out = dx; a.out2 = dx2;
+    a.Mg = d->Cin; a.Kg = tcog * khw; a.groups = tg; a.Kc = tcog; a.src_ctotal = C;
+    a.SRCH = d->OH; a.SRCW = d->OW; a.OUTH = d->H; a.OUTW = d->W; a.Npix = d->B * d->H * d->W;
+    a.KH = d->KH; a.KW = d->KW; a.SH = d->SH; a.SW = d->SW; a.PH = d->PH; a.PW = d->PW;
+    a.bcast = 0;
+    a.a_vec = (a.Kg % 4 == 0);
+    a.ep = up2 ? EP_DGRAD_UP2 : EP_DGRAD;
+    rc = launch_gather(a, true, up2, nullptr, s);
+    if (rc) return rc;
+  }
+
+  // 3. weight gradient
+  if (dw) {
+    WgradArgs a = {};
+    a.dyr = g; a.src = x; a.src2 = x2;
+    a.Cog = d->Cout; a.Cig = d->Cin; a.Kg = d->Cin * khw; a.groups = d->groups;
+    a.src_ctotal = bcast ? d->Cin : d->groups * d->Cin;
+    a.H = d->H; a.W = d->W; a.OH = d->OH; a.OW = d->OW; a.Npix = npix;
+    a.KH = d->KH; a.KW = d->KW; a.SH = d->SH; a.SW = d->SW; a.PH = d->PH; a.PW = d->PW;
+    a.bcast = bcast;
+    rc = launch_wgrad(a, up2, dw, wg_part, s);
+  }
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,650 @@
+// HBM-bound kernels of the path: BatchNorm statistics/apply/backward, activation backward, the
+// AudioEncoder time-lerp, the softmax mixture of the M sub-generators, cross entropy, pose velocity,
+// layout transposes, L1 losses, and the trainer tail (global grad norm + clipped Adam).
+// All reductions run in a fixed order (no float atomics) -> bitwise reproducible.
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace ms {
+
+// ----------------------------------------------------------------------------------------------
+// BatchNorm (training): finalize tile partials -> mean/invstd/scale/shift + running stats
+// stats: [n_tiles][C][2] (sum, M2 about tile mean); tile i holds min(tile_n, N - i*tile_n) values
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int n_tiles, int tile_n,
+                                                          int N, int C, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* running_mean,
+                                                          float* running_var, float* __restrict__ save, float eps,
+                                                          float momentum) {
+  __shared__ double red[4];
+  const int c = blockIdx.x, t = threadIdx.x;
+  double s = 0.0;
+  for (int i = t; i < n_tiles; i += 256) s += (double)stats[((size_t)i * C + c) * 2];
+  s = wave_sum_d(s);
+  if ((t & 63) == 0) red[t >> 6] = s;
+  __syncthreads();
+  const double mean = (red[0] + red[1] + red[2] + red[3]) / (double)N;
+  __syncthreads();
+  double q = 0.0;
+  for (int i = t; i < n_tiles; i += 256) {
+    const float* st = stats + ((size_t)i * C + c) * 2;
+    const int cnt = min(tile_n, N - i * tile_n);
+    const double d = (double)st[0] / (double)cnt - mean;
+    q += (double)st[1] + (double)cnt * d * d;
+  }
+  q = wave_sum_d(q);
+  if ((t & 63) == 0) red[t >> 6] = q;
+  __syncthreads();
+  if (t == 0) {
+    const double m2 = red[0] + red[1] + red[2] + red[3];
+    const float var = (float)(m2 / (double)N);
+    const float invstd = 1.0f / sqrtf(var + eps);
+    const float fmean = (float)mean;
+    const float sc = gamma[c] * invstd;
+    save[c] = fmean;
+    save[C + c] = invstd;
+    save[2 * C + c] = sc;
+    save[3 * C + c] = beta[c] - fmean * sc;
+    const float unbiased = N > 1 ? (float)(m2 / (double)(N - 1)) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * fmean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  }
+}
+
+// y = lrelu(y_raw * scale[c] + shift[c]);  layout (B, C, HW)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ y_raw, float* __restrict__ y,
+                                                       const float* __restrict__ save, int C, int HW, size_t total,
+                                                       float slope) {
+  const float* scale = save + 2 * (size_t)C;
+  const float* shift = save + 3 * (size_t)C;
+  if ((HW & 3) == 0) {
+    const size_t total4 = total >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+      const int c = (int)(((i << 2) / HW) % C);
+      const float sc = scale[c], sh = shift[c];
+      float4 v = reinterpret_cast<const float4*>(y_raw)[i];
+      v.x = lrelu(fmaf(v.x, sc, sh), slope);
+      v.y = lrelu(fmaf(v.y, sc, sh), slope);
+      v.z = lrelu(fmaf(v.z, sc, sh), slope);
+      v.w = lrelu(fmaf(v.w, sc, sh), slope);
+      reinterpret_cast<float4*>(y)[i] = v;
+    }
+  } else {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+      const int c = (int)((i / HW) % C);
+      y[i] = lrelu(fmaf(y_raw[i], scale[c], shift[c]), slope);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// BatchNorm + LeakyReLU backward.  grid (C, nchunk); chunk = contiguous range of batch items.
+//   dz = dy * lrelu'(z), z = y_raw*scale+shift (bit-identical to forward);  xh = (y_raw-mean)*invstd
+//   partial[c][chunk] = (sum dz, sum dz*xh)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y_raw,
+                                                            const float* __restrict__ save, float* __restrict__ partial,
+                                                            int B, int C, int HW, int b_per_chunk, float slope) {
+  __shared__ float red[4];
+  const int c = blockIdx.x, ch = blockIdx.y, t = threadIdx.x;
+  const int b0 = ch * b_per_chunk, nb = min(b_per_chunk, B - b0);
+  const float mean = save[c], invstd = save[C + c], sc = save[2 * C + c], sh = save[3 * C + c];
+  float s1 = 0.f, s2 = 0.f;
+  const int n = nb * HW;
+  for (int e = t; e < n; e += 256) {
+    const int b = b0 + e / HW, pix = e % HW;
+    const size_t off = ((size_t)b * C + c) * HW + pix;
+    const float yr = y_raw[off];
+    const float z = fmaf(yr, sc, sh);
+    const float dz = dy[off] * (z > 0.f ? 1.f : slope);
+    s1 += dz;
+    s2 += dz * ((yr - mean) * invstd);
+  }
+  s1 = block_sum_256(s1, red);
+  s2 = block_sum_256(s2, red);
+  if (t == 0) {
+    partial[((size_t)c * gridDim.y + ch) * 2] = s1;
+    partial[((size_t)c * gridDim.y + ch) * 2 + 1] = s2;
+  }
+}
+
+//   dyr = gamma*invstd*(dz - s1/N - xh*s2/N);  colsum partial of dyr;  dgamma = s2, dbeta = s1
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y_raw,
+                                                           const float* __restrict__ save, const float* __restrict__ gamma,
+                                                           const float* __restrict__ partial, float* __restrict__ dyr,
+                                                           float* __restrict__ colpart, float* dgamma, float* dbeta,
+                                                           int B, int C, int HW, int b_per_chunk, float slope) {
+  __shared__ float red[4];
+  const int c = blockIdx.x, ch = blockIdx.y, t = threadIdx.x, nchunk = gridDim.y;
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = 0; k < nchunk; ++k) {
+    s1 += partial[((size_t)c * nchunk + k) * 2];
+    s2 += partial[((size_t)c * nchunk + k) * 2 + 1];
+  }
+  const float invN = 1.0f / (float)((size_t)B * HW);
+  const float mean = save[c], invstd = save[C + c], sc = save[2 * C + c], sh = save[3 * C + c];
+  const float gi = gamma[c] * invstd, m1 = s1 * invN, m2 = s2 * invN;
+  const int b0 = ch * b_per_chunk, nb = min(b_per_chunk, B - b0);
+  const int n = nb * HW;
+  float cs = 0.f;
+  for (int e = t; e < n; e += 256) {
+    const int b = b0 + e / HW, pix = e % HW;
+    const size_t off = ((size_t)b * C + c) * HW + pix;
+    const float yr = y_raw[off];
+    const float z = fmaf(yr, sc, sh);
+    const float dz = dy[off] * (z > 0.f ? 1.f : slope);
+    const float xh = (yr - mean) * invstd;
+    const float v = gi * (dz - m1 - xh * m2);
+    dyr[off] = v;
+    cs += v;
+  }
+  cs = block_sum_256(cs, red);
+  if (t == 0) {
+    colpart[(size_t)c * nchunk + ch] = cs;
+    if (ch == 0 && dgamma) { dgamma[c] = s2; dbeta[c] = s1; }
+  }
+}
+
+// activation backward for blocks without BN: mode 1 (LRELU): dyr = dy * (y>0 ? 1 : slope); mode 0 (BARE): no
+// write (dyr == dy).  Always emits per-channel colsum partials (the bias gradient).
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                      float* __restrict__ dyr, float* __restrict__ colpart, int B, int C,
+                                                      int HW, int b_per_chunk, int mode, float slope) {
+  __shared__ float red[4];
+  const int c = blockIdx.x, ch = blockIdx.y, t = threadIdx.x, nchunk = gridDim.y;
+  const int b0 = ch * b_per_chunk, nb = min(b_per_chunk, B - b0);
+  const int n = nb * HW;
+  float cs = 0.f;
+  for (int e = t; e < n; e += 256) {
+    const int b = b0 + e / HW, pix = e % HW;
+    const size_t off = ((size_t)b * C + c) * HW + pix;
+    float v = dy[off];
+    if (mode == 1) {
+      v *= (y[off] > 0.f ? 1.f : slope);
+      dyr[off] = v;
+    }
+    cs += v;
+  }
+  cs = block_sum_256(cs, red);
+  if (t == 0) colpart[(size_t)c * nchunk + ch] = cs;
+}
+
+__global__ void colsum_finalize_kernel(const float* __restrict__ colpart, float* __restrict__ out, int C, int nchunk) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int k = 0; k < nchunk; ++k) s += colpart[(size_t)c * nchunk + k];
+  out[c] = s;
+}
+
+// ----------------------------------------------------------------------------------------------
+// AudioEncoder resize: bilinear (align_corners=False) of (Tin,F) -> (Tout,1)
+__device__ inline void lerp_coords(int d, int in, int out, int& i0, int& i1, float& lam) {
+  const float scale = (float)in / (float)out;
+  float src = scale * ((float)d + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  lam = src - (float)i0;
+}
+
+__global__ void lerp_time_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int BC, int Tin, int F, int Tout) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= BC * Tout) return;
+  const int bc = i / Tout, d = i - bc * Tout;
+  int t0, t1, f0, f1;
+  float lt, lf;
+  lerp_coords(d, Tin, Tout, t0, t1, lt);
+  lerp_coords(0, F, 1, f0, f1, lf);
+  const float* xp = x + (size_t)bc * Tin * F;
+  const float r0 = (1.f - lf) * xp[t0 * F + f0] + lf * xp[t0 * F + f1];
+  const float r1 = (1.f - lf) * xp[t1 * F + f0] + lf * xp[t1 * F + f1];
+  y[i] = (1.f - lt) * r0 + lt * r1;
+}
+
+// gather form of the backward: one thread per input element, loops over the Tout outputs
+__global__ void lerp_time_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int BC, int Tin, int F, int Tout) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= BC * Tin * F) return;
+  const int f = i % F, t = (i / F) % Tin, bc = i / (F * Tin);
+  int f0, f1;
+  float lf;
+  lerp_coords(0, F, 1, f0, f1, lf);
+  float wf = 0.f;
+  if (f == f0) wf += 1.f - lf;
+  if (f == f1) wf += lf;
+  float acc = 0.f;
+  if (wf != 0.f) {
+    for (int d = 0; d < Tout; ++d) {
+      int t0, t1;
+      float lt;
+      lerp_coords(d, Tin, Tout, t0, t1, lt);
+      float wt = 0.f;
+      if (t == t0) wt += 1.f - lt;
+      if (t == t1) wt += lt;
+      if (wt != 0.f) acc += wt * dy[(size_t)bc * Tout + d];
+    }
+    acc *= wf;
+  }
+  dx[i] = acc;
+}
+
+// ----------------------------------------------------------------------------------------------
+// softmax mixture of the M sub-generators.  One workgroup per (b, 64-step time tile); lane = time.
+#define MIX_TT 64
+__global__ __launch_bounds__(256) void softmax_mix_fwd_kernel(const float* __restrict__ z, const float* __restrict__ score,
+                                                              float* __restrict__ soft, float* __restrict__ out, int M,
+                                                              int P, int T) {
+  extern __shared__ float sm[];  // wsm[M][64] | tile[64][P+1]
+  float* wsm = sm;
+  float* tile = sm + (size_t)M * MIX_TT;
+  const int b = blockIdx.y, t0 = blockIdx.x * MIX_TT, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int tt = t0 + lane;
+  const bool tv = tt < T;
+  if (w == 0) {
+    float mx = -INFINITY;
+    for (int m = 0; m < M; ++m) mx = fmaxf(mx, tv ? score[((size_t)b * M + m) * T + tt] : 0.f);
+    float den = 0.f;
+    for (int m = 0; m < M; ++m) {
+      const float e = expf((tv ? score[((size_t)b * M + m) * T + tt] : 0.f) - mx);
+      wsm[m * MIX_TT + lane] = e;
+      den += e;
+    }
+    const float inv = 1.f / den;
+    for (int m = 0; m < M; ++m) {
+      const float v = wsm[m * MIX_TT + lane] * inv;
+      wsm[m * MIX_TT + lane] = v;
+      if (tv) soft[((size_t)b * T + tt) * M + m] = v;
+    }
+  }
+  __syncthreads();
+  for (int f = w; f < P; f += 4) {
+    float acc = 0.f;
+    for (int m = 0; m < M; ++m)
+      acc += wsm[m * MIX_TT + lane] * (tv ? z[((size_t)b * M * P + (size_t)m * P + f) * T + tt] : 0.f);
+    tile[lane * (P + 1) + f] = acc;
+  }
+  __syncthreads();
+  const int nt = min(MIX_TT, T - t0);
+  for (int e = t; e < nt * P; e += 256) {
+    const int r = e / P, f = e - r * P;
+    out[((size_t)b * T + t0 + r) * P + f] = tile[r * (P + 1) + f];
+  }
+}
+
+__global__ __launch_bounds__(256) void softmax_mix_bwd_kernel(const float* __restrict__ z, const float* __restrict__ soft,
+                                                              const float* __restrict__ dout, float* __restrict__ dz,
+                                                              float* __restrict__ dscore, int M, int P, int T) {
+  extern __shared__ float sm[];  // dso[M][64] | tile[64][P+1]
+  float* dso = sm;
+  float* tile = sm + (size_t)M * MIX_TT;
+  const int b = blockIdx.y, t0 = blockIdx.x * MIX_TT, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int tt = t0 + lane;
+  const bool tv = tt < T;
+  const int nt = min(MIX_TT, T - t0);
+  for (int e = t; e < nt * P; e += 256) {
+    const int r = e / P, f = e - r * P;
+    tile[r * (P + 1) + f] = dout[((size_t)b * T + t0 + r) * P + f];
+  }
+  __syncthreads();
+  for (int m = w; m < M; m += 4) {
+    const float sw = tv ? soft[((size_t)b * T + tt) * M + m] : 0.f;
+    float ds = 0.f;
+    for (int f = 0; f < P; ++f) {
+      const size_t off = ((size_t)b * M * P + (size_t)m * P + f) * T + tt;
+      const float g = tv ? tile[lane * (P + 1) + f] : 0.f;
+      if (tv) {
+        ds += g * z[off];
+        dz[off] = sw * g;
+      }
+    }
+    dso[m * MIX_TT + lane] = ds;
+  }
+  __syncthreads();
+  if (w == 0 && tv) {
+    float dot = 0.f;
+    for (int m = 0; m < M; ++m) dot += soft[((size_t)b * T + tt) * M + m] * dso[m * MIX_TT + lane];
+    for (int m = 0; m < M; ++m)
+      dscore[((size_t)b * M + m) * T + tt] = soft[((size_t)b * T + tt) * M + m] * (dso[m * MIX_TT + lane] - dot);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// cross entropy (mean over rows); single workgroup, fixed order
+__global__ __launch_bounds__(256) void cross_entropy_fwd_kernel(const float* __restrict__ score, const int64_t* __restrict__ target,
+                                                                float* __restrict__ loss, int n_outer, int n_inner, int C,
+                                                                int so, int sc, int si) {
+  __shared__ float red[4];
+  const int rows = n_outer * n_inner;
+  float acc = 0.f;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    const int o = r / n_inner, i = r - o * n_inner;
+    const float* sp = score + (size_t)o * so + (size_t)i * si;
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, sp[(size_t)c * sc]);
+    float den = 0.f;
+    for (int c = 0; c < C; ++c) den += expf(sp[(size_t)c * sc] - mx);
+    acc += (logf(den) + mx) - sp[(size_t)target[r] * sc];
+  }
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) loss[0] = acc / (float)rows;
+}
+
+__global__ void cross_entropy_bwd_kernel(const float* __restrict__ score, const int64_t* __restrict__ target,
+                                         const float* __restrict__ gscale, float* __restrict__ dscore, int n_outer,
+                                         int n_inner, int C, int so, int sc, int si, int accumulate) {
+  const int rows = n_outer * n_inner;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const int o = r / n_inner, i = r - o * n_inner;
+  const size_t base = (size_t)o * so + (size_t)i * si;
+  const float* sp = score + base;
+  float* dp = dscore + base;
+  float mx = -INFINITY;
+  for (int c = 0; c < C; ++c) mx = fmaxf(mx, sp[(size_t)c * sc]);
+  float den = 0.f;
+  for (int c = 0; c < C; ++c) den += expf(sp[(size_t)c * sc] - mx);
+  const float g = gscale[0] / (float)rows, inv = 1.f / den;
+  const int tg = (int)target[r];
+  for (int c = 0; c < C; ++c) {
+    const float v = g * (expf(sp[(size_t)c * sc] - mx) * inv - (c == tg ? 1.f : 0.f));
+    if (accumulate) dp[(size_t)c * sc] += v; else dp[(size_t)c * sc] = v;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// velocity (+ transpose to channel-major) and plain transposes, via a 32x32 LDS tile
+// in: (B, R, Cc) row-major -> out: (B, Cc, R);  diff: out[b,c,r] = in[b,r,c] - in[b,r-1,c], out[.,.,0] = 0
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc,
+                                                        int diff) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float* ip = in + (size_t)b * R * Cc;
+  for (int j = ty; j < 32; j += 8) {
+    const int r = r0 + j, c = c0 + tx;
+    float v = 0.f;
+    if (r < R && c < Cc) {
+      v = ip[(size_t)r * Cc + c];
+      if (diff) v = r > 0 ? v - ip[(size_t)(r - 1) * Cc + c] : 0.f;
+    }
+    tile[j][tx] = v;
+  }
+  __syncthreads();
+  float* op = out + (size_t)b * R * Cc;
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, r = r0 + tx;
+    if (r < R && c < Cc) op[(size_t)c * R + r] = tile[tx][j];
+  }
+}
+
+// dv (B,P,T) -> dx (B,T,P): dx[b,t,p] = (t>=1 ? dv[b,p,t] : 0) - (t+1<T ? dv[b,p,t+1] : 0)
+__global__ __launch_bounds__(256) void velocity_bwd_kernel(const float* __restrict__ dv, float* __restrict__ dx, int T, int P) {
+  __shared__ float tile[32][34];
+  const int b = blockIdx.z, t0 = blockIdx.x * 32, p0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* ip = dv + (size_t)b * P * T;
+  for (int j = ty; j < 32; j += 8) {
+    const int p = p0 + j;
+    for (int k = tx; k < 33; k += 32) {
+      const int tt = t0 + k;
+      tile[j][k] = (p < P && tt < T) ? ip[(size_t)p * T + tt] : 0.f;
+    }
+  }
+  __syncthreads();
+  float* op = dx + (size_t)b * T * P;
+  for (int j = ty; j < 32; j += 8) {
+    const int tt = t0 + j, p = p0 + tx;
+    if (tt < T && p < P) {
+      const float a = tt >= 1 ? tile[tx][j] : 0.f;
+      const float c = tt + 1 < T ? tile[tx][j + 1] : 0.f;
+      op[(size_t)tt * P + p] = a - c;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// deterministic two-stage reductions
+#define RED_MAX_BLOCKS 1024
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, float target,
+                                                         float* __restrict__ partials, size_t n) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    s += fabsf(a[i] - (b ? b[i] : target));
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void sq_partial_kernel(const float* __restrict__ g, float* __restrict__ partials, size_t n) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += g[i] * g[i];
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// mode 0: out = sum * scale ; mode 1: out = sqrt(sum)
+__global__ __launch_bounds__(256) void reduce_final_kernel(const float* __restrict__ partials, int n, float* out, float scale,
+                                                           int mode) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += (double)partials[i];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double tot = red[0] + red[1] + red[2] + red[3];
+    out[0] = mode == 1 ? (float)sqrt(tot) : (float)(tot * (double)scale);
+  }
+}
+
+__global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, float target,
+                                                     const float* __restrict__ gscale, float* __restrict__ da, size_t n) {
+  const float g = gscale[0] / (float)n;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float d = a[i] - (b ? b[i] : target);
+    da[i] = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+  }
+}
+
+// Adam (torch.optim.Adam defaults: no amsgrad, no weight decay) with clip_grad_norm_ folded in.
+// state words: [0] step (int32), [1] clip coef, [2] step_size = lr/bc1, [3] sqrt(bc2)
+__global__ void adam_prep_kernel(int32_t* state, const float* norm, float max_norm, float lr, float beta1, float beta2) {
+  const int step = state[0] + 1;
+  state[0] = step;
+  float* f = reinterpret_cast<float*>(state);
+  float coef = 1.f;
+  if (norm) {
+    coef = max_norm / (norm[0] + 1e-6f);
+    if (coef > 1.f) coef = 1.f;
+  }
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  f[1] = coef;
+  f[2] = (float)((double)lr / bc1);
+  f[3] = (float)sqrt(bc2);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, size_t n, const int32_t* __restrict__ state,
+                                                   float beta1, float beta2, float eps) {
+  const float* f = reinterpret_cast<const float*>(state);
+  const float coef = f[1], step_size = f[2], bc2s = f[3];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float gi = g[i] * coef;
+    const float mi = m[i] + (1.f - beta1) * (gi - m[i]);
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= step_size * (mi / (sqrtf(vi) / bc2s + eps));
+  }
+}
+
+static inline int red_blocks(size_t n) {
+  size_t b = (n + 256 * 8 - 1) / (256 * 8);
+  if (b < 1) b = 1;
+  if (b > RED_MAX_BLOCKS) b = RED_MAX_BLOCKS;
+  return (int)b;
+}
+
+// ---- launchers used by api.hip
+int launch_bn_finalize(const float* stats, int n_tiles, int tile_n, int N, int C, const float* gamma, const float* beta,
+                       float* rm, float* rv, float* save, float eps, float momentum, hipStream_t s) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, s, stats, n_tiles, tile_n, N, C, gamma, beta, rm, rv, save,
+                     eps, momentum);
+  return check_launch("bn_finalize_kernel");
+}
+
+int launch_bn_apply(const float* y_raw, float* y, const float* save, int C, int HW, size_t total, float slope, hipStream_t s) {
+  const size_t work = (HW & 3) == 0 ? total / 4 : total;
+  int blocks = (int)std::min<size_t>((work + 255) / 256, 4096);
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, s, y_raw, y, save, C, HW, total, slope);
+  return check_launch("bn_apply_kernel");
+}
+
+int bwd_chunks(int B, int C, int* b_per_chunk) {
+  int want = C >= 1024 ? 1 : (1024 + C - 1) / C;
+  if (want > B) want = B;
+  if (want < 1) want = 1;
+  const int bpc = (B + want - 1) / want;
+  *b_per_chunk = bpc;
+  return (B + bpc - 1) / bpc;
+}
+
+int launch_bn_bwd(const float* dy, const float* y_raw, const float* save, const float* gamma, float* partial, float* dyr,
+                  float* colpart, float* dgamma, float* dbeta, int B, int C, int HW, float slope, hipStream_t s) {
+  int bpc;
+  const int nchunk = bwd_chunks(B, C, &bpc);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, nchunk), dim3(256), 0, s, dy, y_raw, save, partial, B, C, HW, bpc, slope);
+  int rc = check_launch("bn_bwd_reduce_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(C, nchunk), dim3(256), 0, s, dy, y_raw, save, gamma, partial, dyr, colpart,
+                     dgamma, dbeta, B, C, HW, bpc, slope);
+  return check_launch("bn_bwd_apply_kernel");
+}
+
+int launch_act_bwd(const float* dy, const float* y, float* dyr, float* colpart, int B, int C, int HW, int mode, float slope,
+                   hipStream_t s) {
+  int bpc;
+  const int nchunk = bwd_chunks(B, C, &bpc);
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(C, nchunk), dim3(256), 0, s, dy, y, dyr, colpart, B, C, HW, bpc, mode, slope);
+  return check_launch("act_bwd_kernel");
+}
+
+int launch_colsum_finalize(const float* colpart, float* out, int B, int C, hipStream_t s) {
+  int bpc;
+  const int nchunk = bwd_chunks(B, C, &bpc);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, colpart, out, C, nchunk);
+  return check_launch("colsum_finalize_kernel");
+}
+
+}  // namespace ms
+
+using namespace ms;
+
+extern "C" {
+
+int ms_lerp_time_fwd(const float* x, float* y, int B, int C, int Tin, int F, int Tout, void* stream) {
+  const int n = B * C * Tout;
+  hipLaunchKernelGGL(lerp_time_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, B * C, Tin, F, Tout);
+  return check_launch("lerp_time_fwd_kernel");
+}
+
+int ms_lerp_time_bwd(const float* dy, float* dx, int B, int C, int Tin, int F, int Tout, void* stream) {
+  const int n = B * C * Tin * F;
+  hipLaunchKernelGGL(lerp_time_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, B * C, Tin, F, Tout);
+  return check_launch("lerp_time_bwd_kernel");
+}
+
+int ms_softmax_mix_fwd(const float* z, const float* score, float* soft, float* out, int B, int M, int P, int T, void* stream) {
+  const size_t lds = ((size_t)M * MIX_TT + (size_t)MIX_TT * (P + 1)) * sizeof(float);
+  if (lds > 160 * 1024) return set_error("ms_softmax_mix_fwd: M=%d P=%d needs %zu B of LDS", M, P, lds);
+  hipLaunchKernelGGL(softmax_mix_fwd_kernel, dim3(cdiv(T, MIX_TT), B), dim3(256), lds, (hipStream_t)stream, z, score, soft, out,
+                     M, P, T);
+  return check_launch("softmax_mix_fwd_kernel");
+}
+
+int ms_softmax_mix_bwd(const float* z, const float* soft, const float* dout, float* dz, float* dscore, int B, int M, int P,
+                       int T, void* stream) {
+  const size_t lds = ((size_t)M * MIX_TT + (size_t)MIX_TT * (P + 1)) * sizeof(float);
+  if (lds > 160 * 1024) return set_error("ms_softmax_mix_bwd: M=%d P=%d needs %zu B of LDS", M, P, lds);
+  hipLaunchKernelGGL(softmax_mix_bwd_kernel, dim3(cdiv(T, MIX_TT), B), dim3(256), lds, (hipStream_t)stream, z, soft, dout, dz,
+                     dscore, M, P, T);
+  return check_launch("softmax_mix_bwd_kernel");
+}
+
+int ms_cross_entropy_fwd(const float* score, const int64_t* target, float* loss, float* row_scratch, int n_outer, int n_inner,
+                         int C, int stride_outer, int stride_c, int stride_inner, void* stream) {
+  (void)row_scratch;
+  hipLaunchKernelGGL(cross_entropy_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, score, target, loss, n_outer, n_inner,
+                     C, stride_outer, stride_c, stride_inner);
+  return check_launch("cross_entropy_fwd_kernel");
+}
+
+int ms_cross_entropy_bwd(const float* score, const int64_t* target, const float* gscale, float* dscore, int n_outer, int n_inner,
+                         int C, int stride_outer, int stride_c, int stride_inner, int accumulate, void* stream) {
+  const int rows = n_outer * n_inner;
+  hipLaunchKernelGGL(cross_entropy_bwd_kernel, dim3(cdiv(rows, 64)), dim3(64), 0, (hipStream_t)stream, score, target, gscale,
+                     dscore, n_outer, n_inner, C, stride_outer, stride_c, stride_inner, accumulate);
+  return check_launch("cross_entropy_bwd_kernel");
+}
+
+int ms_velocity_fwd(const float* x, float* v, int B, int T, int P, void* stream) {
+  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(P, 32), cdiv(T, 32), B), dim3(256), 0, (hipStream_t)stream, x, v, T, P, 1);
+  return check_launch("transpose_kernel(velocity)");
+}
+
+int ms_velocity_bwd(const float* dv, float* dx, int B, int T, int P, void* stream) {
+  hipLaunchKernelGGL(velocity_bwd_kernel, dim3(cdiv(T, 32), cdiv(P, 32), B), dim3(256), 0, (hipStream_t)stream, dv, dx, T, P);
+  return check_launch("velocity_bwd_kernel");
+}
+
+int ms_transpose_btc(const float* x, float* y, int B, int T, int C, void* stream) {
+  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(C, 32), cdiv(T, 32), B), dim3(256), 0, (hipStream_t)stream, x, y, T, C, 0);
+  return check_launch("transpose_kernel");
+}
+
+int ms_transpose_bct(const float* x, float* y, int B, int C, int T, void* stream) {
+  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(T, 32), cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream, x, y, C, T, 0);
+  return check_launch("transpose_kernel");
+}
+
+size_t ms_reduce_partials_count(size_t n) { return (size_t)red_blocks(n); }
+
+int ms_l1_mean_fwd(const float* a, const float* b, float target, float* loss, float* partials, size_t n, void* stream) {
+  const int nb = red_blocks(n);
+  hipLaunchKernelGGL(l1_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, b, target, partials, n);
+  int rc = check_launch("l1_partial_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nb, loss, 1.0f / (float)n, 0);
+  return check_launch("reduce_final_kernel");
+}
+
+int ms_l1_mean_bwd(const float* a, const float* b, float target, const float* gscale, float* da, size_t n, void* stream) {
+  hipLaunchKernelGGL(l1_bwd_kernel, dim3(red_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, target, gscale, da, n);
+  return check_launch("l1_bwd_kernel");
+}
+
+int ms_sqnorm(const float* g, size_t n, float* norm_out, float* partials, void* stream) {
+  const int nb = red_blocks(n);
+  hipLaunchKernelGGL(sq_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, partials, n);
+  int rc = check_launch("sq_partial_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nb, norm_out, 1.0f, 1);
+  return check_launch("reduce_final_kernel");
+}
+
+int ms_adam_step(float* p, const float* g, float* m, float* v, size_t n, const float* norm, float max_norm, float lr,
+                 float beta1, float beta2, float eps, int32_t* step_state, void* stream) {
+  hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_state, norm, max_norm, lr, beta1, beta2);
+  int rc = check_launch("adam_prep_kernel");
+  if (rc) return rc;
+  int blocks = (int)std::min<size_t>((n + 1023) / 1024, 2048);
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, step_state, beta1, beta2, eps);
+  return check_launch("adam_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,53 @@
+// Internal launcher interface shared by the translation units of libmixstage_hip.so.
+#pragma once
+#include "common.h"
+
+namespace ms {
+
+enum { EP_BARE = 0, EP_LRELU = 1, EP_BN_EVAL = 2, EP_RAW_STATS = 3, EP_DGRAD = 4, EP_DGRAD_UP2 = 5 };
+
+struct GatherArgs {
+  const float* A;     // [groups][Mg][Kg]
+  const float* src;   // gathered tensor
+  const float* src2;  // UP2 forward: residual
+  float* out;         // [B][groups*Mg][OUTH][OUTW]
+  float* out2;        // UP2 dgrad: grad of the residual
+  const float* bias;
+  const float* bn_g;
+  const float* bn_b;
+  const float* bn_m;
+  const float* bn_v;
+  float* stats;  // EP_RAW_STATS: [n_tiles][groups*Mg][2] = (sum, M2 about the tile mean)
+  int Mg, Kg, groups, Kc, src_ctotal, SRCH, SRCW, OUTH, OUTW, Npix;
+  int KH, KW, SH, SW, PH, PW;
+  int bcast, a_vec, ep;
+  float slope, eps;
+};
+
+struct WgradArgs {
+  const float* dyr;   // [B][groups*Cog][OH][OW]
+  const float* src;   // x (UP2: half-resolution a)
+  const float* src2;  // UP2: residual r
+  float* out;         // [splits][groups*Cog][Kg]
+  int Cog, Cig, Kg, groups, src_ctotal, H, W, OH, OW, Npix;
+  int KH, KW, SH, SW, PH, PW;
+  int bcast, splits, r_per_split;
+};
+
+int launch_gather(const GatherArgs& a, bool transposed, bool up2, int* n_tiles_out, hipStream_t s);
+int gather_n_tiles(int Mg, int Npix, int groups);
+int gather_tile_n(int Mg, int Npix, int groups);
+int wgrad_splits(int Cog, int Kg, int groups, int Npix);
+int launch_wgrad(WgradArgs a, bool up2, float* dw, float* partial_ws, hipStream_t s);
+int launch_transpose_weight(const float* w, float* wt, int groups, int Cog, int Cig, int KHW, hipStream_t s);
+int launch_bn_finalize(const float* stats, int n_tiles, int tile_n, int N, int C, const float* gamma, const float* beta,
+                       float* rm, float* rv, float* save, float eps, float momentum, hipStream_t s);
+int launch_bn_apply(const float* y_raw, float* y, const float* save, int C, int HW, size_t total, float slope, hipStream_t s);
+int bwd_chunks(int B, int C, int* b_per_chunk);
+int launch_bn_bwd(const float* dy, const float* y_raw, const float* save, const float* gamma, float* partial, float* dyr,
+                  float* colpart, float* dgamma, float* dbeta, int B, int C, int HW, float slope, hipStream_t s);
+int launch_act_bwd(const float* dy, const float* y, float* dyr, float* colpart, int B, int C, int HW, int mode, float slope,
+                   hipStream_t s);
+int launch_colsum_finalize(const float* colpart, float* out, int B, int C, hipStream_t s);
+
+}  // namespace ms

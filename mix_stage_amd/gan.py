@@ -1,0 +1,152 @@
+"""GAN wrapper (reference: src/model/gan.py:18-164) on the HIP kernels: D-step / G-step selection,
+pose velocity, GAN + pose losses.  Same constructor (kwargs['input_modalities'] required),
+forward(x_audio, y_pose, **kwargs) -> (fake_pose, losses, {'W': W}), flags G_flag / fake_flag / D_prob."""
+import contextlib
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class ConstantLambdaScheduler:
+  """Stand-in for pycasper.torchUtils.LambdaScheduler (not vendored, unpinned; gan.py:30-33,103): returns the
+  initial [lambda_D, lambda_gan] on every step().  Inject another object with .step() to change it."""
+
+  def __init__(self, lmbdas, **kwargs):
+    self.lmbdas = list(lmbdas)
+
+  def step(self):
+    return list(self.lmbdas)
+
+
+_SUPPORTED = {'L1Loss'}
+
+
+class GAN(nn.Module):
+  def __init__(self, G, D, dg_iter_ratio=1, lambda_D=1, lambda_gan=1, lr=0.0001, criterion='MSELoss', optim='Adam',
+               joint=False, update_D_prob_flag=True, no_grad=True, **kwargs):
+    super(GAN, self).__init__()
+    self.G = G
+    self.D = D
+    self.D_prob = dg_iter_ratio / (dg_iter_ratio + 1)
+    self.lambda_D = lambda_D
+    self.lambda_gan = lambda_gan
+    self.lambda_scheduler = kwargs.get('lambda_scheduler') or ConstantLambdaScheduler(
+        [self.lambda_D, self.lambda_gan], kind='incremental', max_interval=300, max_lambda=2)
+    self.G_flag = True
+    self.fake_flag = True
+    self.lr = lr
+    if criterion not in _SUPPORTED:
+      raise NotImplementedError('criterion %s: the HIP path implements L1Loss (what src/jobs/mix-stage.py trains '
+                                'with)' % criterion)
+    self.criterion_name = criterion
+    self.joint = joint
+    if joint:
+      raise NotImplementedError('joint=True (D sees pose||audio) is not on the Mix-StAGE path')
+    self.input_modalities = kwargs['input_modalities']
+    self.update_D_prob_flag = update_D_prob_flag
+    self.no_grad = no_grad
+    # In the G-step the reference also back-propagates into D's weights and then discards those gradients
+    # (trainer.py:1104-1107,1140-1142).  Skipping that weight-gradient work changes no result.
+    self.skip_D_weight_grads_in_G_step = True
+
+  # API parity helpers -------------------------------------------------------------------------
+  def get_velocity(self, x, x_audio=None):
+    """(B,T,P) -> (B,T,P) velocity (gan.py:47-52)."""
+    return ops.to_time_major(ops.velocity_cm(x))
+
+  def get_real_gt(self, x):
+    return torch.ones_like(x)
+
+  def get_fake_gt(self, x):
+    return torch.zeros_like(x)
+
+  def get_gan_loss(self, y_cap, y, W=None):
+    return ops.l1_mean(y_cap, y)
+
+  def get_loss(self, y_cap, y, W=None):
+    return ops.l1_mean(y_cap, y)
+
+  def estimate_weights(self, x_audio, y_pose, **kwargs):
+    return torch.ones(y_pose.shape[0]).to(y_pose.device), None
+
+  def estimate_weights_loss(self, W):
+    return W
+
+  def update_D_prob(self, W):
+    pass
+
+  @contextlib.contextmanager
+  def _frozen_D(self):
+    flags = [(p, p.requires_grad) for p in self.D.parameters()]
+    for p, _ in flags:
+      p.requires_grad_(False)
+    try:
+      yield
+    finally:
+      for p, f in flags:
+        p.requires_grad_(f)
+
+  def _score(self, pose):
+    """D(get_velocity(pose)) with the velocity produced channel-major for D's first conv."""
+    v = ops.velocity_cm(pose)
+    if hasattr(self.D, 'forward_channel_major'):
+      return self.D.forward_channel_major(v)[0]
+    return self.D(ops.to_time_major(v))[0]
+
+  def forward(self, x_audio, y_pose, **kwargs):
+    internal_losses = []
+    if 'confidence' in kwargs and not (isinstance(kwargs['confidence'], (int, float)) and kwargs['confidence'] == 1):
+      raise NotImplementedError('confidence weighting is not on the Mix-StAGE path (confidence == 1)')
+    W, outputs = self.estimate_weights(x_audio, y_pose, **kwargs)      # ones: sample weights are 1 (gan.py:77-78)
+    if self.update_D_prob_flag:
+      self.update_D_prob(W)
+
+    if self.training:
+      self.lambda_D, self.lambda_gan = self.lambda_scheduler.step()
+      if torch.rand(1).item() < self.D_prob:                           # host RNG draw (gan.py:105)
+        ## D-step: G in eval mode under no_grad, D on fake then real velocity (gan.py:106-132)
+        self.G.eval()
+        with torch.no_grad():
+          fake_pose, partial_i_loss, *args = self.G(x_audio, y_pose, **kwargs)
+          args = args[0] if len(args) > 0 else {}
+        self.G.train(self.training)
+        self.fake_flag = True
+        fake_pose_score = self._score(fake_pose.detach())
+        fake_D_loss = ops.l1_mean(fake_pose_score, target=0.0, scale=self.lambda_D)
+        real_pose_score = self._score(y_pose)
+        real_D_loss = ops.l1_mean(real_pose_score, target=1.0)
+        internal_losses.append(real_D_loss)
+        internal_losses.append(fake_D_loss)
+        internal_losses += partial_i_loss
+        self.G_flag = False
+      else:
+        ## G-step (gan.py:134-152)
+        fake_pose, partial_i_loss, *args = self.G(x_audio, y_pose, **kwargs)
+        args = args[0] if len(args) > 0 else {}
+        if self.no_grad:
+          with torch.no_grad():
+            fake_pose_score = self._score(fake_pose)
+        elif self.skip_D_weight_grads_in_G_step:
+          with self._frozen_D():
+            fake_pose_score = self._score(fake_pose)
+        else:
+          fake_pose_score = self._score(fake_pose)
+        G_gan_loss = ops.l1_mean(fake_pose_score, target=1.0, scale=self.lambda_gan)
+        pose_loss = ops.l1_mean(fake_pose, y_pose)
+        internal_losses.append(pose_loss)
+        internal_losses.append(G_gan_loss)
+        internal_losses += partial_i_loss
+        self.G_flag = True
+    else:
+      fake_pose, partial_i_loss, *args = self.G(x_audio, y_pose, **kwargs)
+      args = args[0] if len(args) > 0 else {}
+      pose_loss = ops.l1_mean(fake_pose, y_pose)
+      internal_losses.append(pose_loss)
+      internal_losses.append(torch.tensor(0))
+      internal_losses += partial_i_loss
+      self.G_flag = True
+
+    args.update(dict(W=W))
+    return fake_pose, internal_losses, args

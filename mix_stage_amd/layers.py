@@ -1,0 +1,357 @@
+"""Host-side mirror of the reference's building blocks (src/model/layers.py) on the HIP kernels.
+
+Same class names, constructor signatures, forward() signatures, sub-module attribute names and
+state_dict keys as the reference, so checkpoints and callers carry over unchanged:
+
+  ConvNormRelu      layers.py:32-78      UNet1D        layers.py:80-157
+  AudioEncoder      layers.py:159-199    PoseEncoder   layers.py:201-240
+  PoseStyleEncoder  layers.py:246-289    TextEncoder1D layers.py:339-373
+  ClusterClassify   layers.py:446-467    Group         layers.py:593-650
+  EmbLin            layers.py:652-663    Curriculum    layers.py:677-696
+
+`self.conv` / `self.norm` are torch.nn containers for the parameters and running statistics only
+(same default initialisation and RNG consumption as the reference); their forward() is never called --
+the arithmetic runs in libmixstage_hip.so (ops.conv_block).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import MS_BARE, MS_BN_EVAL, MS_BN_TRAIN, MS_IN_BCAST, MS_IN_PLAIN, MS_IN_UP2ADD, MS_LRELU
+
+
+# set to a list while a training step is being graph-captured: the ConvNormRelu blocks that ran with batch
+# statistics are recorded so graph replays can keep their num_batches_tracked counts right (train_step.py)
+_train_tape = None
+
+
+def set_train_tape(tape):
+  global _train_tape
+  _train_tape = tape
+
+
+def num_powers_of_two(x):
+  n = 0
+  while x > 1 and x % 2 == 0:
+    x //= 2
+    n += 1
+  return n
+
+
+def next_multiple_power_of_two(x, power=5):
+  have = num_powers_of_two(x)
+  return x * (2 ** (power - have)) if have < power else x
+
+
+def _default_padding(kernel_size, stride):
+  # layers.py:46-55 (tuple/tuple is (ks-ks)/2 = 0 in the reference: kept bug-compatible)
+  kt, st = isinstance(kernel_size, tuple), isinstance(stride, tuple)
+  if not kt and st:
+    return tuple(int((kernel_size - s) / 2) for s in stride)
+  if kt and not st:
+    return tuple(int((k - stride) / 2) for k in kernel_size)
+  if kt and st:
+    assert len(kernel_size) == len(stride), \
+        'dims in kernel_size are {} and stride are {}. They must be the same'.format(len(kernel_size), len(stride))
+    return tuple(0 for _ in kernel_size)
+  return int((kernel_size - stride) / 2)
+
+
+def bare_conv(conv, x, lrelu_slope=None):
+  """An nn.Conv1d/2d container evaluated on the HIP kernels (JL:83 logits, layers.py:459, S2G:50-51,63)."""
+  geom = getattr(conv, '_ms_geom', None)
+  if geom is None:
+    nd = 1 if isinstance(conv, nn.Conv1d) else 2
+    geom = ops.ConvGeom(nd, conv.groups, conv.kernel_size, conv.stride, conv.padding,
+                        slope=0.0 if lrelu_slope is None else lrelu_slope)
+    conv._ms_geom = geom
+  return ops.conv_block(x, conv.weight, conv.bias, geom, MS_BARE if lrelu_slope is None else MS_LRELU)
+
+
+class ConvNormRelu(nn.Module):
+  def __init__(self, in_channels, out_channels, type='1d', leaky=False, downsample=False, kernel_size=None,
+               stride=None, padding=None, p=0, groups=1):
+    super(ConvNormRelu, self).__init__()
+    if kernel_size is None and stride is None:
+      kernel_size, stride = (4, 2) if downsample else (3, 1)
+    if padding is None:
+      padding = _default_padding(kernel_size, stride)
+    in_channels, out_channels = in_channels * groups, out_channels * groups
+    if type == '1d':
+      self.conv = nn.Conv1d(in_channels=in_channels, out_channels=out_channels, kernel_size=kernel_size,
+                            stride=stride, padding=padding, groups=groups)
+      self.norm = nn.BatchNorm1d(out_channels)
+      self.dropout = nn.Dropout(p=p)
+    elif type == '2d':
+      self.conv = nn.Conv2d(in_channels=in_channels, out_channels=out_channels, kernel_size=kernel_size,
+                            stride=stride, padding=padding, groups=groups)
+      self.norm = nn.BatchNorm2d(out_channels)
+      self.dropout = nn.Dropout2d(p=p)
+    self.relu = nn.LeakyReLU(negative_slope=0.2) if leaky else nn.ReLU()
+    self._nd = 1 if type == '1d' else 2
+    self._slope = 0.2 if leaky else 0.0
+    self._p = p
+    self._geom = None
+    # nn.BatchNorm's num_batches_tracked is kept as a host-side pending count and folded into the buffer
+    # when the state is read: no per-layer device increment inside the (graph-captured) step.
+    self._pending_batches = 0
+    self._register_state_dict_hook(ConvNormRelu._flush_hook)
+    self._register_load_state_dict_pre_hook(self._reset_pending)
+
+  @staticmethod
+  def _flush_hook(module, state_dict, prefix, local_metadata):
+    if module._pending_batches and module.norm.num_batches_tracked is not None:
+      module.norm.num_batches_tracked += module._pending_batches
+      module._pending_batches = 0
+      state_dict[prefix + 'norm.num_batches_tracked'] = module.norm.num_batches_tracked.detach()
+
+  def _reset_pending(self, *args, **kwargs):
+    self._pending_batches = 0
+
+  def _geometry(self):
+    if self._geom is None:
+      c, n = self.conv, self.norm
+      self._geom = ops.ConvGeom(self._nd, c.groups, c.kernel_size, c.stride, c.padding, slope=self._slope,
+                                eps=n.eps, momentum=0.1 if n.momentum is None else n.momentum)
+    return self._geom
+
+  def _run(self, x, x2=None, in_mode=MS_IN_PLAIN):
+    if self._p and self.training:
+      raise NotImplementedError('dropout p>0 is not on the Mix-StAGE path (p=0 everywhere, JL:26)')
+    n = self.norm
+    if self.training and n.track_running_stats:
+      mode = MS_BN_TRAIN
+      self._pending_batches += 1           # nn.BatchNorm's num_batches_tracked (see __init__)
+      if _train_tape is not None:
+        _train_tape.append(self)
+    else:
+      mode = MS_BN_EVAL
+    return ops.conv_block(x, self.conv.weight, self.conv.bias, self._geometry(), mode, n.weight, n.bias,
+                          n.running_mean, n.running_var, x2=x2, in_mode=in_mode)
+
+  def forward(self, x, **kwargs):
+    return self._run(x)
+
+  # fused input forms used inside this package (not part of the reference API)
+  def forward_upsample_add(self, a, residual):
+    """== self(upsample_nearest2(a) + residual) without materialising the sum (layers.py:151)."""
+    return self._run(a, x2=residual, in_mode=MS_IN_UP2ADD)
+
+  def forward_broadcast(self, x):
+    """== self(torch.cat([x]*groups, dim=1)) without the replication (JL:190)."""
+    return self._run(x, in_mode=MS_IN_BCAST)
+
+
+class UNet1D(nn.Module):
+  def __init__(self, input_channels, output_channels, max_depth=5, kernel_size=None, stride=None, p=0, groups=1):
+    super(UNet1D, self).__init__()
+    self.pre_downsampling_conv = nn.ModuleList([])
+    self.conv1 = nn.ModuleList([])
+    self.conv2 = nn.ModuleList([])
+    self.upconv = nn.Upsample(scale_factor=2, mode='nearest')
+    self.max_depth = max_depth
+    self.groups = groups
+    common = dict(type='1d', leaky=True, kernel_size=kernel_size, stride=stride, p=p, groups=groups)
+    self.pre_downsampling_conv.append(ConvNormRelu(input_channels, output_channels, downsample=False, **common))
+    self.pre_downsampling_conv.append(ConvNormRelu(output_channels, output_channels, downsample=False, **common))
+    for _ in range(self.max_depth):
+      self.conv1.append(ConvNormRelu(output_channels, output_channels, downsample=True, **common))
+    for _ in range(self.max_depth):
+      self.conv2.append(ConvNormRelu(output_channels, output_channels, downsample=False, **common))
+
+  def forward(self, x, return_bottleneck=False):
+    input_size = x.shape[-1]
+    assert input_size / (2 ** (self.max_depth - 1)) >= 1, \
+        'Input size is {}. It must be >= {}'.format(input_size, 2 ** (self.max_depth - 1))
+    assert num_powers_of_two(input_size) >= self.max_depth, \
+        'Input size is {}. It must be a multiple of 2^(max_depth) = 2^{} = {}'.format(
+            input_size, self.max_depth, 2 ** self.max_depth)
+    for m in self.pre_downsampling_conv:
+      x = m(x)
+    residuals = [x]
+    for i, down in enumerate(self.conv1):
+      x = down(x)
+      if i < self.max_depth - 1:
+        residuals.append(x)
+    bn = x
+    for i, up in enumerate(self.conv2):
+      x = up.forward_upsample_add(x, residuals[self.max_depth - i - 1])
+    return (x, bn) if return_bottleneck else x
+
+
+class AudioEncoder(nn.Module):
+  '''
+  input_shape:  (N, C, time, frequency)
+  output_shape: (N, 256, output_feats)
+  '''
+
+  def __init__(self, output_feats=64, input_channels=1, kernel_size=None, stride=None, p=0, groups=1):
+    super(AudioEncoder, self).__init__()
+    self.conv = nn.ModuleList([])
+    common = dict(type='2d', leaky=True, kernel_size=kernel_size, stride=stride, p=p, groups=groups)
+    for cin, cout, down in ((input_channels, 64, False), (64, 64, True), (64, 128, False), (128, 128, True),
+                            (128, 256, False), (256, 256, True), (256, 256, False)):
+      self.conv.append(ConvNormRelu(cin, cout, downsample=down, **common))
+    self.conv.append(ConvNormRelu(256, 256, type='2d', leaky=True, downsample=False, kernel_size=(3, 8), stride=1,
+                                  p=p, groups=groups))
+
+  def forward(self, x, time_steps=None):
+    if time_steps is None:
+      time_steps = x.shape[-2]
+    for m in self.conv:
+      x = m(x)
+    return ops.lerp_time(x, time_steps)
+
+
+class _TimeMajorStack(nn.Module):
+  """(N, time, feats) -> channel-major -> a chain of 1-D ConvNormRelu blocks."""
+
+  def _build(self, specs, kernel_size, stride, p, groups):
+    self.conv = nn.ModuleList([])
+    for cin, cout, down in specs:
+      self.conv.append(ConvNormRelu(cin, cout, type='1d', leaky=True, downsample=down, kernel_size=kernel_size,
+                                    stride=stride, p=p, groups=groups))
+
+  def _chain(self, x):
+    x = ops.to_channel_major(x)
+    for m in self.conv:
+      x = m(x)
+    return x
+
+
+def _same_res_specs(cin):
+  return ((cin, 64, False), (64, 64, False), (64, 128, False), (128, 128, False), (128, 256, False),
+          (256, 256, False))
+
+
+class PoseEncoder(_TimeMajorStack):
+  '''
+  input_shape:  (N, time, pose_features)
+  output_shape: (N, 256, time)
+  '''
+
+  def __init__(self, output_feats=64, input_channels=96, kernel_size=None, stride=None, p=0, groups=1):
+    super(PoseEncoder, self).__init__()
+    self._build(_same_res_specs(input_channels), kernel_size, stride, p, groups)
+
+  def forward(self, x, time_steps=None):
+    return self._chain(x).squeeze(dim=-1)
+
+
+class TextEncoder1D(_TimeMajorStack):
+  '''
+  input_shape:  (N, time, text_features: 300)
+  output_shape: (N, 256, time)
+  '''
+
+  def __init__(self, output_feats=64, input_channels=300, kernel_size=None, stride=None, p=0, groups=1):
+    super().__init__()
+    self._build(_same_res_specs(input_channels), kernel_size, stride, p, groups)
+
+  def forward(self, x, time_steps=None, **kwargs):
+    return self._chain(x).squeeze(dim=-1)
+
+
+class PoseStyleEncoder(_TimeMajorStack):
+  '''
+  input_shape:  (N, time, pose_features)
+  output_shape: (N, num_speakers)
+  '''
+
+  def __init__(self, output_feats=64, input_channels=96, kernel_size=None, stride=None, p=0, groups=1,
+               num_speakers=4):
+    super().__init__()
+    self._build(((input_channels, 64, False), (64, 64, True), (64, 128, True), (128, 128, True), (128, 256, True),
+                 (256, 256, True), (256, num_speakers, True)), kernel_size, stride, p, groups)
+
+  def forward(self, x, time_steps=None):
+    x = self._chain(x)
+    x = x.mean(-1) if x.shape[-1] > 1 else x.squeeze(-1)   # mean over a length-1 axis is the identity
+    return x.squeeze(dim=-1)
+
+
+class ClusterClassify(nn.Module):
+  '''
+  input_shape: (B, C, T)
+  output_shape: (B, num_clusters, T)
+  '''
+
+  def __init__(self, num_clusters=8, kernel_size=None, stride=None, p=0, groups=1, input_channels=256):
+    super().__init__()
+    self.conv = nn.ModuleList()
+    common = dict(type='1d', leaky=True, downsample=False, kernel_size=kernel_size, stride=stride, p=p, groups=groups)
+    self.conv.append(ConvNormRelu(input_channels, 256, **common))
+    self.conv += nn.ModuleList([ConvNormRelu(256, 256, **common) for i in range(5)])
+    self.logits = nn.Conv1d(256 * groups, num_clusters * groups, kernel_size=1, stride=1, groups=groups)
+
+  def forward(self, x, time_steps=None):
+    for m in self.conv:
+      x = m(x)
+    return bare_conv(self.logits, x)
+
+
+class Group(nn.Module):
+  """layers.py:593-650.  Constructed by the generator (state_dict keys style_dec_gr.*) but never called
+  on the audio path; forward() is provided for API parity using this package's ops."""
+
+  def __init__(self, models, groups=1, dim=1):
+    super().__init__()
+    if not isinstance(models, list):
+      models = [models]
+    self.models = nn.ModuleList(models)
+    self.groups = groups
+    self.dim = dim
+
+  def index_select_outputs(self, x, labels):
+    x = x.transpose(2, 1)
+    x = x.view(x.shape[0], x.shape[1], self.groups, -1)
+    labels = labels.view(x.shape[0], x.shape[1], x.shape[2])
+    return (x * labels.unsqueeze(-1)).sum(dim=-2)
+
+  def forward(self, x, labels=None, transpose=True, **kwargs):
+    if self.dim == 0:
+      self.groups = len(x)
+    if isinstance(x, list):
+      x = torch.cat(x, dim=self.dim)
+    if transpose:
+      x = x.transpose(-1, -2)
+    for model in self.models:
+      x = model(x, **kwargs) if kwargs else model(x)
+    if labels is not None:
+      return self.index_select_outputs(x, labels).transpose(-1, -2)
+    channels = int(x.shape[self.dim] / self.groups)
+    return list(torch.split(x, channels, dim=self.dim % x.dim()))
+
+
+class EmbLin(nn.Module):
+  def __init__(self, num_embeddings, embedding_dim):
+    super().__init__()
+    self.num_embeddings = num_embeddings
+    self.embedding_dim = embedding_dim
+    self.emb = nn.Embedding(num_embeddings, embedding_dim)
+
+  def forward(self, x, mode='lin'):
+    if mode == 'lin':
+      return x.matmul(self.emb.weight)
+    elif mode == 'emb':
+      return torch.nn.functional.embedding(x, self.emb.weight)
+
+
+class Curriculum():
+  def __init__(self, start, end, num_iters):
+    self.start = start
+    self.end = end
+    self.num_iters = num_iters
+    self.iters = 0
+    self.diff = (end - start) / num_iters
+    self.value = start
+
+  def step(self, flag=True):
+    if not flag:
+      return self.value
+    if self.iters >= self.num_iters:
+      return self.end
+    previous = self.value
+    self.value += self.diff
+    self.iters += 1
+    return previous

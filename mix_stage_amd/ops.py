@@ -1,0 +1,354 @@
+"""torch.autograd bindings of the HIP kernels (libmixstage_hip.so, include/mixstage.h).
+
+PyTorch is plumbing here: it owns HBM allocations, the current HIP stream and the autograd tape.
+Every function below enqueues hand-written gfx950 kernels through the C-ABI with raw device
+pointers; there is no eager/CPU fallback -- a CPU tensor or a missing library raises.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (ConvDesc, MS_BARE, MS_BN_EVAL, MS_BN_TRAIN, MS_IN_BCAST, MS_IN_PLAIN,
+                   MS_IN_UP2ADD, MS_LRELU, check, lib)
+
+_vp = ctypes.c_void_p
+
+
+def _ptr(t):
+  return None if t is None else _vp(t.data_ptr())
+
+
+def _stream():
+  return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_hip(*tensors):
+  for t in tensors:
+    if t is None:
+      continue
+    if not t.is_cuda:
+      raise _lib.MixStageLibError('mix_stage_amd ops run on the MI355X only (got a %s tensor); there is no CPU '
+                                  'fallback' % t.device)
+    if t.is_floating_point() and t.dtype != torch.float32:
+      raise TypeError('the HIP path computes in float32 (got %s); call .float() on the model and inputs' % t.dtype)
+
+
+_workspaces = {}
+
+
+def workspace(nbytes, device):
+  """Per-device scratch, grown geometrically; all users are serialised by the stream."""
+  key = (device.type, device.index)
+  ws = _workspaces.get(key)
+  if ws is None or ws.numel() < nbytes:
+    size = max(int(nbytes * 1.5), 1 << 22)
+    ws = torch.empty(size, dtype=torch.uint8, device=device)
+    _workspaces[key] = ws
+  return ws
+
+
+# ------------------------------------------------------------------------------------------------
+# conv block
+class ConvGeom:
+  """Static geometry of one conv block (the part of ms_conv_desc that does not depend on the input)."""
+  __slots__ = ('nd', 'groups', 'KH', 'KW', 'SH', 'SW', 'PH', 'PW', 'slope', 'eps', 'momentum', '_cache')
+
+  def __init__(self, nd, groups, kernel, stride, padding, slope=0.2, eps=1e-5, momentum=0.1):
+    def two(v):
+      if isinstance(v, (tuple, list)):
+        return (1, int(v[0])) if len(v) == 1 else (int(v[0]), int(v[1]))
+      return (int(v), int(v)) if nd == 2 else (1, int(v))
+    self.nd, self.groups = nd, groups
+    self.KH, self.KW = two(kernel)
+    self.SH, self.SW = two(stride)
+    ph, pw = two(padding)
+    self.PH, self.PW = (ph, pw) if nd == 2 else (0, pw)
+    if nd == 1:
+      self.KH, self.SH = 1, 1
+    self.slope, self.eps, self.momentum = float(slope), float(eps), float(momentum)
+    self._cache = {}
+
+  def desc(self, B, Cin_g, H, W, Cout_g, mode, in_mode):
+    key = (B, Cin_g, H, W, Cout_g, mode, in_mode)
+    d = self._cache.get(key)
+    if d is None:
+      OH = (H + 2 * self.PH - self.KH) // self.SH + 1
+      OW = (W + 2 * self.PW - self.KW) // self.SW + 1
+      if OH < 1 or OW < 1:
+        raise RuntimeError('conv block: input (%d,%d) too small for kernel (%d,%d)' % (H, W, self.KH, self.KW))
+      d = ConvDesc(B, Cin_g, H, W, Cout_g, self.groups, self.KH, self.KW, self.SH, self.SW, self.PH, self.PW,
+                   OH, OW, mode, in_mode, self.slope, self.eps, self.momentum, 0)
+      L = lib()
+      d._fwd_ws = L.ms_conv_block_fwd_workspace(ctypes.byref(d))
+      d._bwd_ws = L.ms_conv_block_bwd_workspace(ctypes.byref(d))
+      self._cache[key] = d
+    return d
+
+
+class _ConvBlockFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x, x2, w, bias, gamma, beta, geom, mode, in_mode, stats):
+    rm, rv = stats if stats is not None else (None, None)
+    _need_hip(x, x2, w, bias, gamma, beta, rm, rv)
+    x = x.contiguous()
+    x2 = x2.contiguous() if x2 is not None else None
+    nd = geom.nd
+    if x.dim() != nd + 2:
+      raise RuntimeError('conv block expects a %d-D input, got %s' % (nd + 2, tuple(x.shape)))
+    B = x.shape[0]
+    ref = x2 if in_mode == MS_IN_UP2ADD else x
+    H, W = (ref.shape[2], ref.shape[3]) if nd == 2 else (1, ref.shape[2])
+    ctot = w.shape[0]
+    Cout_g = ctot // geom.groups
+    Cin_g = w.shape[1]
+    exp_c = Cin_g if in_mode == MS_IN_BCAST else Cin_g * geom.groups
+    if x.shape[1] != exp_c:
+      raise RuntimeError('conv block: expected %d input channels, got %d' % (exp_c, x.shape[1]))
+    if in_mode == MS_IN_UP2ADD and (x.shape[2] * 2 != W or x2.shape[1] != exp_c):
+      raise RuntimeError('UP2ADD: a %s and residual %s do not match' % (tuple(x.shape), tuple(x2.shape)))
+    d = geom.desc(B, Cin_g, H, W, Cout_g, mode, in_mode)
+    oshape = (B, ctot, d.OH, d.OW) if nd == 2 else (B, ctot, d.OW)
+    y = torch.empty(oshape, dtype=torch.float32, device=x.device)
+    y_raw = save = None
+    if mode == MS_BN_TRAIN:
+      y_raw = torch.empty_like(y)
+      save = torch.empty(4 * ctot, dtype=torch.float32, device=x.device)
+    ws = workspace(d._fwd_ws, x.device)
+    check(lib().ms_conv_block_fwd(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(bias), _ptr(gamma), _ptr(beta),
+                                  _ptr(rm), _ptr(rv), _ptr(y_raw), _ptr(y), _ptr(save), _ptr(ws), ws.numel(),
+                                  _stream()), 'ms_conv_block_fwd')
+    ctx.geom_desc = d
+    ctx.mode, ctx.in_mode = mode, in_mode
+    ctx.has_bias = bias is not None
+    ctx.save_for_backward(x, x2, w, gamma, y_raw, y if mode == MS_LRELU else None, save)
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    x, x2, w, gamma, y_raw, y, save = ctx.saved_tensors
+    d, mode, in_mode = ctx.geom_desc, ctx.mode, ctx.in_mode
+    if mode == MS_BN_EVAL:
+      raise RuntimeError('backward through an eval-mode (running-stats) ConvNormRelu is not on the path')
+    need_x, need_x2, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+    need_bn = mode == MS_BN_TRAIN and ctx.needs_input_grad[4]
+    dy = dy.contiguous()
+    dev = dy.device
+    dyr = torch.empty_like(dy) if mode != MS_BARE else None
+    up2 = in_mode == MS_IN_UP2ADD
+    want_dx = need_x or (up2 and need_x2)
+    dx = torch.empty_like(x) if want_dx else None
+    dx2 = torch.empty_like(x2) if (want_dx and up2) else None
+    dw = torch.empty_like(w) if need_w else None
+    dbias = torch.empty(w.shape[0], dtype=torch.float32, device=dev) if (need_w and ctx.has_bias) else None
+    dgamma = torch.empty_like(gamma) if need_bn else None
+    dbeta = torch.empty_like(gamma) if need_bn else None
+    ws = workspace(d._bwd_ws, dev)
+    check(lib().ms_conv_block_bwd(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(gamma), None, None, _ptr(y_raw),
+                                  _ptr(y), _ptr(save), _ptr(dy), _ptr(dyr), _ptr(dx), _ptr(dx2), _ptr(dw), _ptr(dbias),
+                                  _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), _stream()), 'ms_conv_block_bwd')
+    return dx, dx2, dw, dbias, dgamma, dbeta, None, None, None, None
+
+
+def conv_block(x, w, bias, geom, mode, gamma=None, beta=None, running_mean=None, running_var=None, x2=None,
+               in_mode=MS_IN_PLAIN):
+  """One conv block of the path on the HIP kernels (see include/mixstage.h: ms_conv_block_fwd/bwd)."""
+  stats = (running_mean, running_var) if running_mean is not None else None
+  return _ConvBlockFn.apply(x, x2, w, bias, gamma, beta, geom, mode, in_mode, stats)
+
+
+# ------------------------------------------------------------------------------------------------
+class _LerpTimeFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x, t_out):
+    _need_hip(x)
+    x = x.contiguous()
+    B, C, Tin, F = x.shape
+    y = torch.empty((B, C, t_out), dtype=torch.float32, device=x.device)
+    check(lib().ms_lerp_time_fwd(_ptr(x), _ptr(y), B, C, Tin, F, t_out, _stream()), 'ms_lerp_time_fwd')
+    ctx.shape = (B, C, Tin, F, t_out)
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    B, C, Tin, F, t_out = ctx.shape
+    dy = dy.contiguous()
+    dx = torch.empty((B, C, Tin, F), dtype=torch.float32, device=dy.device)
+    check(lib().ms_lerp_time_bwd(_ptr(dy), _ptr(dx), B, C, Tin, F, t_out, _stream()), 'ms_lerp_time_bwd')
+    return dx, None
+
+
+def lerp_time(x, t_out):
+  """F.interpolate(x, size=(t_out, 1), mode='bilinear').squeeze(-1) (layers.py:197-198)."""
+  return _LerpTimeFn.apply(x, int(t_out))
+
+
+class _SoftmaxMixFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, z, score, P):
+    _need_hip(z, score)
+    z, score = z.contiguous(), score.contiguous()
+    B, M, T = score.shape
+    assert z.shape == (B, M * P, T), (z.shape, score.shape, P)
+    soft = torch.empty((B, T, M), dtype=torch.float32, device=z.device)
+    out = torch.empty((B, T, P), dtype=torch.float32, device=z.device)
+    check(lib().ms_softmax_mix_fwd(_ptr(z), _ptr(score), _ptr(soft), _ptr(out), B, M, P, T, _stream()),
+          'ms_softmax_mix_fwd')
+    ctx.save_for_backward(z, soft)
+    ctx.dims = (B, M, P, T)
+    ctx.mark_non_differentiable(soft)
+    return out, soft
+
+  @staticmethod
+  def backward(ctx, dout, _dsoft):
+    z, soft = ctx.saved_tensors
+    B, M, P, T = ctx.dims
+    dout = dout.contiguous()
+    dz = torch.empty_like(z)
+    dscore = torch.empty((B, M, T), dtype=torch.float32, device=z.device)
+    check(lib().ms_softmax_mix_bwd(_ptr(z), _ptr(soft), _ptr(dout), _ptr(dz), _ptr(dscore), B, M, P, T, _stream()),
+          'ms_softmax_mix_bwd')
+    return dz, dscore, None
+
+
+def softmax_mix(z, score, P):
+  """(out (B,T,P), softmax (B,T,M)) of JL:186-187,194 from channel-major z (B,M*P,T), score (B,M,T).
+  The returned softmax is a detached monitor (the reference's labels_cap_soft is only read by the
+  trainer for histograms); the gradient into `score` flows through `out`."""
+  return _SoftmaxMixFn.apply(z, score, int(P))
+
+
+class _CrossEntropyFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, score, target, layout, scale):
+    _need_hip(score, target)
+    score = score.contiguous()
+    target = target.contiguous()
+    if target.dtype != torch.int64:
+      raise TypeError('cross entropy targets must be int64')
+    if layout == 'bct':      # score (B, C, T), rows = (b, t)
+      B, C, T = score.shape
+      dims = (B, T, C, C * T, T, 1)
+    else:                    # score (N, C)
+      N, C = score.shape
+      dims = (N, 1, C, C, 1, 1)
+    assert target.numel() == dims[0] * dims[1]
+    loss = torch.empty((), dtype=torch.float32, device=score.device)
+    check(lib().ms_cross_entropy_fwd(_ptr(score), _ptr(target), _ptr(loss), None, *dims, _stream()),
+          'ms_cross_entropy_fwd')
+    ctx.save_for_backward(score, target)
+    ctx.dims, ctx.scale = dims, scale
+    return loss * scale if scale != 1.0 else loss
+
+  @staticmethod
+  def backward(ctx, g):
+    score, target = ctx.saved_tensors
+    g = (g * ctx.scale if ctx.scale != 1.0 else g).contiguous()
+    dscore = torch.empty_like(score)
+    check(lib().ms_cross_entropy_bwd(_ptr(score), _ptr(target), _ptr(g), _ptr(dscore), *ctx.dims, 0, _stream()),
+          'ms_cross_entropy_bwd')
+    return dscore, None, None, None
+
+
+def cross_entropy(score, target, layout='nc', scale=1.0):
+  """scale * F.cross_entropy(...) with mean reduction; layout 'bct' = class axis 1 of (B,C,T)."""
+  return _CrossEntropyFn.apply(score, target, layout, float(scale))
+
+
+class _VelocityFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x):
+    _need_hip(x)
+    x = x.contiguous()
+    B, T, P = x.shape
+    v = torch.empty((B, P, T), dtype=torch.float32, device=x.device)
+    check(lib().ms_velocity_fwd(_ptr(x), _ptr(v), B, T, P, _stream()), 'ms_velocity_fwd')
+    ctx.dims = (B, T, P)
+    return v
+
+  @staticmethod
+  def backward(ctx, dv):
+    B, T, P = ctx.dims
+    dv = dv.contiguous()
+    dx = torch.empty((B, T, P), dtype=torch.float32, device=dv.device)
+    check(lib().ms_velocity_bwd(_ptr(dv), _ptr(dx), B, T, P, _stream()), 'ms_velocity_bwd')
+    return dx
+
+
+def velocity_cm(x):
+  """GAN.get_velocity (gan.py:47-52) of x (B,T,P), returned channel-major (B,P,T) for D's first conv."""
+  return _VelocityFn.apply(x)
+
+
+class _TransposeFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x, to_cm):
+    _need_hip(x)
+    x = x.contiguous()
+    B, R, C = x.shape
+    y = torch.empty((B, C, R), dtype=torch.float32, device=x.device)
+    fn = lib().ms_transpose_btc if to_cm else lib().ms_transpose_bct
+    check(fn(_ptr(x), _ptr(y), B, R, C, _stream()), 'ms_transpose')
+    ctx.to_cm = to_cm
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    return _TransposeFn.apply(dy, not ctx.to_cm), None
+
+
+def to_channel_major(x):
+  """(B,T,C) -> contiguous (B,C,T)."""
+  return _TransposeFn.apply(x, True)
+
+
+def to_time_major(x):
+  """(B,C,T) -> contiguous (B,T,C)."""
+  return _TransposeFn.apply(x, False)
+
+
+class _L1MeanFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, a, b, target, scale):
+    _need_hip(a, b)
+    a = a.contiguous()
+    b = b.contiguous() if b is not None else None
+    n = a.numel()
+    loss = torch.empty((), dtype=torch.float32, device=a.device)
+    part = torch.empty(lib().ms_reduce_partials_count(n), dtype=torch.float32, device=a.device)
+    check(lib().ms_l1_mean_fwd(_ptr(a), _ptr(b), target, _ptr(loss), _ptr(part), n, _stream()), 'ms_l1_mean_fwd')
+    ctx.save_for_backward(a, b)
+    ctx.target, ctx.scale = target, scale
+    return loss * scale if scale != 1.0 else loss
+
+  @staticmethod
+  def backward(ctx, g):
+    a, b = ctx.saved_tensors
+    g = (g * ctx.scale if ctx.scale != 1.0 else g).contiguous()
+    da = torch.empty_like(a)
+    check(lib().ms_l1_mean_bwd(_ptr(a), _ptr(b), ctx.target, _ptr(g), _ptr(da), a.numel(), _stream()),
+          'ms_l1_mean_bwd')
+    return da, None, None, None
+
+
+def l1_mean(a, b=None, target=0.0, scale=1.0):
+  """scale * mean|a - b| (b a tensor without grad, or the constant `target`): gan.py:64-75 with L1Loss."""
+  return _L1MeanFn.apply(a, b, float(target), float(scale))
+
+
+# ------------------------------------------------------------------------------------------------
+def grad_norm(flat_grad, out, partials):
+  check(lib().ms_sqnorm(_ptr(flat_grad), flat_grad.numel(), _ptr(out), _ptr(partials), _stream()), 'ms_sqnorm')
+
+
+def adam_step(p, g, m, v, norm, max_norm, lr, beta1, beta2, eps, step_state):
+  check(lib().ms_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(norm), max_norm, lr, beta1, beta2,
+                           eps, _ptr(step_state), _stream()), 'ms_adam_step')
+
+
+def selftest_mfma(A, B):
+  _need_hip(A, B)
+  K = A.shape[1]
+  C = torch.empty((32, 32), dtype=torch.float32, device=A.device)
+  check(lib().ms_selftest_mfma(_ptr(A.contiguous()), _ptr(B.contiguous()), _ptr(C), K, _stream()), 'ms_selftest_mfma')
+  return C

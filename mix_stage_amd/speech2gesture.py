@@ -1,0 +1,44 @@
+"""Speech2Gesture_D -- the 1-D PatchGAN pose discriminator (reference: src/model/speech2gesture.py:41-74)
+on the HIP kernels.  Same constructor, forward(x) -> (scores, []), attribute names and state_dict keys."""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .layers import ConvNormRelu, bare_conv
+
+
+class Speech2Gesture_D(nn.Module):
+  '''
+  input_shape:  (N, time, pose_feats)
+  output_shape: (N, *, 1) ## discriminator scores
+  '''
+
+  def __init__(self, in_channels=104, out_channels=64, n_downsampling=2, p=0, groups=1, **kwargs):
+    super(Speech2Gesture_D, self).__init__()
+    self.conv1 = nn.Sequential(torch.nn.Conv1d(in_channels * groups, out_channels * groups, 4, 2, padding=1,
+                                               groups=groups),
+                               torch.nn.LeakyReLU(negative_slope=0.2))
+    self.conv2 = nn.ModuleList([])
+    for n in range(1, n_downsampling):
+      ch_mul = min(2 ** n, 8)
+      self.conv2.append(ConvNormRelu(out_channels, out_channels * ch_mul, type='1d', downsample=True, leaky=True,
+                                     p=p, groups=groups))
+    self.conv2 = nn.Sequential(*self.conv2)
+    ch_mul_new = min(2 ** n_downsampling, 8)
+    self.conv3 = ConvNormRelu(out_channels * ch_mul, out_channels * ch_mul_new, type='1d', leaky=True, kernel_size=4,
+                              stride=1, p=p, groups=groups)
+    out_shape = 1 if 'out_shape' not in kwargs else kwargs['out_shape']
+    self.logits = nn.Conv1d(out_channels * ch_mul_new * groups, out_shape * groups, kernel_size=4, stride=1,
+                            groups=groups)
+
+  def forward_channel_major(self, x):
+    """x: (N, pose_feats, time), e.g. straight from ops.velocity_cm (skips the transpose of S2G:67)."""
+    x = bare_conv(self.conv1[0], x, lrelu_slope=self.conv1[1].negative_slope)
+    for m in self.conv2:
+      x = m(x)
+    x = self.conv3(x)
+    x = bare_conv(self.logits, x)
+    return x.transpose(-1, -2).squeeze(dim=-1), []
+
+  def forward(self, x):
+    return self.forward_channel_major(ops.to_channel_major(x))

@@ -1,0 +1,253 @@
+"""GPU parity of every C-ABI entry point against the CPU oracle (fp64 truth), op by op.
+
+Tolerances (fp32 kernels, exact-fp32 MFMA): forward <= 2e-5, gradients <= 1e-4, relative to the tensor's
+max-abs; index/argmax outputs bit-exact."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import mixstage_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda:0'
+
+
+def rel_err(a, b):
+  a, b = a.detach().double().cpu(), b.detach().double().cpu()
+  assert a.shape == b.shape, (a.shape, b.shape)
+  return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def test_library_loads_on_gpu_box():
+  from mix_stage_amd import _lib
+  assert _lib.lib().ms_abi_version() == 1
+  assert torch.cuda.is_available()
+
+
+def test_mfma_fragment_maps():
+  from mix_stage_amd import ops
+  g = torch.Generator().manual_seed(0)
+  for K in (2, 6, 64):
+    A = torch.randn(32, K, generator=g)
+    B = torch.randn(K, 32, generator=g)        # asymmetric operands
+    C = ops.selftest_mfma(A.to(DEV), B.to(DEV))
+    assert rel_err(C, A.double() @ B.double()) < 1e-6
+
+
+# (name, type, cin, cout, kernel, stride, groups, input spatial, in_mode)
+BLOCK_CASES = [
+    ('dec0_bcast', '1d', 266, 256, None, None, 8, (64,), 'bcast'),
+    ('dec1', '1d', 256, 256, None, None, 8, (64,), 'plain'),
+    ('unet_pre', '1d', 256, 256, None, None, 1, (64,), 'plain'),
+    ('unet_down64', '1d', 256, 256, 4, 2, 1, (64,), 'plain'),
+    ('unet_down4', '1d', 256, 256, 4, 2, 1, (4,), 'plain'),
+    ('unet_down2', '1d', 256, 256, 4, 2, 1, (2,), 'plain'),
+    ('unet_up2', '1d', 256, 256, None, None, 1, (2,), 'up2'),
+    ('unet_up64', '1d', 256, 256, None, None, 1, (64,), 'up2'),
+    ('pse0', '1d', 104, 64, None, None, 1, (64,), 'plain'),
+    ('pse2', '1d', 64, 128, 4, 2, 1, (32,), 'plain'),
+    ('pse6', '1d', 256, 8, 4, 2, 1, (2,), 'plain'),
+    ('cls0', '1d', 266, 256, None, None, 1, (64,), 'plain'),
+    ('d_conv3', '1d', 128, 256, 4, 1, 1, (16,), 'plain'),
+    ('ragged_g3', '1d', 7, 5, 3, 1, 3, (37,), 'plain'),
+    ('ragged_bcast', '1d', 10, 33, 3, 1, 3, (19,), 'bcast'),
+    ('ae0', '2d', 1, 64, None, None, 1, (64, 128), 'plain'),
+    ('ae1', '2d', 64, 64, 4, 2, 1, (32, 48), 'plain'),
+    ('ae2', '2d', 64, 128, None, None, 1, (16, 24), 'plain'),
+    ('ae5', '2d', 256, 256, 4, 2, 1, (16, 32), 'plain'),
+    ('ae7', '2d', 256, 256, (3, 8), 1, 1, (8, 16), 'plain'),
+    ('ragged2d', '2d', 3, 6, (3, 8), 1, 1, (5, 11), 'plain'),
+]
+
+
+def _mk_block(mod, case, seed=0):
+  name, typ, cin, cout, k, s, g, sp, in_mode = case
+  ds = (k is None and s is None and False)
+  kw = dict(type=typ, leaky=True, groups=g)
+  if k is not None:
+    kw.update(kernel_size=k, stride=s)
+  blk = mod.ConvNormRelu(cin, cout, **kw)
+  sd = O.deterministic_state({('blk%d.' % seed) + kk: v for kk, v in blk.state_dict().items()})
+  blk.load_state_dict({kk.split('.', 1)[1]: v for kk, v in sd.items()})
+  return blk
+
+
+@pytest.mark.parametrize('case', BLOCK_CASES, ids=[c[0] for c in BLOCK_CASES])
+@pytest.mark.parametrize('B', [3])
+def test_conv_block_train_fwd_bwd(case, B):
+  import mix_stage_amd as A
+  name, typ, cin, cout, k, s, g, sp, in_mode = case
+  gen = torch.Generator().manual_seed(hash(name) % 1000)
+  ref = _mk_block(O, case).double().train()
+  hip = _mk_block(A, case).to(DEV).train()
+  if in_mode == 'bcast':
+    x = torch.randn(B, cin, *sp, generator=gen)
+    xr = torch.cat([x] * g, dim=1)
+  elif in_mode == 'up2':
+    a = torch.randn(B, cin * g, sp[0] // 2, generator=gen)
+    r = torch.randn(B, cin * g, sp[0], generator=gen)
+  else:
+    x = torch.randn(B, cin * g, *sp, generator=gen)
+    xr = x
+
+  if in_mode == 'up2':
+    a64, r64 = a.double().requires_grad_(), r.double().requires_grad_()
+    y_ref = ref(F.interpolate(a64, scale_factor=2, mode='nearest') + r64)
+    ah, rh = a.to(DEV).requires_grad_(), r.to(DEV).requires_grad_()
+    y = hip.forward_upsample_add(ah, rh)
+  else:
+    x64 = x.double().requires_grad_()
+    y_ref = ref(torch.cat([x64] * g, dim=1) if in_mode == 'bcast' else x64)
+    xh = x.to(DEV).requires_grad_()
+    y = hip.forward_broadcast(xh) if in_mode == 'bcast' else hip(xh)
+  assert rel_err(y, y_ref) < 2e-5, 'forward'
+  gy = torch.randn(y_ref.shape, generator=gen)
+  y_ref.backward(gy.double())
+  y.backward(gy.to(DEV))
+  if in_mode == 'up2':
+    assert rel_err(ah.grad, a64.grad) < 1e-4, 'd(a)'
+    assert rel_err(rh.grad, r64.grad) < 1e-4, 'd(residual)'
+  else:
+    assert rel_err(xh.grad, x64.grad) < 1e-4, 'dx'
+  assert rel_err(hip.conv.weight.grad, ref.conv.weight.grad) < 1e-4, 'dw'
+  assert rel_err(hip.norm.weight.grad, ref.norm.weight.grad) < 1e-4, 'dgamma'
+  assert rel_err(hip.norm.bias.grad, ref.norm.bias.grad) < 1e-4, 'dbeta'
+  # conv bias before BN: the true gradient is 0; both sides hold rounding noise
+  scale = ref.conv.weight.grad.abs().max().item()
+  assert hip.conv.bias.grad.abs().max().item() < 1e-4 * max(scale, 1.0)
+  assert rel_err(hip.norm.running_mean, ref.norm.running_mean) < 1e-5
+  assert rel_err(hip.norm.running_var, ref.norm.running_var) < 1e-5
+  assert int(hip.state_dict()['norm.num_batches_tracked']) == 1
+
+
+@pytest.mark.parametrize('case', [BLOCK_CASES[1], BLOCK_CASES[3], BLOCK_CASES[16], BLOCK_CASES[19]],
+                         ids=lambda c: c[0])
+def test_conv_block_eval_mode(case):
+  import mix_stage_amd as A
+  name, typ, cin, cout, k, s, g, sp, in_mode = case
+  gen = torch.Generator().manual_seed(5)
+  ref = _mk_block(O, case).double().eval()
+  hip = _mk_block(A, case).to(DEV).eval()
+  x = torch.randn(2, cin * g, *sp, generator=gen)
+  with torch.no_grad():
+    y = hip(x.to(DEV))
+    y_ref = ref(x.double())
+  assert rel_err(y, y_ref) < 2e-5
+  assert rel_err(hip.norm.running_mean, ref.norm.running_mean) == 0.0     # untouched
+
+
+@pytest.mark.parametrize('cin,cout,k,s,p,g,T,lrelu', [(256, 104, 1, 1, 0, 8, 64, None), (256, 8, 1, 1, 0, 1, 64, None),
+                                                      (104, 64, 4, 2, 1, 1, 64, 0.2), (256, 1, 4, 1, 0, 1, 15, None),
+                                                      (6, 5, 3, 2, 1, 2, 21, 0.2)])
+def test_bare_conv_fwd_bwd(cin, cout, k, s, p, g, T, lrelu):
+  from mix_stage_amd.layers import bare_conv
+  gen = torch.Generator().manual_seed(cin + cout)
+  conv = torch.nn.Conv1d(cin * g, cout * g, k, s, padding=p, groups=g)
+  sd = O.deterministic_state({'c.' + kk: v for kk, v in conv.state_dict().items()})
+  conv.load_state_dict({kk[2:]: v for kk, v in sd.items()})
+  import copy
+  ref = copy.deepcopy(conv).double()
+  hip = conv.to(DEV)
+  x = torch.randn(3, cin * g, T, generator=gen)
+  x64 = x.double().requires_grad_()
+  y_ref = ref(x64)
+  if lrelu is not None:
+    y_ref = F.leaky_relu(y_ref, lrelu)
+  xh = x.to(DEV).requires_grad_()
+  y = bare_conv(hip, xh, lrelu_slope=lrelu)
+  assert rel_err(y, y_ref) < 2e-5
+  gy = torch.randn(y_ref.shape, generator=gen)
+  y_ref.backward(gy.double()); y.backward(gy.to(DEV))
+  assert rel_err(xh.grad, x64.grad) < 1e-4
+  assert rel_err(hip.weight.grad, ref.weight.grad) < 1e-4
+  assert rel_err(hip.bias.grad, ref.bias.grad) < 1e-4
+
+
+@pytest.mark.parametrize('Tin,F_,Tout', [(8, 15, 64), (8, 7, 64), (8, 16, 64), (32, 15, 256), (5, 3, 7)])
+def test_lerp_time(Tin, F_, Tout):
+  from mix_stage_amd import ops
+  gen = torch.Generator().manual_seed(1)
+  x = torch.randn(2, 5, Tin, F_, generator=gen)
+  x64 = x.double().requires_grad_()
+  y_ref = F.interpolate(x64, size=(Tout, 1), mode='bilinear').squeeze(-1)
+  xh = x.to(DEV).requires_grad_()
+  y = ops.lerp_time(xh, Tout)
+  assert rel_err(y, y_ref) < 1e-6
+  gy = torch.randn(y_ref.shape, generator=gen)
+  y_ref.backward(gy.double()); y.backward(gy.to(DEV))
+  assert rel_err(xh.grad, x64.grad) < 1e-6
+
+
+@pytest.mark.parametrize('B,M,P,T', [(3, 8, 104, 64), (2, 1, 104, 64), (2, 25, 104, 96), (1, 4, 7, 33)])
+def test_softmax_mix(B, M, P, T):
+  from mix_stage_amd import ops
+  gen = torch.Generator().manual_seed(2)
+  z = torch.randn(B, M * P, T, generator=gen)
+  sc = torch.randn(B, M, T, generator=gen) * 2
+  z64, s64 = z.double().requires_grad_(), sc.double().requires_grad_()
+  soft_ref = torch.softmax(s64.transpose(2, 1), dim=-1)
+  out_ref = O.mix_outputs(z64, soft_ref, M)
+  zh, sh = z.to(DEV).requires_grad_(), sc.to(DEV).requires_grad_()
+  out, soft = ops.softmax_mix(zh, sh, P)
+  assert rel_err(out, out_ref) < 1e-5 and rel_err(soft, soft_ref) < 1e-5
+  gy = torch.randn(out_ref.shape, generator=gen)
+  out_ref.backward(gy.double()); out.backward(gy.to(DEV))
+  assert rel_err(zh.grad, z64.grad) < 1e-5
+  assert rel_err(sh.grad, s64.grad) < 1e-5
+
+
+def test_cross_entropy_both_layouts():
+  from mix_stage_amd import ops
+  gen = torch.Generator().manual_seed(3)
+  sc = torch.randn(4, 8, 64, generator=gen) * 3
+  tg = torch.randint(0, 8, (4, 64), generator=gen)
+  s64 = sc.double().requires_grad_()
+  l_ref = F.cross_entropy(s64.transpose(2, 1).reshape(-1, 8), tg.reshape(-1))
+  sh = sc.to(DEV).requires_grad_()
+  l = ops.cross_entropy(sh, tg.to(DEV), layout='bct')
+  assert abs(l.item() - l_ref.item()) < 1e-5
+  (l_ref * 0.7).backward(); (l * 0.7).backward()
+  assert rel_err(sh.grad, s64.grad) < 1e-5
+  sc2 = torch.randn(5, 3, generator=gen)
+  tg2 = torch.randint(0, 3, (5,), generator=gen)
+  s64 = sc2.double().requires_grad_()
+  l_ref = 0.1 * F.cross_entropy(s64, tg2)
+  sh = sc2.to(DEV).requires_grad_()
+  l = ops.cross_entropy(sh, tg2.to(DEV), scale=0.1)
+  assert abs(l.item() - l_ref.item()) < 1e-6
+  l_ref.backward(); l.backward()
+  assert rel_err(sh.grad, s64.grad) < 1e-5
+
+
+@pytest.mark.parametrize('B,T,P', [(3, 64, 104), (2, 33, 7)])
+def test_velocity_transposes_l1(B, T, P):
+  from mix_stage_amd import ops
+  gen = torch.Generator().manual_seed(4)
+  x = torch.randn(B, T, P, generator=gen)
+  x64 = x.double().requires_grad_()
+  v_ref = torch.cat([torch.zeros_like(x64[:, 0:1]), x64[:, 1:] - x64[:, :-1]], dim=1).transpose(1, 2)
+  xh = x.to(DEV).requires_grad_()
+  v = ops.velocity_cm(xh)
+  assert rel_err(v, v_ref) < 1e-6
+  gy = torch.randn(v_ref.shape, generator=gen)
+  v_ref.backward(gy.double()); v.backward(gy.to(DEV))
+  assert rel_err(xh.grad, x64.grad) < 1e-6
+  assert torch.equal(ops.to_channel_major(x.to(DEV)).cpu(), x.transpose(1, 2).contiguous())
+  assert torch.equal(ops.to_time_major(ops.to_channel_major(x.to(DEV))).cpu(), x)
+  y = torch.randn(B, T, P, generator=gen)
+  xh = x.to(DEV).requires_grad_(); x64 = x.double().requires_grad_()
+  l = ops.l1_mean(xh, y.to(DEV), scale=2.0); l_ref = 2.0 * (x64 - y.double()).abs().mean()
+  assert abs(l.item() - l_ref.item()) < 1e-6
+  l.backward(); l_ref.backward()
+  assert rel_err(xh.grad, x64.grad) < 1e-6
+  l = ops.l1_mean(x.to(DEV), target=1.0)
+  assert abs(l.item() - (x.double() - 1).abs().mean().item()) < 1e-6
+
+
+def test_cpu_tensor_fails_loudly():
+  from mix_stage_amd import ops, _lib
+  with pytest.raises(_lib.MixStageLibError):
+    ops.velocity_cm(torch.zeros(1, 4, 3))
+  with pytest.raises(TypeError):
+    ops.velocity_cm(torch.zeros(1, 4, 3, dtype=torch.float64, device=DEV))
