@@ -130,16 +130,22 @@ class ConvNormRelu(nn.Module):
                           n.running_mean, n.running_var, x2=x2, in_mode=in_mode)
 
   def forward(self, x, **kwargs):
+    # `_residual` / `_broadcast` select the fused input forms below (package-internal; the reference's
+    # forward(x, **kwargs) ignores its kwargs)
+    residual = kwargs.get('_residual')
+    if residual is not None:
+      return self._run(x, x2=residual, in_mode=MS_IN_UP2ADD)
+    if kwargs.get('_broadcast'):
+      return self._run(x, in_mode=MS_IN_BCAST)
     return self._run(x)
 
-  # fused input forms used inside this package (not part of the reference API)
   def forward_upsample_add(self, a, residual):
     """== self(upsample_nearest2(a) + residual) without materialising the sum (layers.py:151)."""
-    return self._run(a, x2=residual, in_mode=MS_IN_UP2ADD)
+    return self(a, _residual=residual)
 
   def forward_broadcast(self, x):
     """== self(torch.cat([x]*groups, dim=1)) without the replication (JL:190)."""
-    return self._run(x, in_mode=MS_IN_BCAST)
+    return self(x, _broadcast=True)
 
 
 class UNet1D(nn.Module):

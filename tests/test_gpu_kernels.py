@@ -2,6 +2,8 @@
 
 Tolerances (fp32 kernels, exact-fp32 MFMA): forward <= 2e-5, gradients <= 1e-4, relative to the tensor's
 max-abs; index/argmax outputs bit-exact."""
+import zlib
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -78,7 +80,18 @@ def _mk_block(mod, case, seed=0):
 def test_conv_block_train_fwd_bwd(case, B):
   import mix_stage_amd as A
   name, typ, cin, cout, k, s, g, sp, in_mode = case
-  gen = torch.Generator().manual_seed(hash(name) % 1000)
+  # deterministic inputs.  (LeakyReLU is discontinuous in its derivative: a pre-activation within fp32 rounding of
+  # 0 may take the other slope than in the fp64 oracle; such a draw is detected on the outputs and re-drawn.)
+  for attempt in range(4):
+    if _conv_block_case(case, B, zlib.crc32(name.encode()) % 1000 + attempt):
+      return
+  raise AssertionError('no draw without a sign flip at a LeakyReLU kink')
+
+
+def _conv_block_case(case, B, seed):
+  import mix_stage_amd as A
+  name, typ, cin, cout, k, s, g, sp, in_mode = case
+  gen = torch.Generator().manual_seed(seed)
   ref = _mk_block(O, case).double().train()
   hip = _mk_block(A, case).to(DEV).train()
   if in_mode == 'bcast':
@@ -101,24 +114,30 @@ def test_conv_block_train_fwd_bwd(case, B):
     y_ref = ref(torch.cat([x64] * g, dim=1) if in_mode == 'bcast' else x64)
     xh = x.to(DEV).requires_grad_()
     y = hip.forward_broadcast(xh) if in_mode == 'bcast' else hip(xh)
-  assert rel_err(y, y_ref) < 2e-5, 'forward'
+  errs = {'fwd': (rel_err(y, y_ref), 2e-5)}
+  if ((y.detach().cpu() > 0) != (y_ref.detach() > 0)).any():
+    assert errs['fwd'][0] < errs['fwd'][1]
+    return False
   gy = torch.randn(y_ref.shape, generator=gen)
   y_ref.backward(gy.double())
   y.backward(gy.to(DEV))
   if in_mode == 'up2':
-    assert rel_err(ah.grad, a64.grad) < 1e-4, 'd(a)'
-    assert rel_err(rh.grad, r64.grad) < 1e-4, 'd(residual)'
+    errs['d(a)'] = (rel_err(ah.grad, a64.grad), 1e-4)
+    errs['d(res)'] = (rel_err(rh.grad, r64.grad), 1e-4)
   else:
-    assert rel_err(xh.grad, x64.grad) < 1e-4, 'dx'
-  assert rel_err(hip.conv.weight.grad, ref.conv.weight.grad) < 1e-4, 'dw'
-  assert rel_err(hip.norm.weight.grad, ref.norm.weight.grad) < 1e-4, 'dgamma'
-  assert rel_err(hip.norm.bias.grad, ref.norm.bias.grad) < 1e-4, 'dbeta'
+    errs['dx'] = (rel_err(xh.grad, x64.grad), 1e-4)
+  errs['dw'] = (rel_err(hip.conv.weight.grad, ref.conv.weight.grad), 1e-4)
+  errs['dgamma'] = (rel_err(hip.norm.weight.grad, ref.norm.weight.grad), 1e-4)
+  errs['dbeta'] = (rel_err(hip.norm.bias.grad, ref.norm.bias.grad), 1e-4)
   # conv bias before BN: the true gradient is 0; both sides hold rounding noise
   scale = ref.conv.weight.grad.abs().max().item()
-  assert hip.conv.bias.grad.abs().max().item() < 1e-4 * max(scale, 1.0)
-  assert rel_err(hip.norm.running_mean, ref.norm.running_mean) < 1e-5
-  assert rel_err(hip.norm.running_var, ref.norm.running_var) < 1e-5
+  errs['dbias(~0)'] = (hip.conv.bias.grad.abs().max().item(), 1e-4 * max(scale, 1.0))
+  errs['running_mean'] = (rel_err(hip.norm.running_mean, ref.norm.running_mean), 1e-5)
+  errs['running_var'] = (rel_err(hip.norm.running_var, ref.norm.running_var), 1e-5)
+  bad = {k: v for k, v in errs.items() if not v[0] < v[1]}
+  assert not bad, 'errors (value, bar): %s | all: %s' % (bad, {k: '%.2e' % v[0] for k, v in errs.items()})
   assert int(hip.state_dict()['norm.num_batches_tracked']) == 1
+  return True
 
 
 @pytest.mark.parametrize('case', [BLOCK_CASES[1], BLOCK_CASES[3], BLOCK_CASES[16], BLOCK_CASES[19]],
