@@ -1,0 +1,238 @@
+"""The trainer-step contract of the reference, MI355X-native.
+
+One step == what src/model/trainer.py does per batch (TrainerLateClusterStyleGAN):
+  zero_grad (TR:604,1104-1107) -> model(x, y, **kwargs) (TR:1158-1165) -> loss = sum(internal_losses)
+  (TR:1268-1285) -> loss.backward(); clip_grad_norm_(G or D params, 1); G_optim|D_optim.step() by
+  model.G_flag (TR:1138-1146), with torch.optim.Adam(lr=1e-4) per network (TR:262-287, ARGS:180-183).
+
+MI355X-first structure:
+  * parameters, gradients and Adam moments of each network live in ONE flat fp32 HBM buffer each
+    (FlatAdam): zero_grad is one memset, the global grad-norm one reduction, clip + Adam one kernel,
+    and the data-parallel exchange one RCCL all-reduce over the flat gradient buffer;
+  * the whole step (about 600 kernel launches) is captured into a HIP graph per step kind (G / D);
+    with world_size > 1 the graph is split around the (eager) all-reduce;
+  * one process per GPU, pure data parallel over clips; BatchNorm statistics are per rank
+    (bn_sync='local'); host-side random decisions come from identically seeded CPU generators so all
+    ranks take the same D-vs-G branch (gan.py:105) and curriculum branch (JL:127).
+"""
+import torch
+import torch.distributed as dist
+
+from . import layers, ops
+
+_ALIGN = 64  # elements: every parameter starts 256-B aligned inside the flat buffer
+
+
+class FlatAdam:
+  """torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8) + clip_grad_norm_(params, max_norm) over flat buffers."""
+
+  def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0):
+    self.params = [p for p in params if p.requires_grad]
+    if not self.params:
+      raise ValueError('no trainable parameters')
+    dev = self.params[0].device
+    if dev.type != 'cuda':
+      raise RuntimeError('FlatAdam runs on the MI355X only (parameters are on %s)' % dev)
+    offs, total = [], 0
+    for p in self.params:
+      offs.append(total)
+      total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+    self.offsets, self.total = offs, total
+    self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+    self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+    self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+    self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+    self._grad_views = []
+    with torch.no_grad():
+      for p, o in zip(self.params, offs):
+        if p.dtype != torch.float32:
+          raise TypeError('FlatAdam: float32 parameters only')
+        view = self.flat_p[o:o + p.numel()].view_as(p)
+        view.copy_(p)
+        p.data = view
+        g = self.flat_g[o:o + p.numel()].view_as(p)
+        p.grad = g
+        self._grad_views.append(g)
+    self.lr, self.betas, self.eps, self.max_norm = lr, betas, eps, max_norm
+    self.norm = torch.zeros(1, dtype=torch.float32, device=dev)
+    self.partials = torch.zeros(ops.lib().ms_reduce_partials_count(total), dtype=torch.float32, device=dev)
+    self.step_state = torch.zeros(4, dtype=torch.int32, device=dev)
+
+  def zero_grad(self):
+    self.flat_g.zero_()
+
+  def gather_foreign_grads(self):
+    """If someone replaced p.grad (e.g. model.zero_grad(set_to_none=True) then backward), fold it back."""
+    with torch.no_grad():
+      for p, g in zip(self.params, self._grad_views):
+        if p.grad is None:
+          g.zero_()
+          p.grad = g
+        elif p.grad is not g:
+          g.copy_(p.grad)
+          p.grad = g
+
+  def clip_and_step(self):
+    """total_norm = ||g||_2 over all parameters; g *= min(1, max_norm/(norm+1e-6)); Adam update."""
+    ops.grad_norm(self.flat_g, self.norm, self.partials)
+    ops.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.norm, self.max_norm, self.lr,
+                  self.betas[0], self.betas[1], self.eps, self.step_state)
+
+  @property
+  def step_count(self):
+    return int(self.step_state[0])
+
+
+class MixStageTrainStep:
+  """Runs reference-equivalent training steps for GAN(G, D) on one GPU or data-parallel over ranks."""
+
+  def __init__(self, model, lr=1e-4, clip=1.0, use_graphs=True, process_group=None, time_steps=64):
+    self.model = model
+    self.optim_G = FlatAdam(model.G.parameters(), lr=lr, max_norm=clip)
+    self.optim_D = FlatAdam(model.D.parameters(), lr=lr, max_norm=clip)
+    self.use_graphs = use_graphs
+    self.time_steps = time_steps
+    self.pg = process_group
+    self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+    self._graphs = {}
+    self._static = None
+    self.losses = None       # list of 0-dim device tensors of the last step (reference order)
+    self.fake_pose = None
+
+  # ---- the eager pieces ------------------------------------------------------------------------------------
+  def _kwargs(self, style):
+    return dict(input_modalities=self.model.input_modalities, desc='train', sample_flag=0, description='train',
+                style=style, time_steps=self.time_steps)
+
+  def _forward_backward(self, audio, labels, pose, style):
+    m = self.model
+    self.optim_G.zero_grad()
+    self.optim_D.zero_grad()
+    fake, losses, _ = m([audio, labels], pose, **self._kwargs(style))
+    dev_losses = [l for l in losses if l.is_cuda and l.requires_grad]
+    torch.autograd.backward(dev_losses, [torch.ones_like(l) for l in dev_losses])   # == sum(losses).backward()
+    return fake, losses
+
+  def _all_reduce(self, opt):
+    if self.world > 1:
+      if dist.get_backend(self.pg) == 'nccl':
+        dist.all_reduce(opt.flat_g, op=dist.ReduceOp.AVG, group=self.pg)
+      else:
+        dist.all_reduce(opt.flat_g, op=dist.ReduceOp.SUM, group=self.pg)
+        opt.flat_g.mul_(1.0 / self.world)
+
+  def _peek_decisions(self):
+    """What gan.py:105 and JL:127 will draw, without consuming the host generator."""
+    m = self.model
+    state = torch.get_rng_state()
+    r_gan, r_branch = torch.rand(1).item(), torch.rand(1).item()
+    torch.set_rng_state(state)
+    kind = 'D' if r_gan < m.D_prob else 'G'
+    th = m.G.thresh
+    thresh_now = (th.value if th.iters < th.num_iters else th.end) if kind == 'G' else th.value
+    pose_branch = kind == 'G' and r_branch > thresh_now
+    return kind, pose_branch
+
+  def _consume_decisions(self, kind):
+    torch.rand(1)
+    torch.rand(1)
+    self.model.G.thresh.step(kind == 'G')
+    self.model.G_flag = kind == 'G'
+    self.model.fake_flag = True
+
+  # ---- public ----------------------------------------------------------------------------------------------
+  def step(self, audio, labels, pose, style, kind=None):
+    """One training step.  kind=None follows the reference's coin flip (host generator); 'G'/'D' pins it.
+    Returns the step kind.  self.losses / self.fake_pose hold device tensors (no host sync here)."""
+    m = self.model
+    m.train()
+    if kind is not None:
+      saved = m.D_prob
+      m.D_prob = 1.1 if kind == 'D' else -1.0
+    try:
+      k, pose_branch = self._peek_decisions()
+      if not self.use_graphs:
+        self.fake_pose, self.losses = self._forward_backward(audio, labels, pose, style)
+        opt = self.optim_G if m.G_flag else self.optim_D
+        self._all_reduce(opt)
+        opt.clip_and_step()
+      else:
+        self._graph_step(k, pose_branch, audio, labels, pose, style)
+    finally:
+      if kind is not None:
+        m.D_prob = saved
+    return k
+
+  def _graph_step(self, k, pose_branch, audio, labels, pose, style):
+    key = (k, pose_branch, tuple(audio.shape), tuple(pose.shape))
+    if self._static is None or self._static['key_shapes'] != key[2:]:
+      self._static = dict(key_shapes=key[2:], audio=audio.clone(), labels=labels.clone(), pose=pose.clone(),
+                          style=style.clone())
+      self._graphs = {}
+    st = self._static
+    for name, src in (('audio', audio), ('labels', labels), ('pose', pose), ('style', style)):
+      if src.data_ptr() != st[name].data_ptr():
+        st[name].copy_(src, non_blocking=True)
+    entry = self._graphs.get(key)
+    opt = self.optim_G if k == 'G' else self.optim_D
+    if entry is None:
+      entry = self._capture(key, k, st, opt)       # capture executes nothing: replay below does the step
+    else:
+      self._consume_decisions(k)
+    for mod in entry['bn_tape']:
+      mod._pending_batches += 1
+    entry['fwd_bwd'].replay()
+    if self.world > 1:
+      self._all_reduce(opt)
+      entry['opt'].replay()
+    self.fake_pose, self.losses = entry['fake'], entry['losses']
+
+  def _capture(self, key, k, st, opt):
+    m = self.model
+    rng = torch.get_rng_state()
+    thresh = (m.G.thresh.value, m.G.thresh.iters)
+    bn_state = {n: b.clone() for n, b in m.named_buffers()}
+    # one eager pass on a side stream sizes the workspace and warms the allocator, then undo its side effects
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    warm_tape = []
+    layers.set_train_tape(warm_tape)
+    try:
+      with torch.cuda.stream(side):
+        self._forward_backward(st['audio'], st['labels'], st['pose'], st['style'])
+    finally:
+      layers.set_train_tape(None)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+      for n, b in m.named_buffers():
+        b.copy_(bn_state[n])
+    for mod in warm_tape:
+      mod._pending_batches -= 1
+    torch.set_rng_state(rng)
+    m.G.thresh.value, m.G.thresh.iters = thresh
+    tape = []
+    layers.set_train_tape(tape)
+    g1 = torch.cuda.CUDAGraph()
+    try:
+      with torch.cuda.graph(g1):
+        fake, losses = self._forward_backward(st['audio'], st['labels'], st['pose'], st['style'])
+        if self.world == 1:
+          opt.clip_and_step()
+    finally:
+      layers.set_train_tape(None)
+    for mod in tape:                      # the capture pass itself ran no kernels
+      mod._pending_batches -= 1
+    g2 = None
+    if self.world > 1:
+      g2 = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(g2):
+        opt.clip_and_step()
+    entry = dict(fwd_bwd=g1, opt=g2, fake=fake, losses=losses, bn_tape=tape)
+    self._graphs[key] = entry
+    return entry
+
+  def state_checksums(self):
+    """(sum, l2) of the flat parameter buffers -- cheap parity probe."""
+    return {n: (float(o.flat_p.double().sum()), float(o.flat_p.double().norm()))
+            for n, o in (('G', self.optim_G), ('D', self.optim_D))}
