@@ -144,6 +144,12 @@ int ms_adam_step(float* p, const float* g, float* m, float* v, size_t n, const f
                  float lr, float beta1, float beta2, float eps, int32_t* step_state, void* stream);
 size_t ms_reduce_partials_count(size_t n); /* floats needed in `partials` of ms_sqnorm / ms_l1_mean_fwd */
 
+/* Measurement aid (bench.py): when enabled, every conv / BN launch is bracketed by HIP events on its stream.
+ * ms_timing_report writes "label\tcount\ttotal_ms\tflops_per_launch\tbytes_per_launch\n" lines and returns the
+ * bytes needed.  Not for use during graph capture. */
+int ms_timing_enable(int on);
+size_t ms_timing_report(char* buf, size_t cap);
+
 /* Self-test kernel: C(32x32) = A(32xK) * B(Kx32) through the fp32 MFMA path (checks fragment maps). */
 int ms_selftest_mfma(const float* A, const float* B, float* C, int K, void* stream);
 

@@ -428,6 +428,11 @@ int launch_gather(const GatherArgs& a, bool transposed, bool up2, int* n_tiles_o
   dim3 grid(cdiv(a.Npix, bn), cdiv(a.Mg, bm), a.groups);
   if (n_tiles_out) *n_tiles_out = grid.x;
   if (grid.y > 65535 || grid.z > 65535) return set_error("conv grid too large");
+  const double batch = (double)a.Npix / ((double)a.OUTH * a.OUTW);
+  TimingScope ts(s, 2.0 * a.Mg * a.Kg * (double)a.Npix * a.groups,
+                 4.0 * ((double)a.groups * a.Mg * a.Kg + batch * a.src_ctotal * a.SRCH * a.SRCW + (double)a.Npix * a.groups * a.Mg),
+                 "%s k%dx%d s%d Mg%d Kg%d g%d N%d tile%d%s", transposed ? "conv_dgrad" : "conv_fwd", a.KH, a.KW, a.SW, a.Mg,
+                 a.Kg, a.groups, a.Npix, bm, a.ep == EP_RAW_STATS ? " +bnstats" : "");
   if (transposed) up2 = false;  // the UP2 split store of the data gradient is a runtime epilogue (EP_DGRAD_UP2)
   if (c.tm == 2) {
     if (transposed) launch_gather_khw<2, 2, true, false>(a, grid, s);
@@ -485,11 +490,20 @@ int launch_wgrad(WgradArgs a, bool up2, float* dw, float* partial_ws, hipStream_
   a.out = a.splits > 1 ? partial_ws : dw;
   dim3 grid(cdiv(a.Kg, 64), cdiv(a.Cog, 64), a.groups * a.splits);
   if (grid.y > 65535 || grid.z > 65535) return set_error("wgrad grid too large");
-  if (up2) launch_wgrad_khw<true>(a, grid, s); else launch_wgrad_khw<false>(a, grid, s);
-  int rc = check_launch("wgrad_kernel");
+  int rc;
+  {
+    const double batch = (double)a.Npix / ((double)a.OH * a.OW);
+    TimingScope ts(s, 2.0 * a.Cog * a.Kg * (double)a.Npix * a.groups,
+                   4.0 * ((double)a.Npix * ctot + batch * a.src_ctotal * a.H * a.W + (double)ctot * a.Kg),
+                   "conv_wgrad k%dx%d s%d Cog%d Kg%d g%d N%d splits%d", a.KH, a.KW, a.SW, a.Cog, a.Kg, a.groups, a.Npix,
+                   a.splits);
+    if (up2) launch_wgrad_khw<true>(a, grid, s); else launch_wgrad_khw<false>(a, grid, s);
+    rc = check_launch("wgrad_kernel");
+  }
   if (rc) return rc;
   if (a.splits > 1) {
     const int n = ctot * a.Kg;
+    TimingScope ts(s, 0, 4.0 * n * (a.splits + 1), "wgrad_reduce_splits n%d splits%d", n, a.splits);
     hipLaunchKernelGGL(reduce_splits_kernel, dim3(min(cdiv(n, 256), 2048)), dim3(256), 0, s, partial_ws, dw, n, a.splits);
     rc = check_launch("reduce_splits_kernel");
   }
@@ -498,6 +512,7 @@ int launch_wgrad(WgradArgs a, bool up2, float* dw, float* partial_ws, hipStream_
 
 int launch_transpose_weight(const float* w, float* wt, int groups, int Cog, int Cig, int KHW, hipStream_t s) {
   const int total = groups * Cog * Cig * KHW;
+  TimingScope ts(s, 0, 8.0 * total, "transpose_weight n%d", total);
   hipLaunchKernelGGL(transpose_weight_kernel, dim3(min(cdiv(total, 256), 4096)), dim3(256), 0, s, w, wt, groups, Cog, Cig, KHW);
   return check_launch("transpose_weight_kernel");
 }

@@ -491,6 +491,7 @@ static inline int red_blocks(size_t n) {
 // ---- launchers used by api.hip
 int launch_bn_finalize(const float* stats, int n_tiles, int tile_n, int N, int C, const float* gamma, const float* beta,
                        float* rm, float* rv, float* save, float eps, float momentum, hipStream_t s) {
+  TimingScope ts(s, 0, 8.0 * n_tiles * C, "bn_finalize C%d tiles%d", C, n_tiles);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, s, stats, n_tiles, tile_n, N, C, gamma, beta, rm, rv, save,
                      eps, momentum);
   return check_launch("bn_finalize_kernel");
@@ -500,6 +501,7 @@ int launch_bn_apply(const float* y_raw, float* y, const float* save, int C, int 
   const size_t work = (HW & 3) == 0 ? total / 4 : total;
   int blocks = (int)std::min<size_t>((work + 255) / 256, 4096);
   if (blocks < 1) blocks = 1;
+  TimingScope ts(s, 0, 8.0 * total, "bn_apply C%d HW%d n%zu", C, HW, total);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, s, y_raw, y, save, C, HW, total, slope);
   return check_launch("bn_apply_kernel");
 }
@@ -517,6 +519,7 @@ int launch_bn_bwd(const float* dy, const float* y_raw, const float* save, const 
                   float* colpart, float* dgamma, float* dbeta, int B, int C, int HW, float slope, hipStream_t s) {
   int bpc;
   const int nchunk = bwd_chunks(B, C, &bpc);
+  TimingScope ts(s, 0, 20.0 * B * C * HW, "bn_bwd(reduce+apply) C%d HW%d B%d", C, HW, B);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, nchunk), dim3(256), 0, s, dy, y_raw, save, partial, B, C, HW, bpc, slope);
   int rc = check_launch("bn_bwd_reduce_kernel");
   if (rc) return rc;
@@ -529,6 +532,7 @@ int launch_act_bwd(const float* dy, const float* y, float* dyr, float* colpart, 
                    hipStream_t s) {
   int bpc;
   const int nchunk = bwd_chunks(B, C, &bpc);
+  TimingScope ts(s, 0, (mode == 1 ? 12.0 : 4.0) * B * C * HW, "act_bwd C%d HW%d B%d mode%d", C, HW, B, mode);
   hipLaunchKernelGGL(act_bwd_kernel, dim3(C, nchunk), dim3(256), 0, s, dy, y, dyr, colpart, B, C, HW, bpc, mode, slope);
   return check_launch("act_bwd_kernel");
 }

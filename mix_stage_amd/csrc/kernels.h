@@ -34,6 +34,14 @@ struct WgradArgs {
   int bcast, splits, r_per_split;
 };
 
+// RAII pair of HIP events around a launch (no-op unless ms_timing_enable(1)); timing.hip
+struct TimingScope {
+  TimingScope(hipStream_t s, double flops, double bytes, const char* fmt, ...);
+  ~TimingScope();
+  int idx_;
+  hipStream_t s_;
+};
+
 int launch_gather(const GatherArgs& a, bool transposed, bool up2, int* n_tiles_out, hipStream_t s);
 int gather_n_tiles(int Mg, int Npix, int groups);
 int gather_tile_n(int Mg, int Npix, int groups);

@@ -69,7 +69,8 @@ class GAN(nn.Module):
     return ops.l1_mean(y_cap, y)
 
   def estimate_weights(self, x_audio, y_pose, **kwargs):
-    return torch.ones(y_pose.shape[0]).to(y_pose.device), None
+    # allocated on the device directly (a host->device copy would not be capturable in a HIP graph)
+    return torch.ones(y_pose.shape[0], device=y_pose.device, dtype=y_pose.dtype), None
 
   def estimate_weights_loss(self, W):
     return W

@@ -352,3 +352,19 @@ def selftest_mfma(A, B):
   C = torch.empty((32, 32), dtype=torch.float32, device=A.device)
   check(lib().ms_selftest_mfma(_ptr(A.contiguous()), _ptr(B.contiguous()), _ptr(C), K, _stream()), 'ms_selftest_mfma')
   return C
+
+
+def timing_enable(on):
+  """Bracket every conv / BN launch with HIP events on its stream (bench.py's live kernel timing)."""
+  check(lib().ms_timing_enable(1 if on else 0), 'ms_timing_enable')
+
+
+def timing_report():
+  need = lib().ms_timing_report(None, 0)
+  buf = ctypes.create_string_buffer(need + 16)
+  lib().ms_timing_report(buf, need + 16)
+  rows = []
+  for line in buf.value.decode().splitlines():
+    label, count, ms, flops, nbytes = line.split('\t')
+    rows.append(dict(label=label, count=int(count), total_ms=float(ms), flops=float(flops), bytes=float(nbytes)))
+  return rows
