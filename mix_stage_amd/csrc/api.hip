@@ -24,6 +24,14 @@ static int validate(const ms_conv_desc* d, const char* who) {
   return 0;
 }
 
+static GatherPlan dgrad_plan(const ms_conv_desc* d) {
+  const bool bcast = d->in_mode == MS_IN_BCAST;
+  const int tg = bcast ? 1 : d->groups, tcog = bcast ? d->groups * d->Cout : d->Cout;
+  const int ncls = d->SH * d->SW;
+  const int npix_cls = d->B * cdiv(d->H, d->SH) * cdiv(d->W, d->SW);
+  return plan_gather(d->Cin, npix_cls, tg * ncls, tcog * cdiv(d->KH, d->SH) * cdiv(d->KW, d->SW));
+}
+
 static inline int ctot_of(const ms_conv_desc* d) { return d->groups * d->Cout; }
 static inline size_t wsize_of(const ms_conv_desc* d) { return (size_t)d->groups * d->Cout * d->Cin * d->KH * d->KW; }
 
@@ -34,9 +42,13 @@ using namespace ms;
 extern "C" {
 
 size_t ms_conv_block_fwd_workspace(const ms_conv_desc* d) {
-  if (!d || d->mode != MS_BN_TRAIN) return 256;
+  if (!d) return 256;
   const int npix = d->B * d->OH * d->OW;
-  return align_up((size_t)gather_n_tiles(d->Cout, npix, d->groups) * ctot_of(d) * 2 * sizeof(float), 256) + 256;
+  const GatherPlan pl = plan_gather(d->Cout, npix, d->groups, d->Cin * d->KH * d->KW);
+  size_t bytes = 256;
+  if (d->mode == MS_BN_TRAIN) bytes = std::max(bytes, (size_t)pl.n_tiles * ctot_of(d) * 2 * sizeof(float));
+  if (pl.splitk > 1) bytes = std::max(bytes, (size_t)pl.splitk * npix * ctot_of(d) * sizeof(float));
+  return align_up(bytes, 256) + 256;
 }
 
 size_t ms_conv_block_bwd_workspace(const ms_conv_desc* d) {
@@ -48,8 +60,11 @@ size_t ms_conv_block_bwd_workspace(const ms_conv_desc* d) {
   size_t bytes = 0;
   bytes += align_up((size_t)ctot_of(d) * nchunk * 2 * sizeof(float), 256);  // bn partials
   bytes += align_up((size_t)ctot_of(d) * nchunk * sizeof(float), 256);      // colsum partials
-  bytes += align_up(wsize_of(d) * sizeof(float), 256);                      // transposed weights
+  bytes += align_up(dgrad_weight_elems(d->groups, d->Cout, d->Cin, d->KH, d->KW, d->SH, d->SW) * sizeof(float), 256);
   bytes += align_up(wsize_of(d) * sizeof(float) * (splits > 1 ? splits : 0), 256);
+  const GatherPlan pl = dgrad_plan(d);
+  if (pl.splitk > 1)
+    bytes += align_up((size_t)pl.splitk * d->B * (d->in_mode == MS_IN_BCAST ? 1 : d->groups) * d->Cin * d->H * d->W * sizeof(float), 256);
   return bytes + 256;
 }
 
@@ -80,12 +95,21 @@ int ms_conv_block_fwd(const ms_conv_desc* d, const float* x, const float* x2, co
   a.a_vec = (a.Kg % 4 == 0) && (((uintptr_t)w & 15) == 0);
   a.ep = d->mode == MS_BARE ? EP_BARE : d->mode == MS_LRELU ? EP_LRELU : d->mode == MS_BN_EVAL ? EP_BN_EVAL : EP_RAW_STATS;
   a.slope = d->slope; a.eps = d->eps;
-  int n_tiles = 0;
-  rc = launch_gather(a, false, d->in_mode == MS_IN_UP2ADD, &n_tiles, s);
+  const GatherPlan pl = plan_gather(d->Cout, npix, d->groups, a.Kg);
+  if (pl.splitk > 1) {
+    a.part = (float*)workspace;
+    a.part_stride = (size_t)npix * C;
+  }
+  rc = launch_gather(a, false, d->in_mode == MS_IN_UP2ADD, pl, s);
   if (rc) return rc;
+  if (pl.splitk > 1) {
+    // few output pixels: K was sliced over workgroups; one launch sums the slices and finishes the block
+    return launch_splitk_fwd_epilogue(a.part, pl.splitk, a.part_stride, bias, gamma, beta, running_mean, running_var, y_raw, y,
+                                      save, d->B, C, hw, a.ep, d->slope, d->eps, d->momentum, s);
+  }
   if (d->mode == MS_BN_TRAIN) {
-    rc = launch_bn_finalize(a.stats, n_tiles, gather_tile_n(d->Cout, npix, d->groups), npix, C, gamma, beta, running_mean,
-                            running_var, save, d->eps, d->momentum, s);
+    rc = launch_bn_finalize(a.stats, pl.n_tiles, 64 * pl.tn, npix, C, gamma, beta, running_mean, running_var, save, d->eps,
+                            d->momentum, s);
     if (rc) return rc;
     rc = launch_bn_apply(y_raw, y, save, C, hw, (size_t)npix * C, d->slope, s);
   }
@@ -116,8 +140,13 @@ int ms_conv_block_bwd(const ms_conv_desc* d, const float* x, const float* x2, co
   char* wsp = (char*)workspace;
   float* bn_part = (float*)wsp; wsp += align_up((size_t)C * nchunk * 2 * sizeof(float), 256);
   float* colpart = (float*)wsp; wsp += align_up((size_t)C * nchunk * sizeof(float), 256);
-  float* wt = (float*)wsp; wsp += align_up(wsize_of(d) * sizeof(float), 256);
+  float* wt = (float*)wsp; wsp += align_up(dgrad_weight_elems(d->groups, d->Cout, d->Cin, d->KH, d->KW, d->SH, d->SW) * sizeof(float), 256);
   float* wg_part = (float*)wsp;
+  {
+    const int sp = wgrad_splits(d->Cout, d->Cin * d->KH * d->KW, d->groups, npix);
+    wsp += align_up(wsize_of(d) * sizeof(float) * (sp > 1 ? sp : 0), 256);
+  }
+  float* dg_part = (float*)wsp;
 
   // 1. gradient wrt the raw conv output (+ per-channel column sums = bias gradient)
   const float* g = dy;
@@ -140,18 +169,29 @@ int ms_conv_block_bwd(const ms_conv_desc* d, const float* x, const float* x2, co
   if (dx) {
     const int tg = bcast ? 1 : d->groups;          // broadcast input: all groups sum into the same channels
     const int tcog = bcast ? C : d->Cout;
-    rc = launch_transpose_weight(w, wt, tg, tcog, d->Cin, khw, s);
+    rc = launch_transpose_weight(w, wt, tg, tcog, d->Cin, d->KH, d->KW, d->SH, d->SW, d->PH, d->PW, s);
     if (rc) return rc;
+    const int jh = cdiv(d->KH, d->SH), jw = cdiv(d->KW, d->SW);
     GatherArgs a = {};
     a.A = wt; a.src = g; a.out = dx; a.out2 = dx2;
-    a.Mg = d->Cin; a.Kg = tcog * khw; a.groups = tg; a.Kc = tcog; a.src_ctotal = C;
-    a.SRCH = d->OH; a.SRCW = d->OW; a.OUTH = d->H; a.OUTW = d->W; a.Npix = d->B * d->H * d->W;
-    a.KH = d->KH; a.KW = d->KW; a.SH = d->SH; a.SW = d->SW; a.PH = d->PH; a.PW = d->PW;
+    a.Mg = d->Cin; a.Kg = tcog * jh * jw; a.groups = tg; a.Kc = tcog; a.src_ctotal = C;
+    a.SRCH = d->OH; a.SRCW = d->OW; a.OUTH = d->H; a.OUTW = d->W; a.Npix = d->B * d->H * d->W; a.batch = d->B;
+    a.KH = jh; a.KW = jw; a.SH = d->SH; a.SW = d->SW; a.PH = d->PH; a.PW = d->PW;
     a.bcast = 0;
     a.a_vec = (a.Kg % 4 == 0);
     a.ep = up2 ? EP_DGRAD_UP2 : EP_DGRAD;
-    rc = launch_gather(a, true, up2, nullptr, s);
+    const GatherPlan pl = dgrad_plan(d);
+    if (pl.splitk > 1) {
+      a.part = dg_part;
+      a.part_stride = (size_t)d->B * tg * d->Cin * d->H * d->W;
+      a.ep = EP_DGRAD;               // partial tiles use the plain full-resolution layout
+    }
+    rc = launch_gather(a, true, up2, pl, s);
     if (rc) return rc;
+    if (pl.splitk > 1) {
+      rc = launch_splitk_dgrad_epilogue(dg_part, pl.splitk, a.part_stride, dx, dx2, a.part_stride, d->W, up2 ? 1 : 0, s);
+      if (rc) return rc;
+    }
   }
 
   // 3. weight gradient

@@ -9,102 +9,128 @@
 //
 // Replaces what ATen's convolution / convolution_backward compute for the reference's
 // ConvNormRelu / nn.Conv1d calls (layers.py:58-78, JL:83, S2G:50-63).
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace ms {
 
 template <int TM, int TN, int KH_, int KW_, bool TRANSPOSED, bool UP2>
 __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherArgs p) {
-  constexpr int BM = 64 * TM, BN = 64 * TN, BK = 16;
+  constexpr int BM = 64 * TM, BN = 64 * TN, BK = (TM == 1 ? 64 : 32);
   constexpr int LDA = BM + 2, LDB = BN;
   constexpr int STAGE = BK * LDA + BK * LDB;
   constexpr int BROWS = 256 / BN, BITER = BK / BROWS;
+  constexpr int AITER = BM * BK / 1024;       // float4 loads of the A tile per thread
   __shared__ float smem[2 * STAGE];
 
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wm = wid >> 1, wn = wid & 1;
-  const int g = blockIdx.z, m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int KH = KH_ ? KH_ : p.KH, KW = KW_ ? KW_ : p.KW, KHW = KH * KW;
   const int Kg = p.Kg;
 
-  // ---- the B-tile column (output pixel) this thread stages: decoded once
-  const int nl = t % BN, kk0 = t / BN;
+  // Data gradient of a strided conv: blockIdx.z also enumerates the SH*SW output-parity classes; inside one class
+  // the problem is a dense stride-1 gather with ceil(K/S) taps per axis (no work on structural zeros).
+  int zz = blockIdx.z;
+  const int ks = zz % p.splitk;                 // split-K slice
+  zz /= p.splitk;
+  int g = zz, cls = 0, ry = 0, rx = 0, cy = p.PH, cx = p.PW, QH = p.OUTH, QW = p.OUTW;
+  if (TRANSPOSED) {
+    const int ncls = p.SH * p.SW;
+    g = zz / ncls;
+    cls = zz - g * ncls;
+    ry = cls / p.SW;
+    rx = cls - ry * p.SW;
+    const int kh0 = (ry + p.PH) % p.SH, kw0 = (rx + p.PW) % p.SW;
+    cy = (ry + p.PH - kh0) / p.SH;
+    cx = (rx + p.PW - kw0) / p.SW;
+    QH = (p.OUTH - ry + p.SH - 1) / p.SH;
+    QW = (p.OUTW - rx + p.SW - 1) / p.SW;
+  }
+  const int qhw = QH * QW;
+  const int npix = TRANSPOSED ? p.batch * qhw : p.Npix;
+  if (n0 >= npix) return;                       // whole block out of range (uneven parity classes)
+  const int kbeg = ks * p.k_per_split, kend = min(Kg, kbeg + p.k_per_split);
+  const float* Abase = p.A + (size_t)cls * p.groups * p.Mg * Kg;
+
+  // ---- the B-tile column (output pixel) this thread stages: decoded once.  All lanes of a wave stage the same
+  // k rows (BN >= 64), so the k -> (channel, tap) decode below is wave-uniform and lives on the scalar unit.
+  const int nl = t % BN;
+  const int kk0 = __builtin_amdgcn_readfirstlane(t / BN);
   const int n = n0 + nl;
-  const bool nvalid = n < p.Npix;
-  const int ohw = p.OUTH * p.OUTW;
+  const bool nvalid = n < npix;
   int pb = 0, py = 0, px = 0;
   if (nvalid) {
-    pb = n / ohw;
-    const int rem = n - pb * ohw;
-    py = rem / p.OUTW;
-    px = rem - py * p.OUTW;
+    pb = n / qhw;
+    const int rem = n - pb * qhw;
+    py = rem / QW;
+    px = rem - py * QW;
   }
-  const int by = TRANSPOSED ? py + p.PH : py * p.SH - p.PH;
-  const int bx = TRANSPOSED ? px + p.PW : px * p.SW - p.PW;
+  const int by = TRANSPOSED ? py + cy : py * p.SH - p.PH;
+  const int bx = TRANSPOSED ? px + cx : px * p.SW - p.PW;
   const int cbase = p.bcast ? 0 : g * p.Kc;
   const int chan0 = pb * p.src_ctotal + cbase;  // channel-row index of (pb, cbase)
+  const int src_hw = p.SRCH * p.SRCW;
+  const int lane_off = chan0 * src_hw + by * p.SRCW + bx;   // + per-k scalar offset (may be < 0 when out of range)
 
-  float4 ra[TM];
+  float4 ra[AITER];
   float rb[BITER];
 
+  // Loads are branch-free: out-of-range elements read a clamped (valid) address and are zeroed by a select, so the
+  // whole tile's loads issue back to back.
   auto load_tiles = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int idx = t + i * 256, row = idx >> 2, kq = idx & 3;
+    for (int i = 0; i < AITER; ++i) {
+      const int row = (t >> 2) + 64 * (i % TM), kq = (t & 3) + 4 * (i / TM);
       const int m = m0 + row, k = k0 + kq * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < p.Mg && k < Kg) {
-        const float* ap = p.A + (size_t)(g * p.Mg + m) * Kg + k;
-        if (p.a_vec) {
-          v = *reinterpret_cast<const float4*>(ap);
-        } else {
-          v.x = ap[0];
-          if (k + 1 < Kg) v.y = ap[1];
-          if (k + 2 < Kg) v.z = ap[2];
-          if (k + 3 < Kg) v.w = ap[3];
-        }
+      const bool ok = (m < p.Mg) & (k < kend);
+      const unsigned off = ok ? (unsigned)((g * p.Mg + m) * Kg + k) : 0u;
+      float4 v;
+      if (p.a_vec) {
+        v = *reinterpret_cast<const float4*>(Abase + off);
+        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        const unsigned last = (unsigned)(p.groups * p.Mg * Kg - 1);
+        v.x = Abase[off];
+        v.y = Abase[min(off + 1, last)];
+        v.z = Abase[min(off + 2, last)];
+        v.w = Abase[min(off + 3, last)];
+        if (!ok) v.x = 0.f;
+        if (!ok || k + 1 >= kend) v.y = 0.f;
+        if (!ok || k + 2 >= kend) v.z = 0.f;
+        if (!ok || k + 3 >= kend) v.w = 0.f;
       }
       ra[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < BITER; ++i) {
-      const int k = k0 + kk0 + i * BROWS;
-      float v = 0.f;
-      if (nvalid && k < Kg) {
-        const int kc = k / KHW, r = k - kc * KHW, kh = r / KW, kw = r - kh * KW;
-        int sy, sx;
-        bool ok;
-        if (!TRANSPOSED) {
-          sy = by + kh;
-          sx = bx + kw;
-          ok = (unsigned)sy < (unsigned)p.SRCH && (unsigned)sx < (unsigned)p.SRCW;
-        } else {
-          const int ty = by - kh, tx = bx - kw;
-          ok = ty >= 0 && tx >= 0;
-          if (p.SH == 1) { sy = ty; } else if (p.SH == 2) { ok = ok && !(ty & 1); sy = ty >> 1; }
-          else { sy = ty / p.SH; ok = ok && (sy * p.SH == ty); }
-          if (p.SW == 1) { sx = tx; } else if (p.SW == 2) { ok = ok && !(tx & 1); sx = tx >> 1; }
-          else { sx = tx / p.SW; ok = ok && (sx * p.SW == tx); }
-          ok = ok && sy < p.SRCH && sx < p.SRCW;
-        }
-        if (ok) {
-          const int crow = chan0 + kc;
-          if (UP2 && !TRANSPOSED) {
-            v = p.src[(size_t)crow * (p.SRCW >> 1) + (sx >> 1)] + p.src2[(size_t)crow * p.SRCW + sx];
-          } else {
-            v = p.src[((size_t)crow * p.SRCH + sy) * p.SRCW + sx];
-          }
-        }
+      const unsigned k = (unsigned)(k0 + kk0 + i * BROWS);    // wave-uniform -> scalar unit
+      const unsigned kc = k / (unsigned)KHW, r = k - kc * (unsigned)KHW;
+      const unsigned kh = (KH_ == 1) ? 0u : r / (unsigned)KW, kw = r - kh * (unsigned)KW;
+      const int sy = TRANSPOSED ? by - (int)kh : by + (int)kh;
+      const int sx = TRANSPOSED ? bx - (int)kw : bx + (int)kw;
+      const bool ok = nvalid & ((int)k < kend) & ((unsigned)sy < (unsigned)p.SRCH) & ((unsigned)sx < (unsigned)p.SRCW);
+      float v;
+      if (UP2 && !TRANSPOSED) {
+        const int crow = chan0 + (int)kc;
+        const unsigned oa = ok ? (unsigned)(crow * (p.SRCW >> 1) + (sx >> 1)) : 0u;
+        const unsigned orr = ok ? (unsigned)(crow * p.SRCW + sx) : 0u;
+        v = p.src[oa] + p.src2[orr];
+      } else {
+        const int koff = (int)kc * src_hw + (TRANSPOSED ? -(int)(kh * p.SRCW + kw) : (int)(kh * p.SRCW + kw));   // scalar
+        const unsigned off = ok ? (unsigned)(lane_off + koff) : 0u;
+        v = p.src[off];
       }
-      rb[i] = v;
+      rb[i] = ok ? v : 0.f;
     }
   };
   auto store_tiles = [&](int buf) {
     float* As = smem + buf * STAGE;
     float* Bs = As + BK * LDA;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int idx = t + i * 256, row = idx >> 2, kq = idx & 3;
+    for (int i = 0; i < AITER; ++i) {
+      const int row = (t >> 2) + 64 * (i % TM), kq = (t & 3) + 4 * (i / TM);
       As[(kq * 4 + 0) * LDA + row] = ra[i].x;
       As[(kq * 4 + 1) * LDA + row] = ra[i].y;
       As[(kq * 4 + 2) * LDA + row] = ra[i].z;
@@ -122,14 +148,14 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = (Kg + BK - 1) / BK;
-  load_tiles(0);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  load_tiles(kbeg);
   store_tiles(0);
   __syncthreads();
   const int a_off = wm * TM * 32 + (lane & 31), b_off = wn * TN * 32 + (lane & 31), khalf = lane >> 5;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+    if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * BK);
     const float* As = smem + cur * STAGE;
     const float* Bs = As + BK * LDA;
 #pragma unroll
@@ -151,17 +177,36 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherArgs p) {
 
   // ---------------- epilogue ----------------
   const int ctot = p.groups * p.Mg;
+  const int ohw = p.OUTH * p.OUTW;              // full output image (channel stride)
   int ooff[TN];
   bool cval[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int nc = n0 + wn * TN * 32 + j * 32 + (lane & 31);
-    cval[j] = nc < p.Npix;
-    const int b = cval[j] ? nc / ohw : 0;
-    const int pix = nc - b * ohw;
-    ooff[j] = b * ctot * ohw + pix;   // + channel*ohw
+    cval[j] = nc < npix;
+    const int b = cval[j] ? nc / qhw : 0;
+    const int pix = nc - b * qhw;
+    if (TRANSPOSED) {
+      const int qy = pix / QW, qx = pix - qy * QW;
+      ooff[j] = b * ctot * ohw + (qy * p.SH + ry) * p.OUTW + qx * p.SW + rx;
+    } else {
+      ooff[j] = b * ctot * ohw + pix;           // + channel*ohw
+    }
   }
   const int ep = p.ep;
+  if (p.splitk > 1) {                           // raw partial tile; the epilogue runs in the split-K reduce kernel
+    float* part = p.part + (size_t)ks * p.part_stride;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          if (m < p.Mg && cval[j]) part[(size_t)ooff[j] + (size_t)(g * p.Mg + m) * ohw] = acc[i][j][r];
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -175,7 +220,7 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherArgs p) {
         for (int j = 0; j < TN; ++j)
           if (mval && cval[j]) p.out[(size_t)ooff[j] + (size_t)ch * ohw] = acc[i][j][r];
       } else if (ep == EP_DGRAD_UP2) {
-        // out2 = grad of the residual (full resolution); out = grad of the half-resolution tensor
+        // 1-D, stride 1: out2 = grad of the residual (full resolution); out = grad of the half-resolution tensor
         const int hw = ohw >> 1;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -213,7 +258,7 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherArgs p) {
   if (ep == EP_RAW_STATS) {
     // per-channel (sum, M2 about this tile's mean) over the tile's valid pixels, fixed order
     float* red = smem;  // [4][BM]
-    const int cnt = min(BN, p.Npix - n0);
+    const int cnt = min(BN, npix - n0);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -377,30 +422,51 @@ __global__ void reduce_splits_kernel(const float* __restrict__ part, float* __re
   }
 }
 
-// wt[g][ci][co][khw] = w[g][co][ci][khw]
+// Data-gradient weights.  One slab per output-parity class (ry, rx) of a stride-(SH,SW) conv:
+//   wpar[cls][g][ci][co][jh][jw] = w[g][co][ci][kh0 + SH*jh][kw0 + SW*jw]   (0 beyond the kernel)
+// with kh0 = (ry+PH)%SH, kw0 = (rx+PW)%SW, JH = ceil(KH/SH), JW = ceil(KW/SW).  Stride 1 -> one slab, all taps.
 __global__ void transpose_weight_kernel(const float* __restrict__ w, float* __restrict__ wt, int groups, int Cog,
-                                        int Cig, int KHW) {
-  const int per_g = Cog * Cig * KHW;
-  const int total = groups * per_g;
+                                        int Cig, int KH, int KW, int SH, int SW, int PH, int PW) {
+  const int JH = (KH + SH - 1) / SH, JW = (KW + SW - 1) / SW, J = JH * JW;
+  const int per_g = Cog * Cig * J, per_cls = groups * per_g;
+  const int total = SH * SW * per_cls;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int g = i / per_g;
-    int r = i - g * per_g;           // index in wt[g]: (ci, co, khw)
-    const int ci = r / (Cog * KHW);
-    r -= ci * Cog * KHW;
-    const int co = r / KHW, k = r - co * KHW;
-    wt[i] = w[(size_t)g * per_g + ((size_t)co * Cig + ci) * KHW + k];
+    const int cls = i / per_cls;
+    int r = i - cls * per_cls;
+    const int g = r / per_g;
+    r -= g * per_g;                  // index in wpar[cls][g]: (ci, co, jh, jw)
+    const int ci = r / (Cog * J);
+    r -= ci * Cog * J;
+    const int co = r / J, j = r - co * J, jh = j / JW, jw = j - jh * JW;
+    const int ry = cls / SW, rx = cls - ry * SW;
+    const int kh = (ry + PH) % SH + SH * jh, kw = (rx + PW) % SW + SW * jw;
+    float v = 0.f;
+    if (kh < KH && kw < KW) v = w[(((size_t)(g * Cog + co) * Cig + ci) * KH + kh) * KW + kw];
+    wt[i] = v;
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // launch helpers
-struct TileCfg { int tm, tn; };
-
-static TileCfg pick_tile(int Mg, int Npix, int groups) {
+GatherPlan plan_gather(int Mg, int npix, int zcount, int Kg) {
+  GatherPlan pl;
   // big tile only when it still fills the chip (256 CUs) at >= 2 workgroups per CU
-  const long big = (long)cdiv(Mg, 128) * cdiv(Npix, 128) * groups;
-  if (Mg >= 128 && big >= 512) return {2, 2};
-  return {1, 1};
+  const long big = (long)cdiv(Mg, 128) * cdiv(npix, 128) * zcount;
+  if (Mg >= 128 && big >= 512) { pl.tm = 2; pl.tn = 2; } else { pl.tm = 1; pl.tn = 1; }
+  const int bm = 64 * pl.tm, bn = 64 * pl.tn, bk = pl.tm == 1 ? 64 : 32;
+  pl.n_tiles = cdiv(npix, bn);
+  const long base = (long)pl.n_tiles * cdiv(Mg, bm) * zcount;
+  const int nk = cdiv(Kg, bk);
+  int splitk = 1;
+  // few workgroups and a long reduction: slice K so the weight stream is spread over the chip
+  if (base < 96 && nk >= 2) {
+    splitk = (int)std::min<long>(nk, std::max<long>(1, 256 / base));
+    if (splitk > 32) splitk = 32;
+  }
+  const int steps = cdiv(nk, splitk);
+  pl.k_per_split = steps * bk;
+  pl.splitk = cdiv(Kg, pl.k_per_split);
+  return pl;
 }
 
 template <int TM, int TN, bool TR, bool UP2>
@@ -409,6 +475,15 @@ static void launch_gather_khw(const GatherArgs& a, dim3 grid, hipStream_t s) {
 #define MS_GK(KH, KW) hipLaunchKernelGGL((igemm_gather_kernel<TM, TN, KH, KW, TR, UP2>), grid, dim3(256), 0, s, a)
   if constexpr (UP2) {
     if (kh == 1 && kw == 3) MS_GK(1, 3);
+    else MS_GK(0, 0);
+  } else if constexpr (TR) {      // taps per parity class
+    if (kh == 1 && kw == 3) MS_GK(1, 3);
+    else if (kh == 1 && kw == 1) MS_GK(1, 1);
+    else if (kh == 1 && kw == 2) MS_GK(1, 2);
+    else if (kh == 1 && kw == 4) MS_GK(1, 4);
+    else if (kh == 2 && kw == 2) MS_GK(2, 2);
+    else if (kh == 3 && kw == 3) MS_GK(3, 3);
+    else if (kh == 3 && kw == 8) MS_GK(3, 8);
     else MS_GK(0, 0);
   } else {
     if (kh == 1 && kw == 3) MS_GK(1, 3);
@@ -422,19 +497,26 @@ static void launch_gather_khw(const GatherArgs& a, dim3 grid, hipStream_t s) {
 #undef MS_GK
 }
 
-int launch_gather(const GatherArgs& a, bool transposed, bool up2, int* n_tiles_out, hipStream_t s) {
-  const TileCfg c = pick_tile(a.Mg, a.Npix, a.groups);
-  const int bm = 64 * c.tm, bn = 64 * c.tn;
-  dim3 grid(cdiv(a.Npix, bn), cdiv(a.Mg, bm), a.groups);
-  if (n_tiles_out) *n_tiles_out = grid.x;
+// Forward: a.Npix = B*OUTH*OUTW.  Transposed (data gradient): a.KH/a.KW are the taps per parity class, a.SH/a.SW
+// the conv strides (= class counts), a.batch = B, a.A = the class slabs built by transpose_weight_kernel.
+// plan.splitk > 1: a.part / a.part_stride must be set; the caller then runs a split-K epilogue kernel.
+int launch_gather(GatherArgs a, bool transposed, bool up2, const GatherPlan& plan, hipStream_t s) {
+  const int ncls = transposed ? a.SH * a.SW : 1;
+  const int npix_cls = transposed ? a.batch * cdiv(a.OUTH, a.SH) * cdiv(a.OUTW, a.SW) : a.Npix;   // largest class
+  const int bm = 64 * plan.tm, bn = 64 * plan.tn;
+  a.splitk = plan.splitk;
+  a.k_per_split = plan.k_per_split;
+  dim3 grid(cdiv(npix_cls, bn), cdiv(a.Mg, bm), a.groups * ncls * plan.splitk);
   if (grid.y > 65535 || grid.z > 65535) return set_error("conv grid too large");
-  const double batch = (double)a.Npix / ((double)a.OUTH * a.OUTW);
-  TimingScope ts(s, 2.0 * a.Mg * a.Kg * (double)a.Npix * a.groups,
-                 4.0 * ((double)a.groups * a.Mg * a.Kg + batch * a.src_ctotal * a.SRCH * a.SRCW + (double)a.Npix * a.groups * a.Mg),
-                 "%s k%dx%d s%d Mg%d Kg%d g%d N%d tile%d%s", transposed ? "conv_dgrad" : "conv_fwd", a.KH, a.KW, a.SW, a.Mg,
-                 a.Kg, a.groups, a.Npix, bm, a.ep == EP_RAW_STATS ? " +bnstats" : "");
+  if (plan.splitk > 1 && !a.part) return set_error("split-K without a partial buffer");
+  const double batch = transposed ? (double)a.batch : (double)a.Npix / ((double)a.OUTH * a.OUTW);
+  const double opix = batch * a.OUTH * a.OUTW;
+  TimingScope ts(s, 2.0 * a.Mg * a.Kg * (double)npix_cls * ncls * a.groups,
+                 4.0 * ((double)ncls * a.groups * a.Mg * a.Kg + batch * a.src_ctotal * a.SRCH * a.SRCW + opix * a.groups * a.Mg),
+                 "%s k%dx%d s%d Mg%d Kg%d g%d N%.0f tile%d splitk%d%s", transposed ? "conv_dgrad" : "conv_fwd", a.KH, a.KW,
+                 a.SW, a.Mg, a.Kg, a.groups, opix, bm, plan.splitk, a.ep == EP_RAW_STATS ? " +bnstats" : "");
   if (transposed) up2 = false;  // the UP2 split store of the data gradient is a runtime epilogue (EP_DGRAD_UP2)
-  if (c.tm == 2) {
+  if (plan.tm == 2) {
     if (transposed) launch_gather_khw<2, 2, true, false>(a, grid, s);
     else if (up2) launch_gather_khw<2, 2, false, true>(a, grid, s);
     else launch_gather_khw<2, 2, false, false>(a, grid, s);
@@ -446,12 +528,115 @@ int launch_gather(const GatherArgs& a, bool transposed, bool up2, int* n_tiles_o
   return check_launch("igemm_gather_kernel");
 }
 
-int gather_n_tiles(int Mg, int Npix, int groups) {
-  const TileCfg c = pick_tile(Mg, Npix, groups);
-  return cdiv(Npix, 64 * c.tn);
+// ---------------------------------------------------------------------------------------------
+// split-K epilogues.  Forward: one workgroup per output channel sums the partial tiles, adds the bias and applies
+// the block epilogue; for BN_TRAIN the workgroup owns all B*HW values of its channel, so batch statistics,
+// running-stat update, normalisation and LeakyReLU happen here in one launch (two-pass variance).
+__global__ __launch_bounds__(256) void splitk_fwd_epilogue_kernel(const float* __restrict__ part, int splitk,
+                                                                  size_t part_stride, const float* __restrict__ bias,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, float* rm, float* rv,
+                                                                  float* __restrict__ y_raw, float* __restrict__ y,
+                                                                  float* __restrict__ save, int B, int C, int HW, int ep,
+                                                                  float slope, float eps, float momentum) {
+  __shared__ float red[4];
+  const int c = blockIdx.x, t = threadIdx.x;
+  const int N = B * HW;
+  const float bsv = bias ? bias[c] : 0.f;
+  float sc = 1.f, sh = 0.f;
+  if (ep == EP_BN_EVAL) {
+    const float inv = 1.0f / sqrtf(rv[c] + eps);
+    sc = gamma[c] * inv;
+    sh = beta[c] - rm[c] * sc;
+  }
+  float s1 = 0.f;
+  for (int e = t; e < N; e += 256) {
+    const int b = e / HW, pix = e - b * HW;
+    const size_t off = ((size_t)b * C + c) * HW + pix;
+    float v = bsv;
+    for (int k = 0; k < splitk; ++k) v += part[(size_t)k * part_stride + off];
+    if (ep == EP_RAW_STATS) {
+      y_raw[off] = v;
+      s1 += v;
+    } else {
+      if (ep == EP_BN_EVAL) v = lrelu(fmaf(v, sc, sh), slope);
+      if (ep == EP_LRELU) v = lrelu(v, slope);
+      y[off] = v;
+    }
+  }
+  if (ep != EP_RAW_STATS) return;
+  const float mean = block_sum_256(s1, red) / (float)N;
+  float q = 0.f;
+  for (int e = t; e < N; e += 256) {
+    const int b = e / HW, pix = e - b * HW;
+    const float d = y_raw[((size_t)b * C + c) * HW + pix] - mean;   // written by this thread above
+    q += d * d;
+  }
+  const float m2 = block_sum_256(q, red);
+  const float var = m2 / (float)N;
+  const float invstd = 1.0f / sqrtf(var + eps);
+  sc = gamma[c] * invstd;
+  sh = beta[c] - mean * sc;
+  if (t == 0) {
+    save[c] = mean;
+    save[C + c] = invstd;
+    save[2 * C + c] = sc;
+    save[3 * C + c] = sh;
+    const float unbiased = N > 1 ? m2 / (float)(N - 1) : var;
+    rm[c] = (1.f - momentum) * rm[c] + momentum * mean;
+    rv[c] = (1.f - momentum) * rv[c] + momentum * unbiased;
+  }
+  for (int e = t; e < N; e += 256) {
+    const int b = e / HW, pix = e - b * HW;
+    const size_t off = ((size_t)b * C + c) * HW + pix;
+    y[off] = lrelu(fmaf(y_raw[off], sc, sh), slope);
+  }
 }
 
-int gather_tile_n(int Mg, int Npix, int groups) { return 64 * pick_tile(Mg, Npix, groups).tn; }
+// data gradient: dx = sum of partials; UP2: dx2 (residual grad, width W) = sum, dx (half width) = pair sums
+__global__ __launch_bounds__(256) void splitk_dgrad_epilogue_kernel(const float* __restrict__ part, int splitk,
+                                                                    size_t part_stride, float* __restrict__ dx,
+                                                                    float* __restrict__ dx2, size_t n, int up2) {
+  if (!up2) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+      float v = 0.f;
+      for (int k = 0; k < splitk; ++k) v += part[(size_t)k * part_stride + i];
+      dx[i] = v;
+    }
+  } else {
+    const size_t half = n >> 1;   // W is even: pairs never straddle rows
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < half; i += (size_t)gridDim.x * 256) {
+      float v0 = 0.f, v1 = 0.f;
+      for (int k = 0; k < splitk; ++k) {
+        v0 += part[(size_t)k * part_stride + 2 * i];
+        v1 += part[(size_t)k * part_stride + 2 * i + 1];
+      }
+      dx2[2 * i] = v0;
+      dx2[2 * i + 1] = v1;
+      dx[i] = v0 + v1;
+    }
+  }
+}
+
+int launch_splitk_fwd_epilogue(const float* part, int splitk, size_t part_stride, const float* bias, const float* gamma,
+                               const float* beta, float* rm, float* rv, float* y_raw, float* y, float* save, int B, int C,
+                               int HW, int ep, float slope, float eps, float momentum, hipStream_t s) {
+  TimingScope ts(s, 0, 4.0 * B * C * HW * (splitk + 3), "splitk_fwd_epilogue C%d N%d splitk%d ep%d", C, B * HW, splitk, ep);
+  hipLaunchKernelGGL(splitk_fwd_epilogue_kernel, dim3(C), dim3(256), 0, s, part, splitk, part_stride, bias, gamma, beta, rm,
+                     rv, y_raw, y, save, B, C, HW, ep, slope, eps, momentum);
+  return check_launch("splitk_fwd_epilogue_kernel");
+}
+
+int launch_splitk_dgrad_epilogue(const float* part, int splitk, size_t part_stride, float* dx, float* dx2, size_t n, int W,
+                                 int up2, hipStream_t s) {
+  (void)W;
+  TimingScope ts(s, 0, 4.0 * n * (splitk + 1), "splitk_dgrad_epilogue n%zu splitk%d", n, splitk);
+  const size_t work = up2 ? n / 2 : n;
+  int blocks = (int)std::min<size_t>((work + 255) / 256, 2048);
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(splitk_dgrad_epilogue_kernel, dim3(blocks), dim3(256), 0, s, part, splitk, part_stride, dx, dx2, n, up2);
+  return check_launch("splitk_dgrad_epilogue_kernel");
+}
 
 // wgrad: choose split count so the grid fills the chip
 int wgrad_splits(int Cog, int Kg, int groups, int Npix) {
@@ -510,10 +695,17 @@ int launch_wgrad(WgradArgs a, bool up2, float* dw, float* partial_ws, hipStream_
   return rc;
 }
 
-int launch_transpose_weight(const float* w, float* wt, int groups, int Cog, int Cig, int KHW, hipStream_t s) {
-  const int total = groups * Cog * Cig * KHW;
+size_t dgrad_weight_elems(int groups, int Cog, int Cig, int KH, int KW, int SH, int SW) {
+  return (size_t)SH * SW * groups * Cog * Cig * cdiv(KH, SH) * cdiv(KW, SW);
+}
+
+int launch_transpose_weight(const float* w, float* wt, int groups, int Cog, int Cig, int KH, int KW, int SH, int SW,
+                            int PH, int PW, hipStream_t s) {
+  const int J = cdiv(KH, SH) * cdiv(KW, SW);
+  const int total = SH * SW * groups * Cog * Cig * J;
   TimingScope ts(s, 0, 8.0 * total, "transpose_weight n%d", total);
-  hipLaunchKernelGGL(transpose_weight_kernel, dim3(min(cdiv(total, 256), 4096)), dim3(256), 0, s, w, wt, groups, Cog, Cig, KHW);
+  hipLaunchKernelGGL(transpose_weight_kernel, dim3(min(cdiv(total, 256), 4096)), dim3(256), 0, s, w, wt, groups, Cog, Cig, KH,
+                     KW, SH, SW, PH, PW);
   return check_launch("transpose_weight_kernel");
 }
 

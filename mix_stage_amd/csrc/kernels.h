@@ -21,6 +21,10 @@ struct GatherArgs {
   int Mg, Kg, groups, Kc, src_ctotal, SRCH, SRCW, OUTH, OUTW, Npix;
   int KH, KW, SH, SW, PH, PW;
   int bcast, a_vec, ep;
+  int batch;     // transposed (data gradient) only: B
+  int splitk, k_per_split;   // split-K: blockIdx.z also enumerates K slices; raw partial tiles go to `part`
+  float* part;               // [splitk][same layout as out]
+  size_t part_stride;
   float slope, eps;
 };
 
@@ -42,12 +46,21 @@ struct TimingScope {
   hipStream_t s_;
 };
 
-int launch_gather(const GatherArgs& a, bool transposed, bool up2, int* n_tiles_out, hipStream_t s);
-int gather_n_tiles(int Mg, int Npix, int groups);
-int gather_tile_n(int Mg, int Npix, int groups);
+struct GatherPlan { int tm, tn, splitk, k_per_split, n_tiles; };
+// tile shape + split-K factor for an (Mg x npix) output per z-slice (z = groups * parity classes), reduction Kg
+GatherPlan plan_gather(int Mg, int npix, int zcount, int Kg);
+int launch_gather(GatherArgs a, bool transposed, bool up2, const GatherPlan& plan, hipStream_t s);
+// sums the split-K partial tiles and applies the block epilogue; one workgroup per output channel
+int launch_splitk_fwd_epilogue(const float* part, int splitk, size_t part_stride, const float* bias, const float* gamma,
+                               const float* beta, float* rm, float* rv, float* y_raw, float* y, float* save, int B, int C,
+                               int HW, int ep, float slope, float eps, float momentum, hipStream_t s);
+int launch_splitk_dgrad_epilogue(const float* part, int splitk, size_t part_stride, float* dx, float* dx2, size_t n, int W,
+                                 int up2, hipStream_t s);
 int wgrad_splits(int Cog, int Kg, int groups, int Npix);
 int launch_wgrad(WgradArgs a, bool up2, float* dw, float* partial_ws, hipStream_t s);
-int launch_transpose_weight(const float* w, float* wt, int groups, int Cog, int Cig, int KHW, hipStream_t s);
+int launch_transpose_weight(const float* w, float* wt, int groups, int Cog, int Cig, int KH, int KW, int SH, int SW,
+                            int PH, int PW, hipStream_t s);
+size_t dgrad_weight_elems(int groups, int Cog, int Cig, int KH, int KW, int SH, int SW);
 int launch_bn_finalize(const float* stats, int n_tiles, int tile_n, int N, int C, const float* gamma, const float* beta,
                        float* rm, float* rv, float* save, float eps, float momentum, hipStream_t s);
 int launch_bn_apply(const float* y_raw, float* y, const float* save, int C, int HW, size_t total, float slope, hipStream_t s);

@@ -86,7 +86,9 @@ def _compare_step(M, S, B, kind, F_, seed, strict):
   assert hip.G_flag == ref.G_flag
   if strict and flips:
     return flips
-  rel = 2e-3 if not flips else 5e-2
+  # flip-free: every element within 2e-3 of the parameter's max |grad|.  With flips (a handful of activations out of
+  # ~10^6-10^7 took the other LeakyReLU slope) single elements move by a few %, so the bar is on the relative L2
+  # error of each gradient tensor (3 %) plus a loose per-element cap (15 %).
   bad = []
   for (n, p), (_, q) in zip(hip.named_parameters(), ref.named_parameters()):
     skipped_by_design = kind == 'G' and n.startswith('D.')     # D weight grads are not computed in the G-step
@@ -99,11 +101,19 @@ def _compare_step(M, S, B, kind, F_, seed, strict):
         bad.append((n, 'missing grad'))
       continue
     scale = q.grad.abs().max().item()
-    err = (p.grad.cpu().double() - q.grad).abs().max().item()
-    # conv bias in front of BN: the true gradient is 0, both sides hold rounding noise
-    tol = rel * scale + 1e-7 if not n.endswith('conv.bias') else 1e-5
-    if err > tol:
-      bad.append((n, err, scale))
+    diff = p.grad.cpu().double() - q.grad
+    err = diff.abs().max().item()
+    if n.endswith('conv.bias'):      # conv bias in front of BN: the true gradient is 0, both sides hold rounding noise
+      if err > 1e-5:
+        bad.append((n, err, scale))
+      continue
+    if not flips:
+      if err > 2e-3 * scale + 1e-7:
+        bad.append((n, err, scale))
+    else:
+      l2 = diff.norm().item() / (q.grad.norm().item() + 1e-30)
+      if err > 0.15 * scale + 1e-7 or l2 > 3e-2:
+        bad.append((n, err, scale, l2))
   assert not bad, 'flips=%d %s' % (flips, bad[:8])
   for (k, a), (_, b) in zip(hip.state_dict().items(), ref.state_dict().items()):
     if 'running_' in k:
@@ -128,7 +138,7 @@ def test_gan_step_gradients_strict(M, S, B, kind):
 @pytest.mark.parametrize('M,S,B', [(4, 4, 4), (8, 8, 2)])
 @pytest.mark.parametrize('kind', ['G', 'D'])
 def test_gan_step_matches_oracle(M, S, B, kind):
-  """Full-size mel axis: outputs/losses at the 1e-4 bar; gradients at 2e-3 (flip-free) or 5 % (a few activations
+  """Full-size mel axis: outputs/losses at the 1e-4 bar; gradients at 2e-3 (flip-free) or 3 % relative L2 (a few activations
   flipped slope at a kink -- expected with ~10^7 activations in fp32)."""
   _compare_step(M, S, B, kind, F_=128, seed=1234, strict=False)
 
