@@ -23,6 +23,34 @@ from . import layers, ops
 _ALIGN = 64  # elements: every parameter starts 256-B aligned inside the flat buffer
 
 
+def average_flat_gradients(flat_g, process_group=None):
+  """The data-parallel exchange step: one all-reduce (RCCL over xGMI on the GPUs; gloo in the CPU tests) of the flat
+  gradient buffer, leaving the mean over ranks -- what a single device would have computed on the global batch of
+  equally sized shards (up to per-rank BatchNorm statistics)."""
+  if not (dist.is_available() and dist.is_initialized()):
+    return flat_g
+  world = dist.get_world_size(process_group)
+  if world == 1:
+    return flat_g
+  if dist.get_backend(process_group) == 'nccl':
+    dist.all_reduce(flat_g, op=dist.ReduceOp.AVG, group=process_group)
+  else:
+    dist.all_reduce(flat_g, op=dist.ReduceOp.SUM, group=process_group)
+    flat_g.mul_(1.0 / world)
+  return flat_g
+
+
+def peek_step_decisions(D_prob, thresh_value, thresh_iters, thresh_num_iters, thresh_end):
+  """What gan.py:105 (D-step vs G-step) and JL:127 (curriculum branch) will draw from the host generator, without
+  consuming it.  Ranks seed their host generators identically, so every rank takes the same branch."""
+  state = torch.get_rng_state()
+  r_gan, r_branch = torch.rand(1).item(), torch.rand(1).item()
+  torch.set_rng_state(state)
+  kind = 'D' if r_gan < D_prob else 'G'
+  thresh_now = (thresh_value if thresh_iters < thresh_num_iters else thresh_end) if kind == 'G' else thresh_value
+  return kind, (kind == 'G' and r_branch > thresh_now)
+
+
 class FlatAdam:
   """torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8) + clip_grad_norm_(params, max_norm) over flat buffers."""
 
@@ -115,23 +143,11 @@ class MixStageTrainStep:
 
   def _all_reduce(self, opt):
     if self.world > 1:
-      if dist.get_backend(self.pg) == 'nccl':
-        dist.all_reduce(opt.flat_g, op=dist.ReduceOp.AVG, group=self.pg)
-      else:
-        dist.all_reduce(opt.flat_g, op=dist.ReduceOp.SUM, group=self.pg)
-        opt.flat_g.mul_(1.0 / self.world)
+      average_flat_gradients(opt.flat_g, self.pg)
 
   def _peek_decisions(self):
-    """What gan.py:105 and JL:127 will draw, without consuming the host generator."""
-    m = self.model
-    state = torch.get_rng_state()
-    r_gan, r_branch = torch.rand(1).item(), torch.rand(1).item()
-    torch.set_rng_state(state)
-    kind = 'D' if r_gan < m.D_prob else 'G'
-    th = m.G.thresh
-    thresh_now = (th.value if th.iters < th.num_iters else th.end) if kind == 'G' else th.value
-    pose_branch = kind == 'G' and r_branch > thresh_now
-    return kind, pose_branch
+    th = self.model.G.thresh
+    return peek_step_decisions(self.model.D_prob, th.value, th.iters, th.num_iters, th.end)
 
   def _consume_decisions(self, kind):
     torch.rand(1)
