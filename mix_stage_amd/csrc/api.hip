@@ -32,6 +32,11 @@ static GatherPlan dgrad_plan(const ms_conv_desc* d) {
   return plan_gather(d->Cin, npix_cls, tg * ncls, tcog * cdiv(d->KH, d->SH) * cdiv(d->KW, d->SW));
 }
 
+static PatchPlan fwd_patch_plan(const ms_conv_desc* d) {
+  const int nd = (d->H == 1 && d->KH == 1) ? 1 : 2;
+  return plan_patch(nd, d->Cout, d->groups, d->KH, d->KW, d->SH, d->SW, d->B, d->OH, d->OW);
+}
+
 static inline int ctot_of(const ms_conv_desc* d) { return d->groups * d->Cout; }
 static inline size_t wsize_of(const ms_conv_desc* d) { return (size_t)d->groups * d->Cout * d->Cin * d->KH * d->KW; }
 
@@ -45,8 +50,11 @@ size_t ms_conv_block_fwd_workspace(const ms_conv_desc* d) {
   if (!d) return 256;
   const int npix = d->B * d->OH * d->OW;
   const GatherPlan pl = plan_gather(d->Cout, npix, d->groups, d->Cin * d->KH * d->KW);
+  const PatchPlan pp = fwd_patch_plan(d);
   size_t bytes = 256;
   if (d->mode == MS_BN_TRAIN) bytes = std::max(bytes, (size_t)pl.n_tiles * ctot_of(d) * 2 * sizeof(float));
+  if (pp.ok && d->mode == MS_BN_TRAIN)
+    bytes = std::max(bytes, align_up((size_t)pp.n_tiles * ctot_of(d) * 2 * sizeof(float), 256) + (size_t)pp.n_tiles * sizeof(float));
   if (pl.splitk > 1) bytes = std::max(bytes, (size_t)pl.splitk * npix * ctot_of(d) * sizeof(float));
   return align_up(bytes, 256) + 256;
 }
@@ -95,6 +103,39 @@ int ms_conv_block_fwd(const ms_conv_desc* d, const float* x, const float* x2, co
   a.a_vec = (a.Kg % 4 == 0) && (((uintptr_t)w & 15) == 0);
   a.ep = d->mode == MS_BARE ? EP_BARE : d->mode == MS_LRELU ? EP_LRELU : d->mode == MS_BN_EVAL ? EP_BN_EVAL : EP_RAW_STATS;
   a.slope = d->slope; a.eps = d->eps;
+  const PatchPlan pp = fwd_patch_plan(d);
+  if (pp.ok) {
+    // rows >= 16 wide: patch-staged kernel (raw input patch in LDS, no im2col address math in the K loop)
+    const bool one_d = d->H == 1 && d->KH == 1;
+    PatchArgs q = {};
+    q.A = w; q.src = x; q.src2 = x2; q.out = a.out;
+    q.bias = bias; q.bn_g = gamma; q.bn_b = beta; q.bn_m = running_mean; q.bn_v = running_var;
+    q.stats = (float*)workspace;
+    q.counts = (float*)((char*)workspace + align_up((size_t)pp.n_tiles * C * 2 * sizeof(float), 256));
+    q.Mg = d->Cout; q.Kg = a.Kg; q.groups = d->groups; q.Kc = d->Cin; q.bcast = a.bcast; q.a_vec = a.a_vec; q.ep = a.ep;
+    const int cin_tot = a.src_ctotal;
+    if (one_d) {            // the batch axis is the row axis of one image
+      q.SRCH = d->B; q.SRCW = d->W; q.s_img = 0; q.s_chan = d->W; q.s_row = cin_tot * d->W;
+      q.OUTH = d->B; q.OUTW = d->OW; q.o_img = 0; q.o_chan = d->OW; q.o_row = C * d->OW;
+      q.PH = 0;
+    } else {
+      q.SRCH = d->H; q.SRCW = d->W; q.s_img = cin_tot * d->H * d->W; q.s_chan = d->H * d->W; q.s_row = d->W;
+      q.OUTH = d->OH; q.OUTW = d->OW; q.o_img = C * hw; q.o_chan = hw; q.o_row = d->OW;
+      q.PH = d->PH;
+    }
+    q.PW = d->PW; q.tiles_x = pp.tiles_x; q.tiles_y = pp.tiles_y; q.slope = d->slope; q.eps = d->eps;
+    const double flops = 2.0 * d->Cout * a.Kg * (double)npix * d->groups;
+    const double bytes = 4.0 * ((double)C * a.Kg + (double)d->B * cin_tot * d->H * d->W + (double)npix * C);
+    rc = launch_patch(q, pp, d->KH, d->KW, d->SW, d->in_mode == MS_IN_UP2ADD, flops, bytes, s);
+    if (rc) return rc;
+    if (d->mode == MS_BN_TRAIN) {
+      rc = launch_bn_finalize(q.stats, q.counts, pp.n_tiles, 0, npix, C, gamma, beta, running_mean, running_var, save, d->eps,
+                              d->momentum, s);
+      if (rc) return rc;
+      rc = launch_bn_apply(y_raw, y, save, C, hw, (size_t)npix * C, d->slope, s);
+    }
+    return rc;
+  }
   const GatherPlan pl = plan_gather(d->Cout, npix, d->groups, a.Kg);
   if (pl.splitk > 1) {
     a.part = (float*)workspace;
@@ -108,7 +149,7 @@ int ms_conv_block_fwd(const ms_conv_desc* d, const float* x, const float* x2, co
                                       save, d->B, C, hw, a.ep, d->slope, d->eps, d->momentum, s);
   }
   if (d->mode == MS_BN_TRAIN) {
-    rc = launch_bn_finalize(a.stats, pl.n_tiles, 64 * pl.tn, npix, C, gamma, beta, running_mean, running_var, save, d->eps,
+    rc = launch_bn_finalize(a.stats, nullptr, pl.n_tiles, 64 * pl.tn, npix, C, gamma, beta, running_mean, running_var, save, d->eps,
                             d->momentum, s);
     if (rc) return rc;
     rc = launch_bn_apply(y_raw, y, save, C, hw, (size_t)npix * C, d->slope, s);

@@ -11,7 +11,8 @@ namespace ms {
 // ----------------------------------------------------------------------------------------------
 // BatchNorm (training): finalize tile partials -> mean/invstd/scale/shift + running stats
 // stats: [n_tiles][C][2] (sum, M2 about tile mean); tile i holds min(tile_n, N - i*tile_n) values
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int n_tiles, int tile_n,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats,
+                                                          const float* __restrict__ counts, int n_tiles, int tile_n,
                                                           int N, int C, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* running_mean,
                                                           float* running_var, float* __restrict__ save, float eps,
@@ -28,7 +29,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   double q = 0.0;
   for (int i = t; i < n_tiles; i += 256) {
     const float* st = stats + ((size_t)i * C + c) * 2;
-    const int cnt = min(tile_n, N - i * tile_n);
+    const int cnt = counts ? (int)counts[i] : min(tile_n, N - i * tile_n);
     const double d = (double)st[0] / (double)cnt - mean;
     q += (double)st[1] + (double)cnt * d * d;
   }
@@ -489,10 +490,10 @@ static inline int red_blocks(size_t n) {
 }
 
 // ---- launchers used by api.hip
-int launch_bn_finalize(const float* stats, int n_tiles, int tile_n, int N, int C, const float* gamma, const float* beta,
-                       float* rm, float* rv, float* save, float eps, float momentum, hipStream_t s) {
+int launch_bn_finalize(const float* stats, const float* counts, int n_tiles, int tile_n, int N, int C, const float* gamma,
+                       const float* beta, float* rm, float* rv, float* save, float eps, float momentum, hipStream_t s) {
   TimingScope ts(s, 0, 8.0 * n_tiles * C, "bn_finalize C%d tiles%d", C, n_tiles);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, s, stats, n_tiles, tile_n, N, C, gamma, beta, rm, rv, save,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, s, stats, counts, n_tiles, tile_n, N, C, gamma, beta, rm, rv, save,
                      eps, momentum);
   return check_launch("bn_finalize_kernel");
 }

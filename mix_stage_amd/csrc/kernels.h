@@ -46,6 +46,30 @@ struct TimingScope {
   hipStream_t s_;
 };
 
+// ---- patch-staged forward conv (conv_patch.hip)
+struct PatchArgs {
+  const float* A;      // [groups][Mg][Kg]
+  const float* src;    // UP2: the half-resolution tensor a
+  const float* src2;   // UP2: residual r (full resolution); strides below describe r / the plain input
+  float* out;
+  const float* bias;
+  const float* bn_g;
+  const float* bn_b;
+  const float* bn_m;
+  const float* bn_v;
+  float* stats;        // EP_RAW_STATS: [n_tiles][ctot][2]
+  float* counts;       // EP_RAW_STATS: [n_tiles] valid pixels per tile
+  int Mg, Kg, groups, Kc, bcast, a_vec, ep;
+  int SRCH, SRCW, s_img, s_chan, s_row;   // source image rows/cols and element strides
+  int OUTH, OUTW, o_img, o_chan, o_row;
+  int PH, PW, tiles_x, tiles_y;
+  float slope, eps;
+};
+struct PatchPlan { int ok, tm, tw, tiles_y, tiles_x, n_tiles; };
+PatchPlan plan_patch(int nd, int Mg, int groups, int KH, int KW, int SH, int SW, int B, int OH, int OW);
+int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S, bool up2, double flops, double bytes,
+                 hipStream_t s);
+
 struct GatherPlan { int tm, tn, splitk, k_per_split, n_tiles; };
 // tile shape + split-K factor for an (Mg x npix) output per z-slice (z = groups * parity classes), reduction Kg
 GatherPlan plan_gather(int Mg, int npix, int zcount, int Kg);
@@ -61,8 +85,8 @@ int launch_wgrad(WgradArgs a, bool up2, float* dw, float* partial_ws, hipStream_
 int launch_transpose_weight(const float* w, float* wt, int groups, int Cog, int Cig, int KH, int KW, int SH, int SW,
                             int PH, int PW, hipStream_t s);
 size_t dgrad_weight_elems(int groups, int Cog, int Cig, int KH, int KW, int SH, int SW);
-int launch_bn_finalize(const float* stats, int n_tiles, int tile_n, int N, int C, const float* gamma, const float* beta,
-                       float* rm, float* rv, float* save, float eps, float momentum, hipStream_t s);
+int launch_bn_finalize(const float* stats, const float* counts, int n_tiles, int tile_n, int N, int C, const float* gamma,
+                       const float* beta, float* rm, float* rv, float* save, float eps, float momentum, hipStream_t s);
 int launch_bn_apply(const float* y_raw, float* y, const float* save, int C, int HW, size_t total, float slope, hipStream_t s);
 int bwd_chunks(int B, int C, int* b_per_chunk);
 int launch_bn_bwd(const float* dy, const float* y_raw, const float* save, const float* gamma, float* partial, float* dyr,
