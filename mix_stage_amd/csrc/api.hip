@@ -124,6 +124,7 @@ int ms_conv_block_fwd(const ms_conv_desc* d, const float* x, const float* x2, co
       q.PH = d->PH;
     }
     q.PW = d->PW; q.tiles_x = pp.tiles_x; q.tiles_y = pp.tiles_y; q.slope = d->slope; q.eps = d->eps;
+    q.o_sh = 1; q.o_sw = 1; q.o_ry = 0; q.o_rx = 0;
     const double flops = 2.0 * d->Cout * a.Kg * (double)npix * d->groups;
     const double bytes = 4.0 * ((double)C * a.Kg + (double)d->B * cin_tot * d->H * d->W + (double)npix * C);
     rc = launch_patch(q, pp, d->KH, d->KW, d->SW, d->in_mode == MS_IN_UP2ADD, flops, bytes, s);
@@ -210,9 +211,52 @@ int ms_conv_block_bwd(const ms_conv_desc* d, const float* x, const float* x2, co
   if (dx) {
     const int tg = bcast ? 1 : d->groups;          // broadcast input: all groups sum into the same channels
     const int tcog = bcast ? C : d->Cout;
-    rc = launch_transpose_weight(w, wt, tg, tcog, d->Cin, d->KH, d->KW, d->SH, d->SW, d->PH, d->PW, s);
-    if (rc) return rc;
     const int jh = cdiv(d->KH, d->SH), jw = cdiv(d->KW, d->SW);
+    const bool one_d = d->H == 1 && d->KH == 1;
+    const int ncls = d->SH * d->SW;
+    // patch-staged path: each output-parity class is a dense stride-1 forward conv of dy_raw with the class's taps
+    // reversed (weights prepared by transpose_weight_kernel(flip=1)); outputs are scattered with stride (SH, SW)
+    const PatchPlan pp0 = plan_patch(one_d ? 1 : 2, d->Cin, tg, jh, jw, 1, 1, d->B, cdiv(d->H, d->SH), cdiv(d->W, d->SW));
+    rc = launch_transpose_weight(w, wt, tg, tcog, d->Cin, d->KH, d->KW, d->SH, d->SW, d->PH, d->PW, pp0.ok ? 1 : 0, s);
+    if (rc) return rc;
+    if (pp0.ok) {
+      const int Kg2 = tcog * jh * jw;
+      const int cin_tot = tg * d->Cin;
+      for (int cls = 0; cls < ncls; ++cls) {
+        const int ry = cls / d->SW, rx = cls - ry * d->SW;
+        const int kh0 = (ry + d->PH) % d->SH, kw0 = (rx + d->PW) % d->SW;
+        const int cy = (ry + d->PH - kh0) / d->SH, cx = (rx + d->PW - kw0) / d->SW;
+        const int QH = (d->H - ry + d->SH - 1) / d->SH, QW = (d->W - rx + d->SW - 1) / d->SW;
+        if (QH <= 0 || QW <= 0) continue;
+        const PatchPlan pp = plan_patch(one_d ? 1 : 2, d->Cin, tg, jh, jw, 1, 1, d->B, QH, QW);
+        PatchPlan use = pp;
+        if (!pp.ok) {               // a smaller class than the planning one: reuse the plan geometry, recompute tiles
+          use = pp0;
+          const int rows = one_d ? d->B : QH, th = 64 * use.tm / use.tw;
+          use.tiles_y = cdiv(rows, th); use.tiles_x = cdiv(QW, use.tw);
+          use.n_tiles = (one_d ? 1 : d->B) * use.tiles_y * use.tiles_x;
+        }
+        PatchArgs q = {};
+        q.A = wt + (size_t)cls * tg * d->Cin * Kg2; q.src = g; q.out = dx; q.out2 = dx2;
+        q.Mg = d->Cin; q.Kg = Kg2; q.groups = tg; q.Kc = tcog; q.bcast = 0; q.a_vec = (Kg2 % 4 == 0);
+        q.ep = up2 ? EP_DGRAD_UP2 : EP_BARE; q.is_dgrad = 1;
+        if (one_d) {
+          q.SRCH = d->B; q.SRCW = d->OW; q.s_img = 0; q.s_chan = d->OW; q.s_row = C * d->OW;
+          q.OUTH = d->B; q.OUTW = QW; q.o_img = 0; q.o_chan = d->W; q.o_row = cin_tot * d->W;
+          q.PH = 0; q.o_sh = 1; q.o_ry = 0;
+        } else {
+          q.SRCH = d->OH; q.SRCW = d->OW; q.s_img = C * hw; q.s_chan = hw; q.s_row = d->OW;
+          q.OUTH = QH; q.OUTW = QW; q.o_img = cin_tot * d->H * d->W; q.o_chan = d->H * d->W; q.o_row = d->W;
+          q.PH = (jh - 1) - cy; q.o_sh = d->SH; q.o_ry = ry;
+        }
+        q.PW = (jw - 1) - cx; q.o_sw = d->SW; q.o_rx = rx;
+        q.tiles_x = use.tiles_x; q.tiles_y = use.tiles_y;
+        const double flops = 2.0 * d->Cin * Kg2 * (double)d->B * QH * QW * tg;
+        const double bytes = 4.0 * ((double)tg * d->Cin * Kg2 + (double)d->B * C * hw / ncls + (double)d->B * cin_tot * QH * QW);
+        rc = launch_patch(q, use, jh, jw, 1, false, flops, bytes, s);
+        if (rc) return rc;
+      }
+    } else {
     GatherArgs a = {};
     a.A = wt; a.src = g; a.out = dx; a.out2 = dx2;
     a.Mg = d->Cin; a.Kg = tcog * jh * jw; a.groups = tg; a.Kc = tcog; a.src_ctotal = C;
@@ -232,6 +276,7 @@ int ms_conv_block_bwd(const ms_conv_desc* d, const float* x, const float* x2, co
     if (pl.splitk > 1) {
       rc = launch_splitk_dgrad_epilogue(dg_part, pl.splitk, a.part_stride, dx, dx2, a.part_stride, d->W, up2 ? 1 : 0, s);
       if (rc) return rc;
+    }
     }
   }
 

@@ -426,7 +426,7 @@ __global__ void reduce_splits_kernel(const float* __restrict__ part, float* __re
 //   wpar[cls][g][ci][co][jh][jw] = w[g][co][ci][kh0 + SH*jh][kw0 + SW*jw]   (0 beyond the kernel)
 // with kh0 = (ry+PH)%SH, kw0 = (rx+PW)%SW, JH = ceil(KH/SH), JW = ceil(KW/SW).  Stride 1 -> one slab, all taps.
 __global__ void transpose_weight_kernel(const float* __restrict__ w, float* __restrict__ wt, int groups, int Cog,
-                                        int Cig, int KH, int KW, int SH, int SW, int PH, int PW) {
+                                        int Cig, int KH, int KW, int SH, int SW, int PH, int PW, int flip) {
   const int JH = (KH + SH - 1) / SH, JW = (KW + SW - 1) / SW, J = JH * JW;
   const int per_g = Cog * Cig * J, per_cls = groups * per_g;
   const int total = SH * SW * per_cls;
@@ -437,7 +437,9 @@ __global__ void transpose_weight_kernel(const float* __restrict__ w, float* __re
     r -= g * per_g;                  // index in wpar[cls][g]: (ci, co, jh, jw)
     const int ci = r / (Cog * J);
     r -= ci * Cog * J;
-    const int co = r / J, j = r - co * J, jh = j / JW, jw = j - jh * JW;
+    const int co = r / J, j = r - co * J;
+    int jh = j / JW, jw = j - jh * JW;
+    if (flip) { jh = JH - 1 - jh; jw = JW - 1 - jw; }   // taps reversed: the data gradient becomes a forward conv
     const int ry = cls / SW, rx = cls - ry * SW;
     const int kh = (ry + PH) % SH + SH * jh, kw = (rx + PW) % SW + SW * jw;
     float v = 0.f;
@@ -700,12 +702,12 @@ size_t dgrad_weight_elems(int groups, int Cog, int Cig, int KH, int KW, int SH, 
 }
 
 int launch_transpose_weight(const float* w, float* wt, int groups, int Cog, int Cig, int KH, int KW, int SH, int SW,
-                            int PH, int PW, hipStream_t s) {
+                            int PH, int PW, int flip, hipStream_t s) {
   const int J = cdiv(KH, SH) * cdiv(KW, SW);
   const int total = SH * SW * groups * Cog * Cig * J;
   TimingScope ts(s, 0, 8.0 * total, "transpose_weight n%d", total);
   hipLaunchKernelGGL(transpose_weight_kernel, dim3(min(cdiv(total, 256), 4096)), dim3(256), 0, s, w, wt, groups, Cog, Cig, KH,
-                     KW, SH, SW, PH, PW);
+                     KW, SH, SW, PH, PW, flip);
   return check_launch("transpose_weight_kernel");
 }
 

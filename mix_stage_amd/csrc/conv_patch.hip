@@ -20,7 +20,7 @@ template <int KH, int KW>
 struct PatchCfg {
   static constexpr int KHW = KH * KW;
   // channels per K-chunk: K_step = CK*KHW in [36, 64], multiple of 4
-  static constexpr int CK = KHW == 1 ? 64 : KHW == 2 ? 32 : KHW == 3 ? 16 : KHW == 4 ? 16 : KHW == 9 ? 4
+  static constexpr int CK = KHW == 1 ? 32 : KHW == 2 ? 16 : KHW == 3 ? 16 : KHW == 4 ? 16 : KHW == 9 ? 4
                             : KHW == 16 ? 4 : KHW == 24 ? 2 : 4;
   static constexpr int KSTEP = CK * KHW;
 };
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PatchArgs p) {
     const int ty = nloc / TW, tx = nloc - ty * TW;
     const int oy = oy0 + ty, ox = ox0 + tx;
     cval[j] = (oy < p.OUTH) & (ox < p.OUTW);
-    ooff[j] = img * p.o_img + oy * p.o_row + ox;            // + channel * o_chan
+    ooff[j] = img * p.o_img + (oy * p.o_sh + p.o_ry) * p.o_row + ox * p.o_sw + p.o_rx;   // + channel * o_chan
   }
   const int ep = p.ep;
 #pragma unroll
@@ -244,7 +244,17 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PatchArgs p) {
         if (ep == EP_RAW_STATS) acc[i][j][r] = v;
         if (ep == EP_BN_EVAL) v = lrelu(fmaf(v, sc, sh), p.slope);
         if (ep == EP_LRELU) v = lrelu(v, p.slope);
-        if (mval && cval[j]) p.out[(size_t)ooff[j] + (size_t)chn * p.o_chan] = v;
+        if (ep == EP_DGRAD_UP2) {
+          // 1-D stride-1 data gradient of an upsample-add input: out2 = grad of the residual (full resolution),
+          // out = grad of the half-resolution tensor = sum over the pair of columns (adjacent lanes)
+          const float pr = __shfl_xor(v, 1);
+          if (mval && cval[j]) {
+            p.out2[(size_t)ooff[j] + (size_t)chn * p.o_chan] = v;
+            if (!(lane & 1)) p.out[(size_t)(ooff[j] >> 1) + (size_t)chn * (p.o_chan >> 1)] = v + pr;
+          }
+        } else if (mval && cval[j]) {
+          p.out[(size_t)ooff[j] + (size_t)chn * p.o_chan] = v;
+        }
       }
     }
   }
@@ -293,11 +303,12 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PatchArgs p) {
 
 // ---------------------------------------------------------------------------------------------
 // dispatch
+static int g_patch_min_wgs = 96;   // below this many workgroups the split-K im2col path is used instead
 PatchPlan plan_patch(int nd, int Mg, int groups, int KH, int KW, int SH, int SW, int B, int OH, int OW) {
   PatchPlan pl = {0, 1, 64, 0, 0, 0};
   const int S = SW;
   if (nd == 2 && SH != SW) return pl;
-  const bool known = (KH == 1 && KW == 3 && S == 1) || (KH == 1 && KW == 4 && S == 2) || (KH == 1 && KW == 4 && S == 1) ||
+  const bool known = (KH == 1 && KW == 2 && S == 1) || (KH == 2 && KW == 2 && S == 1) || (KH == 1 && KW == 3 && S == 1) || (KH == 1 && KW == 4 && S == 2) || (KH == 1 && KW == 4 && S == 1) ||
                      (KH == 1 && KW == 1 && S == 1) || (KH == 3 && KW == 3 && S == 1) || (KH == 4 && KW == 4 && S == 2) ||
                      (KH == 3 && KW == 8 && S == 1);
   if (!known) return pl;
@@ -318,7 +329,7 @@ PatchPlan plan_patch(int nd, int Mg, int groups, int KH, int KW, int SH, int SW,
   pl.tiles_y = cdiv(rows, th); pl.tiles_x = cdiv(OW, tw);
   pl.n_tiles = imgs * pl.tiles_y * pl.tiles_x;
   // too few workgroups: the split-K im2col path spreads the weight stream better
-  if ((long)pl.n_tiles * cdiv(Mg, 64 * tm) * groups < 96) pl.ok = 0;
+  if ((long)pl.n_tiles * cdiv(Mg, 64 * tm) * groups < g_patch_min_wgs) pl.ok = 0;
   return pl;
 }
 
@@ -344,6 +355,8 @@ static void launch_patch_k(const PatchArgs& a, int kh, int kw, int s_, int tw, b
   } else if (kh == 1 && kw == 4 && s_ == 2) launch_patch_tw<TM, 1, 4, 2, false>(a, tw, grid, s);
   else if (kh == 1 && kw == 4 && s_ == 1) launch_patch_tw<TM, 1, 4, 1, false>(a, tw, grid, s);
   else if (kh == 1 && kw == 1 && s_ == 1) launch_patch_tw<TM, 1, 1, 1, false>(a, tw, grid, s);
+  else if (kh == 1 && kw == 2 && s_ == 1) launch_patch_tw<TM, 1, 2, 1, false>(a, tw, grid, s);
+  else if (kh == 2 && kw == 2 && s_ == 1) launch_patch_tw<TM, 2, 2, 1, false>(a, tw, grid, s);
   else if (kh == 3 && kw == 3 && s_ == 1) launch_patch_tw<TM, 3, 3, 1, false>(a, tw, grid, s);
   else if (kh == 4 && kw == 4 && s_ == 2) launch_patch_tw<TM, 4, 4, 2, false>(a, tw, grid, s);
   else launch_patch_tw<TM, 3, 8, 1, false>(a, tw, grid, s);
@@ -354,7 +367,7 @@ int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S,
   const int bm = 64 * pl.tm;
   dim3 grid(pl.n_tiles, cdiv(a.Mg, bm), a.groups);
   if (grid.y > 65535 || grid.z > 65535) return set_error("conv grid too large");
-  TimingScope ts(s, flops, bytes, "conv_fwd_patch k%dx%d s%d Mg%d Kg%d g%d tiles%d tile%d tw%d%s", KH, KW, S, a.Mg, a.Kg,
+  TimingScope ts(s, flops, bytes, "conv_%s_patch k%dx%d s%d Mg%d Kg%d g%d tiles%d tile%d tw%d%s", a.is_dgrad ? "dgrad" : "fwd", KH, KW, S, a.Mg, a.Kg,
                  a.groups, pl.n_tiles, bm, pl.tw, a.ep == EP_RAW_STATS ? " +bnstats" : "");
   if (pl.tm == 2) launch_patch_k<2>(a, KH, KW, S, pl.tw, up2, grid, s);
   else launch_patch_k<1>(a, KH, KW, S, pl.tw, up2, grid, s);
@@ -362,3 +375,9 @@ int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S,
 }
 
 }  // namespace ms
+
+extern "C" int ms_debug_set_patch_min_workgroups(int n) {
+  const int old = ms::g_patch_min_wgs;
+  ms::g_patch_min_wgs = n;
+  return old;
+}

@@ -62,6 +62,9 @@ struct PatchArgs {
   int Mg, Kg, groups, Kc, bcast, a_vec, ep;
   int SRCH, SRCW, s_img, s_chan, s_row;   // source image rows/cols and element strides
   int OUTH, OUTW, o_img, o_chan, o_row;
+  int o_sh, o_sw, o_ry, o_rx;   // output scatter: (oy*o_sh + o_ry, ox*o_sw + o_rx); data gradient of a strided conv
+  float* out2;                  // EP_DGRAD_UP2: gradient of the residual
+  int is_dgrad;                 // label only
   int PH, PW, tiles_x, tiles_y;
   float slope, eps;
 };
@@ -83,7 +86,7 @@ int launch_splitk_dgrad_epilogue(const float* part, int splitk, size_t part_stri
 int wgrad_splits(int Cog, int Kg, int groups, int Npix);
 int launch_wgrad(WgradArgs a, bool up2, float* dw, float* partial_ws, hipStream_t s);
 int launch_transpose_weight(const float* w, float* wt, int groups, int Cog, int Cig, int KH, int KW, int SH, int SW,
-                            int PH, int PW, hipStream_t s);
+                            int PH, int PW, int flip, hipStream_t s);
 size_t dgrad_weight_elems(int groups, int Cog, int Cig, int KH, int KW, int SH, int SW);
 int launch_bn_finalize(const float* stats, const float* counts, int n_tiles, int tile_n, int N, int C, const float* gamma,
                        const float* beta, float* rm, float* rv, float* save, float eps, float momentum, hipStream_t s);

@@ -75,9 +75,19 @@ def _mk_block(mod, case, seed=0):
   return blk
 
 
+@pytest.fixture(params=['auto', 'patch'])
+def kernel_path(request):
+  """'patch' forces the patch-staged conv kernel wherever its geometry allows (it is normally chosen only for
+  launches with >= 96 workgroups); 'auto' leaves the small test shapes on the split-K im2col kernel."""
+  from mix_stage_amd import _lib
+  old = _lib.lib().ms_debug_set_patch_min_workgroups(0 if request.param == 'patch' else 96)
+  yield request.param
+  _lib.lib().ms_debug_set_patch_min_workgroups(old)
+
+
 @pytest.mark.parametrize('case', BLOCK_CASES, ids=[c[0] for c in BLOCK_CASES])
 @pytest.mark.parametrize('B', [3])
-def test_conv_block_train_fwd_bwd(case, B):
+def test_conv_block_train_fwd_bwd(case, B, kernel_path):
   import mix_stage_amd as A
   name, typ, cin, cout, k, s, g, sp, in_mode = case
   # deterministic inputs.  (LeakyReLU is discontinuous in its derivative: a pre-activation within fp32 rounding of
@@ -142,7 +152,7 @@ def _conv_block_case(case, B, seed):
 
 @pytest.mark.parametrize('case', [BLOCK_CASES[1], BLOCK_CASES[3], BLOCK_CASES[16], BLOCK_CASES[19]],
                          ids=lambda c: c[0])
-def test_conv_block_eval_mode(case):
+def test_conv_block_eval_mode(case, kernel_path):
   import mix_stage_amd as A
   name, typ, cin, cout, k, s, g, sp, in_mode = case
   gen = torch.Generator().manual_seed(5)
@@ -159,7 +169,7 @@ def test_conv_block_eval_mode(case):
 @pytest.mark.parametrize('cin,cout,k,s,p,g,T,lrelu', [(256, 104, 1, 1, 0, 8, 64, None), (256, 8, 1, 1, 0, 1, 64, None),
                                                       (104, 64, 4, 2, 1, 1, 64, 0.2), (256, 1, 4, 1, 0, 1, 15, None),
                                                       (6, 5, 3, 2, 1, 2, 21, 0.2)])
-def test_bare_conv_fwd_bwd(cin, cout, k, s, p, g, T, lrelu):
+def test_bare_conv_fwd_bwd(cin, cout, k, s, p, g, T, lrelu, kernel_path):
   from mix_stage_amd.layers import bare_conv
   gen = torch.Generator().manual_seed(cin + cout)
   conv = torch.nn.Conv1d(cin * g, cout * g, k, s, padding=p, groups=g)
