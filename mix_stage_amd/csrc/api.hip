@@ -192,8 +192,9 @@ int ms_conv_block_bwd(const ms_conv_desc* d, const float* x, const float* x2, co
 
   // 1. gradient wrt the raw conv output (+ per-channel column sums = bias gradient)
   const float* g = dy;
+  int bias_done = 0;
   if (d->mode == MS_BN_TRAIN) {
-    rc = launch_bn_bwd(dy, y_raw, save, gamma, bn_part, dyr, colpart, dgamma, dbeta, d->B, C, hw, d->slope, s);
+    rc = launch_bn_bwd(dy, y_raw, save, gamma, bn_part, dyr, colpart, dbias, dgamma, dbeta, d->B, C, hw, d->slope, &bias_done, s);
     g = dyr;
   } else if (d->mode == MS_LRELU) {
     rc = launch_act_bwd(dy, y, dyr, colpart, d->B, C, hw, 1, d->slope, s);
@@ -202,7 +203,7 @@ int ms_conv_block_bwd(const ms_conv_desc* d, const float* x, const float* x2, co
     rc = launch_act_bwd(dy, nullptr, nullptr, colpart, d->B, C, hw, 0, 0.f, s);
   }
   if (rc) return rc;
-  if (dbias) {
+  if (dbias && !bias_done) {
     rc = launch_colsum_finalize(colpart, dbias, d->B, C, s);
     if (rc) return rc;
   }

@@ -413,6 +413,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     }
 }
 
+// many splits, few outputs: one wave per output element, lanes stride over the splits, fixed-order wave reduction
+__global__ __launch_bounds__(256) void reduce_splits_wave_kernel(const float* __restrict__ part, float* __restrict__ out, int n,
+                                                                 int splits) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = lane; k < splits; k += 64) s += part[(size_t)k * n + i];
+  s = wave_sum(s);
+  if (lane == 0) out[i] = s;
+}
+
 // out[i] = sum_s part[s][i]   (fixed order -> bitwise reproducible)
 __global__ void reduce_splits_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int splits) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -691,7 +703,10 @@ int launch_wgrad(WgradArgs a, bool up2, float* dw, float* partial_ws, hipStream_
   if (a.splits > 1) {
     const int n = ctot * a.Kg;
     TimingScope ts(s, 0, 4.0 * n * (a.splits + 1), "wgrad_reduce_splits n%d splits%d", n, a.splits);
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3(min(cdiv(n, 256), 2048)), dim3(256), 0, s, partial_ws, dw, n, a.splits);
+    if (a.splits >= 32 && n <= 65536)
+      hipLaunchKernelGGL(reduce_splits_wave_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, partial_ws, dw, n, a.splits);
+    else
+      hipLaunchKernelGGL(reduce_splits_kernel, dim3(min(cdiv(n, 256), 2048)), dim3(256), 0, s, partial_ws, dw, n, a.splits);
     rc = check_launch("reduce_splits_kernel");
   }
   return rc;

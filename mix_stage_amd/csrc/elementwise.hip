@@ -145,6 +145,56 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
 }
 
+// Fused BatchNorm+LeakyReLU backward for channels with <= 256*NE values: one workgroup owns a channel, keeps dy / y_raw
+// in registers across the reduction, and writes dy_raw, dgamma, dbeta and the bias gradient in one launch.
+template <int NE>
+__global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const float* __restrict__ dy, const float* __restrict__ y_raw,
+                                                           const float* __restrict__ save, const float* __restrict__ gamma,
+                                                           float* __restrict__ dyr, float* dbias, float* dgamma, float* dbeta,
+                                                           int B, int C, int HW, float slope) {
+  __shared__ float red[4];
+  const int c = blockIdx.x, t = threadIdx.x;
+  const int n = B * HW;
+  const float mean = save[c], invstd = save[C + c], sc = save[2 * C + c], sh = save[3 * C + c];
+  float dz[NE], xh[NE];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = t + i * 256;
+    dz[i] = 0.f; xh[i] = 0.f;
+    if (e < n) {
+      const int b = e / HW, pix = e - b * HW;
+      const size_t off = ((size_t)b * C + c) * HW + pix;
+      const float yr = y_raw[off];
+      const float z = fmaf(yr, sc, sh);
+      dz[i] = dy[off] * (z > 0.f ? 1.f : slope);
+      xh[i] = (yr - mean) * invstd;
+      s1 += dz[i];
+      s2 += dz[i] * xh[i];
+    }
+  }
+  s1 = block_sum_256(s1, red);
+  s2 = block_sum_256(s2, red);
+  const float invN = 1.0f / (float)n;
+  const float gi = gamma[c] * invstd, m1 = s1 * invN, m2 = s2 * invN;
+  float cs = 0.f;
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = t + i * 256;
+    if (e < n) {
+      const int b = e / HW, pix = e - b * HW;
+      const float v = gi * (dz[i] - m1 - xh[i] * m2);
+      dyr[((size_t)b * C + c) * HW + pix] = v;
+      cs += v;
+    }
+  }
+  cs = block_sum_256(cs, red);
+  if (t == 0) {
+    if (dbias) dbias[c] = cs;
+    if (dgamma) { dgamma[c] = s2; dbeta[c] = s1; }
+  }
+}
+
 // activation backward for blocks without BN: mode 1 (LRELU): dyr = dy * (y>0 ? 1 : slope); mode 0 (BARE): no
 // write (dyr == dy).  Always emits per-channel colsum partials (the bias gradient).
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
@@ -516,8 +566,23 @@ int bwd_chunks(int B, int C, int* b_per_chunk) {
   return (B + bpc - 1) / bpc;
 }
 
+// returns 1 if the fused single-launch form was used (dbias already final, no colsum_finalize needed)
 int launch_bn_bwd(const float* dy, const float* y_raw, const float* save, const float* gamma, float* partial, float* dyr,
-                  float* colpart, float* dgamma, float* dbeta, int B, int C, int HW, float slope, hipStream_t s) {
+                  float* colpart, float* dbias, float* dgamma, float* dbeta, int B, int C, int HW, float slope, int* fused,
+                  hipStream_t s) {
+  *fused = 0;
+  const long n = (long)B * HW;
+  if (n <= 256 * 16) {
+    TimingScope ts(s, 0, 12.0 * B * C * HW, "bn_bwd_fused C%d HW%d B%d", C, HW, B);
+    if (n <= 256 * 4)
+      hipLaunchKernelGGL(bn_bwd_fused_kernel<4>, dim3(C), dim3(256), 0, s, dy, y_raw, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope);
+    else if (n <= 256 * 8)
+      hipLaunchKernelGGL(bn_bwd_fused_kernel<8>, dim3(C), dim3(256), 0, s, dy, y_raw, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope);
+    else
+      hipLaunchKernelGGL(bn_bwd_fused_kernel<16>, dim3(C), dim3(256), 0, s, dy, y_raw, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope);
+    *fused = 1;
+    return check_launch("bn_bwd_fused_kernel");
+  }
   int bpc;
   const int nchunk = bwd_chunks(B, C, &bpc);
   TimingScope ts(s, 0, 20.0 * B * C * HW, "bn_bwd(reduce+apply) C%d HW%d B%d", C, HW, B);

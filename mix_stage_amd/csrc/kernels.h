@@ -93,7 +93,8 @@ int launch_bn_finalize(const float* stats, const float* counts, int n_tiles, int
 int launch_bn_apply(const float* y_raw, float* y, const float* save, int C, int HW, size_t total, float slope, hipStream_t s);
 int bwd_chunks(int B, int C, int* b_per_chunk);
 int launch_bn_bwd(const float* dy, const float* y_raw, const float* save, const float* gamma, float* partial, float* dyr,
-                  float* colpart, float* dgamma, float* dbeta, int B, int C, int HW, float slope, hipStream_t s);
+                  float* colpart, float* dbias, float* dgamma, float* dbeta, int B, int C, int HW, float slope, int* fused,
+                  hipStream_t s);
 int launch_act_bwd(const float* dy, const float* y, float* dyr, float* colpart, int B, int C, int HW, int mode, float slope,
                    hipStream_t s);
 int launch_colsum_finalize(const float* colpart, float* out, int B, int C, hipStream_t s);

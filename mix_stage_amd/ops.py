@@ -86,6 +86,18 @@ class ConvGeom:
     return d
 
 
+def _grad_slot(param, shape_like):
+  """Direct gradient write-through: FlatAdam gives every parameter a view into the flat gradient buffer
+  (`_ms_grad_slot`) and marks it fresh at zero_grad.  The first gradient of a step is written straight into the slot
+  by the kernels (autograd then gets None for it: no accumulate kernel); later contributions in the same step fall
+  back to a temporary that autograd adds."""
+  slot = getattr(param, '_ms_grad_slot', None) if param is not None else None
+  if slot is not None and getattr(param, '_ms_grad_fresh', False) and torch.is_grad_enabled() is False:
+    param._ms_grad_fresh = False
+    return slot, True
+  return torch.empty_like(shape_like), False
+
+
 class _ConvBlockFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, x, x2, w, bias, gamma, beta, geom, mode, in_mode, stats):
@@ -121,6 +133,7 @@ class _ConvBlockFn(torch.autograd.Function):
     ctx.geom_desc = d
     ctx.mode, ctx.in_mode = mode, in_mode
     ctx.has_bias = bias is not None
+    ctx.params = (w, bias, gamma, beta)          # parameter objects (for their gradient slots)
     ctx.save_for_backward(x, x2, w, gamma, y_raw, y if mode == MS_LRELU else None, save)
     return y
 
@@ -139,15 +152,22 @@ class _ConvBlockFn(torch.autograd.Function):
     want_dx = need_x or (up2 and need_x2)
     dx = torch.empty_like(x) if want_dx else None
     dx2 = torch.empty_like(x2) if (want_dx and up2) else None
-    dw = torch.empty_like(w) if need_w else None
-    dbias = torch.empty(w.shape[0], dtype=torch.float32, device=dev) if (need_w and ctx.has_bias) else None
-    dgamma = torch.empty_like(gamma) if need_bn else None
-    dbeta = torch.empty_like(gamma) if need_bn else None
+    pw, pbias, pgamma, pbeta = ctx.params
+    dw = dbias = dgamma = dbeta = None
+    direct_w = direct_b = direct_g = direct_be = False
+    if need_w:
+      dw, direct_w = _grad_slot(pw, w)
+      if ctx.has_bias:
+        dbias, direct_b = _grad_slot(pbias, pbias)
+    if need_bn:
+      dgamma, direct_g = _grad_slot(pgamma, gamma)
+      dbeta, direct_be = _grad_slot(pbeta, gamma)
     ws = workspace(d._bwd_ws, dev)
     check(lib().ms_conv_block_bwd(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(gamma), None, None, _ptr(y_raw),
                                   _ptr(y), _ptr(save), _ptr(dy), _ptr(dyr), _ptr(dx), _ptr(dx2), _ptr(dw), _ptr(dbias),
                                   _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), _stream()), 'ms_conv_block_bwd')
-    return dx, dx2, dw, dbias, dgamma, dbeta, None, None, None, None
+    return (dx, dx2, None if direct_w else dw, None if direct_b else dbias, None if direct_g else dgamma,
+            None if direct_be else dbeta, None, None, None, None)
 
 
 def conv_block(x, w, bias, geom, mode, gamma=None, beta=None, running_mean=None, running_var=None, x2=None,

@@ -80,6 +80,8 @@ class FlatAdam:
         p.data = view
         g = self.flat_g[o:o + p.numel()].view_as(p)
         p.grad = g
+        p._ms_grad_slot = g            # kernels write the step's first gradient straight into the flat buffer
+        p._ms_grad_fresh = False
         self._grad_views.append(g)
     self.lr, self.betas, self.eps, self.max_norm = lr, betas, eps, max_norm
     self.norm = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -88,6 +90,8 @@ class FlatAdam:
 
   def zero_grad(self):
     self.flat_g.zero_()
+    for p in self.params:
+      p._ms_grad_fresh = True
 
   def gather_foreign_grads(self):
     """If someone replaced p.grad (e.g. model.zero_grad(set_to_none=True) then backward), fold it back."""
