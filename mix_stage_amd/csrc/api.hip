@@ -34,7 +34,7 @@ static GatherPlan dgrad_plan(const ms_conv_desc* d) {
 
 static PatchPlan fwd_patch_plan(const ms_conv_desc* d) {
   const int nd = (d->H == 1 && d->KH == 1) ? 1 : 2;
-  return plan_patch(nd, d->Cout, d->groups, d->KH, d->KW, d->SH, d->SW, d->B, d->OH, d->OW);
+  return plan_patch(nd, d->Cout, d->groups, d->Cin, d->KH, d->KW, d->SH, d->SW, d->B, d->OH, d->OW);
 }
 
 static inline int ctot_of(const ms_conv_desc* d) { return d->groups * d->Cout; }
@@ -55,6 +55,7 @@ size_t ms_conv_block_fwd_workspace(const ms_conv_desc* d) {
   if (d->mode == MS_BN_TRAIN) bytes = std::max(bytes, (size_t)pl.n_tiles * ctot_of(d) * 2 * sizeof(float));
   if (pp.ok && d->mode == MS_BN_TRAIN)
     bytes = std::max(bytes, align_up((size_t)pp.n_tiles * ctot_of(d) * 2 * sizeof(float), 256) + (size_t)pp.n_tiles * sizeof(float));
+  if (pp.ok && pp.splitk > 1) bytes = std::max(bytes, (size_t)pp.splitk * npix * ctot_of(d) * sizeof(float));
   if (pl.splitk > 1) bytes = std::max(bytes, (size_t)pl.splitk * npix * ctot_of(d) * sizeof(float));
   return align_up(bytes, 256) + 256;
 }
@@ -70,6 +71,14 @@ size_t ms_conv_block_bwd_workspace(const ms_conv_desc* d) {
   bytes += align_up((size_t)ctot_of(d) * nchunk * sizeof(float), 256);      // colsum partials
   bytes += align_up(dgrad_weight_elems(d->groups, d->Cout, d->Cin, d->KH, d->KW, d->SH, d->SW) * sizeof(float), 256);
   bytes += align_up(wsize_of(d) * sizeof(float) * (splits > 1 ? splits : 0), 256);
+  {
+    const bool bc = d->in_mode == MS_IN_BCAST;
+    const int tg2 = bc ? 1 : d->groups, tcog2 = bc ? d->groups * d->Cout : d->Cout;
+    const bool one_d2 = d->H == 1 && d->KH == 1;
+    const PatchPlan pq = plan_patch(one_d2 ? 1 : 2, d->Cin, tg2, tcog2, cdiv(d->KH, d->SH), cdiv(d->KW, d->SW), 1, 1, d->B,
+                                    cdiv(d->H, d->SH), cdiv(d->W, d->SW));
+    if (pq.ok && pq.splitk > 1) bytes += align_up((size_t)pq.splitk * d->B * tg2 * d->Cin * d->H * d->W * sizeof(float), 256);
+  }
   const GatherPlan pl = dgrad_plan(d);
   if (pl.splitk > 1)
     bytes += align_up((size_t)pl.splitk * d->B * (d->in_mode == MS_IN_BCAST ? 1 : d->groups) * d->Cin * d->H * d->W * sizeof(float), 256);
@@ -125,10 +134,15 @@ int ms_conv_block_fwd(const ms_conv_desc* d, const float* x, const float* x2, co
     }
     q.PW = d->PW; q.tiles_x = pp.tiles_x; q.tiles_y = pp.tiles_y; q.slope = d->slope; q.eps = d->eps;
     q.o_sh = 1; q.o_sw = 1; q.o_ry = 0; q.o_rx = 0;
+    q.splitk = pp.splitk; q.chunks_per_split = pp.chunks_per_split;
+    if (pp.splitk > 1) { q.part = (float*)workspace; q.part_stride = (size_t)npix * C; }
     const double flops = 2.0 * d->Cout * a.Kg * (double)npix * d->groups;
     const double bytes = 4.0 * ((double)C * a.Kg + (double)d->B * cin_tot * d->H * d->W + (double)npix * C);
     rc = launch_patch(q, pp, d->KH, d->KW, d->SW, d->in_mode == MS_IN_UP2ADD, flops, bytes, s);
     if (rc) return rc;
+    if (pp.splitk > 1)
+      return launch_splitk_fwd_epilogue(q.part, pp.splitk, q.part_stride, bias, gamma, beta, running_mean, running_var, y_raw,
+                                        y, save, d->B, C, hw, a.ep, d->slope, d->eps, d->momentum, s);
     if (d->mode == MS_BN_TRAIN) {
       rc = launch_bn_finalize(q.stats, q.counts, pp.n_tiles, 0, npix, C, gamma, beta, running_mean, running_var, save, d->eps,
                               d->momentum, s);
@@ -217,7 +231,7 @@ int ms_conv_block_bwd(const ms_conv_desc* d, const float* x, const float* x2, co
     const int ncls = d->SH * d->SW;
     // patch-staged path: each output-parity class is a dense stride-1 forward conv of dy_raw with the class's taps
     // reversed (weights prepared by transpose_weight_kernel(flip=1)); outputs are scattered with stride (SH, SW)
-    const PatchPlan pp0 = plan_patch(one_d ? 1 : 2, d->Cin, tg, jh, jw, 1, 1, d->B, cdiv(d->H, d->SH), cdiv(d->W, d->SW));
+    const PatchPlan pp0 = plan_patch(one_d ? 1 : 2, d->Cin, tg, tcog, jh, jw, 1, 1, d->B, cdiv(d->H, d->SH), cdiv(d->W, d->SW));
     rc = launch_transpose_weight(w, wt, tg, tcog, d->Cin, d->KH, d->KW, d->SH, d->SW, d->PH, d->PW, pp0.ok ? 1 : 0, s);
     if (rc) return rc;
     if (pp0.ok) {
@@ -229,9 +243,10 @@ int ms_conv_block_bwd(const ms_conv_desc* d, const float* x, const float* x2, co
         const int cy = (ry + d->PH - kh0) / d->SH, cx = (rx + d->PW - kw0) / d->SW;
         const int QH = (d->H - ry + d->SH - 1) / d->SH, QW = (d->W - rx + d->SW - 1) / d->SW;
         if (QH <= 0 || QW <= 0) continue;
-        const PatchPlan pp = plan_patch(one_d ? 1 : 2, d->Cin, tg, jh, jw, 1, 1, d->B, QH, QW);
+        const PatchPlan pp = plan_patch(one_d ? 1 : 2, d->Cin, tg, tcog, jh, jw, 1, 1, d->B, QH, QW);
         PatchPlan use = pp;
-        if (!pp.ok) {               // a smaller class than the planning one: reuse the plan geometry, recompute tiles
+        use.splitk = pp0.splitk; use.chunks_per_split = pp0.chunks_per_split;   // one split factor for all classes
+        if (!pp.ok || pp.tm != pp0.tm || pp.tw != pp0.tw) {               // a smaller class than the planning one: reuse the plan geometry, recompute tiles
           use = pp0;
           const int rows = one_d ? d->B : QH, th = 64 * use.tm / use.tw;
           use.tiles_y = cdiv(rows, th); use.tiles_x = cdiv(QW, use.tw);
@@ -252,9 +267,19 @@ int ms_conv_block_bwd(const ms_conv_desc* d, const float* x, const float* x2, co
         }
         q.PW = (jw - 1) - cx; q.o_sw = d->SW; q.o_rx = rx;
         q.tiles_x = use.tiles_x; q.tiles_y = use.tiles_y;
+        q.splitk = use.splitk; q.chunks_per_split = use.chunks_per_split;
+        if (use.splitk > 1) {
+          q.part = dg_part; q.part_stride = (size_t)d->B * cin_tot * d->H * d->W;
+          q.ep = EP_BARE;               // partial tiles: plain full-resolution layout, the reduce kernel splits UP2
+        }
         const double flops = 2.0 * d->Cin * Kg2 * (double)d->B * QH * QW * tg;
         const double bytes = 4.0 * ((double)tg * d->Cin * Kg2 + (double)d->B * C * hw / ncls + (double)d->B * cin_tot * QH * QW);
         rc = launch_patch(q, use, jh, jw, 1, false, flops, bytes, s);
+        if (rc) return rc;
+      }
+      if (pp0.splitk > 1) {
+        const size_t n = (size_t)d->B * cin_tot * d->H * d->W;
+        rc = launch_splitk_dgrad_epilogue(dg_part, pp0.splitk, n, dx, dx2, n, d->W, up2 ? 1 : 0, s);
         if (rc) return rc;
       }
     } else {

@@ -527,7 +527,8 @@ int launch_gather(GatherArgs a, bool transposed, bool up2, const GatherPlan& pla
   const double opix = batch * a.OUTH * a.OUTW;
   TimingScope ts(s, 2.0 * a.Mg * a.Kg * (double)npix_cls * ncls * a.groups,
                  4.0 * ((double)ncls * a.groups * a.Mg * a.Kg + batch * a.src_ctotal * a.SRCH * a.SRCW + opix * a.groups * a.Mg),
-                 "%s k%dx%d s%d Mg%d Kg%d g%d N%.0f tile%d splitk%d%s", transposed ? "conv_dgrad" : "conv_fwd", a.KH, a.KW,
+                 "igemm_gather_kernel<%d,%d,%d,%d,%d,%d>|%s k%dx%d s%d Mg%d Kg%d g%d N%.0f tile%d splitk%d%s", plan.tm, plan.tn,
+                 a.KH, a.KW, transposed ? 1 : 0, (up2 && !transposed) ? 1 : 0, transposed ? "conv_dgrad" : "conv_fwd", a.KH, a.KW,
                  a.SW, a.Mg, a.Kg, a.groups, opix, bm, plan.splitk, a.ep == EP_RAW_STATS ? " +bnstats" : "");
   if (transposed) up2 = false;  // the UP2 split store of the data gradient is a runtime epilogue (EP_DGRAD_UP2)
   if (plan.tm == 2) {
@@ -694,7 +695,8 @@ int launch_wgrad(WgradArgs a, bool up2, float* dw, float* partial_ws, hipStream_
     const double batch = (double)a.Npix / ((double)a.OH * a.OW);
     TimingScope ts(s, 2.0 * a.Cog * a.Kg * (double)a.Npix * a.groups,
                    4.0 * ((double)a.Npix * ctot + batch * a.src_ctotal * a.H * a.W + (double)ctot * a.Kg),
-                   "conv_wgrad k%dx%d s%d Cog%d Kg%d g%d N%d splits%d", a.KH, a.KW, a.SW, a.Cog, a.Kg, a.groups, a.Npix,
+                   "wgrad_kernel<1,1,%d,%d,%d>|conv_wgrad k%dx%d s%d Cog%d Kg%d g%d N%d splits%d", a.KH, a.KW, up2 ? 1 : 0, a.KH,
+                   a.KW, a.SW, a.Cog, a.Kg, a.groups, a.Npix,
                    a.splits);
     if (up2) launch_wgrad_khw<true>(a, grid, s); else launch_wgrad_khw<false>(a, grid, s);
     rc = check_launch("wgrad_kernel");

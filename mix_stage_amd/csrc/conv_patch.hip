@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PatchArgs p) {
 
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wm = wid >> 1, wn = wid & 1, khalf = lane >> 5;
-  const int g = blockIdx.z, m0 = blockIdx.y * BM;
+  const int g = blockIdx.z / p.splitk, ks = blockIdx.z - g * p.splitk, m0 = blockIdx.y * BM;
   const int tiles_per_img = p.tiles_y * p.tiles_x;
   const int img = blockIdx.x / tiles_per_img;
   const int trem = blockIdx.x - img * tiles_per_img;
@@ -83,9 +83,10 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PatchArgs p) {
   const float* Ag = p.A + (size_t)g * p.Mg * Kg;
   const int img_base = img * p.s_img;
 
-  float4 ra[NA];
-  float rb[NP];
-  auto load_chunk = [&](int ci0) {
+  // two register sets: chunk c+2 is in flight from HBM/L2 while chunk c+1 waits in registers and chunk c computes
+  float4 ra0[NA], ra1[NA];
+  float rb0[NP], rb1[NP];
+  auto load_chunk = [&](int ci0, float4 (&ra)[NA], float (&rb)[NP]) {
     const int k0 = ci0 * KHW;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PatchArgs p) {
       }
     }
   };
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](int buf, const float4 (&ra)[NA], const float (&rb)[NP]) {
     float* As = smem + buf * STAGE;
     float* Ps = As + KSTEP * LDA;
 #pragma unroll
@@ -162,13 +163,9 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PatchArgs p) {
     b_chan[j] = base + khalf * (CP - (KH - 1) * RP - (KW - 1));       // k+1 = first tap of the next channel
   }
 
-  const int nchunks = (p.Kc + CK - 1) / CK;
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
-  for (int ch = 0; ch < nchunks; ++ch) {
-    const int cur = ch & 1;
-    if (ch + 1 < nchunks) load_chunk((ch + 1) * CK);
+  const int chunk_beg = ks * p.chunks_per_split;
+  const int nchunks = min((p.Kc + CK - 1) / CK - chunk_beg, p.chunks_per_split);
+  auto compute_chunk = [&](int cur) {
     const float* As = smem + cur * STAGE;
     const float* Ps = As + KSTEP * LDA;
     // operands of the next group of k-pairs are read from LDS while the current group's MFMAs issue
@@ -207,7 +204,20 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PatchArgs p) {
         }
       }
     }
-    if (ch + 1 < nchunks) store_chunk(cur ^ 1);
+  };
+  load_chunk(chunk_beg * CK, ra0, rb0);
+  if (nchunks > 1) load_chunk((chunk_beg + 1) * CK, ra1, rb1);
+  store_chunk(0, ra0, rb0);
+  __syncthreads();
+  for (int ch = 0; ch < nchunks; ch += 2) {
+    if (ch + 2 < nchunks) load_chunk((chunk_beg + ch + 2) * CK, ra0, rb0);
+    compute_chunk(0);
+    if (ch + 1 < nchunks) store_chunk(1, ra1, rb1);
+    __syncthreads();
+    if (ch + 1 >= nchunks) break;
+    if (ch + 3 < nchunks) load_chunk((chunk_beg + ch + 3) * CK, ra1, rb1);
+    compute_chunk(1);
+    if (ch + 2 < nchunks) store_chunk(0, ra0, rb0);
     __syncthreads();
   }
 
@@ -224,6 +234,19 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PatchArgs p) {
     ooff[j] = img * p.o_img + (oy * p.o_sh + p.o_ry) * p.o_row + ox * p.o_sw + p.o_rx;   // + channel * o_chan
   }
   const int ep = p.ep;
+  if (p.splitk > 1) {                 // raw partial tile in the output layout; a split-K epilogue kernel finishes
+    float* part = p.part + (size_t)ks * p.part_stride;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          if (m < p.Mg && cval[j]) part[(size_t)ooff[j] + (size_t)(g * p.Mg + m) * p.o_chan] = acc[i][j][r];
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -304,11 +327,17 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PatchArgs p) {
 // ---------------------------------------------------------------------------------------------
 // dispatch
 static int g_patch_min_wgs = 96;   // below this many workgroups the split-K im2col path is used instead
-PatchPlan plan_patch(int nd, int Mg, int groups, int KH, int KW, int SH, int SW, int B, int OH, int OW) {
-  PatchPlan pl = {0, 1, 64, 0, 0, 0};
+int patch_chunk_channels(int KH, int KW) {
+  const int khw = KH * KW;
+  return khw == 1 ? 32 : khw == 2 ? 16 : khw == 3 ? 16 : khw == 4 ? 16 : khw == 9 ? 4 : khw == 16 ? 4 : khw == 24 ? 2 : 4;
+}
+
+PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH, int SW, int B, int OH, int OW) {
+  PatchPlan pl = {0, 1, 64, 0, 0, 0, 1, 1 << 30};
   const int S = SW;
   if (nd == 2 && SH != SW) return pl;
-  const bool known = (KH == 1 && KW == 2 && S == 1) || (KH == 2 && KW == 2 && S == 1) || (KH == 1 && KW == 3 && S == 1) || (KH == 1 && KW == 4 && S == 2) || (KH == 1 && KW == 4 && S == 1) ||
+  const bool known = (KH == 1 && KW == 2 && S == 1) || (KH == 2 && KW == 2 && S == 1) || (KH == 1 && KW == 3 && S == 1) ||
+                     (KH == 1 && KW == 4 && S == 2) || (KH == 1 && KW == 4 && S == 1) ||
                      (KH == 1 && KW == 1 && S == 1) || (KH == 3 && KW == 3 && S == 1) || (KH == 4 && KW == 4 && S == 2) ||
                      (KH == 3 && KW == 8 && S == 1);
   if (!known) return pl;
@@ -328,8 +357,19 @@ PatchPlan plan_patch(int nd, int Mg, int groups, int KH, int KW, int SH, int SW,
   pl.ok = 1; pl.tm = tm; pl.tw = tw;
   pl.tiles_y = cdiv(rows, th); pl.tiles_x = cdiv(OW, tw);
   pl.n_tiles = imgs * pl.tiles_y * pl.tiles_x;
+  const long base = (long)pl.n_tiles * cdiv(Mg, 64 * tm) * groups;
   // too few workgroups: the split-K im2col path spreads the weight stream better
-  if ((long)pl.n_tiles * cdiv(Mg, 64 * tm) * groups < g_patch_min_wgs) pl.ok = 0;
+  if (base < g_patch_min_wgs) pl.ok = 0;
+  // fewer workgroups than 1.5 per CU and a long reduction: slice the channel chunks over workgroups
+  const int nchunks = cdiv(Kc, patch_chunk_channels(KH, KW));
+  if (pl.ok && base < 384 && nchunks >= 4) {
+    int sk = (int)std::min<long>(nchunks / 2, (384 + base - 1) / base);
+    if (sk > 4) sk = 4;
+    if (sk > 1) {
+      pl.chunks_per_split = cdiv(nchunks, sk);
+      pl.splitk = cdiv(nchunks, pl.chunks_per_split);
+    }
+  }
   return pl;
 }
 
@@ -365,10 +405,12 @@ static void launch_patch_k(const PatchArgs& a, int kh, int kw, int s_, int tw, b
 int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S, bool up2, double flops, double bytes,
                  hipStream_t s) {
   const int bm = 64 * pl.tm;
-  dim3 grid(pl.n_tiles, cdiv(a.Mg, bm), a.groups);
+  dim3 grid(pl.n_tiles, cdiv(a.Mg, bm), a.groups * a.splitk);
   if (grid.y > 65535 || grid.z > 65535) return set_error("conv grid too large");
-  TimingScope ts(s, flops, bytes, "conv_%s_patch k%dx%d s%d Mg%d Kg%d g%d tiles%d tile%d tw%d%s", a.is_dgrad ? "dgrad" : "fwd", KH, KW, S, a.Mg, a.Kg,
-                 a.groups, pl.n_tiles, bm, pl.tw, a.ep == EP_RAW_STATS ? " +bnstats" : "");
+  if (a.splitk < 1 || (a.splitk > 1 && !a.part)) return set_error("patch conv: bad split-K setup");
+  TimingScope ts(s, flops, bytes, "conv_patch_kernel<%d,%d,%d,%d,%d,%d,%d>|conv_%s_patch k%dx%d s%d Mg%d Kg%d g%d tiles%d tile%d tw%d splitk%d%s",
+                 pl.tm, pl.tm, KH, KW, S, pl.tw, up2 ? 1 : 0, a.is_dgrad ? "dgrad" : "fwd", KH, KW, S, a.Mg, a.Kg,
+                 a.groups, pl.n_tiles, bm, pl.tw, a.splitk, a.ep == EP_RAW_STATS ? " +bnstats" : "");
   if (pl.tm == 2) launch_patch_k<2>(a, KH, KW, S, pl.tw, up2, grid, s);
   else launch_patch_k<1>(a, KH, KW, S, pl.tw, up2, grid, s);
   return check_launch("conv_patch_kernel");

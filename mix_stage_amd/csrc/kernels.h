@@ -65,11 +65,15 @@ struct PatchArgs {
   int o_sh, o_sw, o_ry, o_rx;   // output scatter: (oy*o_sh + o_ry, ox*o_sw + o_rx); data gradient of a strided conv
   float* out2;                  // EP_DGRAD_UP2: gradient of the residual
   int is_dgrad;                 // label only
+  int splitk, chunks_per_split; // split-K over workgroups: raw partial tiles go to part[ks] (output layout)
+  float* part;
+  size_t part_stride;
   int PH, PW, tiles_x, tiles_y;
   float slope, eps;
 };
-struct PatchPlan { int ok, tm, tw, tiles_y, tiles_x, n_tiles; };
-PatchPlan plan_patch(int nd, int Mg, int groups, int KH, int KW, int SH, int SW, int B, int OH, int OW);
+struct PatchPlan { int ok, tm, tw, tiles_y, tiles_x, n_tiles, splitk, chunks_per_split; };
+PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH, int SW, int B, int OH, int OW);
+int patch_chunk_channels(int KH, int KW);
 int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S, bool up2, double flops, double bytes,
                  hipStream_t s);
 

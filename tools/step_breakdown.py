@@ -24,7 +24,7 @@ for kind in 'GD':
   tot = sum(r['total_ms'] for r in rows)
   cat = {}
   for r in rows:
-    c = r['label'].split()[0]
+    c = r['label'].split('|')[-1].split()[0]
     cat[c] = cat.get(c, 0) + r['total_ms']
   print('==== %s-step: eager wall %.2f ms, timed kernels %.2f ms, %d launches' % (kind, e0.elapsed_time(e1), tot, sum(r['count'] for r in rows)))
   print('  by category:', {k: round(v, 3) for k, v in sorted(cat.items(), key=lambda kv: -kv[1])})
@@ -32,4 +32,4 @@ for kind in 'GD':
     avg = r['total_ms'] / r['count'] * 1e3
     tf = r['flops'] / (avg * 1e-6) / 1e12 if r['flops'] else 0
     gb = r['bytes'] / (avg * 1e-6) / 1e9
-    print('  %-62s x%-3d avg %8.1f us  tot %6.3f ms  %6.1f TF %7.0f GB/s' % (r['label'], r['count'], avg, r['total_ms'], tf, gb))
+    print('  %-62s x%-3d avg %8.1f us  tot %6.3f ms  %6.1f TF %7.0f GB/s' % (r['label'].split('|')[-1], r['count'], avg, r['total_ms'], tf, gb))
