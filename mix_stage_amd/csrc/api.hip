@@ -24,6 +24,14 @@ static int validate(const ms_conv_desc* d, const char* who) {
   return 0;
 }
 
+static int wgrad_total_splits(const ms_conv_desc* d) {
+  const int npix = d->B * d->OH * d->OW;
+  const bool one_d = d->H == 1 && d->KH == 1;
+  const WgradPatchPlan wp = plan_wgrad_patch(one_d ? 1 : 2, d->Cout, d->Cin * d->KH * d->KW, d->groups, d->KH, d->KW, d->SH,
+                                             d->SW, d->B, d->OH, d->OW);
+  return std::max(wp.ok ? wp.splits : 1, wgrad_splits(d->Cout, d->Cin * d->KH * d->KW, d->groups, npix));
+}
+
 static GatherPlan dgrad_plan(const ms_conv_desc* d) {
   const bool bcast = d->in_mode == MS_IN_BCAST;
   const int tg = bcast ? 1 : d->groups, tcog = bcast ? d->groups * d->Cout : d->Cout;
@@ -65,7 +73,7 @@ size_t ms_conv_block_bwd_workspace(const ms_conv_desc* d) {
   int bpc;
   const int nchunk = bwd_chunks(d->B, ctot_of(d), &bpc);
   const int npix = d->B * d->OH * d->OW;
-  const int splits = wgrad_splits(d->Cout, d->Cin * d->KH * d->KW, d->groups, npix);
+  const int splits = wgrad_total_splits(d);
   size_t bytes = 0;
   bytes += align_up((size_t)ctot_of(d) * nchunk * 2 * sizeof(float), 256);  // bn partials
   bytes += align_up((size_t)ctot_of(d) * nchunk * sizeof(float), 256);      // colsum partials
@@ -199,7 +207,7 @@ int ms_conv_block_bwd(const ms_conv_desc* d, const float* x, const float* x2, co
   float* wt = (float*)wsp; wsp += align_up(dgrad_weight_elems(d->groups, d->Cout, d->Cin, d->KH, d->KW, d->SH, d->SW) * sizeof(float), 256);
   float* wg_part = (float*)wsp;
   {
-    const int sp = wgrad_splits(d->Cout, d->Cin * d->KH * d->KW, d->groups, npix);
+    const int sp = wgrad_total_splits(d);
     wsp += align_up(wsize_of(d) * sizeof(float) * (sp > 1 ? sp : 0), 256);
   }
   float* dg_part = (float*)wsp;
@@ -308,14 +316,39 @@ int ms_conv_block_bwd(const ms_conv_desc* d, const float* x, const float* x2, co
 
   // 3. weight gradient
   if (dw) {
-    WgradArgs a = {};
-    a.dyr = g; a.src = x; a.src2 = x2;
-    a.Cog = d->Cout; a.Cig = d->Cin; a.Kg = d->Cin * khw; a.groups = d->groups;
-    a.src_ctotal = bcast ? d->Cin : d->groups * d->Cin;
-    a.H = d->H; a.W = d->W; a.OH = d->OH; a.OW = d->OW; a.Npix = npix;
-    a.KH = d->KH; a.KW = d->KW; a.SH = d->SH; a.SW = d->SW; a.PH = d->PH; a.PW = d->PW;
-    a.bcast = bcast;
-    rc = launch_wgrad(a, up2, dw, wg_part, s);
+    const bool one_d = d->H == 1 && d->KH == 1;
+    const WgradPatchPlan wp = plan_wgrad_patch(one_d ? 1 : 2, d->Cout, d->Cin * khw, d->groups, d->KH, d->KW, d->SH, d->SW,
+                                               d->B, d->OH, d->OW);
+    if (wp.ok) {
+      const int cin_tot = bcast ? d->Cin : d->groups * d->Cin;
+      WgradPatchArgs q = {};
+      q.dyr = g; q.src = x; q.src2 = x2;
+      q.out = wp.splits > 1 ? wg_part : dw;
+      q.Cog = d->Cout; q.Cig = d->Cin; q.Kg = d->Cin * khw; q.groups = d->groups; q.bcast = bcast;
+      if (one_d) {
+        q.SRCH = d->B; q.SRCW = d->W; q.s_img = 0; q.s_chan = d->W; q.s_row = cin_tot * d->W; q.PH = 0;
+        q.OUTH = d->B; q.OUTW = d->OW; q.o_img = 0; q.o_chan = d->OW; q.o_row = C * d->OW;
+      } else {
+        q.SRCH = d->H; q.SRCW = d->W; q.s_img = cin_tot * d->H * d->W; q.s_chan = d->H * d->W; q.s_row = d->W; q.PH = d->PH;
+        q.OUTH = d->OH; q.OUTW = d->OW; q.o_img = C * hw; q.o_chan = hw; q.o_row = d->OW;
+      }
+      q.PW = d->PW; q.tiles_x = wp.tiles_x; q.tiles_y = wp.tiles_y; q.n_tiles = wp.n_tiles;
+      q.tiles_per_split = wp.tiles_per_split; q.splits = wp.splits;
+      const double flops = 2.0 * d->Cout * q.Kg * (double)npix * d->groups;
+      const double bytes = 4.0 * ((double)npix * C + (double)d->B * cin_tot * d->H * d->W + (double)C * q.Kg);
+      rc = launch_wgrad_patch(q, wp, d->KH, d->KW, d->SW, up2, flops, bytes, s);
+      if (rc) return rc;
+      if (wp.splits > 1) rc = launch_reduce_splits(wg_part, dw, C * q.Kg, wp.splits, s);
+    } else {
+      WgradArgs a = {};
+      a.dyr = g; a.src = x; a.src2 = x2;
+      a.Cog = d->Cout; a.Cig = d->Cin; a.Kg = d->Cin * khw; a.groups = d->groups;
+      a.src_ctotal = bcast ? d->Cin : d->groups * d->Cin;
+      a.H = d->H; a.W = d->W; a.OH = d->OH; a.OW = d->OW; a.Npix = npix;
+      a.KH = d->KH; a.KW = d->KW; a.SH = d->SH; a.SW = d->SW; a.PH = d->PH; a.PW = d->PW;
+      a.bcast = bcast;
+      rc = launch_wgrad(a, up2, dw, wg_part, s);
+    }
   }
   return rc;
 }

@@ -683,6 +683,15 @@ static void launch_wgrad_khw(const WgradArgs& a, dim3 grid, hipStream_t s) {
 #undef MS_WK
 }
 
+int launch_reduce_splits(const float* part, float* out, int n, int splits, hipStream_t s) {
+  TimingScope ts(s, 0, 4.0 * n * (splits + 1), "wgrad_reduce_splits n%d splits%d", n, splits);
+  if (splits >= 32 && n <= 65536)
+    hipLaunchKernelGGL(reduce_splits_wave_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, part, out, n, splits);
+  else
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3(min(cdiv(n, 256), 2048)), dim3(256), 0, s, part, out, n, splits);
+  return check_launch("reduce_splits_kernel");
+}
+
 int launch_wgrad(WgradArgs a, bool up2, float* dw, float* partial_ws, hipStream_t s) {
   const int ctot = a.groups * a.Cog;
   a.splits = wgrad_splits(a.Cog, a.Kg, a.groups, a.Npix);
@@ -702,15 +711,7 @@ int launch_wgrad(WgradArgs a, bool up2, float* dw, float* partial_ws, hipStream_
     rc = check_launch("wgrad_kernel");
   }
   if (rc) return rc;
-  if (a.splits > 1) {
-    const int n = ctot * a.Kg;
-    TimingScope ts(s, 0, 4.0 * n * (a.splits + 1), "wgrad_reduce_splits n%d splits%d", n, a.splits);
-    if (a.splits >= 32 && n <= 65536)
-      hipLaunchKernelGGL(reduce_splits_wave_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, partial_ws, dw, n, a.splits);
-    else
-      hipLaunchKernelGGL(reduce_splits_kernel, dim3(min(cdiv(n, 256), 2048)), dim3(256), 0, s, partial_ws, dw, n, a.splits);
-    rc = check_launch("reduce_splits_kernel");
-  }
+  if (a.splits > 1) rc = launch_reduce_splits(partial_ws, dw, ctot * a.Kg, a.splits, s);
   return rc;
 }
 

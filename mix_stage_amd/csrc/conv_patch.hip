@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PatchArgs p) {
 
 // ---------------------------------------------------------------------------------------------
 // dispatch
-static int g_patch_min_wgs = 96;   // below this many workgroups the split-K im2col path is used instead
+int g_patch_min_wgs = 96;   // below this many workgroups the split-K im2col path is used instead
 int patch_chunk_channels(int KH, int KW) {
   const int khw = KH * KW;
   return khw == 1 ? 32 : khw == 2 ? 16 : khw == 3 ? 16 : khw == 4 ? 16 : khw == 9 ? 4 : khw == 16 ? 4 : khw == 24 ? 2 : 4;

@@ -77,6 +77,25 @@ int patch_chunk_channels(int KH, int KW);
 int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S, bool up2, double flops, double bytes,
                  hipStream_t s);
 
+extern int g_patch_min_wgs;   // test knob (ms_debug_set_patch_min_workgroups): 0 forces the patch kernels
+
+// ---- patch-staged weight gradient (wgrad_patch.hip)
+struct WgradPatchArgs {
+  const float* dyr;    // [.., groups*Cog, OH, OW]
+  const float* src;    // x (UP2: the half-resolution tensor a)
+  const float* src2;   // UP2: residual r
+  float* out;          // [splits][groups*Cog][Kg]
+  int Cog, Cig, Kg, groups, bcast;
+  int SRCH, SRCW, s_img, s_chan, s_row, PH, PW;
+  int OUTH, OUTW, o_img, o_chan, o_row;
+  int tiles_x, tiles_y, n_tiles, tiles_per_split, splits;
+};
+struct WgradPatchPlan { int ok, tw, tiles_y, tiles_x, n_tiles, splits, tiles_per_split; };
+WgradPatchPlan plan_wgrad_patch(int nd, int Cog, int Kg, int groups, int KH, int KW, int SH, int SW, int B, int OH, int OW);
+int launch_wgrad_patch(const WgradPatchArgs& a, const WgradPatchPlan& pl, int KH, int KW, int S, bool up2, double flops,
+                       double bytes, hipStream_t s);
+int launch_reduce_splits(const float* part, float* out, int n, int splits, hipStream_t s);
+
 struct GatherPlan { int tm, tn, splitk, k_per_split, n_tiles; };
 // tile shape + split-K factor for an (Mg x npix) output per z-slice (z = groups * parity classes), reduction Kg
 GatherPlan plan_gather(int Mg, int npix, int zcount, int Kg);

@@ -1,0 +1,227 @@
+// Patch-staged weight gradient for gfx950 (MI355X):  dw[co][(ci,kh,kw)] = sum_pix dy[co][pix] * x[ci][pix*S + tap].
+//
+// A workgroup owns BM output channels x BN consecutive weight columns n = (ci,kh,kw) and walks over TH x TW pixel
+// tiles (its share of the reduction).  Per tile it stages dy^T [64 pixels][BM] and the RAW input patch
+// [channels spanned by the BN columns][(TH-1)*S+KH][(TW-1)*S+KW] in LDS.  The MFMA reduction index is the pixel:
+// A(co, pix) = dyT[pix][co]; B(pix, n) = patch[ci(n)][ty*S+kh(n)][tx*S+kw(n)] = per-lane column base + compile-time
+// pixel offset, so the inner loop is ds_read_b32 with immediate offsets + v_mfma_f32_32x32x2_f32.  Patch pitches are
+// chosen so that consecutive columns n fall in consecutive LDS banks (row pitch = KW, channel pitch = KH*KW mod 32).
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace ms {
+
+__device__ __attribute__((aligned(16))) const float g_wzero_word[4] = {0.f, 0.f, 0.f, 0.f};
+
+constexpr int pitch_mod32(int at_least, int want_mod) {
+  int v = at_least;
+  while (v % 32 != want_mod % 32) ++v;
+  return v;
+}
+
+template <int TM, int TN, int KH, int KW, int S, int TW, bool UP2>
+__global__ __launch_bounds__(256) void wgrad_patch_kernel(const WgradPatchArgs p) {
+  constexpr int BM = 64 * TM, BN = 64 * TN, NPIX = 64, TH = NPIX / TW;
+  constexpr int SV = (KH == 1) ? 1 : S;
+  constexpr int KHW = KH * KW;
+  constexpr int PR = (TH - 1) * SV + KH, PC = (TW - 1) * S + KW;
+  constexpr int RP = pitch_mod32(PC, KW), CP = pitch_mod32(PR * RP, KHW);
+  constexpr int NCH = (BN + 2 * KHW - 2) / KHW;          // channels spanned by BN consecutive columns
+  constexpr int LDA = BM + 1;
+  constexpr int STAGE = NPIX * LDA + NCH * CP + 4;
+  constexpr int NPE = NCH * PR * PC, NP = (NPE + 255) / 256;
+  constexpr int NA = BM * NPIX / 256;                    // dy values per thread per tile
+  __shared__ float smem[2 * STAGE];
+
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int wm = wid >> 1, wn = wid & 1, khalf = lane >> 5;
+  const int g = blockIdx.z / p.splits, sp = blockIdx.z - g * p.splits;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int ctot = p.groups * p.Cog;
+  const int ci_first = n0 / KHW;
+  const int cbase = (p.bcast ? 0 : g * p.Cig) + ci_first;
+  const int tiles_per_img = p.tiles_y * p.tiles_x;
+  const int tile_beg = sp * p.tiles_per_split, tile_end = min(p.n_tiles, tile_beg + p.tiles_per_split);
+
+  // ---- tile-invariant parts of the staging addresses
+  int prow[NP], pcol[NP], prel[NP], ploff[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int e = t + i * 256;
+    const int c = e / (PR * PC), rem = e - c * (PR * PC), r = rem / PC, col = rem - r * PC;
+    const bool ok = (e < NPE) & (ci_first + c < p.Cig);
+    prow[i] = ok ? r : -(1 << 20);                       // forces the bounds test to fail
+    pcol[i] = col;
+    prel[i] = c * p.s_chan + r * p.s_row + col;
+    ploff[i] = e < NPE ? c * CP + r * RP + col : NCH * CP;   // pad word
+  }
+  const int apix = t & 63, am0 = t >> 6;                 // dy element: pixel apix, rows am0 + 4*i
+  const int aty = apix / TW, atx = apix - aty * TW;
+
+  float ra[NA], rb[NP];
+  auto load_tile = [&](int tile) {
+    const int img = tile / tiles_per_img, trem = tile - img * tiles_per_img;
+    const int tyi = trem / p.tiles_x, txi = trem - tyi * p.tiles_x;
+    const int oy0 = tyi * TH, ox0 = txi * TW;
+    // dy^T
+    const int oy = oy0 + aty, ox = ox0 + atx;
+    const bool pok = (oy < p.OUTH) & (ox < p.OUTW);
+    const int abase = img * p.o_img + (g * p.Cog + m0 + am0) * p.o_chan + oy * p.o_row + ox;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const bool ok = pok & (m0 + am0 + 4 * i < p.Cog);
+      const float* ap = ok ? p.dyr + (unsigned)(abase + 4 * i * p.o_chan) : g_wzero_word;
+      ra[i] = *ap;
+    }
+    // raw input patch
+    const int iy0 = oy0 * SV - p.PH, ix0 = ox0 * S - p.PW;
+    const int xbase = img * p.s_img + cbase * p.s_chan + iy0 * p.s_row + ix0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int iy = iy0 + prow[i], ix = ix0 + pcol[i];
+      const bool ok = ((unsigned)iy < (unsigned)p.SRCH) & ((unsigned)ix < (unsigned)p.SRCW);
+      if (UP2) {
+        const int o = ok ? xbase + prel[i] : 0;
+        const int x = o % p.SRCW;
+        const float* pa = ok ? p.src + (unsigned)(((o - x) >> 1) + (x >> 1)) : g_wzero_word;
+        const float* pr = ok ? p.src2 + (unsigned)o : g_wzero_word;
+        rb[i] = *pa + *pr;
+      } else {
+        const float* ps = ok ? p.src + (unsigned)(xbase + prel[i]) : g_wzero_word;
+        rb[i] = *ps;
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* As = smem + buf * STAGE;
+    float* Ps = As + NPIX * LDA;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) As[apix * LDA + am0 + 4 * i] = ra[i];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) Ps[ploff[i]] = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // per-lane operand bases
+  const int a_base = khalf * LDA + wm * TM * 32 + (lane & 31);
+  int nbase[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+    const int c = n / KHW - ci_first, rr = n % KHW, kh = rr / KW, kw = rr - kh * KW;
+    nbase[j] = (n < p.Kg ? c * CP + kh * RP + kw : 0) + khalf * S;   // pixel k+1 is the next column of the same row
+  }
+
+  const int nsteps = tile_end - tile_beg;
+  if (nsteps > 0) {
+    load_tile(tile_beg);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int st = 0; st < nsteps; ++st) {
+    const int cur = st & 1;
+    if (st + 1 < nsteps) load_tile(tile_beg + st + 1);
+    const float* As = smem + cur * STAGE;
+    const float* Ps = As + NPIX * LDA;
+#pragma unroll
+    for (int jj = 0; jj < NPIX / 2; ++jj) {
+      const int k0 = 2 * jj;
+      const int ty = k0 / TW, tx = k0 - ty * TW;
+      const int offb = ty * SV * RP + tx * S;
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[a_base + k0 * LDA + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Ps[nbase[j] + offb];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (st + 1 < nsteps) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  float* outp = p.out + (size_t)sp * ctot * p.Kg;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int nc = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+        if (m < p.Cog && nc < p.Kg) outp[(size_t)(g * p.Cog + m) * p.Kg + nc] = acc[i][j][r];
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+WgradPatchPlan plan_wgrad_patch(int nd, int Cog, int Kg, int groups, int KH, int KW, int SH, int SW, int B, int OH, int OW) {
+  WgradPatchPlan pl = {0, 64, 0, 0, 0, 1, 0};
+  const int S = SW;
+  if (nd == 2 && SH != SW) return pl;
+  const bool known = (KH == 1 && KW == 3 && S == 1) || (KH == 1 && KW == 4 && S == 2) || (KH == 1 && KW == 4 && S == 1) ||
+                     (KH == 1 && KW == 1 && S == 1) || (KH == 3 && KW == 3 && S == 1) || (KH == 4 && KW == 4 && S == 2) ||
+                     (KH == 3 && KW == 8 && S == 1);
+  if (!known) return pl;
+  if (nd == 1 ? OW < 16 : OW < 15) return pl;
+  const int rows = nd == 1 ? B : OH, imgs = nd == 1 ? 1 : B;
+  if (nd == 1) pl.tw = OW > 32 ? 64 : OW > 16 ? 32 : 16;
+  else pl.tw = OW > 16 ? 32 : 16;
+  const int th = 64 / pl.tw;
+  pl.tiles_y = cdiv(rows, th); pl.tiles_x = cdiv(OW, pl.tw);
+  pl.n_tiles = imgs * pl.tiles_y * pl.tiles_x;
+  if (pl.n_tiles < (g_patch_min_wgs > 0 ? 4 : 1)) return pl;
+  const long base = (long)cdiv(Cog, 64) * cdiv(Kg, 64) * groups;
+  int splits = 1;
+  if (base < 512) splits = (int)((512 + base - 1) / base);
+  splits = std::min(splits, std::max(1, pl.n_tiles / 4));      // at least 4 pixel tiles (128 k-pairs) per split
+  pl.tiles_per_split = cdiv(pl.n_tiles, splits);
+  pl.splits = cdiv(pl.n_tiles, pl.tiles_per_split);
+  pl.ok = 1;
+  return pl;
+}
+
+template <int KH, int KW, int S, bool UP2>
+static void launch_wgp_tw(const WgradPatchArgs& a, int tw, dim3 grid, hipStream_t s) {
+#define MS_WP(TW) hipLaunchKernelGGL((wgrad_patch_kernel<1, 1, KH, KW, S, TW, UP2>), grid, dim3(256), 0, s, a)
+  if constexpr (KH == 1) {
+    if (tw == 64) MS_WP(64);
+    else if (tw == 32) MS_WP(32);
+    else MS_WP(16);
+  } else {
+    if (tw == 32) MS_WP(32);
+    else MS_WP(16);
+  }
+#undef MS_WP
+}
+
+int launch_wgrad_patch(const WgradPatchArgs& a, const WgradPatchPlan& pl, int KH, int KW, int S, bool up2, double flops,
+                       double bytes, hipStream_t s) {
+  dim3 grid(cdiv(a.Kg, 64), cdiv(a.Cog, 64), a.groups * a.splits);
+  if (grid.y > 65535 || grid.z > 65535) return set_error("wgrad grid too large");
+  TimingScope ts(s, flops, bytes, "wgrad_patch_kernel<1,1,%d,%d,%d,%d,%d>|conv_wgrad_patch k%dx%d s%d Cog%d Kg%d g%d tiles%d tw%d splits%d",
+                 KH, KW, S, pl.tw, up2 ? 1 : 0, KH, KW, S, a.Cog, a.Kg, a.groups, pl.n_tiles, pl.tw, a.splits);
+  if (KH == 1 && KW == 3 && S == 1) {
+    if (up2) launch_wgp_tw<1, 3, 1, true>(a, pl.tw, grid, s);
+    else launch_wgp_tw<1, 3, 1, false>(a, pl.tw, grid, s);
+  } else if (KH == 1 && KW == 4 && S == 2) launch_wgp_tw<1, 4, 2, false>(a, pl.tw, grid, s);
+  else if (KH == 1 && KW == 4 && S == 1) launch_wgp_tw<1, 4, 1, false>(a, pl.tw, grid, s);
+  else if (KH == 1 && KW == 1 && S == 1) launch_wgp_tw<1, 1, 1, false>(a, pl.tw, grid, s);
+  else if (KH == 3 && KW == 3 && S == 1) launch_wgp_tw<3, 3, 1, false>(a, pl.tw, grid, s);
+  else if (KH == 4 && KW == 4 && S == 2) launch_wgp_tw<4, 4, 2, false>(a, pl.tw, grid, s);
+  else launch_wgp_tw<3, 8, 1, false>(a, pl.tw, grid, s);
+  return check_launch("wgrad_patch_kernel");
+}
+
+}  // namespace ms
