@@ -108,6 +108,14 @@ int ms_softmax_mix_fwd(const float* z, const float* score, float* soft, float* o
 int ms_softmax_mix_bwd(const float* z, const float* soft, const float* dout, float* dz, float* dscore,
                        int B, int M, int P, int T, void* stream);
 
+/* content || style-embedding concat in channel-major layout (replaces EmbLin 'emb' lookup + torch.cat + transposes,
+ * JL:175-180, layers.py:659-663): out (B, C+D, T) = [x (B,C,T) ; E[ids[b,t]] (D)].  ids is addressed as
+ * ids[b*ids_stride_b + t*ids_stride_t] (stride_t = 0: one id per clip).  bwd: dx (B,C,T) and/or dE (S,D), NULL = skip. */
+int ms_concat_style_fwd(const float* x, const float* emb, const int64_t* ids, int ids_stride_b, int ids_stride_t, float* out,
+                        int B, int C, int D, int T, void* stream);
+int ms_concat_style_bwd(const float* dout, const int64_t* ids, int ids_stride_b, int ids_stride_t, float* dx, float* demb,
+                        int B, int C, int D, int T, int S, void* stream);
+
 /* Cross entropy with mean reduction (JL:159,184,203): score addressed as
  * score[n_outer*stride_outer + c*stride_c + n_inner*stride_inner], rows = n_outer*n_inner.
  * loss[0] = mean_rows( logsumexp - score[target] ).  dscore (same addressing) = gscale[0] *

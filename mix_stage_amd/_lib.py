@@ -39,6 +39,8 @@ SIGNATURES = {
     'ms_lerp_time_bwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'ms_softmax_mix_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     'ms_softmax_mix_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    'ms_concat_style_fwd': (c_int, [_P, _P, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P]),
+    'ms_concat_style_bwd': (c_int, [_P, _P, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'ms_cross_entropy_fwd': (c_int, [_P, _P, _P, _P] + [c_int] * 6 + [_P]),
     'ms_cross_entropy_bwd': (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [_P]),
     'ms_velocity_fwd': (c_int, [_P, _P, c_int, c_int, c_int, _P]),

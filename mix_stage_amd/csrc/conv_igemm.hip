@@ -547,6 +547,7 @@ int launch_gather(GatherArgs a, bool transposed, bool up2, const GatherPlan& pla
 // split-K epilogues.  Forward: one workgroup per output channel sums the partial tiles, adds the bias and applies
 // the block epilogue; for BN_TRAIN the workgroup owns all B*HW values of its channel, so batch statistics,
 // running-stat update, normalisation and LeakyReLU happen here in one launch (two-pass variance).
+template <int NE>
 __global__ __launch_bounds__(256) void splitk_fwd_epilogue_kernel(const float* __restrict__ part, int splitk,
                                                                   size_t part_stride, const float* __restrict__ bias,
                                                                   const float* __restrict__ gamma,
@@ -554,6 +555,80 @@ __global__ __launch_bounds__(256) void splitk_fwd_epilogue_kernel(const float* _
                                                                   float* __restrict__ y_raw, float* __restrict__ y,
                                                                   float* __restrict__ save, int B, int C, int HW, int ep,
                                                                   float slope, float eps, float momentum) {
+  // the channel's B*HW <= 256*NE values stay in registers between the passes
+  __shared__ float red[4];
+  const int c = blockIdx.x, t = threadIdx.x;
+  const int N = B * HW;
+  const float bsv = bias ? bias[c] : 0.f;
+  float v[NE];
+  size_t off[NE];
+  float s1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = t + i * 256;
+    const int b = e / HW, pix = e - b * HW;
+    off[i] = ((size_t)b * C + c) * HW + pix;
+    float acc = 0.f;
+    if (e < N) {
+      acc = bsv;
+      for (int k = 0; k < splitk; ++k) acc += part[(size_t)k * part_stride + off[i]];
+    }
+    v[i] = acc;
+    s1 += acc;
+  }
+  if (ep != EP_RAW_STATS) {
+    float sc = 1.f, sh = 0.f;
+    if (ep == EP_BN_EVAL) {
+      const float inv = 1.0f / sqrtf(rv[c] + eps);
+      sc = gamma[c] * inv;
+      sh = beta[c] - rm[c] * sc;
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      float o = v[i];
+      if (ep == EP_BN_EVAL) o = lrelu(fmaf(o, sc, sh), slope);
+      if (ep == EP_LRELU) o = lrelu(o, slope);
+      if (t + i * 256 < N) y[off[i]] = o;
+    }
+    return;
+  }
+  const float mean = block_sum_256(s1, red) / (float)N;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const float d = v[i] - mean;
+    q += (t + i * 256 < N) ? d * d : 0.f;
+  }
+  const float m2 = block_sum_256(q, red);
+  const float var = m2 / (float)N;
+  const float invstd = 1.0f / sqrtf(var + eps);
+  const float sc = gamma[c] * invstd, sh = beta[c] - mean * sc;
+  if (t == 0) {
+    save[c] = mean;
+    save[C + c] = invstd;
+    save[2 * C + c] = sc;
+    save[3 * C + c] = sh;
+    const float unbiased = N > 1 ? m2 / (float)(N - 1) : var;
+    rm[c] = (1.f - momentum) * rm[c] + momentum * mean;
+    rv[c] = (1.f - momentum) * rv[c] + momentum * unbiased;
+  }
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    if (t + i * 256 < N) {
+      y_raw[off[i]] = v[i];
+      y[off[i]] = lrelu(fmaf(v[i], sc, sh), slope);
+    }
+  }
+}
+
+// same, any channel size: values are re-read from y_raw between the passes
+__global__ __launch_bounds__(256) void splitk_fwd_epilogue_big_kernel(const float* __restrict__ part, int splitk,
+                                                                      size_t part_stride, const float* __restrict__ bias,
+                                                                      const float* __restrict__ gamma,
+                                                                      const float* __restrict__ beta, float* rm, float* rv,
+                                                                      float* __restrict__ y_raw, float* __restrict__ y,
+                                                                      float* __restrict__ save, int B, int C, int HW, int ep,
+                                                                      float slope, float eps, float momentum) {
   __shared__ float red[4];
   const int c = blockIdx.x, t = threadIdx.x;
   const int N = B * HW;
@@ -637,8 +712,16 @@ int launch_splitk_fwd_epilogue(const float* part, int splitk, size_t part_stride
                                const float* beta, float* rm, float* rv, float* y_raw, float* y, float* save, int B, int C,
                                int HW, int ep, float slope, float eps, float momentum, hipStream_t s) {
   TimingScope ts(s, 0, 4.0 * B * C * HW * (splitk + 3), "splitk_fwd_epilogue C%d N%d splitk%d ep%d", C, B * HW, splitk, ep);
-  hipLaunchKernelGGL(splitk_fwd_epilogue_kernel, dim3(C), dim3(256), 0, s, part, splitk, part_stride, bias, gamma, beta, rm,
-                     rv, y_raw, y, save, B, C, HW, ep, slope, eps, momentum);
+#define MS_SKE(K) hipLaunchKernelGGL(K, dim3(C), dim3(256), 0, s, part, splitk, part_stride, bias, gamma, beta, rm, rv, \
+                                     y_raw, y, save, B, C, HW, ep, slope, eps, momentum)
+  const long n = (long)B * HW;
+  if (n <= 256) MS_SKE(splitk_fwd_epilogue_kernel<1>);
+  else if (n <= 512) MS_SKE(splitk_fwd_epilogue_kernel<2>);
+  else if (n <= 1024) MS_SKE(splitk_fwd_epilogue_kernel<4>);
+  else if (n <= 2048) MS_SKE(splitk_fwd_epilogue_kernel<8>);
+  else if (n <= 4096) MS_SKE(splitk_fwd_epilogue_kernel<16>);
+  else MS_SKE(splitk_fwd_epilogue_big_kernel);
+#undef MS_SKE
   return check_launch("splitk_fwd_epilogue_kernel");
 }
 

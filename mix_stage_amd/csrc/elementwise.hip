@@ -361,6 +361,44 @@ __global__ __launch_bounds__(256) void softmax_mix_bwd_kernel(const float* __res
 }
 
 // ----------------------------------------------------------------------------------------------
+// content || style concat (JL:175-180) in channel-major layout: out[b,c,t] = c < C ? x[b,c,t] : E[ids[b,t]][c-C]
+__global__ __launch_bounds__(256) void concat_style_fwd_kernel(const float* __restrict__ x, const float* __restrict__ emb,
+                                                               const int64_t* __restrict__ ids, int ids_sb, int ids_st,
+                                                               float* __restrict__ out, int C, int D, int T, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int t = (int)(i % T);
+    const size_t bc = i / T;
+    const int c = (int)(bc % (C + D)), b = (int)(bc / (C + D));
+    out[i] = c < C ? x[((size_t)b * C + c) * T + t] : emb[ids[(size_t)b * ids_sb + (size_t)t * ids_st] * D + (c - C)];
+  }
+}
+
+// dx = dout[:, :C];  dE[s][j] = sum over (b,t) with ids[b,t] == s of dout[b, C+j, t]   (grid (D, S), fixed order)
+__global__ __launch_bounds__(256) void concat_style_bwd_x_kernel(const float* __restrict__ dout, float* __restrict__ dx, int C,
+                                                                 int D, int T, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int t = (int)(i % T);
+    const size_t bc = i / T;
+    const int c = (int)(bc % C), b = (int)(bc / C);
+    dx[i] = dout[((size_t)b * (C + D) + c) * T + t];
+  }
+}
+
+__global__ __launch_bounds__(256) void concat_style_bwd_emb_kernel(const float* __restrict__ dout, const int64_t* __restrict__ ids,
+                                                                   int ids_sb, int ids_st, float* __restrict__ demb, int B, int C,
+                                                                   int D, int T) {
+  __shared__ float red[4];
+  const int j = blockIdx.x, sidx = blockIdx.y;
+  float acc = 0.f;
+  for (int e = threadIdx.x; e < B * T; e += 256) {
+    const int b = e / T, t = e - b * T;
+    if (ids[(size_t)b * ids_sb + (size_t)t * ids_st] == sidx) acc += dout[((size_t)b * (C + D) + C + j) * T + t];
+  }
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) demb[(size_t)sidx * D + j] = acc;
+}
+
+// ----------------------------------------------------------------------------------------------
 // cross entropy (mean over rows); single workgroup, fixed order
 __global__ __launch_bounds__(256) void cross_entropy_fwd_kernel(const float* __restrict__ score, const int64_t* __restrict__ target,
                                                                 float* __restrict__ loss, int n_outer, int n_inner, int C,
@@ -643,6 +681,32 @@ int ms_softmax_mix_bwd(const float* z, const float* soft, const float* dout, flo
   hipLaunchKernelGGL(softmax_mix_bwd_kernel, dim3(cdiv(T, MIX_TT), B), dim3(256), lds, (hipStream_t)stream, z, soft, dout, dz,
                      dscore, M, P, T);
   return check_launch("softmax_mix_bwd_kernel");
+}
+
+int ms_concat_style_fwd(const float* x, const float* emb, const int64_t* ids, int ids_stride_b, int ids_stride_t, float* out,
+                        int B, int C, int D, int T, void* stream) {
+  const size_t total = (size_t)B * (C + D) * T;
+  int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
+  hipLaunchKernelGGL(concat_style_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, emb, ids, ids_stride_b,
+                     ids_stride_t, out, C, D, T, total);
+  return check_launch("concat_style_fwd_kernel");
+}
+
+int ms_concat_style_bwd(const float* dout, const int64_t* ids, int ids_stride_b, int ids_stride_t, float* dx, float* demb,
+                        int B, int C, int D, int T, int S, void* stream) {
+  if (dx) {
+    const size_t total = (size_t)B * C * T;
+    int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL(concat_style_bwd_x_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, dx, C, D, T, total);
+    int rc = check_launch("concat_style_bwd_x_kernel");
+    if (rc) return rc;
+  }
+  if (demb) {
+    hipLaunchKernelGGL(concat_style_bwd_emb_kernel, dim3(D, S), dim3(256), 0, (hipStream_t)stream, dout, ids, ids_stride_b,
+                       ids_stride_t, demb, B, C, D, T);
+    return check_launch("concat_style_bwd_emb_kernel");
+  }
+  return 0;
 }
 
 int ms_cross_entropy_fwd(const float* score, const int64_t* target, float* loss, float* row_scratch, int n_outer, int n_inner,

@@ -140,14 +140,15 @@ class JointLateClusterSoftStyle4_G(nn.Module):
       mode = 'lin'
       pose_style_score = self.pose_style_encoder(y)             # (B, S)
       id_in_loss = ops.cross_entropy(pose_style_score, style[:, 0], scale=self.lambda_id)
-      pose_style_score = pose_style_score.unsqueeze(1).expand(B, T, pose_style_score.shape[-1])
       if self.softmax:
-        pose_style = torch.softmax(pose_style_score, dim=-1)
-        if self.argmax:
-          pose_style = torch.argmax(pose_style, dim=-1)
+        pose_style = torch.softmax(pose_style_score, dim=-1)    # per clip; the reference expands over T first,
+        if self.argmax:                                         # which repeats identical rows (JL:160-165)
+          pose_style = torch.argmax(pose_style, dim=-1).unsqueeze(1).expand(B, T)
           mode = 'emb'
+        else:
+          pose_style = pose_style.unsqueeze(1).expand(B, T, pose_style.shape[-1])
       else:
-        pose_style = pose_style_score
+        pose_style = pose_style_score.unsqueeze(1).expand(B, T, pose_style_score.shape[-1])
     else:
       pose_style = style
       if len(style.shape) == 2:
@@ -155,11 +156,15 @@ class JointLateClusterSoftStyle4_G(nn.Module):
       elif len(style.shape) == 3:
         mode = 'lin'
       id_in_loss = torch.zeros(1)[0]
-    labels_style = self.style_emb(pose_style, mode=mode)       # (B, T, style_dim)
-    if labels_style.shape[1] != T:
-      labels_style = labels_style.view(B, -1, labels_style.shape[-1])
-    ## content || style, channel-major (JL:180)
-    x = torch.cat([x, labels_style.transpose(2, 1)], dim=1)    # (B, 256+style_dim, T)
+    if mode == 'emb' and pose_style.dim() == 2 and pose_style.shape[1] == T:
+      ## content || style embedding, channel-major, one kernel (JL:175-180)
+      self.pose_style_ids = pose_style
+      x = ops.concat_style(x, self.style_emb.emb.weight, pose_style)      # (B, 256+style_dim, T)
+    else:
+      labels_style = self.style_emb(pose_style, mode=mode)     # (B, T, style_dim)
+      if labels_style.shape[1] != T:
+        labels_style = labels_style.view(B, -1, labels_style.shape[-1])
+      x = torch.cat([x, labels_style.transpose(2, 1)], dim=1)  # (B, 256+style_dim, T)
 
     ## cluster scores from content+style (JL:183-187)
     labels_score = self.classify_cluster(x)                     # (B, M, T)

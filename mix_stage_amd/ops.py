@@ -238,6 +238,44 @@ def softmax_mix(z, score, P):
   return _SoftmaxMixFn.apply(z, score, int(P))
 
 
+class _ConcatStyleFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x, emb, ids):
+    _need_hip(x, emb, ids)
+    x, emb = x.contiguous(), emb.contiguous()
+    if ids.dtype != torch.int64 or ids.dim() != 2:
+      raise TypeError('style ids must be an int64 (B,T) tensor (expanded views are fine)')
+    B, C, T = x.shape
+    S, D = emb.shape
+    assert ids.shape == (B, T)
+    sb, st = ids.stride()
+    out = torch.empty((B, C + D, T), dtype=torch.float32, device=x.device)
+    check(lib().ms_concat_style_fwd(_ptr(x), _ptr(emb), _ptr(ids), sb, st, _ptr(out), B, C, D, T, _stream()),
+          'ms_concat_style_fwd')
+    ctx.save_for_backward(ids)
+    ctx.dims = (B, C, D, T, S, sb, st)
+    ctx.emb_param = emb
+    return out
+
+  @staticmethod
+  def backward(ctx, dout):
+    (ids,) = ctx.saved_tensors
+    B, C, D, T, S, sb, st = ctx.dims
+    dout = dout.contiguous()
+    dx = torch.empty((B, C, T), dtype=torch.float32, device=dout.device) if ctx.needs_input_grad[0] else None
+    demb, direct = (None, False)
+    if ctx.needs_input_grad[1]:
+      demb, direct = _grad_slot(ctx.emb_param, ctx.emb_param)
+    check(lib().ms_concat_style_bwd(_ptr(dout), _ptr(ids), sb, st, _ptr(dx), _ptr(demb), B, C, D, T, S, _stream()),
+          'ms_concat_style_bwd')
+    return dx, None if direct else demb, None
+
+
+def concat_style(x, emb_weight, ids):
+  """(B, C+D, T) = [x ; emb_weight[ids]^T]: EmbLin 'emb' lookup + cat of JL:175-180, channel-major."""
+  return _ConcatStyleFn.apply(x, emb_weight, ids)
+
+
 class _CrossEntropyFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, score, target, layout, scale):

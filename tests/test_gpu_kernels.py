@@ -226,6 +226,27 @@ def test_softmax_mix(B, M, P, T):
   assert rel_err(sh.grad, s64.grad) < 1e-5
 
 
+@pytest.mark.parametrize('per_clip', [True, False])
+def test_concat_style(per_clip):
+  from mix_stage_amd import ops
+  gen = torch.Generator().manual_seed(7)
+  B, C, D, T, S = 3, 20, 10, 37, 5
+  x = torch.randn(B, C, T, generator=gen)
+  E = torch.randn(S, D, generator=gen)
+  ids = torch.randint(0, S, (B, 1) if per_clip else (B, T), generator=gen)
+  ids_full = ids.expand(B, T)
+  x64, E64 = x.double().requires_grad_(), E.double().requires_grad_()
+  ref = torch.cat([x64, F.embedding(ids_full, E64).transpose(2, 1)], dim=1)
+  xh, Eh = x.to(DEV).requires_grad_(), E.to(DEV).requires_grad_()
+  idh = ids.to(DEV).expand(B, T)                 # expanded view (stride 0) or a real (B,T) tensor
+  out = ops.concat_style(xh, Eh, idh)
+  assert rel_err(out, ref) == 0.0
+  gy = torch.randn(ref.shape, generator=gen)
+  ref.backward(gy.double()); out.backward(gy.to(DEV))
+  assert rel_err(xh.grad, x64.grad) == 0.0
+  assert rel_err(Eh.grad, E64.grad) < 1e-6
+
+
 def test_cross_entropy_both_layouts():
   from mix_stage_amd import ops
   gen = torch.Generator().manual_seed(3)
