@@ -127,6 +127,14 @@ def kernel_roofline(ts, batch, kinds):
               algorithmic_bytes_per_launch=round(top['bytes'] / top['count']),
               note='dominant kernel symbol by total time over 2 G-steps + 2 D-steps; avg over all its launches (all layer '
                    'shapes), HIP events on the launch stream; same aggregation as rocprofv3 --kernel-trace --stats')
+  # HBM traffic of that kernel from the committed PMC passes (tools/pmc_summary.py; rocprofv3 cannot run inside bench.py)
+  try:
+    pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))['kernels'].get(top['sym'])
+    if pmc:
+      roof['traffic'] = pmc['hbm_bytes_per_launch']
+      roof['traffic_note'] = 'HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r01_pmc_traffic.json'
+  except (OSError, ValueError, KeyError):
+    pass
   rows.sort(key=lambda r: -r['total_ms'])
   return roof, rows
 
