@@ -50,6 +50,14 @@ __device__ inline float block_sum_256(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// XCD-aware workgroup id: MI355X deals consecutive workgroup ids round-robin over its 8 XCDs (each with a private
+// L2).  This bijective remap gives every XCD one CONTIGUOUS range of logical ids, so workgroups that share operand
+// tiles (neighbouring logical ids) hit the same L2.  Speed only, never correctness.
+__device__ inline int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
 __device__ inline float lrelu(float z, float slope) { return z > 0.f ? z : z * slope; }
 
 }  // namespace ms

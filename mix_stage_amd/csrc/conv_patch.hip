@@ -52,10 +52,14 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PatchArgs p) {
 
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wm = wid >> 1, wn = wid & 1, khalf = lane >> 5;
-  const int g = blockIdx.z / p.splitk, ks = blockIdx.z - g * p.splitk, m0 = blockIdx.y * BM;
+  // logical block id: channel tile fastest, then pixel tile, then (group, K slice); one contiguous range per XCD, so the
+  // channel tiles that share an input patch sit behind the same L2
+  const int vid = xcd_remap(blockIdx.x, p.gx * p.gy * p.gz);
+  const int by_ = vid % p.gy, bx_ = (vid / p.gy) % p.gx, bz_ = vid / (p.gy * p.gx);
+  const int g = bz_ / p.splitk, ks = bz_ - g * p.splitk, m0 = by_ * BM;
   const int tiles_per_img = p.tiles_y * p.tiles_x;
-  const int img = blockIdx.x / tiles_per_img;
-  const int trem = blockIdx.x - img * tiles_per_img;
+  const int img = bx_ / tiles_per_img;
+  const int trem = bx_ - img * tiles_per_img;
   const int tyi = trem / p.tiles_x, txi = trem - tyi * p.tiles_x;
   const int oy0 = tyi * TH, ox0 = txi * TW;
   const int iy0 = oy0 * SV - p.PH, ix0 = ox0 * S - p.PW;
@@ -316,11 +320,11 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PatchArgs p) {
       }
     __syncthreads();
     if (t < BM && m0 + t < p.Mg) {
-      float* st = p.stats + ((size_t)blockIdx.x * ctot + g * p.Mg + m0 + t) * 2;
+      float* st = p.stats + ((size_t)bx_ * ctot + g * p.Mg + m0 + t) * 2;
       st[0] = red[t] + red[BM + t];
       st[1] = red[2 * BM + t] + red[3 * BM + t];
     }
-    if (t == 0 && blockIdx.y == 0 && g == 0) p.counts[blockIdx.x] = (float)cnt;
+    if (t == 0 && by_ == 0 && g == 0) p.counts[bx_] = (float)cnt;
   }
 }
 
@@ -405,14 +409,16 @@ static void launch_patch_k(const PatchArgs& a, int kh, int kw, int s_, int tw, b
 int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S, bool up2, double flops, double bytes,
                  hipStream_t s) {
   const int bm = 64 * pl.tm;
-  dim3 grid(pl.n_tiles, cdiv(a.Mg, bm), a.groups * a.splitk);
-  if (grid.y > 65535 || grid.z > 65535) return set_error("conv grid too large");
+  PatchArgs b = a;
+  b.gx = pl.n_tiles; b.gy = cdiv(a.Mg, bm); b.gz = a.groups * a.splitk;
+  if ((double)b.gx * b.gy * b.gz > 2.0e9) return set_error("conv grid too large");
+  dim3 grid(b.gx * b.gy * b.gz);
   if (a.splitk < 1 || (a.splitk > 1 && !a.part)) return set_error("patch conv: bad split-K setup");
   TimingScope ts(s, flops, bytes, "conv_patch_kernel<%d,%d,%d,%d,%d,%d,%d>|conv_%s_patch k%dx%d s%d Mg%d Kg%d g%d tiles%d tile%d tw%d splitk%d%s",
                  pl.tm, pl.tm, KH, KW, S, pl.tw, up2 ? 1 : 0, a.is_dgrad ? "dgrad" : "fwd", KH, KW, S, a.Mg, a.Kg,
                  a.groups, pl.n_tiles, bm, pl.tw, a.splitk, a.ep == EP_RAW_STATS ? " +bnstats" : "");
-  if (pl.tm == 2) launch_patch_k<2>(a, KH, KW, S, pl.tw, up2, grid, s);
-  else launch_patch_k<1>(a, KH, KW, S, pl.tw, up2, grid, s);
+  if (pl.tm == 2) launch_patch_k<2>(b, KH, KW, S, pl.tw, up2, grid, s);
+  else launch_patch_k<1>(b, KH, KW, S, pl.tw, up2, grid, s);
   return check_launch("conv_patch_kernel");
 }
 

@@ -65,6 +65,7 @@ struct PatchArgs {
   int o_sh, o_sw, o_ry, o_rx;   // output scatter: (oy*o_sh + o_ry, ox*o_sw + o_rx); data gradient of a strided conv
   float* out2;                  // EP_DGRAD_UP2: gradient of the residual
   int is_dgrad;                 // label only
+  int gx, gy, gz;               // logical grid (pixel tiles, channel tiles, groups*splitk); launched 1-D, XCD-remapped
   int splitk, chunks_per_split; // split-K over workgroups: raw partial tiles go to part[ks] (output layout)
   float* part;
   size_t part_stride;
@@ -89,6 +90,7 @@ struct WgradPatchArgs {
   int SRCH, SRCW, s_img, s_chan, s_row, PH, PW;
   int OUTH, OUTW, o_img, o_chan, o_row;
   int tiles_x, tiles_y, n_tiles, tiles_per_split, splits;
+  int gx, gy, gz;      // logical grid (column tiles, channel tiles, groups*splits); launched 1-D, XCD-remapped
 };
 struct WgradPatchPlan { int ok, tw, tiles_y, tiles_x, n_tiles, splits, tiles_per_split; };
 WgradPatchPlan plan_wgrad_patch(int nd, int Cog, int Kg, int groups, int KH, int KW, int SH, int SW, int B, int OH, int OW);

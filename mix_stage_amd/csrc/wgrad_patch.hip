@@ -36,8 +36,12 @@ __global__ __launch_bounds__(256) void wgrad_patch_kernel(const WgradPatchArgs p
 
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wm = wid >> 1, wn = wid & 1, khalf = lane >> 5;
-  const int g = blockIdx.z / p.splits, sp = blockIdx.z - g * p.splits;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // logical block id: column tile fastest, then channel tile, then (group, pixel split); one contiguous range per XCD:
+  // all workgroups of a pixel split (which re-read the same dy / x tiles) sit behind the same L2
+  const int vid = xcd_remap(blockIdx.x, p.gx * p.gy * p.gz);
+  const int bx_ = vid % p.gx, by_ = (vid / p.gx) % p.gy, bz_ = vid / (p.gx * p.gy);
+  const int g = bz_ / p.splits, sp = bz_ - g * p.splits;
+  const int m0 = by_ * BM, n0 = bx_ * BN;
   const int ctot = p.groups * p.Cog;
   const int ci_first = n0 / KHW;
   const int cbase = (p.bcast ? 0 : g * p.Cig) + ci_first;
@@ -208,19 +212,21 @@ static void launch_wgp_tw(const WgradPatchArgs& a, int tw, dim3 grid, hipStream_
 
 int launch_wgrad_patch(const WgradPatchArgs& a, const WgradPatchPlan& pl, int KH, int KW, int S, bool up2, double flops,
                        double bytes, hipStream_t s) {
-  dim3 grid(cdiv(a.Kg, 64), cdiv(a.Cog, 64), a.groups * a.splits);
-  if (grid.y > 65535 || grid.z > 65535) return set_error("wgrad grid too large");
+  WgradPatchArgs b = a;
+  b.gx = cdiv(a.Kg, 64); b.gy = cdiv(a.Cog, 64); b.gz = a.groups * a.splits;
+  if ((double)b.gx * b.gy * b.gz > 2.0e9) return set_error("wgrad grid too large");
+  dim3 grid(b.gx * b.gy * b.gz);
   TimingScope ts(s, flops, bytes, "wgrad_patch_kernel<1,1,%d,%d,%d,%d,%d>|conv_wgrad_patch k%dx%d s%d Cog%d Kg%d g%d tiles%d tw%d splits%d",
                  KH, KW, S, pl.tw, up2 ? 1 : 0, KH, KW, S, a.Cog, a.Kg, a.groups, pl.n_tiles, pl.tw, a.splits);
   if (KH == 1 && KW == 3 && S == 1) {
-    if (up2) launch_wgp_tw<1, 3, 1, true>(a, pl.tw, grid, s);
-    else launch_wgp_tw<1, 3, 1, false>(a, pl.tw, grid, s);
-  } else if (KH == 1 && KW == 4 && S == 2) launch_wgp_tw<1, 4, 2, false>(a, pl.tw, grid, s);
-  else if (KH == 1 && KW == 4 && S == 1) launch_wgp_tw<1, 4, 1, false>(a, pl.tw, grid, s);
-  else if (KH == 1 && KW == 1 && S == 1) launch_wgp_tw<1, 1, 1, false>(a, pl.tw, grid, s);
-  else if (KH == 3 && KW == 3 && S == 1) launch_wgp_tw<3, 3, 1, false>(a, pl.tw, grid, s);
-  else if (KH == 4 && KW == 4 && S == 2) launch_wgp_tw<4, 4, 2, false>(a, pl.tw, grid, s);
-  else launch_wgp_tw<3, 8, 1, false>(a, pl.tw, grid, s);
+    if (up2) launch_wgp_tw<1, 3, 1, true>(b, pl.tw, grid, s);
+    else launch_wgp_tw<1, 3, 1, false>(b, pl.tw, grid, s);
+  } else if (KH == 1 && KW == 4 && S == 2) launch_wgp_tw<1, 4, 2, false>(b, pl.tw, grid, s);
+  else if (KH == 1 && KW == 4 && S == 1) launch_wgp_tw<1, 4, 1, false>(b, pl.tw, grid, s);
+  else if (KH == 1 && KW == 1 && S == 1) launch_wgp_tw<1, 1, 1, false>(b, pl.tw, grid, s);
+  else if (KH == 3 && KW == 3 && S == 1) launch_wgp_tw<3, 3, 1, false>(b, pl.tw, grid, s);
+  else if (KH == 4 && KW == 4 && S == 2) launch_wgp_tw<4, 4, 2, false>(b, pl.tw, grid, s);
+  else launch_wgp_tw<3, 8, 1, false>(b, pl.tw, grid, s);
   return check_launch("wgrad_patch_kernel");
 }
 
