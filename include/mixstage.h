@@ -161,6 +161,8 @@ size_t ms_timing_report(char* buf, size_t cap);
 /* Test aid: the patch-staged conv kernel is used when a launch has at least this many workgroups (default 96);
  * tests set 0 to exercise it at small sizes.  Returns the previous value. */
 int ms_debug_set_patch_min_workgroups(int n);
+/* Tuning aid: 128x128 tiles are used when they still yield at least this many workgroups (default 512). */
+int ms_debug_set_patch_big_tile_min(int n);
 
 /* Self-test kernel: C(32x32) = A(32xK) * B(Kx32) through the fp32 MFMA path (checks fragment maps). */
 int ms_selftest_mfma(const float* A, const float* B, float* C, int K, void* stream);

@@ -330,7 +330,8 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PatchArgs p) {
 
 // ---------------------------------------------------------------------------------------------
 // dispatch
-int g_patch_min_wgs = 96;   // below this many workgroups the split-K im2col path is used instead
+int g_patch_min_wgs = 96;
+int g_patch_big_min = 1 << 30;   // 128x128 tiles when they still give this many workgroups (test/tuning knob)   // below this many workgroups the split-K im2col path is used instead
 int patch_chunk_channels(int KH, int KW) {
   const int khw = KH * KW;
   return khw == 1 ? 32 : khw == 2 ? 16 : khw == 3 ? 16 : khw == 4 ? 16 : khw == 9 ? 4 : khw == 16 ? 4 : khw == 24 ? 2 : 4;
@@ -355,7 +356,7 @@ PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH,
   if (Mg >= 128) {
     const int th = 128 / tw;
     const long big = (long)cdiv(Mg, 128) * groups * imgs * cdiv(rows, th) * cdiv(OW, tw);
-    if (big >= 512) tm = 2;
+    if (big >= g_patch_big_min) tm = 2;
   }
   const int th = 64 * tm / tw;
   pl.ok = 1; pl.tm = tm; pl.tw = tw;
@@ -423,6 +424,12 @@ int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S,
 }
 
 }  // namespace ms
+
+extern "C" int ms_debug_set_patch_big_tile_min(int n) {
+  const int old = ms::g_patch_big_min;
+  ms::g_patch_big_min = n;
+  return old;
+}
 
 extern "C" int ms_debug_set_patch_min_workgroups(int n) {
   const int old = ms::g_patch_min_wgs;

@@ -175,6 +175,57 @@ def test_golden_vectors_from_reference(golden_dir, name):
   assert np.abs(fake_s.cpu().numpy() - z['S/pose']).mean() <= 1e-4
 
 
+def test_long_context_full_speaker_set():
+  """BASELINE configs[3] geometry: M = S = 25 (full PATS speaker set), T = 256 (time axis tiled inside the kernels,
+  BN statistics over the full (B,T)); reduced batch so the CPU oracle finishes in seconds."""
+  M = S = 25
+  T = 256
+  batch = O.synthetic_batch(2, T=T, M=M, S=S)
+  ref = O.build_gan(M=M, S=S, T=T)
+  import mix_stage_amd as A
+  G = A.JointLateClusterSoftStyle4_G(time_steps=T, out_feats=104, num_clusters=M, style_dict={i: i for i in range(S)},
+                                     style_dim=10, lambda_id=0.1, argmax=1, some_grad_flag=1, train_only=1, shape={})
+  D = A.Speech2Gesture_D(in_channels=104)
+  hip = A.GAN(G, D, criterion='L1Loss', input_modalities=['audio/log_mel_400'], update_D_prob_flag=0, no_grad=0)
+  hip.load_state_dict(O.deterministic_state(hip.state_dict()))
+  hip.G.thresh.value, hip.G.thresh.iters = 1, 10 ** 9
+  hip = hip.to(DEV)
+  for kind in ('G', 'D'):
+    for m, dev in ((ref, 'cpu'), (hip, DEV)):
+      audio, pose, labels, style = [t.to(dev) for t in batch]
+      m.train(); m.zero_grad()
+      m.D_prob = 1.1 if kind == 'D' else -1.0
+      fake, losses, _ = m([audio, labels], pose, **O.model_kwargs(style, T))
+      sum(l for l in losses if l.requires_grad).backward()
+      if dev == 'cpu':
+        f_ref, l_ref = fake.detach(), [float(l) for l in losses]
+      else:
+        f_hip, l_hip = fake.detach().cpu(), [float(l) for l in losses]
+    assert f_hip.shape == (2, T, 104)
+    assert (f_hip - f_ref).abs().mean().item() <= 1e-4
+    np.testing.assert_allclose(l_hip, l_ref, atol=2e-4)
+    probe = (lambda m: m.G.decoder[1].conv.weight) if kind == 'G' else (lambda m: m.D.conv3.conv.weight)
+    g_ref, g_hip = probe(ref).grad, probe(hip).grad.cpu()
+    assert ((g_hip - g_ref).norm() / g_ref.norm()).item() < 2e-2
+
+
+def test_inference_style_transfer_batch():
+  """BASELINE configs[4] path: eval mode, sample_flag=1 (style ids given, PoseStyleEncoder bypassed), large batch."""
+  B, M, S = 96, 8, 8
+  audio, pose, labels, style = O.synthetic_batch(B, M=M, S=S)
+  style = (style + 3) % S                     # transfer to another speaker's style (trainer.py:1367-1386)
+  ref = O.build_gan(M=M, S=S).eval()
+  hip = build_hip_gan(M, S).eval()
+  kw = O.model_kwargs(style); kw['sample_flag'] = 1
+  with torch.no_grad():
+    f_ref, l_ref, _ = ref([audio, labels], pose, **kw)
+    kw_h = dict(kw); kw_h['style'] = style.to(DEV)
+    f_hip, l_hip, _ = hip([audio.to(DEV), labels.to(DEV)], pose.to(DEV), **kw_h)
+  assert (f_hip.cpu() - f_ref).abs().mean().item() <= 1e-4
+  assert abs(float(l_hip[0]) - float(l_ref[0])) <= 1e-4
+  assert hip.G.labels_cap_soft.shape == (B, 64, M)
+
+
 def test_repeatability_bitwise():
   batch = O.synthetic_batch(2, M=2, S=2)
   outs = []
