@@ -156,6 +156,8 @@ class JointLateClusterSoftStyle4_G(nn.Module):
       elif len(style.shape) == 3:
         mode = 'lin'
       id_in_loss = torch.zeros(1)[0]
+    if mode == 'emb' and pose_style.dim() == 2 and pose_style.shape != (B, T) and pose_style.numel() == B * T:
+      pose_style = pose_style.reshape(B, T)                  # windows concatenated into one long sequence (TR:779-786)
     if mode == 'emb' and pose_style.dim() == 2 and pose_style.shape[1] == T:
       ## content || style embedding, channel-major, one kernel (JL:175-180)
       self.pose_style_ids = pose_style

@@ -1,0 +1,88 @@
+"""Inference / style-transfer driver: the core of the reference's sampling loop, MI355X-native.
+
+Reference: TrainerBase.sample_loop (src/model/trainer.py:740-849) loads one interval, takes ALL of its 64-frame
+windows, reshapes them to a single long sequence x:(1, n*64, F), y:(1, n*64, P) (trainer.py:779-786) and runs the
+fully-convolutional model once per target style with sample_flag=1, eval-mode BatchNorm and no_grad
+(trainer.py:1161-1163); update_kwargs (trainer.py:1367-1386) shifts the style ids modulo the number of styles.
+
+Here the eval forward (running-statistics BatchNorm is folded into each conv kernel's epilogue, MS_BN_EVAL) is captured
+into one HIP graph per sequence length and replayed for every target style; inputs live in static HBM buffers.
+Dataset I/O, ground-truth loading, metrics and rendering around the loop stay out of scope.
+"""
+import torch
+
+
+class StyleTransferSampler:
+  def __init__(self, model, num_styles, speaker_names=None, use_graphs=True):
+    self.model = model
+    self.num_styles = num_styles
+    self.speaker = speaker_names or [str(i) for i in range(num_styles)]
+    self.use_graphs = use_graphs
+    self._graphs = {}
+
+  def _kwargs(self, style, T):
+    return dict(input_modalities=self.model.input_modalities, desc='test', sample_flag=1, description='test',
+                style=style, time_steps=T)
+
+  def style_shifts(self, style, all_styles=True):
+    """(style ids, name) pairs of trainer.py:1367-1386 (`sample_all_styles` on/off)."""
+    style_id = int(style.reshape(-1)[0].item())
+    shifts = range(1, self.num_styles) if all_styles else (1,)
+    out = [(style, None)]
+    for sh in shifts:
+      tgt = (style_id + sh) % self.num_styles
+      name = '{}_{}'.format(self.speaker[style_id], self.speaker[tgt]) if all_styles else 'style'
+      out.append(((style + sh) % self.num_styles, name))
+    return out
+
+  def _forward(self, audio, labels, pose, style):
+    T = pose.shape[1]
+    with torch.no_grad():
+      y_cap, losses, _ = self.model([audio, labels], pose, **self._kwargs(style, T))
+    return y_cap, losses
+
+  def sample_interval(self, audio_windows, labels_windows, pose_windows, style_windows, all_styles=True):
+    """audio (n,64,F), labels (n,64), pose (n,64,P), style (n,64) of ONE interval, on the GPU.
+    Returns [(name, y_cap (1, n*64, P), [losses])] for the speaker's own style and every shifted style."""
+    m = self.model
+    m.eval()
+    n = pose_windows.shape[0]
+    audio = audio_windows.reshape(1, -1, audio_windows.shape[-1]).contiguous()
+    labels = labels_windows.reshape(1, -1).contiguous()
+    pose = pose_windows.reshape(1, -1, pose_windows.shape[-1]).contiguous()
+    style0 = style_windows.reshape(1, -1).contiguous()
+    results = []
+    key = (tuple(audio.shape), tuple(pose.shape))
+    entry = self._graphs.get(key) if self.use_graphs else None
+    for style, name in self.style_shifts(style0, all_styles):
+      if not self.use_graphs:
+        y_cap, losses = self._forward(audio, labels, pose, style)
+        results.append((name, y_cap, losses))
+        continue
+      if entry is None:
+        entry = self._capture(key, audio, labels, pose, style)
+      else:
+        torch.rand(1)                       # the forward draws once from the host generator (JL:127)
+      st = entry['static']
+      for k, src in (('audio', audio), ('labels', labels), ('pose', pose), ('style', style)):
+        st[k].copy_(src, non_blocking=True)
+      entry['graph'].replay()
+      results.append((name, entry['y_cap'].clone(), [l.clone() for l in entry['losses']]))
+    return results
+
+  def _capture(self, key, audio, labels, pose, style):
+    st = dict(audio=audio.clone(), labels=labels.clone(), pose=pose.clone(), style=style.clone())
+    rng = torch.get_rng_state()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+      self._forward(st['audio'], st['labels'], st['pose'], st['style'])    # sizes the workspace
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    torch.set_rng_state(rng)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+      y_cap, losses = self._forward(st['audio'], st['labels'], st['pose'], st['style'])
+    entry = dict(graph=g, static=st, y_cap=y_cap, losses=[l for l in losses])
+    self._graphs[key] = entry
+    return entry

@@ -226,6 +226,33 @@ def test_inference_style_transfer_batch():
   assert hip.G.labels_cap_soft.shape == (B, 64, M)
 
 
+@pytest.mark.parametrize('use_graphs', [False, True])
+def test_sampling_driver_long_sequence_all_styles(use_graphs):
+  """The reference's sampling loop core (trainer.py:779-786, 1367-1386): windows of one interval concatenated into one
+  long sequence, one eval forward per target style -- vs the oracle doing the same on the CPU."""
+  from mix_stage_amd.sample import StyleTransferSampler
+  M = S = 4
+  n = 6                                               # 6 windows -> one sequence of 384 frames
+  audio, pose, labels, style = O.synthetic_batch(n, M=M, S=S)
+  style = torch.full_like(style, 2)                   # one interval = one speaker
+  ref = O.build_gan(M=M, S=S).eval()
+  hip = build_hip_gan(M, S)
+  sampler = StyleTransferSampler(hip, num_styles=S, use_graphs=use_graphs)
+  for rep in range(2):                                # second call replays the captured graph
+    torch.manual_seed(5)
+    got = sampler.sample_interval(audio.to(DEV), labels.to(DEV), pose.to(DEV), style.to(DEV))
+    assert [g[0] for g in got] == [None, '2_3', '2_0', '2_1']
+    torch.manual_seed(5)
+    for (name, y_hip, l_hip), shift in zip(got, range(S)):
+      kw = O.model_kwargs(((style + shift) % S).reshape(1, -1), T=n * 64)
+      kw.update(sample_flag=1, desc='test', description='test')
+      with torch.no_grad():
+        y_ref, l_ref, _ = ref([audio.reshape(1, -1, 128), labels.reshape(1, -1)], pose.reshape(1, -1, 104), **kw)
+      assert y_hip.shape == (1, n * 64, 104)
+      assert (y_hip.cpu() - y_ref).abs().mean().item() <= 1e-4, name
+      assert abs(float(l_hip[0]) - float(l_ref[0])) <= 1e-4
+
+
 def test_repeatability_bitwise():
   batch = O.synthetic_batch(2, M=2, S=2)
   outs = []
