@@ -93,6 +93,17 @@ int ms_conv_block_bwd(const ms_conv_desc* d, const float* x, const float* x2, co
                       float* dx, float* dx2, float* dw, float* dbias, float* dgamma, float* dbeta,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* Same, with the weight gradient (dw) enqueued on `side_stream` (forked from `stream` once dy_raw exists; NOT joined
+ * here: the caller makes `stream` wait for `side_stream` before it reads dw, e.g. before the optimizer step).  The side
+ * stream gets its own scratch of ms_conv_block_bwd_workspace(d) bytes.  side_stream == NULL: identical to
+ * ms_conv_block_bwd.  x, x2, dy and dyr must stay valid until the streams are joined. */
+int ms_conv_block_bwd_overlap(const ms_conv_desc* d, const float* x, const float* x2, const float* w,
+                              const float* gamma, const float* running_mean, const float* running_var,
+                              const float* y_raw, const float* y, const float* save, const float* dy, float* dyr,
+                              float* dx, float* dx2, float* dw, float* dbias, float* dgamma, float* dbeta,
+                              void* workspace, size_t workspace_bytes, void* stream, void* side_stream,
+                              void* side_workspace, size_t side_workspace_bytes);
+
 /* AudioEncoder resize (layers.py:197): bilinear to (T,1), align_corners=False, == 1-D lerp in time
  * of frequency column F/2.   x (B,C,Tin,F) -> y (B,C,Tout). */
 int ms_lerp_time_fwd(const float* x, float* y, int B, int C, int Tin, int F, int Tout, void* stream);

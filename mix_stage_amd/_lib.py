@@ -35,6 +35,7 @@ SIGNATURES = {
     'ms_conv_block_bwd_workspace': (c_size_t, [_DESC]),
     'ms_conv_block_fwd': (c_int, [_DESC] + [_P] * 11 + [_P, c_size_t, _P]),
     'ms_conv_block_bwd': (c_int, [_DESC] + [_P] * 17 + [_P, c_size_t, _P]),
+    'ms_conv_block_bwd_overlap': (c_int, [_DESC] + [_P] * 17 + [_P, c_size_t, _P, _P, _P, c_size_t]),
     'ms_lerp_time_fwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'ms_lerp_time_bwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'ms_softmax_mix_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -184,6 +184,21 @@ int ms_conv_block_bwd(const ms_conv_desc* d, const float* x, const float* x2, co
                       const float* running_mean, const float* running_var, const float* y_raw, const float* y,
                       const float* save, const float* dy, float* dyr, float* dx, float* dx2, float* dw, float* dbias,
                       float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
+  return ms_conv_block_bwd_overlap(d, x, x2, w, gamma, running_mean, running_var, y_raw, y, save, dy, dyr, dx, dx2, dw, dbias,
+                                   dgamma, dbeta, workspace, workspace_bytes, stream, nullptr, nullptr, 0);
+}
+
+static hipEvent_t fork_event() {
+  static thread_local hipEvent_t ev = nullptr;
+  if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+  return ev;
+}
+
+int ms_conv_block_bwd_overlap(const ms_conv_desc* d, const float* x, const float* x2, const float* w, const float* gamma,
+                              const float* running_mean, const float* running_var, const float* y_raw, const float* y,
+                              const float* save, const float* dy, float* dyr, float* dx, float* dx2, float* dw,
+                              float* dbias, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                              void* stream, void* side_stream, void* side_workspace, size_t side_workspace_bytes) {
   (void)running_mean; (void)running_var;
   int rc = validate(d, "ms_conv_block_bwd");
   if (rc) return rc;
@@ -211,6 +226,15 @@ int ms_conv_block_bwd(const ms_conv_desc* d, const float* x, const float* x2, co
     wsp += align_up(wsize_of(d) * sizeof(float) * (sp > 1 ? sp : 0), 256);
   }
   float* dg_part = (float*)wsp;
+  // weight gradient on the side stream (its own scratch): it only needs dy_raw and the saved input, so it runs
+  // concurrently with this block's data gradient and the earlier blocks' backward on `stream`
+  hipStream_t ws_stream = s;
+  if (side_stream && side_stream != stream && dw) {
+    if (!side_workspace || side_workspace_bytes < ms_conv_block_bwd_workspace(d))
+      return set_error("ms_conv_block_bwd_overlap: side workspace too small");
+    ws_stream = (hipStream_t)side_stream;
+    wg_part = (float*)((char*)side_workspace + ((char*)wg_part - (char*)workspace));
+  }
 
   // 1. gradient wrt the raw conv output (+ per-channel column sums = bias gradient)
   const float* g = dy;
@@ -228,6 +252,12 @@ int ms_conv_block_bwd(const ms_conv_desc* d, const float* x, const float* x2, co
   if (dbias && !bias_done) {
     rc = launch_colsum_finalize(colpart, dbias, d->B, C, s);
     if (rc) return rc;
+  }
+
+  if (ws_stream != s) {
+    hipEvent_t ev = fork_event();
+    if (!ev || hipEventRecord(ev, s) != hipSuccess || hipStreamWaitEvent(ws_stream, ev, 0) != hipSuccess)
+      return set_error("ms_conv_block_bwd_overlap: stream fork failed");
   }
 
   // 2. data gradient: transposed gather over dyr with wt[g][ci][co][khw]
@@ -336,9 +366,9 @@ int ms_conv_block_bwd(const ms_conv_desc* d, const float* x, const float* x2, co
       q.tiles_per_split = wp.tiles_per_split; q.splits = wp.splits;
       const double flops = 2.0 * d->Cout * q.Kg * (double)npix * d->groups;
       const double bytes = 4.0 * ((double)npix * C + (double)d->B * cin_tot * d->H * d->W + (double)C * q.Kg);
-      rc = launch_wgrad_patch(q, wp, d->KH, d->KW, d->SW, up2, flops, bytes, s);
+      rc = launch_wgrad_patch(q, wp, d->KH, d->KW, d->SW, up2, flops, bytes, ws_stream);
       if (rc) return rc;
-      if (wp.splits > 1) rc = launch_reduce_splits(wg_part, dw, C * q.Kg, wp.splits, s);
+      if (wp.splits > 1) rc = launch_reduce_splits(wg_part, dw, C * q.Kg, wp.splits, ws_stream);
     } else {
       WgradArgs a = {};
       a.dyr = g; a.src = x; a.src2 = x2;
@@ -347,7 +377,7 @@ int ms_conv_block_bwd(const ms_conv_desc* d, const float* x, const float* x2, co
       a.H = d->H; a.W = d->W; a.OH = d->OH; a.OW = d->OW; a.Npix = npix;
       a.KH = d->KH; a.KW = d->KW; a.SH = d->SH; a.SW = d->SW; a.PH = d->PH; a.PW = d->PW;
       a.bcast = bcast;
-      rc = launch_wgrad(a, up2, dw, wg_part, s);
+      rc = launch_wgrad(a, up2, dw, wg_part, ws_stream);
     }
   }
   return rc;

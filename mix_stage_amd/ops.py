@@ -48,6 +48,36 @@ def workspace(nbytes, device):
   return ws
 
 
+_side_workspaces = {}
+
+
+def side_workspace(nbytes, device):
+  key = (device.type, device.index)
+  ws = _side_workspaces.get(key)
+  if ws is None or ws.numel() < nbytes:
+    ws = torch.empty(max(int(nbytes * 1.5), 1 << 22), dtype=torch.uint8, device=device)
+    _side_workspaces[key] = ws
+  return ws
+
+
+# Backward overlap: weight gradients run on a side HIP stream, concurrently with the data-gradient chain.
+_overlap = {'stream': None, 'keep': []}
+
+
+def set_backward_overlap(side_stream):
+  """side_stream: a torch.cuda.Stream (or None to disable).  The caller must call join_backward_overlap() after the
+  backward pass and before anything reads the weight gradients."""
+  _overlap['stream'] = side_stream
+  _overlap['keep'].clear()
+
+
+def join_backward_overlap():
+  side = _overlap['stream']
+  if side is not None:
+    torch.cuda.current_stream().wait_stream(side)
+  _overlap['keep'].clear()
+
+
 # ------------------------------------------------------------------------------------------------
 # conv block
 class ConvGeom:
@@ -163,9 +193,25 @@ class _ConvBlockFn(torch.autograd.Function):
       dgamma, direct_g = _grad_slot(pgamma, gamma)
       dbeta, direct_be = _grad_slot(pbeta, gamma)
     ws = workspace(d._bwd_ws, dev)
-    check(lib().ms_conv_block_bwd(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(gamma), None, None, _ptr(y_raw),
-                                  _ptr(y), _ptr(save), _ptr(dy), _ptr(dyr), _ptr(dx), _ptr(dx2), _ptr(dw), _ptr(dbias),
-                                  _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), _stream()), 'ms_conv_block_bwd')
+    side = _overlap['stream']
+    if side is not None and need_w and not direct_w:
+      # a second contribution to a parameter in this step (autograd will add it on this stream): the first one may
+      # still be in flight on the side stream
+      torch.cuda.current_stream().wait_stream(side)
+    if side is not None and direct_w and (dbias is None or direct_b):
+      # dw goes straight into the flat gradient buffer, so nothing downstream in autograd reads it: run it on the side
+      # stream.  Its inputs must outlive this function until the streams are joined.
+      ws2 = side_workspace(d._bwd_ws, dev)
+      _overlap['keep'].append((x, x2, dy, dyr))
+      check(lib().ms_conv_block_bwd_overlap(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(gamma), None, None,
+                                            _ptr(y_raw), _ptr(y), _ptr(save), _ptr(dy), _ptr(dyr), _ptr(dx), _ptr(dx2),
+                                            _ptr(dw), _ptr(dbias), _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(),
+                                            _stream(), _vp(side.cuda_stream), _ptr(ws2), ws2.numel()),
+            'ms_conv_block_bwd_overlap')
+    else:
+      check(lib().ms_conv_block_bwd(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(gamma), None, None, _ptr(y_raw),
+                                    _ptr(y), _ptr(save), _ptr(dy), _ptr(dyr), _ptr(dx), _ptr(dx2), _ptr(dw), _ptr(dbias),
+                                    _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), _stream()), 'ms_conv_block_bwd')
     return (dx, dx2, None if direct_w else dw, None if direct_b else dbias, None if direct_g else dgamma,
             None if direct_be else dbeta, None, None, None, None)
 

@@ -94,6 +94,24 @@ def test_three_steps_vs_oracle_and_graph_equals_eager():
     assert torch.equal(v, graph[1][k]), k
 
 
+def test_wgrad_side_stream_overlap_is_bit_identical():
+  """ms_conv_block_bwd_overlap: weight gradients on a side stream give the same bits as the serial path."""
+  from mix_stage_amd.train_step import MixStageTrainStep
+  M = S = 2
+  batch = [t.to(DEV) for t in O.synthetic_batch(3, M=M, S=S)]
+  audio, pose, labels, style = batch
+  out = []
+  for overlap in (False, True):
+    model = _hip(M, S)
+    ts = MixStageTrainStep(model, use_graphs=False, overlap_wgrad=overlap)
+    for k in ('G', 'D', 'G'):
+      ts.step(audio, labels, pose, style, kind=k)
+    torch.cuda.synchronize()
+    out.append({k: v.clone() for k, v in model.state_dict().items()})
+  for k, v in out[0].items():
+    assert torch.equal(v, out[1][k]), k
+
+
 def test_reference_coin_flip_sequence_and_rng_parity():
   """kind=None: the step kind follows gan.py:105's host draw and consumes the host generator exactly like the
   reference (2 draws per step), eager and under graph replay."""
