@@ -61,6 +61,12 @@ typedef struct ms_conv_desc {
 const char* ms_last_error(void);
 int ms_abi_version(void);
 
+/* Optional: a persistent, ZERO-INITIALISED int32 buffer (n >= 4096 words recommended: 65536) for in-launch split-K
+ * reductions: with it, the workgroup that arrives last on a tile sums the K slices inside the conv launch (fixed order,
+ * bitwise reproducible) instead of a separate reduce kernel.  The buffer belongs to the caller, must stay zero between
+ * launches (the kernels restore it) and serves one device.  NULL disables the in-launch form. */
+int ms_set_counter_buffer(int32_t* zeroed_counters, int n);
+
 /* Bytes of scratch the forward / backward of this block needs. */
 size_t ms_conv_block_fwd_workspace(const ms_conv_desc* d);
 size_t ms_conv_block_bwd_workspace(const ms_conv_desc* d);

@@ -31,6 +31,7 @@ _DESC = ctypes.POINTER(ConvDesc)
 SIGNATURES = {
     'ms_last_error': (ctypes.c_char_p, []),
     'ms_abi_version': (c_int, []),
+    'ms_set_counter_buffer': (c_int, [_P, c_int]),
     'ms_conv_block_fwd_workspace': (c_size_t, [_DESC]),
     'ms_conv_block_bwd_workspace': (c_size_t, [_DESC]),
     'ms_conv_block_fwd': (c_int, [_DESC] + [_P] * 11 + [_P, c_size_t, _P]),

@@ -366,9 +366,13 @@ int ms_conv_block_bwd_overlap(const ms_conv_desc* d, const float* x, const float
       q.tiles_per_split = wp.tiles_per_split; q.splits = wp.splits;
       const double flops = 2.0 * d->Cout * q.Kg * (double)npix * d->groups;
       const double bytes = 4.0 * ((double)npix * C + (double)d->B * cin_tot * d->H * d->W + (double)C * q.Kg);
+      if (wp.splits > 1) {
+        q.counters = counter_region(CNT_WGRAD, cdiv(q.Kg, 64) * cdiv(d->Cout, 64) * d->groups);
+        q.final_out = dw;
+      }
       rc = launch_wgrad_patch(q, wp, d->KH, d->KW, d->SW, up2, flops, bytes, ws_stream);
       if (rc) return rc;
-      if (wp.splits > 1) rc = launch_reduce_splits(wg_part, dw, C * q.Kg, wp.splits, ws_stream);
+      if (wp.splits > 1 && !q.counters) rc = launch_reduce_splits(wg_part, dw, C * q.Kg, wp.splits, ws_stream);
     } else {
       WgradArgs a = {};
       a.dyr = g; a.src = x; a.src2 = x2;

@@ -11,7 +11,15 @@ int set_error(const char* fmt, ...) {
   va_end(ap);
   return -1;
 }
+int* g_counters = nullptr;
+int g_counters_n = 0;
 }  // namespace ms
 
 extern "C" const char* ms_last_error(void) { return ms::g_err; }
 extern "C" int ms_abi_version(void) { return MS_ABI_VERSION; }
+
+extern "C" int ms_set_counter_buffer(int32_t* zeroed_counters, int n) {
+  ms::g_counters = zeroed_counters;
+  ms::g_counters_n = zeroed_counters ? n : 0;
+  return 0;
+}

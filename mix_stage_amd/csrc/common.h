@@ -12,6 +12,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 int set_error(const char* fmt, ...);
 
+// persistent, zero-initialised arrival counters for in-launch split reductions (ms_set_counter_buffer); nullptr: the
+// reductions run as separate kernels
+extern int* g_counters;
+extern int g_counters_n;
+enum { CNT_CONV = 0, CNT_WGRAD = 1 };   // halves of the buffer: kernels of the two kinds may run concurrently
+inline int* counter_region(int kind, int need) {
+  const int half = g_counters_n / 2;
+  return (g_counters && need <= half) ? g_counters + kind * half : nullptr;
+}
+
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error("%s: %s", what, hipGetErrorString(e));
@@ -56,6 +66,30 @@ __device__ inline float block_sum_256(float v, float* red) {
 __device__ inline int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// Split-K / split-reduction hand-off inside one launch (cdna_hip_programming.md Guideline 16, counter form): every
+// workgroup of a tile stores its partial slab, then arrives on the tile's counter; the workgroup that arrives LAST
+// (returns true) sees all slabs and finishes the tile.  It sums the slabs in slice order, so the result does not depend
+// on the arrival order (bitwise reproducible).  The last arriver resets the counter for the next launch.
+// `s_flag` is one word of LDS that is no longer in use.
+__device__ inline bool splitk_arrive_last(int* counter, int expected, int* s_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's slab stores have left
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // write back this XCD's L2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int prev = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = prev == expected - 1;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");    // drop this CU's stale L1 lines
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    *s_flag = last;
+  }
+  __syncthreads();
+  return *s_flag != 0;
 }
 
 __device__ inline float lrelu(float z, float slope) { return z > 0.f ? z : z * slope; }

@@ -91,6 +91,8 @@ struct WgradPatchArgs {
   int OUTH, OUTW, o_img, o_chan, o_row;
   int tiles_x, tiles_y, n_tiles, tiles_per_split, splits;
   int gx, gy, gz;      // logical grid (column tiles, channel tiles, groups*splits); launched 1-D, XCD-remapped
+  int* counters;       // per (group, channel tile, column tile) arrival counters: the last split sums the slabs in-launch
+  float* final_out;    // dw, written by the last arriver
 };
 struct WgradPatchPlan { int ok, tw, tiles_y, tiles_x, n_tiles, splits, tiles_per_split; };
 WgradPatchPlan plan_wgrad_patch(int nd, int Cog, int Kg, int groups, int KH, int KW, int SH, int SW, int B, int OH, int OW);

@@ -167,6 +167,26 @@ __global__ __launch_bounds__(256) void wgrad_patch_kernel(const WgradPatchArgs p
         if (m < p.Cog && nc < p.Kg) outp[(size_t)(g * p.Cog + m) * p.Kg + nc] = acc[i][j][r];
       }
     }
+  if (p.counters == nullptr || p.splits == 1) return;
+  // in-launch reduction over the pixel splits: the last workgroup to arrive for this tile sums the slabs in split order
+  if (!splitk_arrive_last(p.counters + (g * p.gy + by_) * p.gx + bx_, p.splits, reinterpret_cast<int*>(smem))) return;
+  const size_t slab = (size_t)ctot * p.Kg;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int nc = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+        if (m < p.Cog && nc < p.Kg) {
+          const size_t off = (size_t)(g * p.Cog + m) * p.Kg + nc;
+          float v = 0.f;
+          for (int k = 0; k < p.splits; ++k) v += p.out[(size_t)k * slab + off];
+          p.final_out[off] = v;
+        }
+      }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
