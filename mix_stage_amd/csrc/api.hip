@@ -284,9 +284,9 @@ int ms_conv_block_bwd_overlap(const ms_conv_desc* d, const float* x, const float
         const PatchPlan pp = plan_patch(one_d ? 1 : 2, d->Cin, tg, tcog, jh, jw, 1, 1, d->B, QH, QW);
         PatchPlan use = pp;
         use.splitk = pp0.splitk; use.chunks_per_split = pp0.chunks_per_split;   // one split factor for all classes
-        if (!pp.ok || pp.tm != pp0.tm || pp.tw != pp0.tw) {               // a smaller class than the planning one: reuse the plan geometry, recompute tiles
+        if (!pp.ok || pp.tm != pp0.tm || pp.tw != pp0.tw || pp.tn != pp0.tn) {               // a smaller class than the planning one: reuse the plan geometry, recompute tiles
           use = pp0;
-          const int rows = one_d ? d->B : QH, th = 64 * use.tm / use.tw;
+          const int rows = one_d ? d->B : QH, th = 64 * use.tn / use.tw;
           use.tiles_y = cdiv(rows, th); use.tiles_x = cdiv(QW, use.tw);
           use.n_tiles = (one_d ? 1 : d->B) * use.tiles_y * use.tiles_x;
         }

@@ -331,6 +331,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PatchArgs p) {
 // ---------------------------------------------------------------------------------------------
 // dispatch
 int g_patch_min_wgs = 96;
+int g_patch_wide_min = 1 << 30;  // 64x128 tiles (TN=2) when they still give this many workgroups (tuning knob)
 int g_patch_big_min = 1 << 30;   // 128x128 tiles when they still give this many workgroups (test/tuning knob)   // below this many workgroups the split-K im2col path is used instead
 int patch_chunk_channels(int KH, int KW) {
   const int khw = KH * KW;
@@ -338,7 +339,7 @@ int patch_chunk_channels(int KH, int KW) {
 }
 
 PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH, int SW, int B, int OH, int OW) {
-  PatchPlan pl = {0, 1, 64, 0, 0, 0, 1, 1 << 30};
+  PatchPlan pl = {0, 1, 64, 0, 0, 0, 1, 1 << 30, 1};
   const int S = SW;
   if (nd == 2 && SH != SW) return pl;
   const bool known = (KH == 1 && KW == 2 && S == 1) || (KH == 2 && KW == 2 && S == 1) || (KH == 1 && KW == 3 && S == 1) ||
@@ -358,8 +359,14 @@ PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH,
     const long big = (long)cdiv(Mg, 128) * groups * imgs * cdiv(rows, th) * cdiv(OW, tw);
     if (big >= g_patch_big_min) tm = 2;
   }
-  const int th = 64 * tm / tw;
-  pl.ok = 1; pl.tm = tm; pl.tw = tw;
+  int tn = tm;
+  if (tm == 1) {
+    const int th2 = 128 / tw;
+    const long wide = (long)cdiv(Mg, 64) * groups * imgs * cdiv(rows, th2) * cdiv(OW, tw);
+    if (wide >= g_patch_wide_min) tn = 2;
+  }
+  const int th = 64 * tn / tw;
+  pl.ok = 1; pl.tm = tm; pl.tw = tw; pl.tn = tn;
   pl.tiles_y = cdiv(rows, th); pl.tiles_x = cdiv(OW, tw);
   pl.n_tiles = imgs * pl.tiles_y * pl.tiles_x;
   const long base = (long)pl.n_tiles * cdiv(Mg, 64 * tm) * groups;
@@ -378,9 +385,9 @@ PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH,
   return pl;
 }
 
-template <int TM, int KH, int KW, int S, bool UP2>
+template <int TM, int TN, int KH, int KW, int S, bool UP2>
 static void launch_patch_tw(const PatchArgs& a, int tw, dim3 grid, hipStream_t s) {
-#define MS_PK(TW) hipLaunchKernelGGL((conv_patch_kernel<TM, TM, KH, KW, S, TW, UP2>), grid, dim3(256), 0, s, a)
+#define MS_PK(TW) hipLaunchKernelGGL((conv_patch_kernel<TM, TN, KH, KW, S, TW, UP2>), grid, dim3(256), 0, s, a)
   if constexpr (KH == 1) {
     if (tw == 64) MS_PK(64);
     else if (tw == 32) MS_PK(32);
@@ -392,19 +399,19 @@ static void launch_patch_tw(const PatchArgs& a, int tw, dim3 grid, hipStream_t s
 #undef MS_PK
 }
 
-template <int TM>
+template <int TM, int TN>
 static void launch_patch_k(const PatchArgs& a, int kh, int kw, int s_, int tw, bool up2, dim3 grid, hipStream_t s) {
   if (kh == 1 && kw == 3 && s_ == 1) {
-    if (up2) launch_patch_tw<TM, 1, 3, 1, true>(a, tw, grid, s);
-    else launch_patch_tw<TM, 1, 3, 1, false>(a, tw, grid, s);
-  } else if (kh == 1 && kw == 4 && s_ == 2) launch_patch_tw<TM, 1, 4, 2, false>(a, tw, grid, s);
-  else if (kh == 1 && kw == 4 && s_ == 1) launch_patch_tw<TM, 1, 4, 1, false>(a, tw, grid, s);
-  else if (kh == 1 && kw == 1 && s_ == 1) launch_patch_tw<TM, 1, 1, 1, false>(a, tw, grid, s);
-  else if (kh == 1 && kw == 2 && s_ == 1) launch_patch_tw<TM, 1, 2, 1, false>(a, tw, grid, s);
-  else if (kh == 2 && kw == 2 && s_ == 1) launch_patch_tw<TM, 2, 2, 1, false>(a, tw, grid, s);
-  else if (kh == 3 && kw == 3 && s_ == 1) launch_patch_tw<TM, 3, 3, 1, false>(a, tw, grid, s);
-  else if (kh == 4 && kw == 4 && s_ == 2) launch_patch_tw<TM, 4, 4, 2, false>(a, tw, grid, s);
-  else launch_patch_tw<TM, 3, 8, 1, false>(a, tw, grid, s);
+    if (up2) launch_patch_tw<TM, TN, 1, 3, 1, true>(a, tw, grid, s);
+    else launch_patch_tw<TM, TN, 1, 3, 1, false>(a, tw, grid, s);
+  } else if (kh == 1 && kw == 4 && s_ == 2) launch_patch_tw<TM, TN, 1, 4, 2, false>(a, tw, grid, s);
+  else if (kh == 1 && kw == 4 && s_ == 1) launch_patch_tw<TM, TN, 1, 4, 1, false>(a, tw, grid, s);
+  else if (kh == 1 && kw == 1 && s_ == 1) launch_patch_tw<TM, TN, 1, 1, 1, false>(a, tw, grid, s);
+  else if (kh == 1 && kw == 2 && s_ == 1) launch_patch_tw<TM, TN, 1, 2, 1, false>(a, tw, grid, s);
+  else if (kh == 2 && kw == 2 && s_ == 1) launch_patch_tw<TM, TN, 2, 2, 1, false>(a, tw, grid, s);
+  else if (kh == 3 && kw == 3 && s_ == 1) launch_patch_tw<TM, TN, 3, 3, 1, false>(a, tw, grid, s);
+  else if (kh == 4 && kw == 4 && s_ == 2) launch_patch_tw<TM, TN, 4, 4, 2, false>(a, tw, grid, s);
+  else launch_patch_tw<TM, TN, 3, 8, 1, false>(a, tw, grid, s);
 }
 
 int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S, bool up2, double flops, double bytes,
@@ -418,16 +425,17 @@ int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S,
   TimingScope ts(s, flops, bytes, "conv_patch_kernel<%d,%d,%d,%d,%d,%d,%d>|conv_%s_patch k%dx%d s%d Mg%d Kg%d g%d tiles%d tile%d tw%d splitk%d%s",
                  pl.tm, pl.tm, KH, KW, S, pl.tw, up2 ? 1 : 0, a.is_dgrad ? "dgrad" : "fwd", KH, KW, S, a.Mg, a.Kg,
                  a.groups, pl.n_tiles, bm, pl.tw, a.splitk, a.ep == EP_RAW_STATS ? " +bnstats" : "");
-  if (pl.tm == 2) launch_patch_k<2>(b, KH, KW, S, pl.tw, up2, grid, s);
-  else launch_patch_k<1>(b, KH, KW, S, pl.tw, up2, grid, s);
+  if (pl.tm == 2) launch_patch_k<2, 2>(b, KH, KW, S, pl.tw, up2, grid, s);
+  else if (pl.tn == 2) launch_patch_k<1, 2>(b, KH, KW, S, pl.tw, up2, grid, s);
+  else launch_patch_k<1, 1>(b, KH, KW, S, pl.tw, up2, grid, s);
   return check_launch("conv_patch_kernel");
 }
 
 }  // namespace ms
 
 extern "C" int ms_debug_set_patch_big_tile_min(int n) {
-  const int old = ms::g_patch_big_min;
-  ms::g_patch_big_min = n;
+  const int old = ms::g_patch_wide_min;
+  ms::g_patch_wide_min = n;
   return old;
 }
 

@@ -72,7 +72,7 @@ struct PatchArgs {
   int PH, PW, tiles_x, tiles_y;
   float slope, eps;
 };
-struct PatchPlan { int ok, tm, tw, tiles_y, tiles_x, n_tiles, splitk, chunks_per_split; };
+struct PatchPlan { int ok, tm, tw, tiles_y, tiles_x, n_tiles, splitk, chunks_per_split, tn; };
 PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH, int SW, int B, int OH, int OW);
 int patch_chunk_channels(int KH, int KW);
 int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S, bool up2, double flops, double bytes,
