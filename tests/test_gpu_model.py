@@ -175,6 +175,37 @@ def test_golden_vectors_from_reference(golden_dir, name):
   assert np.abs(fake_s.cpu().numpy() - z['S/pose']).mean() <= 1e-4
 
 
+def test_curriculum_pose_branch_and_thresh_ramp():
+  """Row a11: while the curriculum threshold is below the host draw, the generator is fed PoseEncoder(y) instead of
+  the audio encoder (JL:127-129); thresh ramps by 1/1000 per training call (layers.py:677-696)."""
+  M = S = 2
+  batch = O.synthetic_batch(3, M=M, S=S)
+  ref = O.build_gan(M=M, S=S)
+  hip = build_hip_gan(M, S)
+  for m in (ref, hip):
+    m.G.thresh.value, m.G.thresh.iters = 0.0, 0          # fresh curriculum: the first draws pick the pose branch
+  for step in range(2):
+    outs = []
+    for m, dev in ((ref, 'cpu'), (hip, DEV)):
+      audio, pose, labels, style = [t.to(dev) for t in batch]
+      m.train(); m.zero_grad()
+      m.D_prob = -1.0
+      torch.manual_seed(21 + step)
+      fake, losses, _ = m([audio, labels], pose, **O.model_kwargs(style))
+      sum(l for l in losses if l.requires_grad).backward()
+      outs.append((fake.detach().cpu(), [float(l) for l in losses]))
+    assert (outs[0][0] - outs[1][0]).abs().mean().item() <= 1e-4
+    np.testing.assert_allclose(outs[1][1], outs[0][1], atol=2e-4)
+    assert hip.G.thresh.value == ref.G.thresh.value == (step + 1) / 1000
+    # the pose branch trains pose_encoder and leaves audio_encoder without gradients
+    for m in (ref, hip):
+      assert m.G.pose_encoder.conv[0].conv.weight.grad is not None
+      assert m.G.audio_encoder.conv[0].conv.weight.grad is None
+    g_ref = ref.G.pose_encoder.conv[2].conv.weight.grad
+    g_hip = hip.G.pose_encoder.conv[2].conv.weight.grad.cpu()
+    assert ((g_hip - g_ref).norm() / g_ref.norm()).item() < 2e-2
+
+
 def test_long_context_full_speaker_set():
   """BASELINE configs[3] geometry: M = S = 25 (full PATS speaker set), T = 256 (time axis tiled inside the kernels,
   BN statistics over the full (B,T)); reduced batch so the CPU oracle finishes in seconds."""
