@@ -167,6 +167,14 @@ int ms_sqnorm(const float* g, size_t n, float* norm_out, float* partials, void* 
 /* step_state: 4 int32 words on the device, word 0 = step count (starts at 0), words 1..3 scratch. */
 int ms_adam_step(float* p, const float* g, float* m, float* v, size_t n, const float* norm, float max_norm,
                  float lr, float beta1, float beta2, float eps, int32_t* step_state, void* stream);
+/* Same with torch.optim.Adam's PER-PARAMETER step counts: the flat buffer is a sequence of segments (one per parameter,
+ * 64-element aligned); seg_of_chunk[i/64] = segment of element i; seg_first_step[s] = the global step (1-based) at
+ * which segment s first received a gradient, -1 = never (such parameters are skipped, as torch does for grad None);
+ * seg_scratch = 2*n_seg floats of device scratch. */
+int ms_adam_step_segmented(float* p, const float* g, float* m, float* v, size_t n, const float* norm, float max_norm,
+                           float lr, float beta1, float beta2, float eps, int32_t* step_state,
+                           const int32_t* seg_of_chunk, const int32_t* seg_first_step, float* seg_scratch, int n_seg,
+                           void* stream);
 size_t ms_reduce_partials_count(size_t n); /* floats needed in `partials` of ms_sqnorm / ms_l1_mean_fwd */
 
 /* Measurement aid (bench.py): when enabled, every conv / BN launch is bracketed by HIP events on its stream.

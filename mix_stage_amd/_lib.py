@@ -53,6 +53,8 @@ SIGNATURES = {
     'ms_l1_mean_bwd': (c_int, [_P, _P, c_float, _P, _P, c_size_t, _P]),
     'ms_sqnorm': (c_int, [_P, c_size_t, _P, _P, _P]),
     'ms_adam_step': (c_int, [_P, _P, _P, _P, c_size_t, _P, c_float, c_float, c_float, c_float, c_float, _P, _P]),
+    'ms_adam_step_segmented': (c_int, [_P, _P, _P, _P, c_size_t, _P, c_float, c_float, c_float, c_float, c_float, _P, _P, _P, _P,
+                                       c_int, _P]),
     'ms_reduce_partials_count': (c_size_t, [c_size_t]),
     'ms_timing_enable': (c_int, [c_int]),
     'ms_timing_report': (c_size_t, [ctypes.c_char_p, c_size_t]),

@@ -570,6 +570,54 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// Segmented form: torch.optim.Adam keeps one step count PER PARAMETER, started when the parameter first receives a
+// gradient, and skips parameters that never had one.  seg_first[s] = global step (1-based) of the segment's first
+// gradient, or -1; seg_scratch[2s..2s+1] = (lr/bc1, sqrt(bc2)) of the segment for this step (0,0 = inactive).
+__global__ void adam_prep_seg_kernel(int32_t* state, const float* norm, float max_norm, float lr, float beta1, float beta2,
+                                     const int32_t* __restrict__ seg_first, float* __restrict__ seg_scratch, int n_seg) {
+  const int step = state[0] + 1;
+  for (int sidx = threadIdx.x; sidx < n_seg; sidx += blockDim.x) {
+    const int first = seg_first[sidx];
+    float ss = 0.f, b2 = 0.f;
+    if (first >= 1 && first <= step) {
+      const double t = (double)(step - first + 1);
+      ss = (float)((double)lr / (1.0 - pow((double)beta1, t)));
+      b2 = (float)sqrt(1.0 - pow((double)beta2, t));
+    }
+    seg_scratch[2 * sidx] = ss;
+    seg_scratch[2 * sidx + 1] = b2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    state[0] = step;
+    float coef = 1.f;
+    if (norm) {
+      coef = max_norm / (norm[0] + 1e-6f);
+      if (coef > 1.f) coef = 1.f;
+    }
+    reinterpret_cast<float*>(state)[1] = coef;
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_seg_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, size_t n, const int32_t* __restrict__ state,
+                                                       const int32_t* __restrict__ seg_of_chunk,
+                                                       const float* __restrict__ seg_scratch, float beta1, float beta2,
+                                                       float eps) {
+  const float coef = reinterpret_cast<const float*>(state)[1];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int sidx = seg_of_chunk[i >> 6];
+    const float step_size = seg_scratch[2 * sidx], bc2s = seg_scratch[2 * sidx + 1];
+    if (bc2s == 0.f) continue;                 // never received a gradient: torch.optim.Adam skips it
+    const float gi = g[i] * coef;
+    const float mi = m[i] + (1.f - beta1) * (gi - m[i]);
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= step_size * (mi / (sqrtf(vi) / bc2s + eps));
+  }
+}
+
 static inline int red_blocks(size_t n) {
   size_t b = (n + 256 * 8 - 1) / (256 * 8);
   if (b < 1) b = 1;
@@ -779,6 +827,20 @@ int ms_adam_step(float* p, const float* g, float* m, float* v, size_t n, const f
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, step_state, beta1, beta2, eps);
   return check_launch("adam_kernel");
+}
+
+int ms_adam_step_segmented(float* p, const float* g, float* m, float* v, size_t n, const float* norm, float max_norm, float lr,
+                           float beta1, float beta2, float eps, int32_t* step_state, const int32_t* seg_of_chunk,
+                           const int32_t* seg_first_step, float* seg_scratch, int n_seg, void* stream) {
+  hipLaunchKernelGGL(adam_prep_seg_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, step_state, norm, max_norm, lr, beta1,
+                     beta2, seg_first_step, seg_scratch, n_seg);
+  int rc = check_launch("adam_prep_seg_kernel");
+  if (rc) return rc;
+  int blocks = (int)std::min<size_t>((n + 1023) / 1024, 2048);
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adam_seg_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, step_state, seg_of_chunk,
+                     seg_scratch, beta1, beta2, eps);
+  return check_launch("adam_seg_kernel");
 }
 
 }  // extern "C"

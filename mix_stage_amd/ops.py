@@ -484,6 +484,12 @@ def adam_step(p, g, m, v, norm, max_norm, lr, beta1, beta2, eps, step_state):
                            eps, _ptr(step_state), _stream()), 'ms_adam_step')
 
 
+def adam_step_segmented(p, g, m, v, norm, max_norm, lr, beta1, beta2, eps, step_state, seg_of_chunk, seg_first, seg_scratch):
+  check(lib().ms_adam_step_segmented(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(norm), max_norm, lr, beta1, beta2,
+                                     eps, _ptr(step_state), _ptr(seg_of_chunk), _ptr(seg_first), _ptr(seg_scratch),
+                                     seg_first.numel(), _stream()), 'ms_adam_step_segmented')
+
+
 def selftest_mfma(A, B):
   _need_hip(A, B)
   K = A.shape[1]

@@ -87,11 +87,39 @@ class FlatAdam:
     self.norm = torch.zeros(1, dtype=torch.float32, device=dev)
     self.partials = torch.zeros(ops.lib().ms_reduce_partials_count(total), dtype=torch.float32, device=dev)
     self.step_state = torch.zeros(4, dtype=torch.int32, device=dev)
+    # torch.optim.Adam keeps one step count per parameter, started at the parameter's first gradient (and skips
+    # parameters that never had one): segment table for the flat buffer
+    seg = torch.empty(total // _ALIGN, dtype=torch.int32)
+    for i, (p, o) in enumerate(zip(self.params, offs)):
+      seg[o // _ALIGN:(o + (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN) // _ALIGN] = i
+    self.seg_of_chunk = seg.to(dev)
+    self.host_first = [-1] * len(self.params)          # global step (1-based) of each parameter's first gradient
+    self.seg_first = torch.full((len(self.params),), -1, dtype=torch.int32, device=dev)
+    self.seg_scratch = torch.zeros(2 * len(self.params), dtype=torch.float32, device=dev)
+    self.host_step = 0                                 # optimizer steps executed so far
 
   def zero_grad(self):
     self.flat_g.zero_()
     for p in self.params:
       p._ms_grad_fresh = True
+
+  def active_params(self):
+    """Indices of the parameters that received a gradient since zero_grad() (their kernels wrote into the slot)."""
+    return [i for i, p in enumerate(self.params) if not p._ms_grad_fresh]
+
+  def mark_active(self, indices):
+    """Record first-gradient steps for parameters that get a gradient in the step about to run."""
+    new = [i for i in indices if self.host_first[i] < 0]
+    if new:
+      for i in new:
+        self.host_first[i] = self.host_step + 1
+      self.seg_first.copy_(torch.tensor(self.host_first, dtype=torch.int32), non_blocking=False)
+
+  def reset_state(self):
+    self.exp_avg.zero_(); self.exp_avg_sq.zero_(); self.step_state.zero_()
+    self.host_first = [-1] * len(self.params)
+    self.seg_first.fill_(-1)
+    self.host_step = 0
 
   def gather_foreign_grads(self):
     """If someone replaced p.grad (e.g. model.zero_grad(set_to_none=True) then backward), fold it back."""
@@ -103,12 +131,17 @@ class FlatAdam:
         elif p.grad is not g:
           g.copy_(p.grad)
           p.grad = g
+          p._ms_grad_fresh = False
 
-  def clip_and_step(self):
-    """total_norm = ||g||_2 over all parameters; g *= min(1, max_norm/(norm+1e-6)); Adam update."""
+  def clip_and_step(self, count=True):
+    """total_norm = ||g||_2 over all parameters; g *= min(1, max_norm/(norm+1e-6)); Adam update (per-parameter step
+    counts).  count=False while a HIP graph is being captured (nothing executes)."""
     ops.grad_norm(self.flat_g, self.norm, self.partials)
-    ops.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.norm, self.max_norm, self.lr,
-                  self.betas[0], self.betas[1], self.eps, self.step_state)
+    ops.adam_step_segmented(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.norm, self.max_norm, self.lr,
+                            self.betas[0], self.betas[1], self.eps, self.step_state, self.seg_of_chunk, self.seg_first,
+                            self.seg_scratch)
+    if count:
+      self.host_step += 1
 
   @property
   def step_count(self):
@@ -183,6 +216,7 @@ class MixStageTrainStep:
       if not self.use_graphs:
         self.fake_pose, self.losses = self._forward_backward(audio, labels, pose, style)
         opt = self.optim_G if m.G_flag else self.optim_D
+        opt.mark_active(opt.active_params())
         self._all_reduce(opt)
         opt.clip_and_step()
       else:
@@ -210,10 +244,12 @@ class MixStageTrainStep:
       self._consume_decisions(k)
     for mod in entry['bn_tape']:
       mod._pending_batches += 1
+    opt.mark_active(entry['active'])
     entry['fwd_bwd'].replay()
     if self.world > 1:
       self._all_reduce(opt)
       entry['opt'].replay()
+    opt.host_step += 1
     self.fake_pose, self.losses = entry['fake'], entry['losses']
 
   def _capture(self, key, k, st, opt):
@@ -247,17 +283,18 @@ class MixStageTrainStep:
       with torch.cuda.graph(g1):
         fake, losses = self._forward_backward(st['audio'], st['labels'], st['pose'], st['style'])
         if self.world == 1:
-          opt.clip_and_step()
+          opt.clip_and_step(count=False)
     finally:
       layers.set_train_tape(None)
+    active = opt.active_params()
     for mod in tape:                      # the capture pass itself ran no kernels
       mod._pending_batches -= 1
     g2 = None
     if self.world > 1:
       g2 = torch.cuda.CUDAGraph()
       with torch.cuda.graph(g2):
-        opt.clip_and_step()
-    entry = dict(fwd_bwd=g1, opt=g2, fake=fake, losses=losses, bn_tape=tape)
+        opt.clip_and_step(count=False)
+    entry = dict(fwd_bwd=g1, opt=g2, fake=fake, losses=losses, bn_tape=tape, active=active)
     self._graphs[key] = entry
     return entry
 

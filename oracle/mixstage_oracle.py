@@ -605,9 +605,12 @@ def oracle_train_step(model, optim_G, optim_D, audio, pose, labels, style, step_
   :1138-1146 backward + clip_grad_norm_(.,1) + Adam on G or D).  `step_kind` in {'G','D'}
   pins gan.py:105's coin flip."""
   model.train()
-  model.zero_grad()
-  optim_G.zero_grad()
-  optim_D.zero_grad()
+  # The reference pins torch==1.5.0 (requirements.txt:13), whose zero_grad() ZEROES existing gradients instead of dropping
+  # them: a parameter that has received a gradient once keeps being updated by Adam (zero gradient, decaying momentum) in
+  # steps where it is unused, and a parameter that never had one is skipped.  set_to_none=False reproduces that.
+  model.zero_grad(set_to_none=False)
+  optim_G.zero_grad(set_to_none=False)
+  optim_D.zero_grad(set_to_none=False)
   model.D_prob = 1.1 if step_kind == 'D' else -1.0
   fake, losses, _ = model([audio, labels], pose, **model_kwargs(style, T))
   loss = 0

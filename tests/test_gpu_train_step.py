@@ -63,7 +63,7 @@ def test_three_steps_vs_oracle_and_graph_equals_eager():
       if rep == 1:
         model.load_state_dict(O.deterministic_state(model.state_dict()))
         for o in (ts.optim_G, ts.optim_D):
-          o.exp_avg.zero_(); o.exp_avg_sq.zero_(); o.step_state.zero_()
+          o.reset_state()
         got = []
       for (audio, pose, labels, style), k in zip(batches, kinds):
         ts.step(audio.to(DEV), labels.to(DEV), pose.to(DEV), style.to(DEV), kind=k)
@@ -92,6 +92,45 @@ def test_three_steps_vs_oracle_and_graph_equals_eager():
   assert graph[0] == eager[0]
   for k, v in eager[1].items():
     assert torch.equal(v, graph[1][k]), k
+
+
+@pytest.mark.parametrize('use_graphs', [False, True])
+def test_adam_per_parameter_step_origin_under_the_curriculum(use_graphs):
+  """torch.optim.Adam counts steps per parameter from its first gradient and (torch 1.5 zero_grad semantics) keeps
+  updating a parameter with zero gradients once it has had one: pose_encoder is trained in pose-branch steps only,
+  audio_encoder/unet-input in audio-branch steps only.  Sequence: G(pose) G(audio) D G(pose) G(audio)."""
+  from mix_stage_amd.train_step import MixStageTrainStep
+  M = S = 2
+  batches = [O.synthetic_batch(3, M=M, S=S, seed=70 + i) for i in range(5)]
+  POSE, AUDIO = (0.0, 0), (1.0, 10 ** 9)      # (thresh.value, thresh.iters): fresh curriculum / finished curriculum
+  plan = [('G', POSE), ('G', AUDIO), ('D', AUDIO), ('G', POSE), ('G', AUDIO)]
+  ref = O.build_gan(M=M, S=S)
+  og = torch.optim.Adam(ref.G.parameters(), lr=1e-4)
+  od = torch.optim.Adam(ref.D.parameters(), lr=1e-4)
+  hip = _hip(M, S)
+  ts = MixStageTrainStep(hip, use_graphs=use_graphs)
+  for (audio, pose, labels, style), (kind, th) in zip(batches, plan):
+    for m in (ref, hip):
+      m.G.thresh.value, m.G.thresh.iters = th
+    torch.manual_seed(3)
+    O.oracle_train_step(ref, og, od, audio, pose, labels, style, kind)
+    torch.manual_seed(3)
+    ts.step(audio.to(DEV), labels.to(DEV), pose.to(DEV), style.to(DEV), kind=kind)
+  # first-gradient steps recorded per parameter: pose_encoder at step 1, audio_encoder at step 2 (G optimizer steps)
+  names = [n for n, p in hip.G.named_parameters() if p.requires_grad]
+  first = dict(zip(names, ts.optim_G.host_first))
+  assert first['pose_encoder.conv.0.conv.weight'] == 1 and first['audio_encoder.conv.0.conv.weight'] == 2
+  assert first['text_encoder.conv.0.conv.weight'] == -1 and first['unet.conv1.0.conv.weight'] == 1
+  ref_sd = ref.state_dict()
+  for k, v in hip.state_dict().items():
+    if not v.is_floating_point() or 'running_' in k:
+      continue
+    d = (v.cpu() - ref_sd[k]).abs()
+    # <= 4 Adam steps of <= lr each, direction of near-zero gradients decided by rounding noise
+    assert d.max().item() <= 8.5e-4, (k, d.max().item())
+    assert d.mean().item() <= 1.5e-4, (k, d.mean().item())
+  # a never-used parameter is bit-for-bit untouched
+  assert torch.equal(hip.state_dict()['G.text_encoder.conv.0.conv.weight'].cpu(), ref_sd['G.text_encoder.conv.0.conv.weight'])
 
 
 def test_wgrad_side_stream_overlap_is_bit_identical():
