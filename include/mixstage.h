@@ -125,6 +125,16 @@ int ms_softmax_mix_fwd(const float* z, const float* score, float* soft, float* o
 int ms_softmax_mix_bwd(const float* z, const float* soft, const float* dout, float* dz, float* dscore,
                        int B, int M, int P, int T, void* stream);
 
+/* Pre-step in front of the path ("next" row N1; src/data/transform.py, src/model/trainer.py:1290-1308), on device:
+ * ms_kmeans_labels: KMeans.predict (transform.py:352-410) on RemoveJoints(pose): features [x | velocity], fp64 squared
+ *   distance to `centers` (M, 2*PK), first-minimum argmin -> labels (B,T) int64.  keep[PK] = surviving columns.
+ * ms_znorm_select: ZNorm.znorm (transform.py:221-226) then RemoveJoints (transform.py:481-507):
+ *   y[r][d] = (x[r][keep[d]] - mean[keep[d]]) * inv_std[keep[d]] in fp64 -> fp32; keep == NULL: all P columns. */
+int ms_kmeans_labels(const float* pose, const int32_t* keep, const double* centers, int64_t* labels, int B, int T, int P,
+                     int PK, int M, void* stream);
+int ms_znorm_select(const float* x, const int32_t* keep, const double* mean, const double* inv_std, float* y, size_t rows,
+                    int P, int PK, void* stream);
+
 /* content || style-embedding concat in channel-major layout (replaces EmbLin 'emb' lookup + torch.cat + transposes,
  * JL:175-180, layers.py:659-663): out (B, C+D, T) = [x (B,C,T) ; E[ids[b,t]] (D)].  ids is addressed as
  * ids[b*ids_stride_b + t*ids_stride_t] (stride_t = 0: one id per clip).  bwd: dx (B,C,T) and/or dE (S,D), NULL = skip. */

@@ -361,6 +361,49 @@ __global__ __launch_bounds__(256) void softmax_mix_bwd_kernel(const float* __res
 }
 
 // ----------------------------------------------------------------------------------------------
+// Pre-step ("next" row N1): k-means cluster labels of the raw pose and z-normalisation with joint removal, on device.
+// labels[b,t] = argmin_m sum_d (c[m][d] - f[b,t][d])^2, f = [x | velocity(x)], x = pose[b,t,keep], in fp64 like the
+// reference (transform.py:395-410); first minimum wins.  One wave per (b,t).
+__global__ __launch_bounds__(256) void kmeans_labels_kernel(const float* __restrict__ pose, const int32_t* __restrict__ keep,
+                                                            const double* __restrict__ centers, int64_t* __restrict__ labels,
+                                                            int BT, int T, int P, int PK, int M) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= BT) return;
+  const int t = r % T;
+  const float* xr = pose + (size_t)r * P;
+  int best = 0;
+  double bestd = 0.0;
+  for (int m = 0; m < M; ++m) {
+    const double* c = centers + (size_t)m * 2 * PK;
+    double acc = 0.0;
+    for (int d = lane; d < PK; d += 64) {
+      const int col = keep[d];
+      const double x = (double)xr[col];
+      const double v = t > 0 ? x - (double)xr[col - P] : 0.0;
+      const double dx = c[d] - x, dv = c[PK + d] - v;
+      acc += dx * dx + dv * dv;
+    }
+    acc = wave_sum_d(acc);
+    if (m == 0 || acc < bestd) { bestd = acc; best = m; }
+  }
+  if (lane == 0) labels[r] = best;
+}
+
+// y[r][d] = (x[r][keep[d]] - mean[keep[d]]) * inv_std[keep[d]]  computed in fp64, stored fp32 (transform.py:221-226,481-507)
+__global__ __launch_bounds__(256) void znorm_select_kernel(const float* __restrict__ x, const int32_t* __restrict__ keep,
+                                                           const double* __restrict__ mean, const double* __restrict__ inv_std,
+                                                           float* __restrict__ y, size_t rows, int P, int PK) {
+  const size_t total = rows * PK;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / PK;
+    const int d = (int)(i - r * PK);
+    const int col = keep ? keep[d] : d;
+    y[i] = (float)(((double)x[r * P + col] - mean[col]) * inv_std[col]);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
 // content || style concat (JL:175-180) in channel-major layout: out[b,c,t] = c < C ? x[b,c,t] : E[ids[b,t]][c-C]
 __global__ __launch_bounds__(256) void concat_style_fwd_kernel(const float* __restrict__ x, const float* __restrict__ emb,
                                                                const int64_t* __restrict__ ids, int ids_sb, int ids_st,
@@ -729,6 +772,22 @@ int ms_softmax_mix_bwd(const float* z, const float* soft, const float* dout, flo
   hipLaunchKernelGGL(softmax_mix_bwd_kernel, dim3(cdiv(T, MIX_TT), B), dim3(256), lds, (hipStream_t)stream, z, soft, dout, dz,
                      dscore, M, P, T);
   return check_launch("softmax_mix_bwd_kernel");
+}
+
+int ms_kmeans_labels(const float* pose, const int32_t* keep, const double* centers, int64_t* labels, int B, int T, int P,
+                     int PK, int M, void* stream) {
+  const int BT = B * T;
+  hipLaunchKernelGGL(kmeans_labels_kernel, dim3(cdiv(BT, 4)), dim3(256), 0, (hipStream_t)stream, pose, keep, centers, labels, BT,
+                     T, P, PK, M);
+  return check_launch("kmeans_labels_kernel");
+}
+
+int ms_znorm_select(const float* x, const int32_t* keep, const double* mean, const double* inv_std, float* y, size_t rows, int P,
+                    int PK, void* stream) {
+  int blocks = (int)std::min<size_t>((rows * PK + 255) / 256, 2048);
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(znorm_select_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, keep, mean, inv_std, y, rows, P, PK);
+  return check_launch("znorm_select_kernel");
 }
 
 int ms_concat_style_fwd(const float* x, const float* emb, const int64_t* ids, int ids_stride_b, int ids_stride_t, float* out,
