@@ -278,9 +278,12 @@ class MixStageTrainStep:
     m.G.thresh.value, m.G.thresh.iters = thresh
     tape = []
     layers.set_train_tape(tape)
+    # with a process group alive, RCCL's watchdog thread issues HIP calls of its own: only this thread's calls may
+    # invalidate the capture
+    mode = 'thread_local' if self.world > 1 else 'global'
     g1 = torch.cuda.CUDAGraph()
     try:
-      with torch.cuda.graph(g1):
+      with torch.cuda.graph(g1, capture_error_mode=mode):
         fake, losses = self._forward_backward(st['audio'], st['labels'], st['pose'], st['style'])
         if self.world == 1:
           opt.clip_and_step(count=False)
@@ -292,7 +295,7 @@ class MixStageTrainStep:
     g2 = None
     if self.world > 1:
       g2 = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(g2):
+      with torch.cuda.graph(g2, capture_error_mode=mode):
         opt.clip_and_step(count=False)
     entry = dict(fwd_bwd=g1, opt=g2, fake=fake, losses=losses, bn_tape=tape, active=active)
     self._graphs[key] = entry
