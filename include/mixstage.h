@@ -196,8 +196,9 @@ size_t ms_timing_report(char* buf, size_t cap);
 /* Test aid: the patch-staged conv kernel is used when a launch has at least this many workgroups (default 96);
  * tests set 0 to exercise it at small sizes.  Returns the previous value. */
 int ms_debug_set_patch_min_workgroups(int n);
-/* Tuning aid: 128x128 tiles are used when they still yield at least this many workgroups (default 512). */
-int ms_debug_set_patch_big_tile_min(int n);
+/* Tuning aid for the patch-staged conv kernel: 64x128 tiles when they still yield at least `wide_tile_min_workgroups`
+ * workgroups (0 = never, the default: measured no net gain), and a forced split-K factor (0 = planner's choice). */
+int ms_debug_set_patch_tuning(int wide_tile_min_workgroups, int force_splitk);
 
 /* Self-test kernel: C(32x32) = A(32xK) * B(Kx32) through the fp32 MFMA path (checks fragment maps). */
 int ms_selftest_mfma(const float* A, const float* B, float* C, int K, void* stream);

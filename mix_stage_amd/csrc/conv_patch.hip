@@ -331,6 +331,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PatchArgs p) {
 // ---------------------------------------------------------------------------------------------
 // dispatch
 int g_patch_min_wgs = 96;
+int g_patch_force_splitk = 0;   // tuning knob: > 0 forces this split-K factor in the patch kernel
 int g_patch_wide_min = 1 << 30;  // 64x128 tiles (TN=2) when they still give this many workgroups (tuning knob)
 int g_patch_big_min = 1 << 30;   // 128x128 tiles when they still give this many workgroups (test/tuning knob)   // below this many workgroups the split-K im2col path is used instead
 int patch_chunk_channels(int KH, int KW) {
@@ -374,7 +375,10 @@ PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH,
   if (base < g_patch_min_wgs) pl.ok = 0;
   // fewer workgroups than 1.5 per CU and a long reduction: slice the channel chunks over workgroups
   const int nchunks = cdiv(Kc, patch_chunk_channels(KH, KW));
-  if (pl.ok && base < 384 && nchunks >= 4) {
+  if (pl.ok && g_patch_force_splitk > 0 && nchunks >= g_patch_force_splitk) {
+    pl.chunks_per_split = cdiv(nchunks, g_patch_force_splitk);
+    pl.splitk = cdiv(nchunks, pl.chunks_per_split);
+  } else if (pl.ok && base < 384 && nchunks >= 4) {
     int sk = (int)std::min<long>(nchunks / 2, (384 + base - 1) / base);
     if (sk > 4) sk = 4;
     if (sk > 1) {
@@ -433,10 +437,10 @@ int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S,
 
 }  // namespace ms
 
-extern "C" int ms_debug_set_patch_big_tile_min(int n) {
-  const int old = ms::g_patch_wide_min;
-  ms::g_patch_wide_min = n;
-  return old;
+extern "C" int ms_debug_set_patch_tuning(int wide_tile_min_workgroups, int force_splitk) {
+  ms::g_patch_wide_min = wide_tile_min_workgroups > 0 ? wide_tile_min_workgroups : (1 << 30);
+  ms::g_patch_force_splitk = force_splitk > 0 ? force_splitk : 0;
+  return 0;
 }
 
 extern "C" int ms_debug_set_patch_min_workgroups(int n) {

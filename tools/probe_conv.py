@@ -31,7 +31,8 @@ def time_conv(B, cin, cout, T, k=3, s=1, p=1, groups=1, iters=50, nd=1, H=1):
 if __name__ == '__main__':
   from mix_stage_amd import _lib
   if len(sys.argv) > 1:
-    print('big-tile min set to', sys.argv[1], 'was', _lib.lib().ms_debug_set_patch_big_tile_min(int(sys.argv[1])))
+    _lib.lib().ms_debug_set_patch_tuning(int(sys.argv[1]), 0)
+    print('wide-tile min workgroups set to', sys.argv[1])
   print('--- 1-D k3 s1, M=256, N=2048, sweep Cin (K = 3*Cin)')
   for cin in (8, 21, 64, 128, 256, 512, 1024):
     us, tf = time_conv(32, cin, 256, 64)
