@@ -40,6 +40,15 @@ def average_flat_gradients(flat_g, process_group=None):
   return flat_g
 
 
+def broadcast_from_rank0(tensors, process_group=None):
+  """Start every rank from rank 0's values (parameters, BatchNorm buffers): with identical weights and identical
+  averaged gradients the replicas stay bit-identical without any further parameter traffic."""
+  if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+    return
+  for t in tensors:
+    dist.broadcast(t, src=0, group=process_group)
+
+
 def peek_step_decisions(D_prob, thresh_value, thresh_iters, thresh_num_iters, thresh_end):
   """What gan.py:105 (D-step vs G-step) and JL:127 (curriculum branch) will draw from the host generator, without
   consuming it.  Ranks seed their host generators identically, so every rank takes the same branch."""
@@ -163,6 +172,8 @@ class MixStageTrainStep:
     self.time_steps = time_steps
     self.pg = process_group
     self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+    if self.world > 1:
+      broadcast_from_rank0([self.optim_G.flat_p, self.optim_D.flat_p] + [b for b in model.buffers()], process_group)
     self._graphs = {}
     self._static = None
     self.losses = None       # list of 0-dim device tensors of the last step (reference order)

@@ -22,7 +22,10 @@ def _worker(rank, world, port, out):
   os.environ['MASTER_PORT'] = str(port)
   dist.init_process_group('gloo', rank=rank, world_size=world)
   try:
-    from mix_stage_amd.train_step import average_flat_gradients, peek_step_decisions
+    from mix_stage_amd.train_step import average_flat_gradients, broadcast_from_rank0, peek_step_decisions
+    w = torch.full((1000,), float(rank + 1))
+    broadcast_from_rank0([w])
+    assert torch.equal(w, torch.ones(1000))              # every rank starts from rank 0's weights
     g = torch.Generator().manual_seed(100 + rank)
     flat = torch.randn(100003, generator=g)               # each rank: gradients of its own shard of clips
     mine = flat.clone()
