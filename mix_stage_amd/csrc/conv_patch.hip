@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PatchArgs p) {
   constexpr int CK = Cfg::CK, KHW = Cfg::KHW, KSTEP = Cfg::KSTEP;
   constexpr int PR = (TH - 1) * SV + KH, PC = (TW - 1) * S + KW;
   constexpr int RP = patch_row_pitch(PC, SV, TW), CP = PR * RP;
-  constexpr int LDA = BM + 2;
+  constexpr int LDA = BM + 1;   // odd pitch: the staging stores (4 k-rows apart per lane group) stay <= 2-way conflicted
   constexpr int STAGE = KSTEP * LDA + CK * CP + 3 * LDA + 4;   // + pad words: out-of-range staging stores land there
   constexpr int NPE = CK * PR * PC;                     // patch elements per chunk
   constexpr int NP = (NPE + 255) / 256;
