@@ -14,7 +14,7 @@
 
 namespace ms {
 
-__device__ __attribute__((aligned(16))) const float g_zero_word[4] = {0.f, 0.f, 0.f, 0.f};   // padding loads read this instead of branching
+__device__ __attribute__((aligned(16))) float g_zero_word[4] = {0.f, 0.f, 0.f, 0.f};   // padding loads read this instead of branching
 
 template <int KH, int KW>
 struct PatchCfg {

@@ -12,7 +12,7 @@
 
 namespace ms {
 
-__device__ __attribute__((aligned(16))) const float g_wzero_word[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ __attribute__((aligned(16))) float g_wzero_word[4] = {0.f, 0.f, 0.f, 0.f};
 
 constexpr int pitch_mod32(int at_least, int want_mod) {
   int v = at_least;
