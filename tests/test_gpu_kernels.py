@@ -75,12 +75,13 @@ def _mk_block(mod, case, seed=0):
   return blk
 
 
-@pytest.fixture(params=['auto', 'patch'])
+@pytest.fixture(params=['auto', 'patch', 'gather'])
 def kernel_path(request):
-  """'patch' forces the patch-staged conv kernel wherever its geometry allows (it is normally chosen only for
-  launches with >= 96 workgroups); 'auto' leaves the small test shapes on the split-K im2col kernel."""
+  """'auto': the production dispatch (at these sizes mostly the one-workgroup-per-channel small-conv kernel); 'patch'
+  forces the patch-staged MFMA kernels wherever their geometry allows (normally chosen for launches with >= 96
+  workgroups); 'gather' forces the im2col-gather MFMA kernels with split-K (normally the fallback)."""
   from mix_stage_amd import _lib
-  old = _lib.lib().ms_debug_set_patch_min_workgroups(0 if request.param == 'patch' else 96)
+  old = _lib.lib().ms_debug_set_patch_min_workgroups({'patch': 0, 'gather': 1 << 30}.get(request.param, 96))
   yield request.param
   _lib.lib().ms_debug_set_patch_min_workgroups(old)
 
