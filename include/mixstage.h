@@ -135,6 +135,16 @@ int ms_kmeans_labels(const float* pose, const int32_t* keep, const double* cente
 int ms_znorm_select(const float* x, const int32_t* keep, const double* mean, const double* inv_std, float* y, size_t rows,
                     int P, int PK, void* stream);
 
+/* Step metrics ("next" row N3; src/evaluation/metrics.py:94-131,247-303 as called from trainer.py:865-915), on device:
+ * per clip b, out[b][0] = sum |y - gt| over the kept columns (L1 numerator), out[b][1] = the same on first differences in
+ * time (VelL1 numerator), out[b][2 + a*J + j] = number of time steps where joint j is within alphas[a] * max(h,w) of the
+ * ground truth (PCK hits; poses de-normalised with std/mean, root joint at (0,0), removed joints take the gt values).
+ *   ycap (B,T,PK) prediction on the kept columns; gt (B,T,P) normalised full pose; keep[PK]; slot_of[P] (column -> index
+ *   in the kept layout or -1); mean,stdv[P] fp64; out (B, 2 + n_alpha*P/2) fp64. */
+int ms_step_metrics(const float* ycap, const float* gt, const int32_t* keep, const int32_t* slot_of, const double* mean,
+                    const double* stdv, const float* alphas, int n_alpha, double* out, int B, int T, int P, int PK,
+                    void* stream);
+
 /* content || style-embedding concat in channel-major layout (replaces EmbLin 'emb' lookup + torch.cat + transposes,
  * JL:175-180, layers.py:659-663): out (B, C+D, T) = [x (B,C,T) ; E[ids[b,t]] (D)].  ids is addressed as
  * ids[b*ids_stride_b + t*ids_stride_t] (stride_t = 0: one id per clip).  bwd: dx (B,C,T) and/or dE (S,D), NULL = skip. */

@@ -404,6 +404,66 @@ __global__ __launch_bounds__(256) void znorm_select_kernel(const float* __restri
 }
 
 // ----------------------------------------------------------------------------------------------
+// Step metrics ("next" row N3): L1, VelL1 and PCK numerators of one batch, on device.  One workgroup per clip b;
+// out[b][0] = sum |y - gt| over kept columns, out[b][1] = sum |vel(y) - vel(gt)|, out[b][2 + a*J + j] = PCK hits of
+// joint j at alpha a (root joint moved to (0,0), poses de-normalised with std/mean; removed joints take gt values).
+__global__ __launch_bounds__(256) void step_metrics_kernel(const float* __restrict__ ycap, const float* __restrict__ gt,
+                                                           const int32_t* __restrict__ keep, const int32_t* __restrict__ slot_of,
+                                                           const double* __restrict__ mean, const double* __restrict__ stdv,
+                                                           const float* __restrict__ alphas, int n_alpha,
+                                                           double* __restrict__ out, int T, int P, int PK) {
+  extern __shared__ double sh[];                  // [2 + n_alpha*J] block accumulators + 8 per-wave partials
+  const int b = blockIdx.x, t = threadIdx.x, J = P / 2;
+  const int n_out = 2 + n_alpha * J;
+  for (int i = t; i < n_out; i += 256) sh[i] = 0.0;
+  __syncthreads();
+  const float* yc = ycap + (size_t)b * T * PK;
+  const float* g = gt + (size_t)b * T * P;
+  // L1 / VelL1 over (t, kept column)
+  double l1 = 0.0, v1 = 0.0;
+  for (int e = t; e < T * PK; e += 256) {
+    const int tt = e / PK, d = e - tt * PK, col = keep[d];
+    const double y = (double)yc[(size_t)tt * PK + d], q = (double)g[(size_t)tt * P + col];
+    l1 += fabs(y - q);
+    if (tt > 0) {
+      const double yp = (double)yc[(size_t)(tt - 1) * PK + d], qp = (double)g[(size_t)(tt - 1) * P + col];
+      v1 += fabs((y - yp) - (q - qp));
+    }
+  }
+  l1 = wave_sum_d(l1);
+  v1 = wave_sum_d(v1);
+  // PCK: one wave per time step (4 at a time), lanes over joints
+  const int lane = t & 63, wv = t >> 6;
+  for (int tt = wv; tt < T; tt += 4) {
+    // de-normalised gt coordinates of this lane's joint (root forced to 0), and the pose extent
+    double gx = 0.0, gy = 0.0, px = 0.0, py = 0.0;
+    const bool jv = lane < J;
+    if (jv && lane > 0) {
+      gx = (double)g[(size_t)tt * P + lane] * stdv[lane] + mean[lane];
+      gy = (double)g[(size_t)tt * P + J + lane] * stdv[J + lane] + mean[J + lane];
+      const int sx = slot_of[lane], sy = slot_of[J + lane];        // column in the kept layout, -1: removed joint
+      px = sx >= 0 ? (double)yc[(size_t)tt * PK + sx] * stdv[lane] + mean[lane] : gx;
+      py = sy >= 0 ? (double)yc[(size_t)tt * PK + sy] * stdv[J + lane] + mean[J + lane] : gy;
+    }
+    double mxx = jv ? gx : -1e300, mnx = jv ? gx : 1e300, mxy = jv ? gy : -1e300, mny = jv ? gy : 1e300;
+    for (int o = 32; o > 0; o >>= 1) {
+      mxx = fmax(mxx, __shfl_xor(mxx, o)); mnx = fmin(mnx, __shfl_xor(mnx, o));
+      mxy = fmax(mxy, __shfl_xor(mxy, o)); mny = fmin(mny, __shfl_xor(mny, o));
+    }
+    const double ext = fmax(mxx - mnx, mxy - mny);
+    const double dist = sqrt((px - gx) * (px - gx) + (py - gy) * (py - gy));
+    if (jv)
+      for (int a = 0; a < n_alpha; ++a)
+        if (dist < (double)alphas[a] * ext) atomicAdd(&sh[2 + a * J + lane], 1.0);     // LDS, integer-valued: order-free
+  }
+  if (lane == 0) { sh[n_out + wv] = l1; sh[n_out + 4 + wv] = v1; }        // fixed-order sum over the 4 waves
+  __syncthreads();
+  if (t < 2) sh[t] = (sh[n_out + 4 * t] + sh[n_out + 4 * t + 1]) + (sh[n_out + 4 * t + 2] + sh[n_out + 4 * t + 3]);
+  __syncthreads();
+  for (int i = t; i < n_out; i += 256) out[(size_t)b * n_out + i] = sh[i];
+}
+
+// ----------------------------------------------------------------------------------------------
 // content || style concat (JL:175-180) in channel-major layout: out[b,c,t] = c < C ? x[b,c,t] : E[ids[b,t]][c-C]
 __global__ __launch_bounds__(256) void concat_style_fwd_kernel(const float* __restrict__ x, const float* __restrict__ emb,
                                                                const int64_t* __restrict__ ids, int ids_sb, int ids_st,
@@ -788,6 +848,15 @@ int ms_znorm_select(const float* x, const int32_t* keep, const double* mean, con
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(znorm_select_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, keep, mean, inv_std, y, rows, P, PK);
   return check_launch("znorm_select_kernel");
+}
+
+int ms_step_metrics(const float* ycap, const float* gt, const int32_t* keep, const int32_t* slot_of, const double* mean,
+                    const double* stdv, const float* alphas, int n_alpha, double* out, int B, int T, int P, int PK, void* stream) {
+  if (P / 2 > 64) return set_error("ms_step_metrics: more than 64 joints");
+  const size_t lds = (size_t)(2 + n_alpha * (P / 2) + 8) * sizeof(double);
+  hipLaunchKernelGGL(step_metrics_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, ycap, gt, keep, slot_of, mean, stdv, alphas,
+                     n_alpha, out, T, P, PK);
+  return check_launch("step_metrics_kernel");
 }
 
 int ms_concat_style_fwd(const float* x, const float* emb, const int64_t* ids, int ids_stride_b, int ids_stride_t, float* out,

@@ -1,0 +1,42 @@
+"""N3 step metrics: oracle sanity on the CPU, HIP kernel vs the oracle on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import metrics_oracle as MO
+
+
+def _inputs(B=5, T=64, P=104, seed=3):
+  rng = np.random.default_rng(seed)
+  mask = [0, 7, 8, 9]
+  gt = rng.standard_normal((B, T, P)).astype(np.float32)
+  ycap = (gt.reshape(B, T, 2, 52)[..., [j for j in range(52) if j not in mask]].reshape(B, T, 96)
+          + 0.15 * rng.standard_normal((B, T, 96))).astype(np.float32)
+  mean, var = rng.standard_normal(P) * 20 + 100, rng.random(P) * 400 + 50
+  return ycap, gt, mean, var, mask
+
+
+def test_oracle_identities():
+  ycap, gt, mean, var, mask = _inputs()
+  perfect = gt.reshape(5, 64, 2, 52)[..., [j for j in range(52) if j not in mask]].reshape(5, 64, 96)
+  r = MO.step_metrics(perfect, gt, mean, var, mask)
+  assert r['L1'] == 0 and r['VelL1'] == 0 and r['pck'][0.1][1] == 1.0
+  r = MO.step_metrics(ycap, gt, mean, var, mask)
+  assert 0.05 < r['L1'] < 0.2 and r['VelL1'] > r['L1']
+  assert r['pck'][0.1][1] <= r['pck'][0.2][1] <= 1.0
+  assert np.all(r['pck'][0.1][0][mask] == 1.0)        # re-inserted joints coincide with the ground truth
+
+
+@pytest.mark.gpu
+def test_hip_metrics_match_oracle():
+  from mix_stage_amd.metrics import DeviceStepMetrics
+  ycap, gt, mean, var, mask = _inputs()
+  ref = MO.step_metrics(ycap, gt, mean, var, mask)
+  m = DeviceStepMetrics(mean, var, mask=mask)
+  got = m.update(torch.from_numpy(ycap).cuda(), torch.from_numpy(gt).cuda())
+  assert abs(got['L1'] - ref['L1']) < 1e-9 and abs(got['VelL1'] - ref['VelL1']) < 1e-9
+  for a in (0.1, 0.2):
+    np.testing.assert_allclose(got['pck'][a][0].numpy(), ref['pck'][a][0], atol=1e-12)     # hit counts: exact
+    assert abs(got['pck'][a][1] - ref['pck'][a][1]) < 1e-12
+  avg = m.averages('train')
+  assert abs(avg['train_L1'] - ref['L1']) < 1e-9 and abs(avg['train_pck_0.1'] - ref['pck'][0.1][1]) < 1e-12
