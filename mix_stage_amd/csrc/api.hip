@@ -143,6 +143,7 @@ int ms_conv_block_fwd(const ms_conv_desc* d, const float* x, const float* x2, co
     q.PW = d->PW; q.tiles_x = pp.tiles_x; q.tiles_y = pp.tiles_y; q.slope = d->slope; q.eps = d->eps;
     q.o_sh = 1; q.o_sw = 1; q.o_ry = 0; q.o_rx = 0;
     q.splitk = pp.splitk; q.chunks_per_split = pp.chunks_per_split;
+    q.src_elems = (size_t)d->B * cin_tot * d->H * d->W; q.a_elems = (size_t)C * a.Kg;
     if (pp.splitk > 1) { q.part = (float*)workspace; q.part_stride = (size_t)npix * C; }
     const double flops = 2.0 * d->Cout * a.Kg * (double)npix * d->groups;
     const double bytes = 4.0 * ((double)C * a.Kg + (double)d->B * cin_tot * d->H * d->W + (double)npix * C);
@@ -306,6 +307,7 @@ int ms_conv_block_bwd_overlap(const ms_conv_desc* d, const float* x, const float
         q.PW = (jw - 1) - cx; q.o_sw = d->SW; q.o_rx = rx;
         q.tiles_x = use.tiles_x; q.tiles_y = use.tiles_y;
         q.splitk = use.splitk; q.chunks_per_split = use.chunks_per_split;
+        q.src_elems = (size_t)d->B * C * hw; q.a_elems = (size_t)(cls + 1) * tg * d->Cin * Kg2;
         if (use.splitk > 1) {
           q.part = dg_part; q.part_stride = (size_t)d->B * cin_tot * d->H * d->W;
           q.ep = EP_BARE;               // partial tiles: plain full-resolution layout, the reduce kernel splits UP2

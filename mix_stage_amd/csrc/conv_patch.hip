@@ -9,12 +9,26 @@
 //
 // 1-D convs (KH == 1) treat the batch axis as the row axis of one image, so tiles span batch items.
 #include <algorithm>
+#include <cstdint>
 
 #include "kernels.h"
 
 namespace ms {
 
-__device__ __attribute__((aligned(16))) float g_zero_word[4] = {0.f, 0.f, 0.f, 0.f};   // padding loads read this instead of branching
+// Staging loads are raw buffer loads: one 32-bit byte offset per element against a buffer descriptor in SGPRs (the chunk
+// base travels in the scalar offset), and padding / out-of-range elements use an offset past the descriptor's range, for
+// which the hardware returns 0 -- no pointer selects, no branches, no 64-bit address arithmetic in the K loop.
+constexpr unsigned BUF_OOB = 0x80000000u;
+__device__ inline __amdgpu_buffer_rsrc_t buf_rsrc(const void* ptr) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, 0x7fffffff, 0x00020000);
+}
+__device__ inline float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ inline float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  // (bit_cast of the whole vector: element-wise access of the builtin's result is miscompiled to a dword load by this clang)
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
 
 template <int KH, int KW>
 struct PatchCfg {
@@ -33,10 +47,11 @@ constexpr int patch_row_pitch(int pc, int sv, int tw) {
   return rp;
 }
 
-template <int TM, int TN, int KH, int KW, int S, int TW, bool UP2>
-__global__ __launch_bounds__(256) void conv_patch_kernel(const PatchArgs p) {
+// 1-D kernels (taps <= 3): registers capped at 128 so that 4 workgroups share a CU (the decoder launches 1024 = 4 x 256)
+template <int KH, int KW, int S, int TW, bool UP2, bool AVEC>
+__global__ __launch_bounds__(256, (KH * KW <= 3 ? 4 : 1)) void conv_patch_kernel(const PatchArgs p) {
   using Cfg = PatchCfg<KH, KW>;
-  constexpr int BM = 64 * TM, BN = 64 * TN, TH = BN / TW;
+  constexpr int BM = 64, BN = 64, TH = BN / TW;
   constexpr int SV = (KH == 1) ? 1 : S;                 // KH == 1: rows are independent batch items
   constexpr int CK = Cfg::CK, KHW = Cfg::KHW, KSTEP = Cfg::KSTEP;
   constexpr int PR = (TH - 1) * SV + KH, PC = (TW - 1) * S + KW;
@@ -47,7 +62,9 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PatchArgs p) {
   constexpr int NP = (NPE + 255) / 256;
   constexpr int NAV = BM * (KSTEP / 4);                 // float4 slots of the weight slice
   constexpr int NA = (NAV + 255) / 256;
+  constexpr int LP = 68;                                // pitch of the epilogue's [channel][pixel] tile (4 mod 32)
   static_assert(KSTEP % 4 == 0 && BN % TW == 0, "bad patch configuration");
+  static_assert(2 * STAGE >= BM * LP, "epilogue tile does not fit the staging buffers");
   __shared__ float smem[2 * STAGE];
 
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
@@ -66,25 +83,30 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PatchArgs p) {
   const int cbase = p.bcast ? 0 : g * p.Kc;
   const int Kg = p.Kg;
 
-  // ---- chunk-invariant staging offsets
-  int goff[NP], loff[NP];                               // global offset rel. to the chunk base (-1: padding) / LDS
+  // ---- chunk-invariant staging offsets (bytes; BUF_OOB = reads as zero)
+  unsigned goff[NP], goff_h[UP2 ? NP : 1];
+  int loff[NP];
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const int e = t + i * 256;
     const int ci = e / (PR * PC), rem = e - ci * (PR * PC), r = rem / PC, c = rem - r * PC;
     const int iy = iy0 + r, ix = ix0 + c;
     const bool ok = (e < NPE) & ((unsigned)iy < (unsigned)p.SRCH) & ((unsigned)ix < (unsigned)p.SRCW);
-    goff[i] = ok ? (int)(ci * p.s_chan + iy * p.s_row + ix) : -1;
+    const int rowbase = ci * p.s_chan + iy * p.s_row;
+    goff[i] = ok ? 4u * (unsigned)(rowbase + ix) : BUF_OOB;
+    // x = nearest_up2(a) + r : a has half the row length, hence half of every stride (all strides are even)
+    if (UP2) goff_h[i] = ok ? 4u * (unsigned)((rowbase >> 1) + (ix >> 1)) : BUF_OOB;
     loff[i] = e < NPE ? ci * CP + r * RP + c : CK * CP;   // dummy slot
   }
-  int aoff[NA];                                         // weight offset rel. to (group base + k0); -1: row out of range
+  unsigned aoff[NA];                                    // weight offset rel. to (group base + k0)
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int idx = t + i * 256;
     const int row = idx / (KSTEP / 4), kq = idx - row * (KSTEP / 4);
-    aoff[i] = (idx < NAV && m0 + row < p.Mg) ? (m0 + row) * Kg + kq * 4 : -1;
+    aoff[i] = (idx < NAV && m0 + row < p.Mg) ? 4u * (unsigned)((m0 + row) * Kg + kq * 4) : BUF_OOB;
   }
-  const float* Ag = p.A + (size_t)g * p.Mg * Kg;
+  const __amdgpu_buffer_rsrc_t rsA = buf_rsrc(p.A), rsS = buf_rsrc(p.src), rsS2 = buf_rsrc(UP2 ? p.src2 : p.src);
+  const unsigned a_group = (unsigned)g * p.Mg * Kg;
   const int img_base = img * p.s_img;
 
   // two register sets: chunk c+2 is in flight from HBM/L2 while chunk c+1 waits in registers and chunk c computes
@@ -92,41 +114,33 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PatchArgs p) {
   float rb0[NP], rb1[NP];
   auto load_chunk = [&](int ci0, float4 (&ra)[NA], float (&rb)[NP]) {
     const int k0 = ci0 * KHW;
+    // scalar offsets: values derived from integer divisions live in VGPRs; readfirstlane keeps the loads waterfall-free
+    const unsigned sa = __builtin_amdgcn_readfirstlane(4u * (a_group + (unsigned)k0));
+    const bool full_k = k0 + KSTEP <= Kg;               // uniform: only the last chunk can be partial
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int idx = t + i * 256;
-      const int kq = idx % (KSTEP / 4);
+      const int kq = (t + i * 256) % (KSTEP / 4);
       const int k = k0 + kq * 4;
-      const bool ok = (aoff[i] >= 0) & (k < Kg);
-      const float* ap = ok ? Ag + (unsigned)(aoff[i] + k0) : g_zero_word;    // out of range: read zeros, no select after
-      float4 v;
-      if (p.a_vec) {
-        v = *reinterpret_cast<const float4*>(ap);
+      if (AVEC) {
+        ra[i] = buf_load4(rsA, (full_k | (k < Kg)) ? aoff[i] : BUF_OOB, sa);
       } else {
-        v.x = ap[0];
-        v.y = (ok & (k + 1 < Kg)) ? ap[1] : 0.f;
-        v.z = (ok & (k + 2 < Kg)) ? ap[2] : 0.f;
-        v.w = (ok & (k + 3 < Kg)) ? ap[3] : 0.f;
+        float4 v;
+        v.x = buf_load(rsA, (full_k | (k < Kg)) ? aoff[i] : BUF_OOB, sa);
+        v.y = buf_load(rsA, (full_k | (k + 1 < Kg)) ? aoff[i] + 4u : BUF_OOB, sa);
+        v.z = buf_load(rsA, (full_k | (k + 2 < Kg)) ? aoff[i] + 8u : BUF_OOB, sa);
+        v.w = buf_load(rsA, (full_k | (k + 3 < Kg)) ? aoff[i] + 12u : BUF_OOB, sa);
+        ra[i] = v;
       }
-      ra[i] = v;
     }
-    const int cb = img_base + (cbase + ci0) * p.s_chan;
+    const int cb = __builtin_amdgcn_readfirstlane(img_base + (cbase + ci0) * p.s_chan);
+    const bool full_c = ci0 + CK <= p.Kc;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      const int e = t + i * 256;
-      const int ci = e / (PR * PC);
-      const bool ok = (goff[i] >= 0) & (ci0 + ci < p.Kc);
-      if (UP2) {
-        // x = nearest_up2(a) + r : a has half the row length, hence half of every stride
-        const int o = ok ? cb + goff[i] : 0;
-        const int x = o % p.SRCW;                        // column inside the row (strides are multiples of SRCW)
-        const float* pa = ok ? p.src + (unsigned)(((o - x) >> 1) + (x >> 1)) : g_zero_word;
-        const float* pr = ok ? p.src2 + (unsigned)o : g_zero_word;
-        rb[i] = *pa + *pr;
-      } else {
-        const float* ps = ok ? p.src + (unsigned)(cb + goff[i]) : g_zero_word;
-        rb[i] = *ps;
-      }
+      const int ci = (t + i * 256) / (PR * PC);
+      const bool ok = full_c | (ci0 + ci < p.Kc);
+      if (UP2) rb[i] = buf_load(rsS, ok ? goff_h[i] : BUF_OOB, 4u * (unsigned)(cb >> 1)) +
+                       buf_load(rsS2, ok ? goff[i] : BUF_OOB, 4u * (unsigned)cb);
+      else rb[i] = buf_load(rsS, ok ? goff[i] : BUF_OOB, 4u * (unsigned)cb);
     }
   };
   auto store_chunk = [&](int buf, const float4 (&ra)[NA], const float (&rb)[NP]) {
@@ -146,25 +160,20 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PatchArgs p) {
     for (int i = 0; i < NP; ++i) Ps[loff[i]] = rb[i];
   };
 
-  f32x16 acc[TM][TN];
+  f32x16 acc;
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
   // ---- per-lane operand bases: k and k+1 of an MFMA pair sit in lanes 0-31 / 32-63
-  const int a_base = khalf * LDA + wm * TM * 32 + (lane & 31);
-  int b_same[TN], b_row[TN], b_chan[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int nloc = wn * TN * 32 + j * 32 + (lane & 31);
+  const int a_base = khalf * LDA + wm * 32 + (lane & 31);
+  int b_same, b_row, b_chan;
+  {
+    const int nloc = wn * 32 + (lane & 31);
     const int ty = nloc / TW, tx = nloc - ty * TW;
     const int base = ty * SV * RP + tx * S;
-    b_same[j] = base + khalf;                                         // k+1 = next tap in the same row
-    b_row[j] = base + khalf * (RP - (KW - 1));                        // k+1 = first tap of the next kernel row
-    b_chan[j] = base + khalf * (CP - (KH - 1) * RP - (KW - 1));       // k+1 = first tap of the next channel
+    b_same = base + khalf;                                         // k+1 = next tap in the same row
+    b_row = base + khalf * (RP - (KW - 1));                        // k+1 = first tap of the next kernel row
+    b_chan = base + khalf * (CP - (KH - 1) * RP - (KW - 1));       // k+1 = first tap of the next channel
   }
 
   const int chunk_beg = ks * p.chunks_per_split;
@@ -174,7 +183,7 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PatchArgs p) {
     const float* Ps = As + KSTEP * LDA;
     // operands of the next group of k-pairs are read from LDS while the current group's MFMAs issue
     constexpr int NPAIR = KSTEP / 2, GP = 4, NG = (NPAIR + GP - 1) / GP;
-    float av[2][GP][TM], bv[2][GP][TN];
+    float av[2][GP], bv[2][GP];
     auto read_group = [&](int gi, int slot) {
 #pragma unroll
       for (int q = 0; q < GP; ++q) {
@@ -183,13 +192,9 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PatchArgs p) {
           const int k0 = 2 * jj;
           const int ci = k0 / KHW, rr = k0 - ci * KHW, kh = rr / KW, kw = rr - kh * KW;
           const int offb = ci * CP + kh * RP + kw;
-#pragma unroll
-          for (int i = 0; i < TM; ++i) av[slot][q][i] = As[a_base + k0 * LDA + i * 32];
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const int base = (kw + 1 < KW) ? b_same[j] : (kh + 1 < KH) ? b_row[j] : b_chan[j];
-            bv[slot][q][j] = Ps[base + offb];
-          }
+          av[slot][q] = As[a_base + k0 * LDA];
+          const int base = (kw + 1 < KW) ? b_same : (kh + 1 < KH) ? b_row : b_chan;
+          bv[slot][q] = Ps[base + offb];
         }
       }
     };
@@ -197,16 +202,11 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PatchArgs p) {
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
       if (gi + 1 < NG) read_group(gi + 1, (gi + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);                  // keep the next group's LDS reads ahead of these MFMAs
 #pragma unroll
-      for (int q = 0; q < GP; ++q) {
-        if (gi * GP + q < NPAIR) {
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[gi & 1][q][i], bv[gi & 1][q][j], acc[i][j], 0, 0, 0);
-        }
-      }
+      for (int q = 0; q < GP; ++q)
+        if (gi * GP + q < NPAIR) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[gi & 1][q], bv[gi & 1][q], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   load_chunk(chunk_beg * CK, ra0, rb0);
@@ -227,102 +227,85 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PatchArgs p) {
 
   // ---------------- epilogue ----------------
   const int ctot = p.groups * p.Mg;
-  int ooff[TN];
-  bool cval[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int nloc = wn * TN * 32 + j * 32 + (lane & 31);
-    const int ty = nloc / TW, tx = nloc - ty * TW;
-    const int oy = oy0 + ty, ox = ox0 + tx;
-    cval[j] = (oy < p.OUTH) & (ox < p.OUTW);
-    ooff[j] = img * p.o_img + (oy * p.o_sh + p.o_ry) * p.o_row + ox * p.o_sw + p.o_rx;   // + channel * o_chan
-  }
+  const int nloc = wn * 32 + (lane & 31);
+  const int oy = oy0 + nloc / TW, ox = ox0 + nloc % TW;
+  const bool cval = (oy < p.OUTH) & (ox < p.OUTW);
+  const int ooff = img * p.o_img + (oy * p.o_sh + p.o_ry) * p.o_row + ox * p.o_sw + p.o_rx;   // + channel * o_chan
   const int ep = p.ep;
   if (p.splitk > 1) {                 // raw partial tile in the output layout; a split-K epilogue kernel finishes
     float* part = p.part + (size_t)ks * p.part_stride;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          if (m < p.Mg && cval[j]) part[(size_t)ooff[j] + (size_t)(g * p.Mg + m) * p.o_chan] = acc[i][j][r];
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      if (m < p.Mg && cval) part[(size_t)ooff + (size_t)(g * p.Mg + m) * p.o_chan] = acc[r];
+    }
     return;
   }
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-      const bool mval = m < p.Mg;
-      const int chn = g * p.Mg + (mval ? m : 0);
-      const float bsv = p.bias ? p.bias[chn] : 0.f;
-      float sc = 1.f, sh = 0.f;
-      if (ep == EP_BN_EVAL) {
-        const float inv = 1.0f / sqrtf(p.bn_v[chn] + p.eps);
-        sc = p.bn_g[chn] * inv;
-        sh = p.bn_b[chn] - p.bn_m[chn] * sc;
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+    const bool mval = m < p.Mg;
+    const int chn = g * p.Mg + (mval ? m : 0);
+    const float bsv = p.bias ? p.bias[chn] : 0.f;
+    float sc = 1.f, sh = 0.f;
+    if (ep == EP_BN_EVAL) {
+      const float inv = 1.0f / sqrtf(p.bn_v[chn] + p.eps);
+      sc = p.bn_g[chn] * inv;
+      sh = p.bn_b[chn] - p.bn_m[chn] * sc;
+    }
+    float v = acc[r] + bsv;
+    if (ep == EP_RAW_STATS) acc[r] = v;
+    if (ep == EP_BN_EVAL) v = lrelu(fmaf(v, sc, sh), p.slope);
+    if (ep == EP_LRELU) v = lrelu(v, p.slope);
+    if (ep == EP_DGRAD_UP2) {
+      // 1-D stride-1 data gradient of an upsample-add input: out2 = grad of the residual (full resolution),
+      // out = grad of the half-resolution tensor = sum over the pair of columns (adjacent lanes)
+      const float pr = __shfl_xor(v, 1);
+      if (mval && cval) {
+        p.out2[(size_t)ooff + (size_t)chn * p.o_chan] = v;
+        if (!(lane & 1)) p.out[(size_t)(ooff >> 1) + (size_t)chn * (p.o_chan >> 1)] = v + pr;
       }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        float v = acc[i][j][r] + bsv;
-        if (ep == EP_RAW_STATS) acc[i][j][r] = v;
-        if (ep == EP_BN_EVAL) v = lrelu(fmaf(v, sc, sh), p.slope);
-        if (ep == EP_LRELU) v = lrelu(v, p.slope);
-        if (ep == EP_DGRAD_UP2) {
-          // 1-D stride-1 data gradient of an upsample-add input: out2 = grad of the residual (full resolution),
-          // out = grad of the half-resolution tensor = sum over the pair of columns (adjacent lanes)
-          const float pr = __shfl_xor(v, 1);
-          if (mval && cval[j]) {
-            p.out2[(size_t)ooff[j] + (size_t)chn * p.o_chan] = v;
-            if (!(lane & 1)) p.out[(size_t)(ooff[j] >> 1) + (size_t)chn * (p.o_chan >> 1)] = v + pr;
-          }
-        } else if (mval && cval[j]) {
-          p.out[(size_t)ooff[j] + (size_t)chn * p.o_chan] = v;
-        }
-      }
+    } else if (mval && cval) {
+      p.out[(size_t)ooff + (size_t)chn * p.o_chan] = v;
     }
   }
 
   if (ep == EP_RAW_STATS) {
-    // per-channel (sum, M2 about this tile's mean) over the tile's valid pixels, fixed order
-    float* red = smem;  // [4][BM]
+    // per-channel (sum, M2 about this tile's mean) over the tile's valid pixels, fixed order: the tile goes through LDS
+    // as [channel][pixel]; 4 threads per channel sum 16 pixels each from registers (both passes), then combine
+    float* tile = smem;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ml = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      tile[ml * LP + nloc] = cval ? acc[r] : 0.f;
+    }
+    __syncthreads();
+    const int ch = t >> 2, q = t & 3;
+    float v[16];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      v[i] = tile[ch * LP + q + 4 * i];
+      s += v[i];
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
     const int cnt = min(TH, p.OUTH - oy0) * min(TW, p.OUTW - ox0);
-    __syncthreads();
+    const float mean = s / (float)cnt;
+    float m2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ml = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) s += cval[j] ? acc[i][j][r] : 0.f;
-        s = half_wave_sum(s);
-        if ((lane & 31) == 0) red[wn * BM + ml] = s;
-      }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ml = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        const float mean = (red[ml] + red[BM + ml]) / (float)cnt;
-        float q = 0.f;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const float dlt = acc[i][j][r] - mean;
-          q += cval[j] ? dlt * dlt : 0.f;
-        }
-        q = half_wave_sum(q);
-        if ((lane & 31) == 0) red[2 * BM + wn * BM + ml] = q;
-      }
-    __syncthreads();
-    if (t < BM && m0 + t < p.Mg) {
-      float* st = p.stats + ((size_t)bx_ * ctot + g * p.Mg + m0 + t) * 2;
-      st[0] = red[t] + red[BM + t];
-      st[1] = red[2 * BM + t] + red[3 * BM + t];
+    for (int i = 0; i < 16; ++i) {
+      const int nl = q + 4 * i;
+      const bool ok = (oy0 + nl / TW < p.OUTH) & (ox0 + nl % TW < p.OUTW);
+      const float dlt = v[i] - mean;
+      m2 += ok ? dlt * dlt : 0.f;
+    }
+    m2 += __shfl_xor(m2, 1);
+    m2 += __shfl_xor(m2, 2);
+    if (q == 0 && m0 + ch < p.Mg) {
+      float* st = p.stats + ((size_t)bx_ * ctot + g * p.Mg + m0 + ch) * 2;
+      st[0] = s;
+      st[1] = m2;
     }
     if (t == 0 && by_ == 0 && g == 0) p.counts[bx_] = (float)cnt;
   }
@@ -330,10 +313,8 @@ __global__ __launch_bounds__(256) void conv_patch_kernel(const PatchArgs p) {
 
 // ---------------------------------------------------------------------------------------------
 // dispatch
-int g_patch_min_wgs = 96;
+int g_patch_min_wgs = 96;      // below this many workgroups the split-K im2col path is used instead
 int g_patch_force_splitk = 0;   // tuning knob: > 0 forces this split-K factor in the patch kernel
-int g_patch_wide_min = 1 << 30;  // 64x128 tiles (TN=2) when they still give this many workgroups (tuning knob)
-int g_patch_big_min = 1 << 30;   // 128x128 tiles when they still give this many workgroups (test/tuning knob)   // below this many workgroups the split-K im2col path is used instead
 int patch_chunk_channels(int KH, int KW) {
   const int khw = KH * KW;
   return khw == 1 ? 32 : khw == 2 ? 16 : khw == 3 ? 16 : khw == 4 ? 16 : khw == 9 ? 4 : khw == 16 ? 4 : khw == 24 ? 2 : 4;
@@ -353,19 +334,7 @@ PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH,
   int tw;
   if (nd == 1) tw = OW > 32 ? 64 : OW > 16 ? 32 : 16;
   else tw = OW > 16 ? 32 : 16;
-  // big tile (128x128) only when it still gives >= 2 workgroups per CU
-  int tm = 1;
-  if (Mg >= 128) {
-    const int th = 128 / tw;
-    const long big = (long)cdiv(Mg, 128) * groups * imgs * cdiv(rows, th) * cdiv(OW, tw);
-    if (big >= g_patch_big_min) tm = 2;
-  }
-  int tn = tm;
-  if (tm == 1) {
-    const int th2 = 128 / tw;
-    const long wide = (long)cdiv(Mg, 64) * groups * imgs * cdiv(rows, th2) * cdiv(OW, tw);
-    if (wide >= g_patch_wide_min) tn = 2;
-  }
+  const int tm = 1, tn = 1;
   const int th = 64 * tn / tw;
   pl.ok = 1; pl.tm = tm; pl.tw = tw; pl.tn = tn;
   pl.tiles_y = cdiv(rows, th); pl.tiles_x = cdiv(OW, tw);
@@ -389,9 +358,9 @@ PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH,
   return pl;
 }
 
-template <int TM, int TN, int KH, int KW, int S, bool UP2>
+template <int KH, int KW, int S, bool UP2, bool AVEC>
 static void launch_patch_tw(const PatchArgs& a, int tw, dim3 grid, hipStream_t s) {
-#define MS_PK(TW) hipLaunchKernelGGL((conv_patch_kernel<TM, TN, KH, KW, S, TW, UP2>), grid, dim3(256), 0, s, a)
+#define MS_PK(TW) hipLaunchKernelGGL((conv_patch_kernel<KH, KW, S, TW, UP2, AVEC>), grid, dim3(256), 0, s, a)
   if constexpr (KH == 1) {
     if (tw == 64) MS_PK(64);
     else if (tw == 32) MS_PK(32);
@@ -403,19 +372,19 @@ static void launch_patch_tw(const PatchArgs& a, int tw, dim3 grid, hipStream_t s
 #undef MS_PK
 }
 
-template <int TM, int TN>
+template <bool AVEC>
 static void launch_patch_k(const PatchArgs& a, int kh, int kw, int s_, int tw, bool up2, dim3 grid, hipStream_t s) {
   if (kh == 1 && kw == 3 && s_ == 1) {
-    if (up2) launch_patch_tw<TM, TN, 1, 3, 1, true>(a, tw, grid, s);
-    else launch_patch_tw<TM, TN, 1, 3, 1, false>(a, tw, grid, s);
-  } else if (kh == 1 && kw == 4 && s_ == 2) launch_patch_tw<TM, TN, 1, 4, 2, false>(a, tw, grid, s);
-  else if (kh == 1 && kw == 4 && s_ == 1) launch_patch_tw<TM, TN, 1, 4, 1, false>(a, tw, grid, s);
-  else if (kh == 1 && kw == 1 && s_ == 1) launch_patch_tw<TM, TN, 1, 1, 1, false>(a, tw, grid, s);
-  else if (kh == 1 && kw == 2 && s_ == 1) launch_patch_tw<TM, TN, 1, 2, 1, false>(a, tw, grid, s);
-  else if (kh == 2 && kw == 2 && s_ == 1) launch_patch_tw<TM, TN, 2, 2, 1, false>(a, tw, grid, s);
-  else if (kh == 3 && kw == 3 && s_ == 1) launch_patch_tw<TM, TN, 3, 3, 1, false>(a, tw, grid, s);
-  else if (kh == 4 && kw == 4 && s_ == 2) launch_patch_tw<TM, TN, 4, 4, 2, false>(a, tw, grid, s);
-  else launch_patch_tw<TM, TN, 3, 8, 1, false>(a, tw, grid, s);
+    if (up2) launch_patch_tw<1, 3, 1, true, AVEC>(a, tw, grid, s);
+    else launch_patch_tw<1, 3, 1, false, AVEC>(a, tw, grid, s);
+  } else if (kh == 1 && kw == 4 && s_ == 2) launch_patch_tw<1, 4, 2, false, AVEC>(a, tw, grid, s);
+  else if (kh == 1 && kw == 4 && s_ == 1) launch_patch_tw<1, 4, 1, false, AVEC>(a, tw, grid, s);
+  else if (kh == 1 && kw == 1 && s_ == 1) launch_patch_tw<1, 1, 1, false, AVEC>(a, tw, grid, s);
+  else if (kh == 1 && kw == 2 && s_ == 1) launch_patch_tw<1, 2, 1, false, AVEC>(a, tw, grid, s);
+  else if (kh == 2 && kw == 2 && s_ == 1) launch_patch_tw<2, 2, 1, false, AVEC>(a, tw, grid, s);
+  else if (kh == 3 && kw == 3 && s_ == 1) launch_patch_tw<3, 3, 1, false, AVEC>(a, tw, grid, s);
+  else if (kh == 4 && kw == 4 && s_ == 2) launch_patch_tw<4, 4, 2, false, AVEC>(a, tw, grid, s);
+  else launch_patch_tw<3, 8, 1, false, AVEC>(a, tw, grid, s);
 }
 
 int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S, bool up2, double flops, double bytes,
@@ -426,19 +395,19 @@ int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S,
   if ((double)b.gx * b.gy * b.gz > 2.0e9) return set_error("conv grid too large");
   dim3 grid(b.gx * b.gy * b.gz);
   if (a.splitk < 1 || (a.splitk > 1 && !a.part)) return set_error("patch conv: bad split-K setup");
-  TimingScope ts(s, flops, bytes, "conv_patch_kernel<%d,%d,%d,%d,%d,%d,%d>|conv_%s_patch k%dx%d s%d Mg%d Kg%d g%d tiles%d tile%d tw%d splitk%d%s",
-                 pl.tm, pl.tm, KH, KW, S, pl.tw, up2 ? 1 : 0, a.is_dgrad ? "dgrad" : "fwd", KH, KW, S, a.Mg, a.Kg,
+  if (a.src_elems >= (1u << 29) || a.a_elems >= (1u << 29)) return set_error("patch conv: operand of 2 GiB or more");
+  TimingScope ts(s, flops, bytes, "conv_patch_kernel<%d,%d,%d,%d,%d,%d>|conv_%s_patch k%dx%d s%d Mg%d Kg%d g%d tiles%d tile%d tw%d splitk%d%s",
+                 KH, KW, S, pl.tw, up2 ? 1 : 0, (a.a_vec && ((uintptr_t)a.A & 15) == 0) ? 1 : 0, a.is_dgrad ? "dgrad" : "fwd", KH, KW, S, a.Mg, a.Kg,
                  a.groups, pl.n_tiles, bm, pl.tw, a.splitk, a.ep == EP_RAW_STATS ? " +bnstats" : "");
-  if (pl.tm == 2) launch_patch_k<2, 2>(b, KH, KW, S, pl.tw, up2, grid, s);
-  else if (pl.tn == 2) launch_patch_k<1, 2>(b, KH, KW, S, pl.tw, up2, grid, s);
-  else launch_patch_k<1, 1>(b, KH, KW, S, pl.tw, up2, grid, s);
+  if (a.a_vec && ((uintptr_t)a.A & 15) == 0) launch_patch_k<true>(b, KH, KW, S, pl.tw, up2, grid, s);
+  else launch_patch_k<false>(b, KH, KW, S, pl.tw, up2, grid, s);
   return check_launch("conv_patch_kernel");
 }
 
 }  // namespace ms
 
 extern "C" int ms_debug_set_patch_tuning(int wide_tile_min_workgroups, int force_splitk) {
-  ms::g_patch_wide_min = wide_tile_min_workgroups > 0 ? wide_tile_min_workgroups : (1 << 30);
+  (void)wide_tile_min_workgroups;   // 64x128 / 128x128 tiles were measured, gave nothing and are retired
   ms::g_patch_force_splitk = force_splitk > 0 ? force_splitk : 0;
   return 0;
 }

@@ -71,6 +71,7 @@ struct PatchArgs {
   size_t part_stride;
   int PH, PW, tiles_x, tiles_y;
   float slope, eps;
+  size_t src_elems, a_elems;    // extents of src (UP2: of src2) and A, for the 32-bit buffer offsets
 };
 struct PatchPlan { int ok, tm, tw, tiles_y, tiles_x, n_tiles, splitk, chunks_per_split, tn; };
 PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH, int SW, int B, int OH, int OW);

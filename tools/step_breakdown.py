@@ -28,7 +28,7 @@ for kind in 'GD':
     cat[c] = cat.get(c, 0) + r['total_ms']
   print('==== %s-step: eager wall %.2f ms, timed kernels %.2f ms, %d launches' % (kind, e0.elapsed_time(e1), tot, sum(r['count'] for r in rows)))
   print('  by category:', {k: round(v, 3) for k, v in sorted(cat.items(), key=lambda kv: -kv[1])})
-  for r in rows[:28]:
+  for r in rows[:60]:
     avg = r['total_ms'] / r['count'] * 1e3
     tf = r['flops'] / (avg * 1e-6) / 1e12 if r['flops'] else 0
     gb = r['bytes'] / (avg * 1e-6) / 1e9
