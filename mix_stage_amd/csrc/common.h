@@ -92,6 +92,21 @@ __device__ inline bool splitk_arrive_last(int* counter, int expected, int* s_fla
   return *s_flag != 0;
 }
 
+// Staging loads are raw buffer loads: one 32-bit byte offset per element against a buffer descriptor in SGPRs (the chunk
+// base travels in the scalar offset), and padding / out-of-range elements use an offset past the descriptor's range, for
+// which the hardware returns 0 -- no pointer selects, no branches, no 64-bit address arithmetic in the K loop.
+constexpr unsigned BUF_OOB = 0x80000000u;
+__device__ inline __amdgpu_buffer_rsrc_t buf_rsrc(const void* ptr) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, 0x7fffffff, 0x00020000);
+}
+__device__ inline float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ inline float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  // (bit_cast of the whole vector: element-wise access of the builtin's result is miscompiled to a dword load by this clang)
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+
 __device__ inline float lrelu(float z, float slope) { return z > 0.f ? z : z * slope; }
 
 }  // namespace ms

@@ -15,21 +15,6 @@
 
 namespace ms {
 
-// Staging loads are raw buffer loads: one 32-bit byte offset per element against a buffer descriptor in SGPRs (the chunk
-// base travels in the scalar offset), and padding / out-of-range elements use an offset past the descriptor's range, for
-// which the hardware returns 0 -- no pointer selects, no branches, no 64-bit address arithmetic in the K loop.
-constexpr unsigned BUF_OOB = 0x80000000u;
-__device__ inline __amdgpu_buffer_rsrc_t buf_rsrc(const void* ptr) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, 0x7fffffff, 0x00020000);
-}
-__device__ inline float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
-}
-__device__ inline float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  // (bit_cast of the whole vector: element-wise access of the builtin's result is miscompiled to a dword load by this clang)
-  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
-}
-
 template <int KH, int KW>
 struct PatchCfg {
   static constexpr int KHW = KH * KW;
@@ -49,7 +34,7 @@ constexpr int patch_row_pitch(int pc, int sv, int tw) {
 
 // 1-D kernels (taps <= 3): registers capped at 128 so that 4 workgroups share a CU (the decoder launches 1024 = 4 x 256)
 template <int KH, int KW, int S, int TW, bool UP2, bool AVEC>
-__global__ __launch_bounds__(256, (KH * KW <= 3 ? 4 : 1)) void conv_patch_kernel(const PatchArgs p) {
+__global__ __launch_bounds__(256, (KH * KW <= 3 && TW >= 32 ? 4 : 1)) void conv_patch_kernel(const PatchArgs p) {
   using Cfg = PatchCfg<KH, KW>;
   constexpr int BM = 64, BN = 64, TH = BN / TW;
   constexpr int SV = (KH == 1) ? 1 : S;                 // KH == 1: rows are independent batch items

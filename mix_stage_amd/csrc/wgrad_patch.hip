@@ -12,17 +12,15 @@
 
 namespace ms {
 
-__device__ __attribute__((aligned(16))) float g_wzero_word[4] = {0.f, 0.f, 0.f, 0.f};
-
 constexpr int pitch_mod32(int at_least, int want_mod) {
   int v = at_least;
   while (v % 32 != want_mod % 32) ++v;
   return v;
 }
 
-template <int TM, int TN, int KH, int KW, int S, int TW, bool UP2>
+template <int KH, int KW, int S, int TW, bool UP2>
 __global__ __launch_bounds__(256) void wgrad_patch_kernel(const WgradPatchArgs p) {
-  constexpr int BM = 64 * TM, BN = 64 * TN, NPIX = 64, TH = NPIX / TW;
+  constexpr int BM = 64, BN = 64, NPIX = 64, TH = NPIX / TW;
   constexpr int SV = (KH == 1) ? 1 : S;
   constexpr int KHW = KH * KW;
   constexpr int PR = (TH - 1) * SV + KH, PC = (TW - 1) * S + KW;
@@ -48,8 +46,8 @@ __global__ __launch_bounds__(256) void wgrad_patch_kernel(const WgradPatchArgs p
   const int tiles_per_img = p.tiles_y * p.tiles_x;
   const int tile_beg = sp * p.tiles_per_split, tile_end = min(p.n_tiles, tile_beg + p.tiles_per_split);
 
-  // ---- tile-invariant parts of the staging addresses
-  int prow[NP], pcol[NP], prel[NP], ploff[NP];
+  // ---- tile-invariant parts of the staging addresses (raw buffer loads: see conv_patch.hip)
+  int prow[NP], pcol[NP], prc[NP], ploff[NP];
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const int e = t + i * 256;
@@ -57,44 +55,40 @@ __global__ __launch_bounds__(256) void wgrad_patch_kernel(const WgradPatchArgs p
     const bool ok = (e < NPE) & (ci_first + c < p.Cig);
     prow[i] = ok ? r : -(1 << 20);                       // forces the bounds test to fail
     pcol[i] = col;
-    prel[i] = c * p.s_chan + r * p.s_row + col;
+    prc[i] = c * p.s_chan + r * p.s_row;
     ploff[i] = e < NPE ? c * CP + r * RP + col : NCH * CP;   // pad word
   }
   const int apix = t & 63, am0 = t >> 6;                 // dy element: pixel apix, rows am0 + 4*i
   const int aty = apix / TW, atx = apix - aty * TW;
+  const unsigned a_inv = 4u * (unsigned)((g * p.Cog + m0 + am0) * p.o_chan + aty * p.o_row + atx);
+  const unsigned a_step = 16u * (unsigned)p.o_chan;
+  const bool full_m = m0 + BM <= p.Cog;
+  const __amdgpu_buffer_rsrc_t rsD = buf_rsrc(p.dyr), rsS = buf_rsrc(p.src), rsS2 = buf_rsrc(UP2 ? p.src2 : p.src);
 
   float ra[NA], rb[NP];
   auto load_tile = [&](int tile) {
     const int img = tile / tiles_per_img, trem = tile - img * tiles_per_img;
     const int tyi = trem / p.tiles_x, txi = trem - tyi * p.tiles_x;
     const int oy0 = tyi * TH, ox0 = txi * TW;
-    // dy^T
-    const int oy = oy0 + aty, ox = ox0 + atx;
-    const bool pok = (oy < p.OUTH) & (ox < p.OUTW);
-    const int abase = img * p.o_img + (g * p.Cog + m0 + am0) * p.o_chan + oy * p.o_row + ox;
+    // dy^T: the tile base is uniform and travels in the scalar offset
+    const bool pok = (oy0 + aty < p.OUTH) & (ox0 + atx < p.OUTW);
+    const unsigned sd = __builtin_amdgcn_readfirstlane(4u * (unsigned)(img * p.o_img + oy0 * p.o_row + ox0));
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const bool ok = pok & (m0 + am0 + 4 * i < p.Cog);
-      const float* ap = ok ? p.dyr + (unsigned)(abase + 4 * i * p.o_chan) : g_wzero_word;
-      ra[i] = *ap;
+      const bool ok = pok & (full_m | (m0 + am0 + 4 * i < p.Cog));
+      ra[i] = buf_load(rsD, ok ? a_inv + i * a_step : BUF_OOB, sd);
     }
     // raw input patch
     const int iy0 = oy0 * SV - p.PH, ix0 = ox0 * S - p.PW;
-    const int xbase = img * p.s_img + cbase * p.s_chan + iy0 * p.s_row + ix0;
+    const int xrow = img * p.s_img + cbase * p.s_chan + iy0 * p.s_row;   // even for UP2 (all strides are even)
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int iy = iy0 + prow[i], ix = ix0 + pcol[i];
       const bool ok = ((unsigned)iy < (unsigned)p.SRCH) & ((unsigned)ix < (unsigned)p.SRCW);
-      if (UP2) {
-        const int o = ok ? xbase + prel[i] : 0;
-        const int x = o % p.SRCW;
-        const float* pa = ok ? p.src + (unsigned)(((o - x) >> 1) + (x >> 1)) : g_wzero_word;
-        const float* pr = ok ? p.src2 + (unsigned)o : g_wzero_word;
-        rb[i] = *pa + *pr;
-      } else {
-        const float* ps = ok ? p.src + (unsigned)(xbase + prel[i]) : g_wzero_word;
-        rb[i] = *ps;
-      }
+      const int o = xrow + prc[i];
+      if (UP2) rb[i] = buf_load(rsS, ok ? 4u * (unsigned)((o >> 1) + (ix >> 1)) : BUF_OOB, 0) +
+                       buf_load(rsS2, ok ? 4u * (unsigned)(o + ix) : BUF_OOB, 0);
+      else rb[i] = buf_load(rsS, ok ? 4u * (unsigned)(o + ix) : BUF_OOB, 0);
     }
   };
   auto store_tile = [&](int buf) {
@@ -106,22 +100,17 @@ __global__ __launch_bounds__(256) void wgrad_patch_kernel(const WgradPatchArgs p
     for (int i = 0; i < NP; ++i) Ps[ploff[i]] = rb[i];
   };
 
-  f32x16 acc[TM][TN];
+  f32x16 acc;
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
   // per-lane operand bases
-  const int a_base = khalf * LDA + wm * TM * 32 + (lane & 31);
-  int nbase[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+  const int a_base = khalf * LDA + wm * 32 + (lane & 31);
+  int nbase;
+  {
+    const int n = n0 + wn * 32 + (lane & 31);
     const int c = n / KHW - ci_first, rr = n % KHW, kh = rr / KW, kw = rr - kh * KW;
-    nbase[j] = (n < p.Kg ? c * CP + kh * RP + kw : 0) + khalf * S;   // pixel k+1 is the next column of the same row
+    nbase = (n < p.Kg ? c * CP + kh * RP + kw : 0) + khalf * S;   // pixel k+1 is the next column of the same row
   }
 
   const int nsteps = tile_end - tile_beg;
@@ -135,58 +124,52 @@ __global__ __launch_bounds__(256) void wgrad_patch_kernel(const WgradPatchArgs p
     if (st + 1 < nsteps) load_tile(tile_beg + st + 1);
     const float* As = smem + cur * STAGE;
     const float* Ps = As + NPIX * LDA;
+    // operands of the next group of pixel pairs are read from LDS while the current group's MFMAs issue
+    constexpr int NPAIR = NPIX / 2, GP = 4, NG = NPAIR / GP;
+    float av[2][GP], bv[2][GP];
+    auto read_group = [&](int gi, int slot) {
 #pragma unroll
-    for (int jj = 0; jj < NPIX / 2; ++jj) {
-      const int k0 = 2 * jj;
-      const int ty = k0 / TW, tx = k0 - ty * TW;
-      const int offb = ty * SV * RP + tx * S;
-      float a[TM], b[TN];
+      for (int q = 0; q < GP; ++q) {
+        const int k0 = 2 * (gi * GP + q);
+        const int ty = k0 / TW, tx = k0 - ty * TW;
+        av[slot][q] = As[a_base + k0 * LDA];
+        bv[slot][q] = Ps[nbase + ty * SV * RP + tx * S];
+      }
+    };
+    read_group(0, 0);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = As[a_base + k0 * LDA + i * 32];
+    for (int gi = 0; gi < NG; ++gi) {
+      if (gi + 1 < NG) read_group(gi + 1, (gi + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Ps[nbase[j] + offb];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      for (int q = 0; q < GP; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[gi & 1][q], bv[gi & 1][q], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (st + 1 < nsteps) store_tile(cur ^ 1);
     __syncthreads();
   }
 
   float* outp = p.out + (size_t)sp * ctot * p.Kg;
+  const int nc = n0 + wn * 32 + (lane & 31);
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int nc = n0 + wn * TN * 32 + j * 32 + (lane & 31);
-        if (m < p.Cog && nc < p.Kg) outp[(size_t)(g * p.Cog + m) * p.Kg + nc] = acc[i][j][r];
-      }
-    }
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+    if (m < p.Cog && nc < p.Kg) outp[(size_t)(g * p.Cog + m) * p.Kg + nc] = acc[r];
+  }
   if (p.counters == nullptr || p.splits == 1) return;
   // in-launch reduction over the pixel splits: the last workgroup to arrive for this tile sums the slabs in split order
   if (!splitk_arrive_last(p.counters + (g * p.gy + by_) * p.gx + bx_, p.splits, reinterpret_cast<int*>(smem))) return;
   const size_t slab = (size_t)ctot * p.Kg;
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int nc = n0 + wn * TN * 32 + j * 32 + (lane & 31);
-        if (m < p.Cog && nc < p.Kg) {
-          const size_t off = (size_t)(g * p.Cog + m) * p.Kg + nc;
-          float v = 0.f;
-          for (int k = 0; k < p.splits; ++k) v += p.out[(size_t)k * slab + off];
-          p.final_out[off] = v;
-        }
-      }
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+    if (m < p.Cog && nc < p.Kg) {
+      const size_t off = (size_t)(g * p.Cog + m) * p.Kg + nc;
+      float v = 0.f;
+      for (int k = 0; k < p.splits; ++k) v += p.out[(size_t)k * slab + off];
+      p.final_out[off] = v;
     }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -218,7 +201,7 @@ WgradPatchPlan plan_wgrad_patch(int nd, int Cog, int Kg, int groups, int KH, int
 
 template <int KH, int KW, int S, bool UP2>
 static void launch_wgp_tw(const WgradPatchArgs& a, int tw, dim3 grid, hipStream_t s) {
-#define MS_WP(TW) hipLaunchKernelGGL((wgrad_patch_kernel<1, 1, KH, KW, S, TW, UP2>), grid, dim3(256), 0, s, a)
+#define MS_WP(TW) hipLaunchKernelGGL((wgrad_patch_kernel<KH, KW, S, TW, UP2>), grid, dim3(256), 0, s, a)
   if constexpr (KH == 1) {
     if (tw == 64) MS_WP(64);
     else if (tw == 32) MS_WP(32);
@@ -236,7 +219,7 @@ int launch_wgrad_patch(const WgradPatchArgs& a, const WgradPatchPlan& pl, int KH
   b.gx = cdiv(a.Kg, 64); b.gy = cdiv(a.Cog, 64); b.gz = a.groups * a.splits;
   if ((double)b.gx * b.gy * b.gz > 2.0e9) return set_error("wgrad grid too large");
   dim3 grid(b.gx * b.gy * b.gz);
-  TimingScope ts(s, flops, bytes, "wgrad_patch_kernel<1,1,%d,%d,%d,%d,%d>|conv_wgrad_patch k%dx%d s%d Cog%d Kg%d g%d tiles%d tw%d splits%d",
+  TimingScope ts(s, flops, bytes, "wgrad_patch_kernel<%d,%d,%d,%d,%d>|conv_wgrad_patch k%dx%d s%d Cog%d Kg%d g%d tiles%d tw%d splits%d",
                  KH, KW, S, pl.tw, up2 ? 1 : 0, KH, KW, S, a.Cog, a.Kg, a.groups, pl.n_tiles, pl.tw, a.splits);
   if (KH == 1 && KW == 3 && S == 1) {
     if (up2) launch_wgp_tw<1, 3, 1, true>(b, pl.tw, grid, s);
