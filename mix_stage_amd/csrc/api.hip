@@ -271,8 +271,12 @@ int ms_conv_block_bwd_overlap(const ms_conv_desc* d, const float* x, const float
     // patch-staged path: each output-parity class is a dense stride-1 forward conv of dy_raw with the class's taps
     // reversed (weights prepared by transpose_weight_kernel(flip=1)); outputs are scattered with stride (SH, SW)
     const PatchPlan pp0 = plan_patch(one_d ? 1 : 2, d->Cin, tg, tcog, jh, jw, 1, 1, d->B, cdiv(d->H, d->SH), cdiv(d->W, d->SW));
-    rc = launch_transpose_weight(w, wt, tg, tcog, d->Cin, d->KH, d->KW, d->SH, d->SW, d->PH, d->PW, pp0.ok ? 1 : 0, s);
-    if (rc) return rc;
+    // stride-1 convs with whole 64-channel tiles: the patch kernel reads w in place, no transposed copy
+    const bool direct = pp0.ok && patch_dgrad_direct_ok(w, d->Cin, d->KH, d->KW, d->SH, d->SW, bcast != 0);
+    if (!direct) {
+      rc = launch_transpose_weight(w, wt, tg, tcog, d->Cin, d->KH, d->KW, d->SH, d->SW, d->PH, d->PW, pp0.ok ? 1 : 0, s);
+      if (rc) return rc;
+    }
     if (pp0.ok) {
       const int Kg2 = tcog * jh * jw;
       const int cin_tot = tg * d->Cin;
@@ -294,6 +298,7 @@ int ms_conv_block_bwd_overlap(const ms_conv_desc* d, const float* x, const float
         PatchArgs q = {};
         q.A = wt + (size_t)cls * tg * d->Cin * Kg2; q.src = g; q.out = dx; q.out2 = dx2;
         q.Mg = d->Cin; q.Kg = Kg2; q.groups = tg; q.Kc = tcog; q.bcast = 0; q.a_vec = (Kg2 % 4 == 0);
+        if (direct) { q.A = w; q.a_vec = 2; }
         q.ep = up2 ? EP_DGRAD_UP2 : EP_BARE; q.is_dgrad = 1;
         if (one_d) {
           q.SRCH = d->B; q.SRCW = d->OW; q.s_img = 0; q.s_chan = d->OW; q.s_row = C * d->OW;

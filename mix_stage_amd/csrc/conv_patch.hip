@@ -33,7 +33,10 @@ constexpr int patch_row_pitch(int pc, int sv, int tw) {
 }
 
 // 1-D kernels (taps <= 3): registers capped at 128 so that 4 workgroups share a CU (the decoder launches 1024 = 4 x 256)
-template <int KH, int KW, int S, int TW, bool UP2, bool AVEC>
+// AM: layout of the A operand.  0: [Mg][Kg] rows, scalar loads (Kg % 4 != 0); 1: the same, 16-B loads;
+// 2: data gradient straight from the conv weight w[co][ci][tap] (stride-1 convs): A(ci, (co,tap')) = w[co][ci][KHW-1-tap'],
+//    Mg = Cin_g, Kc = Cout_g; per output channel the 64 x KHW block of a channel tile is one contiguous run
+template <int KH, int KW, int S, int TW, bool UP2, int AM>
 __global__ __launch_bounds__(256, (KH * KW <= 3 && TW >= 32 ? 4 : 1)) void conv_patch_kernel(const PatchArgs p) {
   using Cfg = PatchCfg<KH, KW>;
   constexpr int BM = 64, BN = 64, TH = BN / TW;
@@ -46,6 +49,7 @@ __global__ __launch_bounds__(256, (KH * KW <= 3 && TW >= 32 ? 4 : 1)) void conv_
   constexpr int NPE = CK * PR * PC;                     // patch elements per chunk
   constexpr int NP = (NPE + 255) / 256;
   constexpr int NAV = BM * (KSTEP / 4);                 // float4 slots of the weight slice
+  constexpr int RUN4 = BM * KHW / 4;                    // AM 2: float4 slots per output channel
   constexpr int NA = (NAV + 255) / 256;
   constexpr int LP = 68;                                // pitch of the epilogue's [channel][pixel] tile (4 mod 32)
   static_assert(KSTEP % 4 == 0 && BN % TW == 0, "bad patch configuration");
@@ -83,15 +87,26 @@ __global__ __launch_bounds__(256, (KH * KW <= 3 && TW >= 32 ? 4 : 1)) void conv_
     if (UP2) goff_h[i] = ok ? 4u * (unsigned)((rowbase >> 1) + (ix >> 1)) : BUF_OOB;
     loff[i] = e < NPE ? ci * CP + r * RP + c : CK * CP;   // dummy slot
   }
-  unsigned aoff[NA];                                    // weight offset rel. to (group base + k0)
+  unsigned aoff[NA];                                    // weight offset rel. to the chunk base
+  int lsto[AM == 2 ? NA : 1][4];                        // AM 2: LDS slots of the 4 elements of a float4
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int idx = t + i * 256;
-    const int row = idx / (KSTEP / 4), kq = idx - row * (KSTEP / 4);
-    aoff[i] = (idx < NAV && m0 + row < p.Mg) ? 4u * (unsigned)((m0 + row) * Kg + kq * 4) : BUF_OOB;
+    if (AM == 2) {
+      const int co = idx / RUN4, q4 = idx - co * RUN4;
+      aoff[i] = idx < NAV ? 4u * (unsigned)((co * p.Mg + m0) * KHW + 4 * q4) : BUF_OOB;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = 4 * q4 + j, cil = e / KHW, tap = e - cil * KHW;
+        lsto[i][j] = idx < NAV ? (co * KHW + (KHW - 1 - tap)) * LDA + cil : KSTEP * LDA + CK * CP + j;   // pad words
+      }
+    } else {
+      const int row = idx / (KSTEP / 4), kq = idx - row * (KSTEP / 4);
+      aoff[i] = (idx < NAV && m0 + row < p.Mg) ? 4u * (unsigned)((m0 + row) * Kg + kq * 4) : BUF_OOB;
+    }
   }
   const __amdgpu_buffer_rsrc_t rsA = buf_rsrc(p.A), rsS = buf_rsrc(p.src), rsS2 = buf_rsrc(UP2 ? p.src2 : p.src);
-  const unsigned a_group = (unsigned)g * p.Mg * Kg;
+  const unsigned a_group = (unsigned)g * p.Mg * Kg;     // (AM 2: Kg = Kc*KHW, so this is the group's first output channel)
   const int img_base = img * p.s_img;
 
   // two register sets: chunk c+2 is in flight from HBM/L2 while chunk c+1 waits in registers and chunk c computes
@@ -100,13 +115,19 @@ __global__ __launch_bounds__(256, (KH * KW <= 3 && TW >= 32 ? 4 : 1)) void conv_
   auto load_chunk = [&](int ci0, float4 (&ra)[NA], float (&rb)[NP]) {
     const int k0 = ci0 * KHW;
     // scalar offsets: values derived from integer divisions live in VGPRs; readfirstlane keeps the loads waterfall-free
-    const unsigned sa = __builtin_amdgcn_readfirstlane(4u * (a_group + (unsigned)k0));
+    const unsigned sa = __builtin_amdgcn_readfirstlane(AM == 2 ? 4u * (a_group + (unsigned)(ci0 * p.Mg * KHW))
+                                                               : 4u * (a_group + (unsigned)k0));
     const bool full_k = k0 + KSTEP <= Kg;               // uniform: only the last chunk can be partial
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
+      if (AM == 2) {
+        const int co = (t + i * 256) / RUN4;
+        ra[i] = buf_load4(rsA, (full_k | (ci0 + co < p.Kc)) ? aoff[i] : BUF_OOB, sa);
+        continue;
+      }
       const int kq = (t + i * 256) % (KSTEP / 4);
       const int k = k0 + kq * 4;
-      if (AVEC) {
+      if (AM == 1) {
         ra[i] = buf_load4(rsA, (full_k | (k < Kg)) ? aoff[i] : BUF_OOB, sa);
       } else {
         float4 v;
@@ -133,6 +154,13 @@ __global__ __launch_bounds__(256, (KH * KW <= 3 && TW >= 32 ? 4 : 1)) void conv_
     float* Ps = As + KSTEP * LDA;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
+      if (AM == 2) {
+        As[lsto[i][0]] = ra[i].x;
+        As[lsto[i][1]] = ra[i].y;
+        As[lsto[i][2]] = ra[i].z;
+        As[lsto[i][3]] = ra[i].w;
+        continue;
+      }
       const int idx = t + i * 256;
       const int row = idx / (KSTEP / 4), kq = idx - row * (KSTEP / 4);
       const int base = idx < NAV ? kq * 4 * LDA + row : KSTEP * LDA + CK * CP;   // out of range: the pad words
@@ -343,9 +371,9 @@ PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH,
   return pl;
 }
 
-template <int KH, int KW, int S, bool UP2, bool AVEC>
+template <int KH, int KW, int S, bool UP2, int AM>
 static void launch_patch_tw(const PatchArgs& a, int tw, dim3 grid, hipStream_t s) {
-#define MS_PK(TW) hipLaunchKernelGGL((conv_patch_kernel<KH, KW, S, TW, UP2, AVEC>), grid, dim3(256), 0, s, a)
+#define MS_PK(TW) hipLaunchKernelGGL((conv_patch_kernel<KH, KW, S, TW, UP2, AM>), grid, dim3(256), 0, s, a)
   if constexpr (KH == 1) {
     if (tw == 64) MS_PK(64);
     else if (tw == 32) MS_PK(32);
@@ -357,19 +385,32 @@ static void launch_patch_tw(const PatchArgs& a, int tw, dim3 grid, hipStream_t s
 #undef MS_PK
 }
 
-template <bool AVEC>
+template <int AM>
 static void launch_patch_k(const PatchArgs& a, int kh, int kw, int s_, int tw, bool up2, dim3 grid, hipStream_t s) {
-  if (kh == 1 && kw == 3 && s_ == 1) {
-    if (up2) launch_patch_tw<1, 3, 1, true, AVEC>(a, tw, grid, s);
-    else launch_patch_tw<1, 3, 1, false, AVEC>(a, tw, grid, s);
-  } else if (kh == 1 && kw == 4 && s_ == 2) launch_patch_tw<1, 4, 2, false, AVEC>(a, tw, grid, s);
-  else if (kh == 1 && kw == 4 && s_ == 1) launch_patch_tw<1, 4, 1, false, AVEC>(a, tw, grid, s);
-  else if (kh == 1 && kw == 1 && s_ == 1) launch_patch_tw<1, 1, 1, false, AVEC>(a, tw, grid, s);
-  else if (kh == 1 && kw == 2 && s_ == 1) launch_patch_tw<1, 2, 1, false, AVEC>(a, tw, grid, s);
-  else if (kh == 2 && kw == 2 && s_ == 1) launch_patch_tw<2, 2, 1, false, AVEC>(a, tw, grid, s);
-  else if (kh == 3 && kw == 3 && s_ == 1) launch_patch_tw<3, 3, 1, false, AVEC>(a, tw, grid, s);
-  else if (kh == 4 && kw == 4 && s_ == 2) launch_patch_tw<4, 4, 2, false, AVEC>(a, tw, grid, s);
-  else launch_patch_tw<3, 8, 1, false, AVEC>(a, tw, grid, s);
+  if constexpr (AM == 2) {   // data gradient of stride-1 convs only
+    if (kh == 1 && kw == 3) launch_patch_tw<1, 3, 1, false, 2>(a, tw, grid, s);
+    else if (kh == 1 && kw == 1) launch_patch_tw<1, 1, 1, false, 2>(a, tw, grid, s);
+    else if (kh == 3 && kw == 3) launch_patch_tw<3, 3, 1, false, 2>(a, tw, grid, s);
+    else launch_patch_tw<3, 8, 1, false, 2>(a, tw, grid, s);
+  } else {
+    if (kh == 1 && kw == 3 && s_ == 1) {
+      if (up2) launch_patch_tw<1, 3, 1, true, AM>(a, tw, grid, s);
+      else launch_patch_tw<1, 3, 1, false, AM>(a, tw, grid, s);
+    } else if (kh == 1 && kw == 4 && s_ == 2) launch_patch_tw<1, 4, 2, false, AM>(a, tw, grid, s);
+    else if (kh == 1 && kw == 4 && s_ == 1) launch_patch_tw<1, 4, 1, false, AM>(a, tw, grid, s);
+    else if (kh == 1 && kw == 1 && s_ == 1) launch_patch_tw<1, 1, 1, false, AM>(a, tw, grid, s);
+    else if (kh == 1 && kw == 2 && s_ == 1) launch_patch_tw<1, 2, 1, false, AM>(a, tw, grid, s);
+    else if (kh == 2 && kw == 2 && s_ == 1) launch_patch_tw<2, 2, 1, false, AM>(a, tw, grid, s);
+    else if (kh == 3 && kw == 3 && s_ == 1) launch_patch_tw<3, 3, 1, false, AM>(a, tw, grid, s);
+    else if (kh == 4 && kw == 4 && s_ == 2) launch_patch_tw<4, 4, 2, false, AM>(a, tw, grid, s);
+    else launch_patch_tw<3, 8, 1, false, AM>(a, tw, grid, s);
+  }
+}
+
+// the data gradient can read the conv weight in place (AM 2) when whole 64-channel tiles of contiguous runs exist
+bool patch_dgrad_direct_ok(const float* w, int Cin_g, int KH, int KW, int SH, int SW, bool up2_or_bcast) {
+  const bool shape = (KH == 1 && KW == 3) || (KH == 1 && KW == 1) || (KH == 3 && KW == 3) || (KH == 3 && KW == 8);
+  return shape && SH == 1 && SW == 1 && !up2_or_bcast && Cin_g % 64 == 0 && ((uintptr_t)w & 15) == 0;
 }
 
 int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S, bool up2, double flops, double bytes,
@@ -381,11 +422,14 @@ int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S,
   dim3 grid(b.gx * b.gy * b.gz);
   if (a.splitk < 1 || (a.splitk > 1 && !a.part)) return set_error("patch conv: bad split-K setup");
   if (a.src_elems >= (1u << 29) || a.a_elems >= (1u << 29)) return set_error("patch conv: operand of 2 GiB or more");
+  const int am = a.a_vec == 2 ? 2 : (a.a_vec && ((uintptr_t)a.A & 15) == 0) ? 1 : 0;
+  if (am == 2 && (S != 1 || up2)) return set_error("patch conv: in-place weights need a stride-1 data gradient");
   TimingScope ts(s, flops, bytes, "conv_patch_kernel<%d,%d,%d,%d,%d,%d>|conv_%s_patch k%dx%d s%d Mg%d Kg%d g%d tiles%d tile%d tw%d splitk%d%s",
-                 KH, KW, S, pl.tw, up2 ? 1 : 0, (a.a_vec && ((uintptr_t)a.A & 15) == 0) ? 1 : 0, a.is_dgrad ? "dgrad" : "fwd", KH, KW, S, a.Mg, a.Kg,
+                 KH, KW, S, pl.tw, up2 ? 1 : 0, am, a.is_dgrad ? "dgrad" : "fwd", KH, KW, S, a.Mg, a.Kg,
                  a.groups, pl.n_tiles, bm, pl.tw, a.splitk, a.ep == EP_RAW_STATS ? " +bnstats" : "");
-  if (a.a_vec && ((uintptr_t)a.A & 15) == 0) launch_patch_k<true>(b, KH, KW, S, pl.tw, up2, grid, s);
-  else launch_patch_k<false>(b, KH, KW, S, pl.tw, up2, grid, s);
+  if (am == 2) launch_patch_k<2>(b, KH, KW, S, pl.tw, up2, grid, s);
+  else if (am == 1) launch_patch_k<1>(b, KH, KW, S, pl.tw, up2, grid, s);
+  else launch_patch_k<0>(b, KH, KW, S, pl.tw, up2, grid, s);
   return check_launch("conv_patch_kernel");
 }
 

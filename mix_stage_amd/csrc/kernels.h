@@ -59,7 +59,7 @@ struct PatchArgs {
   const float* bn_v;
   float* stats;        // EP_RAW_STATS: [n_tiles][ctot][2]
   float* counts;       // EP_RAW_STATS: [n_tiles] valid pixels per tile
-  int Mg, Kg, groups, Kc, bcast, a_vec, ep;
+  int Mg, Kg, groups, Kc, bcast, a_vec, ep;   // a_vec: 0 scalar A loads, 1 16-B loads, 2 A is the conv weight in place
   int SRCH, SRCW, s_img, s_chan, s_row;   // source image rows/cols and element strides
   int OUTH, OUTW, o_img, o_chan, o_row;
   int o_sh, o_sw, o_ry, o_rx;   // output scatter: (oy*o_sh + o_ry, ox*o_sw + o_rx); data gradient of a strided conv
@@ -76,6 +76,7 @@ struct PatchArgs {
 struct PatchPlan { int ok, tm, tw, tiles_y, tiles_x, n_tiles, splitk, chunks_per_split, tn; };
 PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH, int SW, int B, int OH, int OW);
 int patch_chunk_channels(int KH, int KW);
+bool patch_dgrad_direct_ok(const float* w, int Cin_g, int KH, int KW, int SH, int SW, bool up2_or_bcast);
 int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S, bool up2, double flops, double bytes,
                  hipStream_t s);
 
