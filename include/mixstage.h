@@ -110,6 +110,30 @@ int ms_conv_block_bwd_overlap(const ms_conv_desc* d, const float* x, const float
                               void* workspace, size_t workspace_bytes, void* stream, void* side_stream,
                               void* side_workspace, size_t side_workspace_bytes);
 
+/* Full form of the backward.  All fields optional (zero = the behaviour of ms_conv_block_bwd). */
+typedef struct ms_bwd_options {
+  void* side_stream;            /* weight gradient on this stream, as ms_conv_block_bwd_overlap */
+  void* side_workspace;
+  size_t side_workspace_bytes;
+  const float* wt_prepared;     /* this block's buffer from ms_dgrad_weights_prepare (built for the same descriptor and
+                                 * the current w): the backward then skips its per-call transposed copy of w */
+} ms_bwd_options;
+int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2, const float* w,
+                         const float* gamma, const float* running_mean, const float* running_var,
+                         const float* y_raw, const float* y, const float* save, const float* dy, float* dyr,
+                         float* dx, float* dx2, float* dw, float* dbias, float* dgamma, float* dbeta,
+                         void* workspace, size_t workspace_bytes, void* stream, const ms_bwd_options* opt);
+
+/* Data-gradient weights.  The data gradient of a block multiplies by w transposed (split into stride-parity classes for
+ * strided convs); ms_conv_block_bwd builds that copy in its scratch on every call.  It depends on w and the descriptor
+ * only, so a trainer builds it once per optimizer update -- for many blocks in ONE launch -- and passes it back through
+ * ms_bwd_options.wt_prepared (autograd has no counterpart: torch's conv backward re-derives its layouts per call).
+ *   ms_dgrad_weights_elems   floats the block's copy needs; 0 = its data gradient reads w in place, nothing to prepare
+ *   ms_dgrad_weights_prepare descs[n], w[n], wt[n] (wt[i] may be NULL where elems == 0) */
+size_t ms_dgrad_weights_elems(const ms_conv_desc* d, const float* w);
+int ms_tuning_epoch(void);   /* bumped by the ms_debug_set_* knobs: prepared weights built under another value are stale */
+int ms_dgrad_weights_prepare(int n, const ms_conv_desc* descs, const float* const* w, float* const* wt, void* stream);
+
 /* AudioEncoder resize (layers.py:197): bilinear to (T,1), align_corners=False, == 1-D lerp in time
  * of frequency column F/2.   x (B,C,Tin,F) -> y (B,C,Tout). */
 int ms_lerp_time_fwd(const float* x, float* y, int B, int C, int Tin, int F, int Tout, void* stream);

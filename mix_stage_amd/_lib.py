@@ -13,6 +13,12 @@ LIB_PATH = os.path.join(_HERE, 'libmixstage_hip.so')
 c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 
 
+class BwdOptions(ctypes.Structure):
+  """struct ms_bwd_options"""
+  _fields_ = [('side_stream', ctypes.c_void_p), ('side_workspace', ctypes.c_void_p), ('side_workspace_bytes', ctypes.c_size_t),
+              ('wt_prepared', ctypes.c_void_p)]
+
+
 class ConvDesc(ctypes.Structure):
   """struct ms_conv_desc"""
   _fields_ = [(n, ctypes.c_int32) for n in
@@ -37,6 +43,10 @@ SIGNATURES = {
     'ms_conv_block_fwd': (c_int, [_DESC] + [_P] * 11 + [_P, c_size_t, _P]),
     'ms_conv_block_bwd': (c_int, [_DESC] + [_P] * 17 + [_P, c_size_t, _P]),
     'ms_conv_block_bwd_overlap': (c_int, [_DESC] + [_P] * 17 + [_P, c_size_t, _P, _P, _P, c_size_t]),
+    'ms_conv_block_bwd_ex': (c_int, [_DESC] + [_P] * 17 + [_P, c_size_t, _P, _P]),
+    'ms_dgrad_weights_elems': (c_size_t, [_DESC, _P]),
+    'ms_dgrad_weights_prepare': (c_int, [c_int, _P, _P, _P, _P]),
+    'ms_tuning_epoch': (c_int, []),
     'ms_lerp_time_fwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'ms_lerp_time_bwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'ms_softmax_mix_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

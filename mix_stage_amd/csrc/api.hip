@@ -181,12 +181,61 @@ int ms_conv_block_fwd(const ms_conv_desc* d, const float* x, const float* x2, co
   return rc;
 }
 
+// The data-gradient weights of block d: none (the patch kernel reads w in place), or the transposed / parity-class-split
+// copy, with the taps reversed when the patch-staged kernels will consume it.  Shared by the backward and the prepare
+// entry points so that both take the same decision.
+struct DgradWeights { int need, flip, tg, tcog; size_t elems; };
+static DgradWeights dgrad_weights_of(const ms_conv_desc* d, const float* w) {
+  const bool bcast = d->in_mode == MS_IN_BCAST;
+  DgradWeights r;
+  r.tg = bcast ? 1 : d->groups;
+  r.tcog = bcast ? d->groups * d->Cout : d->Cout;
+  const int jh = cdiv(d->KH, d->SH), jw = cdiv(d->KW, d->SW);
+  const bool one_d = d->H == 1 && d->KH == 1;
+  const PatchPlan pp0 = plan_patch(one_d ? 1 : 2, d->Cin, r.tg, r.tcog, jh, jw, 1, 1, d->B, cdiv(d->H, d->SH), cdiv(d->W, d->SW));
+  const bool direct = pp0.ok && patch_dgrad_direct_ok(w, d->Cin, d->KH, d->KW, d->SH, d->SW, bcast);
+  r.need = direct ? 0 : 1;
+  r.flip = pp0.ok ? 1 : 0;
+  r.elems = dgrad_weight_elems(d->groups, d->Cout, d->Cin, d->KH, d->KW, d->SH, d->SW);
+  return r;
+}
+
+size_t ms_dgrad_weights_elems(const ms_conv_desc* d, const float* w) {
+  if (validate(d, "ms_dgrad_weights_elems")) return 0;
+  const DgradWeights dw = dgrad_weights_of(d, w);
+  return dw.need ? dw.elems : 0;
+}
+
+int ms_dgrad_weights_prepare(int n, const ms_conv_desc* descs, const float* const* w, float* const* wt, void* stream) {
+  if (n < 0 || (n && (!descs || !w || !wt))) return set_error("ms_dgrad_weights_prepare: null argument");
+  TransposeBatch tb;
+  tb.n = 0;
+  for (int i = 0; i < n; ++i) {
+    const ms_conv_desc* d = descs + i;
+    int rc = validate(d, "ms_dgrad_weights_prepare");
+    if (rc) return rc;
+    const DgradWeights dw = dgrad_weights_of(d, w[i]);
+    if (!dw.need) continue;
+    if (!wt[i]) return set_error("ms_dgrad_weights_prepare: block %d needs a buffer of ms_dgrad_weights_elems floats", i);
+    TransposeJob jb = {w[i], wt[i], dw.tg, dw.tcog, d->Cin, d->KH, d->KW, d->SH, d->SW, d->PH, d->PW, dw.flip, 0};
+    tb.job[tb.n++] = jb;
+    if (tb.n == TRANSPOSE_BATCH_MAX || i == n - 1) {
+      rc = launch_transpose_weight_multi(tb, (hipStream_t)stream);
+      if (rc) return rc;
+      tb.n = 0;
+    }
+  }
+  if (tb.n) return launch_transpose_weight_multi(tb, (hipStream_t)stream);
+  return 0;
+}
+
 int ms_conv_block_bwd(const ms_conv_desc* d, const float* x, const float* x2, const float* w, const float* gamma,
                       const float* running_mean, const float* running_var, const float* y_raw, const float* y,
                       const float* save, const float* dy, float* dyr, float* dx, float* dx2, float* dw, float* dbias,
                       float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
-  return ms_conv_block_bwd_overlap(d, x, x2, w, gamma, running_mean, running_var, y_raw, y, save, dy, dyr, dx, dx2, dw, dbias,
-                                   dgamma, dbeta, workspace, workspace_bytes, stream, nullptr, nullptr, 0);
+  ms_bwd_options o = {};
+  return ms_conv_block_bwd_ex(d, x, x2, w, gamma, running_mean, running_var, y_raw, y, save, dy, dyr, dx, dx2, dw, dbias,
+                              dgamma, dbeta, workspace, workspace_bytes, stream, &o);
 }
 
 static hipEvent_t fork_event() {
@@ -200,7 +249,24 @@ int ms_conv_block_bwd_overlap(const ms_conv_desc* d, const float* x, const float
                               const float* save, const float* dy, float* dyr, float* dx, float* dx2, float* dw,
                               float* dbias, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
                               void* stream, void* side_stream, void* side_workspace, size_t side_workspace_bytes) {
+  ms_bwd_options o = {};
+  o.side_stream = side_stream; o.side_workspace = side_workspace; o.side_workspace_bytes = side_workspace_bytes;
+  return ms_conv_block_bwd_ex(d, x, x2, w, gamma, running_mean, running_var, y_raw, y, save, dy, dyr, dx, dx2, dw, dbias,
+                              dgamma, dbeta, workspace, workspace_bytes, stream, &o);
+}
+
+int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2, const float* w, const float* gamma,
+                         const float* running_mean, const float* running_var, const float* y_raw, const float* y,
+                         const float* save, const float* dy, float* dyr, float* dx, float* dx2, float* dw, float* dbias,
+                         float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream,
+                         const ms_bwd_options* opt) {
   (void)running_mean; (void)running_var;
+  ms_bwd_options none = {};
+  if (!opt) opt = &none;
+  void* side_stream = opt->side_stream;
+  void* side_workspace = opt->side_workspace;
+  const size_t side_workspace_bytes = opt->side_workspace_bytes;
+  const float* wt_prepared = opt->wt_prepared;
   int rc = validate(d, "ms_conv_block_bwd");
   if (rc) return rc;
   if (d->mode == MS_BN_EVAL) return set_error("ms_conv_block_bwd: BN_EVAL blocks are never differentiated on the path");
@@ -273,7 +339,9 @@ int ms_conv_block_bwd_overlap(const ms_conv_desc* d, const float* x, const float
     const PatchPlan pp0 = plan_patch(one_d ? 1 : 2, d->Cin, tg, tcog, jh, jw, 1, 1, d->B, cdiv(d->H, d->SH), cdiv(d->W, d->SW));
     // stride-1 convs with whole 64-channel tiles: the patch kernel reads w in place, no transposed copy
     const bool direct = pp0.ok && patch_dgrad_direct_ok(w, d->Cin, d->KH, d->KW, d->SH, d->SW, bcast != 0);
-    if (!direct) {
+    if (wt_prepared) {
+      wt = const_cast<float*>(wt_prepared);      // built by ms_dgrad_weights_prepare for this very descriptor
+    } else if (!direct) {
       rc = launch_transpose_weight(w, wt, tg, tcog, d->Cin, d->KH, d->KW, d->SH, d->SW, d->PH, d->PW, pp0.ok ? 1 : 0, s);
       if (rc) return rc;
     }

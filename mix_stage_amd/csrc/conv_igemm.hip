@@ -437,12 +437,12 @@ __global__ void reduce_splits_kernel(const float* __restrict__ part, float* __re
 // Data-gradient weights.  One slab per output-parity class (ry, rx) of a stride-(SH,SW) conv:
 //   wpar[cls][g][ci][co][jh][jw] = w[g][co][ci][kh0 + SH*jh][kw0 + SW*jw]   (0 beyond the kernel)
 // with kh0 = (ry+PH)%SH, kw0 = (rx+PW)%SW, JH = ceil(KH/SH), JW = ceil(KW/SW).  Stride 1 -> one slab, all taps.
-__global__ void transpose_weight_kernel(const float* __restrict__ w, float* __restrict__ wt, int groups, int Cog,
-                                        int Cig, int KH, int KW, int SH, int SW, int PH, int PW, int flip) {
+__device__ inline void transpose_weight_elems(const TransposeJob& jb, int first, int stride) {
+  const int KH = jb.KH, KW = jb.KW, SH = jb.SH, SW = jb.SW, Cog = jb.Cog, Cig = jb.Cig;
   const int JH = (KH + SH - 1) / SH, JW = (KW + SW - 1) / SW, J = JH * JW;
-  const int per_g = Cog * Cig * J, per_cls = groups * per_g;
+  const int per_g = Cog * Cig * J, per_cls = jb.groups * per_g;
   const int total = SH * SW * per_cls;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+  for (int i = first; i < total; i += stride) {
     const int cls = i / per_cls;
     int r = i - cls * per_cls;
     const int g = r / per_g;
@@ -451,13 +451,25 @@ __global__ void transpose_weight_kernel(const float* __restrict__ w, float* __re
     r -= ci * Cog * J;
     const int co = r / J, j = r - co * J;
     int jh = j / JW, jw = j - jh * JW;
-    if (flip) { jh = JH - 1 - jh; jw = JW - 1 - jw; }   // taps reversed: the data gradient becomes a forward conv
+    if (jb.flip) { jh = JH - 1 - jh; jw = JW - 1 - jw; }   // taps reversed: the data gradient becomes a forward conv
     const int ry = cls / SW, rx = cls - ry * SW;
-    const int kh = (ry + PH) % SH + SH * jh, kw = (rx + PW) % SW + SW * jw;
+    const int kh = (ry + jb.PH) % SH + SH * jh, kw = (rx + jb.PW) % SW + SW * jw;
     float v = 0.f;
-    if (kh < KH && kw < KW) v = w[(((size_t)(g * Cog + co) * Cig + ci) * KH + kh) * KW + kw];
-    wt[i] = v;
+    if (kh < KH && kw < KW) v = jb.w[(((size_t)(g * Cog + co) * Cig + ci) * KH + kh) * KW + kw];
+    jb.wt[i] = v;
   }
+}
+
+__global__ void transpose_weight_kernel(const TransposeJob jb) {
+  transpose_weight_elems(jb, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// many blocks' data-gradient weights in ONE launch: job j owns workgroups [block_end[j-1], block_end[j])
+__global__ void transpose_weight_multi_kernel(const TransposeBatch tb) {
+  int j = 0;
+  while (j + 1 < tb.n && (int)blockIdx.x >= tb.job[j].block_end) ++j;
+  const int b0 = j ? tb.job[j - 1].block_end : 0;
+  transpose_weight_elems(tb.job[j], ((int)blockIdx.x - b0) * blockDim.x + threadIdx.x, (tb.job[j].block_end - b0) * blockDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -802,14 +814,31 @@ size_t dgrad_weight_elems(int groups, int Cog, int Cig, int KH, int KW, int SH, 
   return (size_t)SH * SW * groups * Cog * Cig * cdiv(KH, SH) * cdiv(KW, SW);
 }
 
+static int transpose_total(const TransposeJob& jb) {
+  return jb.SH * jb.SW * jb.groups * jb.Cog * jb.Cig * cdiv(jb.KH, jb.SH) * cdiv(jb.KW, jb.SW);
+}
+
 int launch_transpose_weight(const float* w, float* wt, int groups, int Cog, int Cig, int KH, int KW, int SH, int SW,
                             int PH, int PW, int flip, hipStream_t s) {
-  const int J = cdiv(KH, SH) * cdiv(KW, SW);
-  const int total = SH * SW * groups * Cog * Cig * J;
+  TransposeJob jb = {w, wt, groups, Cog, Cig, KH, KW, SH, SW, PH, PW, flip, 0};
+  const int total = transpose_total(jb);
   TimingScope ts(s, 0, 8.0 * total, "transpose_weight n%d", total);
-  hipLaunchKernelGGL(transpose_weight_kernel, dim3(min(cdiv(total, 256), 4096)), dim3(256), 0, s, w, wt, groups, Cog, Cig, KH,
-                     KW, SH, SW, PH, PW, flip);
+  hipLaunchKernelGGL(transpose_weight_kernel, dim3(min(cdiv(total, 256), 4096)), dim3(256), 0, s, jb);
   return check_launch("transpose_weight_kernel");
+}
+
+int launch_transpose_weight_multi(TransposeBatch& tb, hipStream_t s) {
+  int blocks = 0;
+  double total = 0;
+  for (int j = 0; j < tb.n; ++j) {
+    const int n = transpose_total(tb.job[j]);
+    blocks += std::max(1, std::min(cdiv(n, 1024), 256));
+    tb.job[j].block_end = blocks;
+    total += n;
+  }
+  TimingScope ts(s, 0, 8.0 * total, "transpose_weight_multi jobs%d n%.0f", tb.n, total);
+  hipLaunchKernelGGL(transpose_weight_multi_kernel, dim3(blocks), dim3(256), 0, s, tb);
+  return check_launch("transpose_weight_multi_kernel");
 }
 
 // ---------------------------------------------------------------------------------------------

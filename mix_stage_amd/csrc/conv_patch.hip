@@ -435,7 +435,11 @@ int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S,
 
 }  // namespace ms
 
+static int g_tuning_epoch = 0;
+extern "C" int ms_tuning_epoch(void) { return g_tuning_epoch; }
+
 extern "C" int ms_debug_set_patch_tuning(int wide_tile_min_workgroups, int force_splitk) {
+  ++g_tuning_epoch;
   (void)wide_tile_min_workgroups;   // 64x128 / 128x128 tiles were measured, gave nothing and are retired
   ms::g_patch_force_splitk = force_splitk > 0 ? force_splitk : 0;
   return 0;
@@ -443,6 +447,7 @@ extern "C" int ms_debug_set_patch_tuning(int wide_tile_min_workgroups, int force
 
 extern "C" int ms_debug_set_patch_min_workgroups(int n) {
   const int old = ms::g_patch_min_wgs;
+  ++g_tuning_epoch;
   ms::g_patch_min_wgs = n;
   return old;
 }

@@ -114,6 +114,15 @@ int launch_splitk_dgrad_epilogue(const float* part, int splitk, size_t part_stri
                                  int up2, hipStream_t s);
 int wgrad_splits(int Cog, int Kg, int groups, int Npix);
 int launch_wgrad(WgradArgs a, bool up2, float* dw, float* partial_ws, hipStream_t s);
+struct TransposeJob {
+  const float* w;
+  float* wt;
+  int groups, Cog, Cig, KH, KW, SH, SW, PH, PW, flip;
+  int block_end;     // multi launch: one past this job's last workgroup
+};
+enum { TRANSPOSE_BATCH_MAX = 48 };   // 48 x 64 B of kernel arguments
+struct TransposeBatch { int n; TransposeJob job[TRANSPOSE_BATCH_MAX]; };
+int launch_transpose_weight_multi(TransposeBatch& tb, hipStream_t s);
 int launch_transpose_weight(const float* w, float* wt, int groups, int Cog, int Cig, int KH, int KW, int SH, int SW,
                             int PH, int PW, int flip, hipStream_t s);
 size_t dgrad_weight_elems(int groups, int Cog, int Cig, int KH, int KW, int SH, int SW);

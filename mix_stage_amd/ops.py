@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import (ConvDesc, MS_BARE, MS_BN_EVAL, MS_BN_TRAIN, MS_IN_BCAST, MS_IN_PLAIN,
+from ._lib import (BwdOptions, ConvDesc, MS_BARE, MS_BN_EVAL, MS_BN_TRAIN, MS_IN_BCAST, MS_IN_PLAIN,
                    MS_IN_UP2ADD, MS_LRELU, check, lib)
 
 _vp = ctypes.c_void_p
@@ -110,6 +110,69 @@ def join_backward_overlap():
   if side is not None:
     torch.cuda.current_stream().wait_stream(side)
   _overlap['keep'].clear()
+
+
+# ------------------------------------------------------------------------------------------------
+# prepared data-gradient weights (ms_dgrad_weights_prepare): built once per optimizer update for all blocks of a network in
+# ONE launch instead of one transposed copy per block and backward call.  Off unless a trainer that owns the parameter
+# updates (MixStageTrainStep) switches it on and calls refresh_prepared_weights() after every update.
+_prepared = {'on': False, 'entries': {}, 'by_storage': {}}
+
+
+def enable_prepared_weights(on):
+  _prepared['on'] = bool(on)
+  if not on:
+    _prepared['entries'].clear()
+    _prepared['by_storage'].clear()
+
+
+def _prepare_entries(entries):
+  entries = [e for e in entries if e['n']]
+  if not entries:
+    return
+  L = lib()
+  n = len(entries)
+  descs = (ConvDesc * n)(*[e['d'] for e in entries])
+  ws = (ctypes.c_void_p * n)(*[e['w'].data_ptr() for e in entries])
+  wts = (ctypes.c_void_p * n)(*[e['wt'].data_ptr() for e in entries])
+  check(L.ms_dgrad_weights_prepare(n, descs, ws, wts, _stream()), 'ms_dgrad_weights_prepare')
+  tune = L.ms_tuning_epoch()
+  for e in entries:
+    e['version'], e['tune'] = e['w']._version, tune
+
+
+def _prepared_for(w, d):
+  """The block's prepared buffer (None: not needed / feature off).  Builds or rebuilds it when w was modified in place
+  by anything torch knows about (w._version) or a tuning knob moved."""
+  if not _prepared['on']:
+    return None
+  L = lib()
+  key = (w.data_ptr(), id(d))
+  tune = L.ms_tuning_epoch()
+  e = _prepared['entries'].get(key)
+  if e is None or e['tune'] != tune:
+    n = L.ms_dgrad_weights_elems(ctypes.byref(d), _ptr(w))
+    if e is None:
+      e = dict(w=w, d=d, n=0, wt=None, version=-1, tune=-1)
+      _prepared['entries'][key] = e
+      _prepared['by_storage'].setdefault(w.untyped_storage().data_ptr(), []).append(e)
+    if n != e['n']:
+      e['n'], e['wt'] = n, (torch.empty(n, dtype=torch.float32, device=w.device) if n else None)
+    e['version'] = -1
+    if not n:
+      e['tune'] = tune
+  if not e['n']:
+    return None
+  if e['version'] != w._version or e['tune'] != tune:
+    _prepare_entries([e])
+  return e['wt']
+
+
+def refresh_prepared_weights(flat_params):
+  """Rebuild every prepared buffer whose weight lives in `flat_params`' storage: one launch (per 48 blocks).  Call after
+  each update of that storage that torch cannot see (the HIP Adam kernels write through raw pointers)."""
+  if _prepared['on']:
+    _prepare_entries(_prepared['by_storage'].get(flat_params.untyped_storage().data_ptr(), ()))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -243,9 +306,18 @@ class _ConvBlockFn(torch.autograd.Function):
                                             _stream(), _vp(side.cuda_stream), _ptr(ws2), ws2.numel()),
             'ms_conv_block_bwd_overlap')
     else:
-      check(lib().ms_conv_block_bwd(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(gamma), None, None, _ptr(y_raw),
-                                    _ptr(y), _ptr(save), _ptr(dy), _ptr(dyr), _ptr(dx), _ptr(dx2), _ptr(dw), _ptr(dbias),
-                                    _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), _stream()), 'ms_conv_block_bwd')
+      wt = _prepared_for(w, d) if want_dx else None
+      if wt is not None:
+        opt = BwdOptions(None, None, 0, wt.data_ptr())
+        check(lib().ms_conv_block_bwd_ex(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(gamma), None, None, _ptr(y_raw),
+                                         _ptr(y), _ptr(save), _ptr(dy), _ptr(dyr), _ptr(dx), _ptr(dx2), _ptr(dw),
+                                         _ptr(dbias), _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), _stream(),
+                                         ctypes.byref(opt)), 'ms_conv_block_bwd_ex')
+      else:
+        check(lib().ms_conv_block_bwd(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(gamma), None, None, _ptr(y_raw),
+                                      _ptr(y), _ptr(save), _ptr(dy), _ptr(dyr), _ptr(dx), _ptr(dx2), _ptr(dw),
+                                      _ptr(dbias), _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), _stream()),
+              'ms_conv_block_bwd')
     return (dx, dx2, None if direct_w else dw, None if direct_b else dbias, None if direct_g else dgamma,
             None if direct_be else dbeta, None, None, None, None)
 

@@ -149,8 +149,22 @@ class FlatAdam:
     ops.adam_step_segmented(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.norm, self.max_norm, self.lr,
                             self.betas[0], self.betas[1], self.eps, self.step_state, self.seg_of_chunk, self.seg_first,
                             self.seg_scratch)
+    ops.refresh_prepared_weights(self.flat_p)        # data-gradient weights of all blocks of this network: one launch
+    self.seen_version = self._param_versions()
     if count:
       self.host_step += 1
+
+  def resync_if_modified(self):
+    """Parameters changed behind the optimizer's back (load_state_dict, manual edits: torch bumps the version counter the
+    views share with the flat buffer): rebuild what was derived from them before a captured step replays."""
+    v = self._param_versions()
+    if v != getattr(self, 'seen_version', None):
+      ops.refresh_prepared_weights(self.flat_p)
+      self.seen_version = v
+
+  def _param_versions(self):
+    # p.data was re-pointed into the flat buffer, so every parameter keeps its own version counter
+    return sum(p._version for p in self.params) + self.flat_p._version
 
   @property
   def step_count(self):
@@ -166,6 +180,7 @@ class MixStageTrainStep:
     # inside the captured step it is SLOWER (5.01 vs 4.67 ms/step: cross-stream edges in the HIP graph cost more than the
     # concurrency buys), so it is off by default.
     self.side_stream = torch.cuda.Stream() if overlap_wgrad else None
+    ops.enable_prepared_weights(True)
     self.optim_G = FlatAdam(model.G.parameters(), lr=lr, max_norm=clip)
     self.optim_D = FlatAdam(model.D.parameters(), lr=lr, max_norm=clip)
     self.use_graphs = use_graphs
@@ -224,6 +239,8 @@ class MixStageTrainStep:
       m.D_prob = 1.1 if kind == 'D' else -1.0
     try:
       k, pose_branch = self._peek_decisions()
+      self.optim_G.resync_if_modified()
+      self.optim_D.resync_if_modified()
       if not self.use_graphs:
         self.fake_pose, self.losses = self._forward_backward(audio, labels, pose, style)
         opt = self.optim_G if m.G_flag else self.optim_D

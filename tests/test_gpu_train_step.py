@@ -173,3 +173,37 @@ def test_reference_coin_flip_sequence_and_rng_parity():
     kinds = [ts.step(audio.to(DEV), labels.to(DEV), pose.to(DEV), style.to(DEV)) for _ in range(6)]
     assert kinds == ref_kinds and torch.rand(1).item() == tail_ref
     assert len(set(kinds)) == 2          # the seed exercises both step kinds
+
+
+def test_prepared_dgrad_weights_follow_every_weight_change():
+  """The data-gradient weights are built once per optimizer update (ms_dgrad_weights_prepare) instead of per backward
+  call.  They must track (a) the HIP Adam updates inside captured steps and (b) edits torch makes behind the optimizer's
+  back (load_state_dict), and the feature must not change a single bit of the parameters."""
+  from mix_stage_amd import ops
+  from mix_stage_amd.train_step import MixStageTrainStep
+  M = S = 4
+  batches = [O.synthetic_batch(4, M=M, S=S, seed=70 + i) for i in range(6)]
+  kinds = ['G', 'D', 'G', 'G', 'D', 'G']
+
+  def run(prepared, use_graphs):
+    torch.manual_seed(5)
+    model = _hip(M, S)
+    ts = MixStageTrainStep(model, use_graphs=use_graphs)
+    ops.enable_prepared_weights(prepared)
+    snap = None
+    for i, ((audio, pose, labels, style), k) in enumerate(zip(batches, kinds)):
+      if i == 3:      # perturb every parameter the way a checkpoint load does (in-place copy_ into the views)
+        sd = {n: v * 1.01 if v.dtype.is_floating_point else v for n, v in model.state_dict().items()}
+        model.load_state_dict(sd)
+      ts.step(audio.to(DEV), labels.to(DEV), pose.to(DEV), style.to(DEV), kind=k)
+    torch.cuda.synchronize()
+    snap = (ts.optim_G.flat_p.clone(), ts.optim_D.flat_p.clone(), len(ops._prepared['entries']))
+    ops.enable_prepared_weights(False)
+    return snap
+
+  base = run(False, False)
+  assert base[2] == 0
+  for use_graphs in (False, True):
+    got = run(True, use_graphs)
+    assert got[2] > 0, 'no block used prepared weights'
+    assert torch.equal(got[0], base[0]) and torch.equal(got[1], base[1]), 'prepared weights changed the result'

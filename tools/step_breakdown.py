@@ -22,12 +22,13 @@ for kind in 'GD':
   rows = ops.timing_report(); ops.timing_enable(False)
   rows.sort(key=lambda r: -r['total_ms'])
   tot = sum(r['total_ms'] for r in rows)
-  cat = {}
+  cat = {}; ncat = {}
   for r in rows:
     c = r['label'].split('|')[-1].split()[0]
     cat[c] = cat.get(c, 0) + r['total_ms']
+    ncat[c] = ncat.get(c, 0) + r['count']
   print('==== %s-step: eager wall %.2f ms, timed kernels %.2f ms, %d launches' % (kind, e0.elapsed_time(e1), tot, sum(r['count'] for r in rows)))
-  print('  by category:', {k: round(v, 3) for k, v in sorted(cat.items(), key=lambda kv: -kv[1])})
+  print('  by category (ms, launches):', {k: (round(v, 3), ncat[k]) for k, v in sorted(cat.items(), key=lambda kv: -kv[1])})
   for r in rows[:60]:
     avg = r['total_ms'] / r['count'] * 1e3
     tf = r['flops'] / (avg * 1e-6) / 1e12 if r['flops'] else 0
