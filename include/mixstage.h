@@ -117,6 +117,9 @@ typedef struct ms_bwd_options {
   size_t side_workspace_bytes;
   const float* wt_prepared;     /* this block's buffer from ms_dgrad_weights_prepare (built for the same descriptor and
                                  * the current w): the backward then skips its per-call transposed copy of w */
+  float* wgrad_partials;        /* ms_wgrad_partials_elems(d) floats: the pixel-split partial weight gradients are left
+                                 * here and dw is NOT written; the caller adds them into dw later, for many blocks in one
+                                 * launch, with ms_wgrad_reduce_multi.  Ignored by blocks whose dw needs no split. */
 } ms_bwd_options;
 int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2, const float* w,
                          const float* gamma, const float* running_mean, const float* running_var,
@@ -133,6 +136,15 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
 size_t ms_dgrad_weights_elems(const ms_conv_desc* d, const float* w);
 int ms_tuning_epoch(void);   /* bumped by the ms_debug_set_* knobs: prepared weights built under another value are stale */
 int ms_dgrad_weights_prepare(int n, const ms_conv_desc* descs, const float* const* w, float* const* wt, void* stream);
+
+/* Deferred weight-gradient reduction.  Small layers split the pixel reduction of dw over workgroups and sum the partial
+ * slabs in a second kernel; a trainer can leave the slabs (ms_bwd_options.wgrad_partials) and sum all blocks' slabs in ONE
+ * launch at the end of the backward pass.  dw[i][e] += sum_k partials[i][k][e], k ascending (same order as the per-block
+ * kernel), so dw must hold zeros or the step's other contributions.
+ *   ms_wgrad_partials_elems   floats of slab space for block d (0: dw is written directly), *splits = slab count */
+size_t ms_wgrad_partials_elems(const ms_conv_desc* d, int* splits);
+int ms_wgrad_reduce_multi(int n, const float* const* partials, float* const* dw, const int* elems, const int* splits,
+                          void* stream);
 
 /* AudioEncoder resize (layers.py:197): bilinear to (T,1), align_corners=False, == 1-D lerp in time
  * of frequency column F/2.   x (B,C,Tin,F) -> y (B,C,Tout). */

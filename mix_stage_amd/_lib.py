@@ -16,7 +16,7 @@ c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_flo
 class BwdOptions(ctypes.Structure):
   """struct ms_bwd_options"""
   _fields_ = [('side_stream', ctypes.c_void_p), ('side_workspace', ctypes.c_void_p), ('side_workspace_bytes', ctypes.c_size_t),
-              ('wt_prepared', ctypes.c_void_p)]
+              ('wt_prepared', ctypes.c_void_p), ('wgrad_partials', ctypes.c_void_p)]
 
 
 class ConvDesc(ctypes.Structure):
@@ -47,6 +47,8 @@ SIGNATURES = {
     'ms_dgrad_weights_elems': (c_size_t, [_DESC, _P]),
     'ms_dgrad_weights_prepare': (c_int, [c_int, _P, _P, _P, _P]),
     'ms_tuning_epoch': (c_int, []),
+    'ms_wgrad_partials_elems': (c_size_t, [_DESC, _P]),
+    'ms_wgrad_reduce_multi': (c_int, [c_int, _P, _P, _P, _P, _P]),
     'ms_lerp_time_fwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'ms_lerp_time_bwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'ms_softmax_mix_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

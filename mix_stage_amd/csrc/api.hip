@@ -200,6 +200,39 @@ static DgradWeights dgrad_weights_of(const ms_conv_desc* d, const float* w) {
   return r;
 }
 
+// Pixel splits of the block's weight gradient as the backward will run it (1: dw is written directly).
+static int wgrad_splits_used(const ms_conv_desc* d) {
+  const bool one_d = d->H == 1 && d->KH == 1;
+  const WgradPatchPlan wp = plan_wgrad_patch(one_d ? 1 : 2, d->Cout, d->Cin * d->KH * d->KW, d->groups, d->KH, d->KW, d->SH,
+                                             d->SW, d->B, d->OH, d->OW);
+  return wp.ok ? wp.splits : wgrad_splits(d->Cout, d->Cin * d->KH * d->KW, d->groups, d->B * d->OH * d->OW);
+}
+
+size_t ms_wgrad_partials_elems(const ms_conv_desc* d, int* splits) {
+  if (validate(d, "ms_wgrad_partials_elems")) return 0;
+  const int sp = wgrad_splits_used(d);
+  if (splits) *splits = sp;
+  return sp > 1 ? (size_t)sp * wsize_of(d) : 0;
+}
+
+int ms_wgrad_reduce_multi(int n, const float* const* partials, float* const* dw, const int* elems, const int* splits,
+                          void* stream) {
+  if (n < 0 || (n && (!partials || !dw || !elems || !splits))) return set_error("ms_wgrad_reduce_multi: null argument");
+  ReduceBatch rb;
+  rb.n = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!partials[i] || !dw[i] || elems[i] <= 0 || splits[i] < 1) return set_error("ms_wgrad_reduce_multi: bad job %d", i);
+    ReduceJob jb = {partials[i], dw[i], elems[i], splits[i], 0, 0};
+    rb.job[rb.n++] = jb;
+    if (rb.n == REDUCE_BATCH_MAX) {
+      const int rc = launch_reduce_splits_multi(rb, (hipStream_t)stream);
+      if (rc) return rc;
+      rb.n = 0;
+    }
+  }
+  return rb.n ? launch_reduce_splits_multi(rb, (hipStream_t)stream) : 0;
+}
+
 size_t ms_dgrad_weights_elems(const ms_conv_desc* d, const float* w) {
   if (validate(d, "ms_dgrad_weights_elems")) return 0;
   const DgradWeights dw = dgrad_weights_of(d, w);
@@ -267,6 +300,7 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
   void* side_workspace = opt->side_workspace;
   const size_t side_workspace_bytes = opt->side_workspace_bytes;
   const float* wt_prepared = opt->wt_prepared;
+  const bool defer_wgrad = opt->wgrad_partials != nullptr;
   int rc = validate(d, "ms_conv_block_bwd");
   if (rc) return rc;
   if (d->mode == MS_BN_EVAL) return set_error("ms_conv_block_bwd: BN_EVAL blocks are never differentiated on the path");
@@ -295,8 +329,10 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
   float* dg_part = (float*)wsp;
   // weight gradient on the side stream (its own scratch): it only needs dy_raw and the saved input, so it runs
   // concurrently with this block's data gradient and the earlier blocks' backward on `stream`
+  if (defer_wgrad) wg_part = opt->wgrad_partials;   // pixel-split partial slabs stay there; the caller reduces them later
   hipStream_t ws_stream = s;
   if (side_stream && side_stream != stream && dw) {
+    if (defer_wgrad) return set_error("ms_conv_block_bwd_ex: wgrad_partials and side_stream are exclusive");
     if (!side_workspace || side_workspace_bytes < ms_conv_block_bwd_workspace(d))
       return set_error("ms_conv_block_bwd_overlap: side workspace too small");
     ws_stream = (hipStream_t)side_stream;
@@ -441,13 +477,13 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
       q.tiles_per_split = wp.tiles_per_split; q.splits = wp.splits;
       const double flops = 2.0 * d->Cout * q.Kg * (double)npix * d->groups;
       const double bytes = 4.0 * ((double)npix * C + (double)d->B * cin_tot * d->H * d->W + (double)C * q.Kg);
-      if (wp.splits > 1) {
+      if (wp.splits > 1 && !defer_wgrad) {
         q.counters = counter_region(CNT_WGRAD, cdiv(q.Kg, 64) * cdiv(d->Cout, 64) * d->groups);
         q.final_out = dw;
       }
       rc = launch_wgrad_patch(q, wp, d->KH, d->KW, d->SW, up2, flops, bytes, ws_stream);
       if (rc) return rc;
-      if (wp.splits > 1 && !q.counters) rc = launch_reduce_splits(wg_part, dw, C * q.Kg, wp.splits, ws_stream);
+      if (wp.splits > 1 && !q.counters && !defer_wgrad) rc = launch_reduce_splits(wg_part, dw, C * q.Kg, wp.splits, ws_stream);
     } else {
       WgradArgs a = {};
       a.dyr = g; a.src = x; a.src2 = x2;
@@ -456,7 +492,7 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
       a.H = d->H; a.W = d->W; a.OH = d->OH; a.OW = d->OW; a.Npix = npix;
       a.KH = d->KH; a.KW = d->KW; a.SH = d->SH; a.SW = d->SW; a.PH = d->PH; a.PW = d->PW;
       a.bcast = bcast;
-      rc = launch_wgrad(a, up2, dw, wg_part, ws_stream);
+      rc = launch_wgrad(a, up2, dw, wg_part, defer_wgrad, ws_stream);
     }
   }
   return rc;

@@ -434,6 +434,31 @@ __global__ void reduce_splits_kernel(const float* __restrict__ part, float* __re
   }
 }
 
+// many blocks' split reductions in ONE launch, ACCUMULATING into out (the caller zeroes out once per step); each job keeps
+// the summation order of the single-job kernel it replaces (wave: lanes stride over the splits), so results are the same
+__global__ __launch_bounds__(256) void reduce_splits_multi_kernel(const ReduceBatch rb) {
+  int j = 0;
+  while (j + 1 < rb.n && (int)blockIdx.x >= rb.job[j].block_end) ++j;
+  const ReduceJob jb = rb.job[j];
+  const int b = (int)blockIdx.x - (j ? rb.job[j - 1].block_end : 0);
+  const int nb = jb.block_end - (j ? rb.job[j - 1].block_end : 0);
+  if (jb.wave) {
+    const int lane = threadIdx.x & 63;
+    const int i = b * 4 + (threadIdx.x >> 6);
+    if (i >= jb.n) return;
+    float s = 0.f;
+    for (int k = lane; k < jb.splits; k += 64) s += jb.part[(size_t)k * jb.n + i];
+    s = wave_sum(s);
+    if (lane == 0) jb.out[i] += s;
+  } else {
+    for (int i = b * 256 + threadIdx.x; i < jb.n; i += nb * 256) {
+      float s = 0.f;
+      for (int k = 0; k < jb.splits; ++k) s += jb.part[(size_t)k * jb.n + i];
+      jb.out[i] += s;
+    }
+  }
+}
+
 // Data-gradient weights.  One slab per output-parity class (ry, rx) of a stride-(SH,SW) conv:
 //   wpar[cls][g][ci][co][jh][jw] = w[g][co][ci][kh0 + SH*jh][kw0 + SW*jw]   (0 beyond the kernel)
 // with kh0 = (ry+PH)%SH, kw0 = (rx+PW)%SW, JH = ceil(KH/SH), JW = ceil(KW/SW).  Stride 1 -> one slab, all taps.
@@ -787,7 +812,22 @@ int launch_reduce_splits(const float* part, float* out, int n, int splits, hipSt
   return check_launch("reduce_splits_kernel");
 }
 
-int launch_wgrad(WgradArgs a, bool up2, float* dw, float* partial_ws, hipStream_t s) {
+int launch_reduce_splits_multi(ReduceBatch& rb, hipStream_t s) {
+  int blocks = 0;
+  double bytes = 0;
+  for (int j = 0; j < rb.n; ++j) {
+    ReduceJob& jb = rb.job[j];
+    jb.wave = (jb.splits >= 32 && jb.n <= 65536) ? 1 : 0;          // as launch_reduce_splits
+    blocks += jb.wave ? cdiv(jb.n, 4) : std::max(1, std::min(cdiv(jb.n, 256), 512));
+    jb.block_end = blocks;
+    bytes += 4.0 * jb.n * (jb.splits + 2);
+  }
+  TimingScope ts(s, 0, bytes, "wgrad_reduce_multi jobs%d", rb.n);
+  hipLaunchKernelGGL(reduce_splits_multi_kernel, dim3(blocks), dim3(256), 0, s, rb);
+  return check_launch("reduce_splits_multi_kernel");
+}
+
+int launch_wgrad(WgradArgs a, bool up2, float* dw, float* partial_ws, bool defer_reduce, hipStream_t s) {
   const int ctot = a.groups * a.Cog;
   a.splits = wgrad_splits(a.Cog, a.Kg, a.groups, a.Npix);
   a.r_per_split = cdiv(cdiv(a.Npix, a.splits), 32) * 32;
@@ -806,7 +846,7 @@ int launch_wgrad(WgradArgs a, bool up2, float* dw, float* partial_ws, hipStream_
     rc = check_launch("wgrad_kernel");
   }
   if (rc) return rc;
-  if (a.splits > 1) rc = launch_reduce_splits(partial_ws, dw, ctot * a.Kg, a.splits, s);
+  if (a.splits > 1 && !defer_reduce) rc = launch_reduce_splits(partial_ws, dw, ctot * a.Kg, a.splits, s);
   return rc;
 }
 

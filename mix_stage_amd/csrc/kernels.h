@@ -113,7 +113,15 @@ int launch_splitk_fwd_epilogue(const float* part, int splitk, size_t part_stride
 int launch_splitk_dgrad_epilogue(const float* part, int splitk, size_t part_stride, float* dx, float* dx2, size_t n, int W,
                                  int up2, hipStream_t s);
 int wgrad_splits(int Cog, int Kg, int groups, int Npix);
-int launch_wgrad(WgradArgs a, bool up2, float* dw, float* partial_ws, hipStream_t s);
+int launch_wgrad(WgradArgs a, bool up2, float* dw, float* partial_ws, bool defer_reduce, hipStream_t s);
+struct ReduceJob {
+  const float* part;   // [splits][n]
+  float* out;          // [n], accumulated into
+  int n, splits, wave, block_end;
+};
+enum { REDUCE_BATCH_MAX = 96 };   // 96 x 32 B of kernel arguments
+struct ReduceBatch { int n; ReduceJob job[REDUCE_BATCH_MAX]; };
+int launch_reduce_splits_multi(ReduceBatch& rb, hipStream_t s);
 struct TransposeJob {
   const float* w;
   float* wt;

@@ -176,6 +176,60 @@ def refresh_prepared_weights(flat_params):
 
 
 # ------------------------------------------------------------------------------------------------
+# deferred weight-gradient reductions (ms_wgrad_reduce_multi): blocks that split dw's pixel reduction leave their partial
+# slabs in per-block buffers; ONE launch at the end of the backward pass adds them all into the gradient slots.  Only for
+# gradients written straight into the flat buffer (nobody downstream in autograd reads them).  Opt-in, like the above.
+_deferred = {'on': False, 'jobs': [], 'queued': False, 'bufs': {}}
+
+
+def enable_deferred_wgrad(on):
+  _deferred['on'] = bool(on)
+  _deferred['jobs'].clear()
+  _deferred['queued'] = False
+  if not on:
+    _deferred['bufs'].clear()
+
+
+def reset_deferred_wgrad():
+  """Drop jobs a failed backward pass may have left behind."""
+  _deferred['jobs'].clear()
+  _deferred['queued'] = False
+
+
+def _wgrad_partials_for(w, d):
+  """(buffer, splits) when this block's dw reduction can be deferred, else (None, 1)."""
+  info = getattr(d, '_wg_split', None)
+  tune = lib().ms_tuning_epoch()
+  if info is None or info[2] != tune:
+    sp = ctypes.c_int(1)
+    n = lib().ms_wgrad_partials_elems(ctypes.byref(d), ctypes.byref(sp))
+    info = d._wg_split = (n, sp.value, tune)
+  if not info[0]:
+    return None, 1
+  key = (w.data_ptr(), id(d))
+  buf = _deferred['bufs'].get(key)
+  if buf is None or buf[0].numel() != info[0]:
+    buf = _deferred['bufs'][key] = (torch.empty(info[0], dtype=torch.float32, device=w.device), d)   # d: keeps id(d) unique
+  return buf[0], info[1]
+
+
+def _flush_deferred_wgrad():
+  jobs = _deferred['jobs']
+  _deferred['queued'] = False
+  if not jobs:
+    return
+  n = len(jobs)
+  parts = (ctypes.c_void_p * n)(*[j[0].data_ptr() for j in jobs])
+  outs = (ctypes.c_void_p * n)(*[j[1].data_ptr() for j in jobs])
+  elems = (ctypes.c_int * n)(*[j[1].numel() for j in jobs])
+  splits = (ctypes.c_int * n)(*[j[2] for j in jobs])
+  try:
+    check(lib().ms_wgrad_reduce_multi(n, parts, outs, elems, splits, _stream()), 'ms_wgrad_reduce_multi')
+  finally:
+    jobs.clear()
+
+
+# ------------------------------------------------------------------------------------------------
 # conv block
 class ConvGeom:
   """Static geometry of one conv block (the part of ms_conv_desc that does not depend on the input)."""
@@ -307,12 +361,21 @@ class _ConvBlockFn(torch.autograd.Function):
             'ms_conv_block_bwd_overlap')
     else:
       wt = _prepared_for(w, d) if want_dx else None
-      if wt is not None:
-        opt = BwdOptions(None, None, 0, wt.data_ptr())
+      part, nsplit = (None, 1)
+      if _deferred['on'] and direct_w:
+        part, nsplit = _wgrad_partials_for(w, d)
+      if wt is not None or part is not None:
+        opt = BwdOptions(None, None, 0, wt.data_ptr() if wt is not None else None,
+                         part.data_ptr() if part is not None else None)
         check(lib().ms_conv_block_bwd_ex(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(gamma), None, None, _ptr(y_raw),
                                          _ptr(y), _ptr(save), _ptr(dy), _ptr(dyr), _ptr(dx), _ptr(dx2), _ptr(dw),
                                          _ptr(dbias), _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), _stream(),
                                          ctypes.byref(opt)), 'ms_conv_block_bwd_ex')
+        if part is not None:
+          _deferred['jobs'].append((part, dw, nsplit))
+          if not _deferred['queued']:
+            _deferred['queued'] = True
+            torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred_wgrad)
       else:
         check(lib().ms_conv_block_bwd(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(gamma), None, None, _ptr(y_raw),
                                       _ptr(y), _ptr(save), _ptr(dy), _ptr(dyr), _ptr(dx), _ptr(dx2), _ptr(dw),

@@ -181,6 +181,7 @@ class MixStageTrainStep:
     # concurrency buys), so it is off by default.
     self.side_stream = torch.cuda.Stream() if overlap_wgrad else None
     ops.enable_prepared_weights(True)
+    ops.enable_deferred_wgrad(True)
     self.optim_G = FlatAdam(model.G.parameters(), lr=lr, max_norm=clip)
     self.optim_D = FlatAdam(model.D.parameters(), lr=lr, max_norm=clip)
     self.use_graphs = use_graphs
@@ -205,6 +206,7 @@ class MixStageTrainStep:
     self.optim_D.zero_grad()
     fake, losses, _ = m([audio, labels], pose, **self._kwargs(style))
     dev_losses = [l for l in losses if l.is_cuda and l.requires_grad]
+    ops.reset_deferred_wgrad()
     ops.set_backward_overlap(self.side_stream)      # weight gradients on a side stream, joined below
     try:
       torch.autograd.backward(dev_losses, [torch.ones_like(l) for l in dev_losses])   # == sum(losses).backward()

@@ -175,8 +175,8 @@ def test_reference_coin_flip_sequence_and_rng_parity():
     assert len(set(kinds)) == 2          # the seed exercises both step kinds
 
 
-def test_prepared_dgrad_weights_follow_every_weight_change():
-  """The data-gradient weights are built once per optimizer update (ms_dgrad_weights_prepare) instead of per backward
+def test_prepared_dgrad_weights_and_deferred_wgrad_reductions_change_nothing():
+  """Deferred weight-gradient reductions (one ms_wgrad_reduce_multi launch at the end of backward) and: the data-gradient weights are built once per optimizer update (ms_dgrad_weights_prepare) instead of per backward
   call.  They must track (a) the HIP Adam updates inside captured steps and (b) edits torch makes behind the optimizer's
   back (load_state_dict), and the feature must not change a single bit of the parameters."""
   from mix_stage_amd import ops
@@ -190,6 +190,7 @@ def test_prepared_dgrad_weights_follow_every_weight_change():
     model = _hip(M, S)
     ts = MixStageTrainStep(model, use_graphs=use_graphs)
     ops.enable_prepared_weights(prepared)
+    ops.enable_deferred_wgrad(prepared)
     snap = None
     for i, ((audio, pose, labels, style), k) in enumerate(zip(batches, kinds)):
       if i == 3:      # perturb every parameter the way a checkpoint load does (in-place copy_ into the views)
@@ -197,13 +198,14 @@ def test_prepared_dgrad_weights_follow_every_weight_change():
         model.load_state_dict(sd)
       ts.step(audio.to(DEV), labels.to(DEV), pose.to(DEV), style.to(DEV), kind=k)
     torch.cuda.synchronize()
-    snap = (ts.optim_G.flat_p.clone(), ts.optim_D.flat_p.clone(), len(ops._prepared['entries']))
+    snap = (ts.optim_G.flat_p.clone(), ts.optim_D.flat_p.clone(), len(ops._prepared['entries']), len(ops._deferred['bufs']))
     ops.enable_prepared_weights(False)
+    ops.enable_deferred_wgrad(False)
     return snap
 
   base = run(False, False)
-  assert base[2] == 0
+  assert base[2] == 0 and base[3] == 0
   for use_graphs in (False, True):
     got = run(True, use_graphs)
-    assert got[2] > 0, 'no block used prepared weights'
+    assert got[2] > 0 and got[3] > 0, 'no block used prepared weights / deferred reductions'
     assert torch.equal(got[0], base[0]) and torch.equal(got[1], base[1]), 'prepared weights changed the result'
