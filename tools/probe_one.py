@@ -10,3 +10,5 @@ elif kind == 'mid':
   print(time_conv(32, 256, 256, 64, iters=20))
 elif kind == '3x3':
   print(time_conv(32, 128, 256, 32, k=3, s=1, p=1, nd=2, H=16, iters=20))
+elif kind == 'longk':
+  print(time_conv(256, 2048, 256, 64, iters=10))
