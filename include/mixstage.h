@@ -242,9 +242,9 @@ size_t ms_timing_report(char* buf, size_t cap);
 /* Test aid: the patch-staged conv kernel is used when a launch has at least this many workgroups (default 96);
  * tests set 0 to exercise it at small sizes.  Returns the previous value. */
 int ms_debug_set_patch_min_workgroups(int n);
-/* Tuning aid for the patch-staged conv kernel: 64x128 tiles when they still yield at least `wide_tile_min_workgroups`
- * workgroups (0 = never, the default: measured no net gain), and a forced split-K factor (0 = planner's choice). */
-int ms_debug_set_patch_tuning(int wide_tile_min_workgroups, int force_splitk);
+/* Tuning aid for the patch-staged conv kernel: intra_split < 0 switches the intra-workgroup K split of small 1-D k3
+ * layers off (0 = planner's choice), and a forced split-K factor over workgroups (0 = planner's choice). */
+int ms_debug_set_patch_tuning(int intra_split, int force_splitk);
 
 /* Self-test kernel: C(32x32) = A(32xK) * B(Kx32) through the fp32 MFMA path (checks fragment maps). */
 int ms_selftest_mfma(const float* A, const float* B, float* C, int K, void* stream);

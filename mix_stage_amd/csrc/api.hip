@@ -63,7 +63,7 @@ size_t ms_conv_block_fwd_workspace(const ms_conv_desc* d) {
   if (d->mode == MS_BN_TRAIN) bytes = std::max(bytes, (size_t)pl.n_tiles * ctot_of(d) * 2 * sizeof(float));
   if (pp.ok && d->mode == MS_BN_TRAIN)
     bytes = std::max(bytes, align_up((size_t)pp.n_tiles * ctot_of(d) * 2 * sizeof(float), 256) + (size_t)pp.n_tiles * sizeof(float));
-  if (pp.ok && pp.splitk > 1) bytes = std::max(bytes, (size_t)pp.splitk * npix * ctot_of(d) * sizeof(float));
+  if (pp.ok && (pp.splitk > 1 || pp.ksi > 1)) bytes = std::max(bytes, (size_t)pp.splitk * npix * ctot_of(d) * sizeof(float));
   if (pl.splitk > 1) bytes = std::max(bytes, (size_t)pl.splitk * npix * ctot_of(d) * sizeof(float));
   return align_up(bytes, 256) + 256;
 }
@@ -144,12 +144,15 @@ int ms_conv_block_fwd(const ms_conv_desc* d, const float* x, const float* x2, co
     q.o_sh = 1; q.o_sw = 1; q.o_ry = 0; q.o_rx = 0;
     q.splitk = pp.splitk; q.chunks_per_split = pp.chunks_per_split;
     q.src_elems = (size_t)d->B * cin_tot * d->H * d->W; q.a_elems = (size_t)C * a.Kg;
-    if (pp.splitk > 1) { q.part = (float*)workspace; q.part_stride = (size_t)npix * C; }
+    // BN_TRAIN with the intra-workgroup split: raw tile out, then the split-K epilogue (1 slice) does bias + batch
+    // statistics + normalisation in ONE launch instead of finalize + apply
+    const bool raw_out = pp.splitk > 1 || (pp.ksi > 1 && d->mode == MS_BN_TRAIN);
+    if (raw_out) { q.part = (float*)workspace; q.part_stride = (size_t)npix * C; }
     const double flops = 2.0 * d->Cout * a.Kg * (double)npix * d->groups;
     const double bytes = 4.0 * ((double)C * a.Kg + (double)d->B * cin_tot * d->H * d->W + (double)npix * C);
     rc = launch_patch(q, pp, d->KH, d->KW, d->SW, d->in_mode == MS_IN_UP2ADD, flops, bytes, s);
     if (rc) return rc;
-    if (pp.splitk > 1)
+    if (raw_out)
       return launch_splitk_fwd_epilogue(q.part, pp.splitk, q.part_stride, bias, gamma, beta, running_mean, running_var, y_raw,
                                         y, save, d->B, C, hw, a.ep, d->slope, d->eps, d->momentum, s);
     if (d->mode == MS_BN_TRAIN) {
@@ -393,6 +396,7 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
         const PatchPlan pp = plan_patch(one_d ? 1 : 2, d->Cin, tg, tcog, jh, jw, 1, 1, d->B, QH, QW);
         PatchPlan use = pp;
         use.splitk = pp0.splitk; use.chunks_per_split = pp0.chunks_per_split;   // one split factor for all classes
+        use.wm = pp0.wm; use.ksi = pp0.ksi;
         if (!pp.ok || pp.tm != pp0.tm || pp.tw != pp0.tw || pp.tn != pp0.tn) {               // a smaller class than the planning one: reuse the plan geometry, recompute tiles
           use = pp0;
           const int rows = one_d ? d->B : QH, th = 64 * use.tn / use.tw;

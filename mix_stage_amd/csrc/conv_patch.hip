@@ -36,28 +36,37 @@ constexpr int patch_row_pitch(int pc, int sv, int tw) {
 // AM: layout of the A operand.  0: [Mg][Kg] rows, scalar loads (Kg % 4 != 0); 1: the same, 16-B loads;
 // 2: data gradient straight from the conv weight w[co][ci][tap] (stride-1 convs): A(ci, (co,tap')) = w[co][ci][KHW-1-tap'],
 //    Mg = Cin_g, Kc = Cout_g; per output channel the 64 x KHW block of a channel tile is one contiguous run
-template <int KH, int KW, int S, int TW, bool UP2, int AM>
-__global__ __launch_bounds__(256, (KH * KW <= 3 && TW >= 32 ? 4 : 1)) void conv_patch_kernel(const PatchArgs p) {
+// WM: 32-row wave tiles along the channels (tile = 32*WM channels x 64 pixels).  KS: wave groups that split every K chunk
+// among themselves (intra-workgroup split-K: 2*WM*KS waves; the groups' accumulators are added through LDS in a fixed
+// order at the end) -- for layers with too few tiles to fill the chip: no partial tiles in HBM, no second kernel.
+template <int KH, int KW, int S, int TW, bool UP2, int AM, int WM = 2, int KS = 1>
+__global__ __launch_bounds__(128 * WM * KS, (KS == 1 && WM == 2 && KH * KW <= 3 && TW >= 32 ? 4 : 1))
+void conv_patch_kernel(const PatchArgs p) {
   using Cfg = PatchCfg<KH, KW>;
-  constexpr int BM = 64, BN = 64, TH = BN / TW;
+  constexpr int NT = 128 * WM * KS;                     // threads
+  constexpr int BM = 32 * WM, BN = 64, TH = BN / TW;
   constexpr int SV = (KH == 1) ? 1 : S;                 // KH == 1: rows are independent batch items
-  constexpr int CK = Cfg::CK, KHW = Cfg::KHW, KSTEP = Cfg::KSTEP;
+  // intra-split workgroups run alone on their CU: 4x longer chunks keep the MFMA share of a chunk above its fixed cost
+  constexpr int CK = Cfg::CK * (KS > 1 ? 4 : 1), KHW = Cfg::KHW, KSTEP = CK * KHW;
   constexpr int PR = (TH - 1) * SV + KH, PC = (TW - 1) * S + KW;
   constexpr int RP = patch_row_pitch(PC, SV, TW), CP = PR * RP;
   constexpr int LDA = BM + 1;   // odd pitch: the staging stores (4 k-rows apart per lane group) stay <= 2-way conflicted
   constexpr int STAGE = KSTEP * LDA + CK * CP + 3 * LDA + 4;   // + pad words: out-of-range staging stores land there
   constexpr int NPE = CK * PR * PC;                     // patch elements per chunk
-  constexpr int NP = (NPE + 255) / 256;
+  constexpr int NP = (NPE + NT - 1) / NT;
   constexpr int NAV = BM * (KSTEP / 4);                 // float4 slots of the weight slice
   constexpr int RUN4 = BM * KHW / 4;                    // AM 2: float4 slots per output channel
-  constexpr int NA = (NAV + 255) / 256;
+  constexpr int NA = (NAV + NT - 1) / NT;
   constexpr int LP = 68;                                // pitch of the epilogue's [channel][pixel] tile (4 mod 32)
   static_assert(KSTEP % 4 == 0 && BN % TW == 0, "bad patch configuration");
   static_assert(2 * STAGE >= BM * LP, "epilogue tile does not fit the staging buffers");
+  static_assert(CK % KS == 0 && (KSTEP / KS) % 2 == 0, "the wave groups split a chunk by whole channels");
+  static_assert(KS == 1 || 2 * STAGE >= (KS / 2) * 2 * WM * 1024, "accumulator exchange does not fit the staging buffers");
   __shared__ float smem[2 * STAGE];
 
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
-  const int wm = wid >> 1, wn = wid & 1, khalf = lane >> 5;
+  const int kg = wid / (2 * WM), wv = wid - kg * (2 * WM);   // wave group (K split), wave inside the group
+  const int wm = wv >> 1, wn = wv & 1, khalf = lane >> 5;
   // logical block id: channel tile fastest, then pixel tile, then (group, K slice); one contiguous range per XCD, so the
   // channel tiles that share an input patch sit behind the same L2
   const int vid = xcd_remap(blockIdx.x, p.gx * p.gy * p.gz);
@@ -77,7 +86,7 @@ __global__ __launch_bounds__(256, (KH * KW <= 3 && TW >= 32 ? 4 : 1)) void conv_
   int loff[NP];
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
-    const int e = t + i * 256;
+    const int e = t + i * NT;
     const int ci = e / (PR * PC), rem = e - ci * (PR * PC), r = rem / PC, c = rem - r * PC;
     const int iy = iy0 + r, ix = ix0 + c;
     const bool ok = (e < NPE) & ((unsigned)iy < (unsigned)p.SRCH) & ((unsigned)ix < (unsigned)p.SRCW);
@@ -91,7 +100,7 @@ __global__ __launch_bounds__(256, (KH * KW <= 3 && TW >= 32 ? 4 : 1)) void conv_
   int lsto[AM == 2 ? NA : 1][4];                        // AM 2: LDS slots of the 4 elements of a float4
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    const int idx = t + i * 256;
+    const int idx = t + i * NT;
     if (AM == 2) {
       const int co = idx / RUN4, q4 = idx - co * RUN4;
       aoff[i] = idx < NAV ? 4u * (unsigned)((co * p.Mg + m0) * KHW + 4 * q4) : BUF_OOB;
@@ -121,11 +130,11 @@ __global__ __launch_bounds__(256, (KH * KW <= 3 && TW >= 32 ? 4 : 1)) void conv_
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       if (AM == 2) {
-        const int co = (t + i * 256) / RUN4;
+        const int co = (t + i * NT) / RUN4;
         ra[i] = buf_load4(rsA, (full_k | (ci0 + co < p.Kc)) ? aoff[i] : BUF_OOB, sa);
         continue;
       }
-      const int kq = (t + i * 256) % (KSTEP / 4);
+      const int kq = (t + i * NT) % (KSTEP / 4);
       const int k = k0 + kq * 4;
       if (AM == 1) {
         ra[i] = buf_load4(rsA, (full_k | (k < Kg)) ? aoff[i] : BUF_OOB, sa);
@@ -142,7 +151,7 @@ __global__ __launch_bounds__(256, (KH * KW <= 3 && TW >= 32 ? 4 : 1)) void conv_
     const bool full_c = ci0 + CK <= p.Kc;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      const int ci = (t + i * 256) / (PR * PC);
+      const int ci = (t + i * NT) / (PR * PC);
       const bool ok = full_c | (ci0 + ci < p.Kc);
       if (UP2) rb[i] = buf_load(rsS, ok ? goff_h[i] : BUF_OOB, 4u * (unsigned)(cb >> 1)) +
                        buf_load(rsS2, ok ? goff[i] : BUF_OOB, 4u * (unsigned)cb);
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(256, (KH * KW <= 3 && TW >= 32 ? 4 : 1)) void conv_
         As[lsto[i][3]] = ra[i].w;
         continue;
       }
-      const int idx = t + i * 256;
+      const int idx = t + i * NT;
       const int row = idx / (KSTEP / 4), kq = idx - row * (KSTEP / 4);
       const int base = idx < NAV ? kq * 4 * LDA + row : KSTEP * LDA + CK * CP;   // out of range: the pad words
       As[base + 0 * LDA] = ra[i].x;
@@ -178,12 +187,13 @@ __global__ __launch_bounds__(256, (KH * KW <= 3 && TW >= 32 ? 4 : 1)) void conv_
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
   // ---- per-lane operand bases: k and k+1 of an MFMA pair sit in lanes 0-31 / 32-63
-  const int a_base = khalf * LDA + wm * 32 + (lane & 31);
+  // (wave group kg owns channels [kg*CK/KS, (kg+1)*CK/KS) of every chunk: a constant shift of both operand bases)
+  const int a_base = khalf * LDA + wm * 32 + (lane & 31) + kg * (KSTEP / KS) * LDA;
   int b_same, b_row, b_chan;
   {
     const int nloc = wn * 32 + (lane & 31);
     const int ty = nloc / TW, tx = nloc - ty * TW;
-    const int base = ty * SV * RP + tx * S;
+    const int base = ty * SV * RP + tx * S + kg * (CK / KS) * CP;
     b_same = base + khalf;                                         // k+1 = next tap in the same row
     b_row = base + khalf * (RP - (KW - 1));                        // k+1 = first tap of the next kernel row
     b_chan = base + khalf * (CP - (KH - 1) * RP - (KW - 1));       // k+1 = first tap of the next channel
@@ -195,7 +205,7 @@ __global__ __launch_bounds__(256, (KH * KW <= 3 && TW >= 32 ? 4 : 1)) void conv_
     const float* As = smem + cur * STAGE;
     const float* Ps = As + KSTEP * LDA;
     // operands of the next group of k-pairs are read from LDS while the current group's MFMAs issue
-    constexpr int NPAIR = KSTEP / 2, GP = 4, NG = (NPAIR + GP - 1) / GP;
+    constexpr int NPAIR = KSTEP / 2 / KS, GP = 4, NG = (NPAIR + GP - 1) / GP;   // k-pairs of this wave group
     float av[2][GP], bv[2][GP];
     auto read_group = [&](int gi, int slot) {
 #pragma unroll
@@ -238,14 +248,33 @@ __global__ __launch_bounds__(256, (KH * KW <= 3 && TW >= 32 ? 4 : 1)) void conv_
     __syncthreads();
   }
 
+  // ---------------- wave groups: add the accumulators (tree, fixed order), group 0 keeps the result ----------------
+  if (KS > 1) {
+    float* xch = smem;                                  // [slot][wave][r][lane]
+#pragma unroll
+    for (int step = KS / 2; step >= 1; step >>= 1) {
+      if (kg >= step && kg < 2 * step) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[(((kg - step) * 2 * WM + wv) * 16 + r) * 64 + lane] = acc[r];
+      }
+      __syncthreads();
+      if (kg < step) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += xch[((kg * 2 * WM + wv) * 16 + r) * 64 + lane];
+      }
+      __syncthreads();
+    }
+  }
+  const bool lead = kg == 0;                            // the other groups only keep the barriers company from here on
+
   // ---------------- epilogue ----------------
   const int ctot = p.groups * p.Mg;
   const int nloc = wn * 32 + (lane & 31);
   const int oy = oy0 + nloc / TW, ox = ox0 + nloc % TW;
-  const bool cval = (oy < p.OUTH) & (ox < p.OUTW);
+  const bool cval = lead & (oy < p.OUTH) & (ox < p.OUTW);
   const int ooff = img * p.o_img + (oy * p.o_sh + p.o_ry) * p.o_row + ox * p.o_sw + p.o_rx;   // + channel * o_chan
   const int ep = p.ep;
-  if (p.splitk > 1) {                 // raw partial tile in the output layout; a split-K epilogue kernel finishes
+  if (p.part) {                       // raw partial tile in the output layout; a split-K epilogue kernel finishes
     float* part = p.part + (size_t)ks * p.part_stride;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -290,9 +319,10 @@ __global__ __launch_bounds__(256, (KH * KW <= 3 && TW >= 32 ? 4 : 1)) void conv_
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ml = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-      tile[ml * LP + nloc] = cval ? acc[r] : 0.f;
+      if (lead) tile[ml * LP + nloc] = cval ? acc[r] : 0.f;
     }
     __syncthreads();
+    if (!lead) return;                                  // t < 4*BM from here: 4 threads per channel
     const int ch = t >> 2, q = t & 3;
     float v[16];
     float s = 0.f;
@@ -328,13 +358,14 @@ __global__ __launch_bounds__(256, (KH * KW <= 3 && TW >= 32 ? 4 : 1)) void conv_
 // dispatch
 int g_patch_min_wgs = 96;      // below this many workgroups the split-K im2col path is used instead
 int g_patch_force_splitk = 0;   // tuning knob: > 0 forces this split-K factor in the patch kernel
+int g_patch_intra = 1;          // tuning knob: intra-workgroup K split for small 1-D k3 layers
 int patch_chunk_channels(int KH, int KW) {
   const int khw = KH * KW;
   return khw == 1 ? 32 : khw == 2 ? 16 : khw == 3 ? 16 : khw == 4 ? 16 : khw == 9 ? 4 : khw == 16 ? 4 : khw == 24 ? 2 : 4;
 }
 
 PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH, int SW, int B, int OH, int OW) {
-  PatchPlan pl = {0, 1, 64, 0, 0, 0, 1, 1 << 30, 1};
+  PatchPlan pl = {0, 1, 64, 0, 0, 0, 1, 1 << 30, 1, 2, 1};
   const int S = SW;
   if (nd == 2 && SH != SW) return pl;
   const bool known = (KH == 1 && KW == 2 && S == 1) || (KH == 2 && KW == 2 && S == 1) || (KH == 1 && KW == 3 && S == 1) ||
@@ -361,11 +392,21 @@ PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH,
     pl.chunks_per_split = cdiv(nchunks, g_patch_force_splitk);
     pl.splitk = cdiv(nchunks, pl.chunks_per_split);
   } else if (pl.ok && base < 384 && nchunks >= 4) {
-    int sk = (int)std::min<long>(nchunks / 2, (384 + base - 1) / base);
-    if (sk > 4) sk = 4;
-    if (sk > 1) {
-      pl.chunks_per_split = cdiv(nchunks, sk);
-      pl.splitk = cdiv(nchunks, pl.chunks_per_split);
+    const long base32 = (long)pl.n_tiles * cdiv(Mg, 32) * groups;
+    if (g_patch_intra && KH == 1 && KW == 3 && S == 1 && tw >= 32 && base32 >= 192) {
+      // 1-D k3 layers with few tiles: 32-channel tiles, every K chunk split over 4 wave groups INSIDE the workgroup
+      // (no partial tiles in HBM, no reduction kernel)
+      pl.wm = 1; pl.ksi = 4;
+    } else {
+      // one workgroup per CU (256) measured better than 1.5 for the 128-tile mid layers (both kernels of the pair: conv
+      // 19.3 vs 19.8 us, epilogue 11.3 vs 13.3 us); from 256 tiles up, two slices (512 workgroups) stay
+      const long target = base <= 128 ? 256 : 384;
+      int sk = (int)std::min<long>(nchunks / 2, (target + base - 1) / base);
+      if (sk > 4) sk = 4;
+      if (sk > 1) {
+        pl.chunks_per_split = cdiv(nchunks, sk);
+        pl.splitk = cdiv(nchunks, pl.chunks_per_split);
+      }
     }
   }
   return pl;
@@ -407,6 +448,18 @@ static void launch_patch_k(const PatchArgs& a, int kh, int kw, int s_, int tw, b
   }
 }
 
+template <int AM>
+static void launch_patch_intra(const PatchArgs& a, int tw, bool up2, dim3 grid, hipStream_t s) {
+#define MS_PI(TW, UP2) hipLaunchKernelGGL((conv_patch_kernel<1, 3, 1, TW, UP2, AM, 1, 4>), grid, dim3(512), 0, s, a)
+  if constexpr (AM == 2) {
+    if (tw == 64) MS_PI(64, false); else MS_PI(32, false);
+  } else {
+    if (up2) { if (tw == 64) MS_PI(64, true); else MS_PI(32, true); }
+    else { if (tw == 64) MS_PI(64, false); else MS_PI(32, false); }
+  }
+#undef MS_PI
+}
+
 // the data gradient can read the conv weight in place (AM 2) when whole 64-channel tiles of contiguous runs exist
 bool patch_dgrad_direct_ok(const float* w, int Cin_g, int KH, int KW, int SH, int SW, bool up2_or_bcast) {
   const bool shape = (KH == 1 && KW == 3) || (KH == 1 && KW == 1) || (KH == 3 && KW == 3) || (KH == 3 && KW == 8);
@@ -415,7 +468,7 @@ bool patch_dgrad_direct_ok(const float* w, int Cin_g, int KH, int KW, int SH, in
 
 int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S, bool up2, double flops, double bytes,
                  hipStream_t s) {
-  const int bm = 64 * pl.tm;
+  const int bm = 32 * pl.wm;
   PatchArgs b = a;
   b.gx = pl.n_tiles; b.gy = cdiv(a.Mg, bm); b.gz = a.groups * a.splitk;
   if ((double)b.gx * b.gy * b.gz > 2.0e9) return set_error("conv grid too large");
@@ -423,11 +476,18 @@ int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S,
   if (a.splitk < 1 || (a.splitk > 1 && !a.part)) return set_error("patch conv: bad split-K setup");
   if (a.src_elems >= (1u << 29) || a.a_elems >= (1u << 29)) return set_error("patch conv: operand of 2 GiB or more");
   const int am = a.a_vec == 2 ? 2 : (a.a_vec && ((uintptr_t)a.A & 15) == 0) ? 1 : 0;
+  if (am == 2 && a.Mg % bm) return set_error("patch conv: in-place weights need whole channel tiles");
   if (am == 2 && (S != 1 || up2)) return set_error("patch conv: in-place weights need a stride-1 data gradient");
-  TimingScope ts(s, flops, bytes, "conv_patch_kernel<%d,%d,%d,%d,%d,%d>|conv_%s_patch k%dx%d s%d Mg%d Kg%d g%d tiles%d tile%d tw%d splitk%d%s",
-                 KH, KW, S, pl.tw, up2 ? 1 : 0, am, a.is_dgrad ? "dgrad" : "fwd", KH, KW, S, a.Mg, a.Kg,
-                 a.groups, pl.n_tiles, bm, pl.tw, a.splitk, a.ep == EP_RAW_STATS ? " +bnstats" : "");
-  if (am == 2) launch_patch_k<2>(b, KH, KW, S, pl.tw, up2, grid, s);
+  TimingScope ts(s, flops, bytes, "conv_patch_kernel<%d,%d,%d,%d,%d,%d,%d,%d>|conv_%s_patch k%dx%d s%d Mg%d Kg%d g%d tiles%d tile%d tw%d splitk%d%s%s",
+                 KH, KW, S, pl.tw, up2 ? 1 : 0, am, pl.wm, pl.ksi, a.is_dgrad ? "dgrad" : "fwd", KH, KW, S, a.Mg, a.Kg,
+                 a.groups, pl.n_tiles, bm, pl.tw, a.splitk, pl.ksi > 1 ? " intra4" : "",
+                 (a.ep == EP_RAW_STATS && !a.part) ? " +bnstats" : "");
+  if (pl.ksi > 1) {
+    if (pl.wm != 1 || pl.ksi != 4 || KH != 1 || KW != 3 || S != 1 || pl.tw < 32) return set_error("patch conv: no such intra-split kernel");
+    if (am == 2) launch_patch_intra<2>(b, pl.tw, up2, grid, s);
+    else if (am == 1) launch_patch_intra<1>(b, pl.tw, up2, grid, s);
+    else launch_patch_intra<0>(b, pl.tw, up2, grid, s);
+  } else if (am == 2) launch_patch_k<2>(b, KH, KW, S, pl.tw, up2, grid, s);
   else if (am == 1) launch_patch_k<1>(b, KH, KW, S, pl.tw, up2, grid, s);
   else launch_patch_k<0>(b, KH, KW, S, pl.tw, up2, grid, s);
   return check_launch("conv_patch_kernel");
@@ -438,9 +498,9 @@ int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S,
 static int g_tuning_epoch = 0;
 extern "C" int ms_tuning_epoch(void) { return g_tuning_epoch; }
 
-extern "C" int ms_debug_set_patch_tuning(int wide_tile_min_workgroups, int force_splitk) {
+extern "C" int ms_debug_set_patch_tuning(int intra_split, int force_splitk) {
   ++g_tuning_epoch;
-  (void)wide_tile_min_workgroups;   // 64x128 / 128x128 tiles were measured, gave nothing and are retired
+  ms::g_patch_intra = intra_split < 0 ? 0 : 1;
   ms::g_patch_force_splitk = force_splitk > 0 ? force_splitk : 0;
   return 0;
 }

@@ -73,13 +73,14 @@ struct PatchArgs {
   float slope, eps;
   size_t src_elems, a_elems;    // extents of src (UP2: of src2) and A, for the 32-bit buffer offsets
 };
-struct PatchPlan { int ok, tm, tw, tiles_y, tiles_x, n_tiles, splitk, chunks_per_split, tn; };
+struct PatchPlan { int ok, tm, tw, tiles_y, tiles_x, n_tiles, splitk, chunks_per_split, tn, wm, ksi; };   // wm: 32-row wave tiles per tile; ksi: intra-workgroup K split
 PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH, int SW, int B, int OH, int OW);
 int patch_chunk_channels(int KH, int KW);
 bool patch_dgrad_direct_ok(const float* w, int Cin_g, int KH, int KW, int SH, int SW, bool up2_or_bcast);
 int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S, bool up2, double flops, double bytes,
                  hipStream_t s);
 
+extern int g_patch_intra;
 extern int g_patch_min_wgs;   // test knob (ms_debug_set_patch_min_workgroups): 0 forces the patch kernels
 
 // ---- patch-staged weight gradient (wgrad_patch.hip)
