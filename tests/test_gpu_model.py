@@ -104,7 +104,7 @@ def _compare_step(M, S, B, kind, F_, seed, strict):
     diff = p.grad.cpu().double() - q.grad
     err = diff.abs().max().item()
     if n.endswith('conv.bias'):      # conv bias in front of BN: the true gradient is 0, both sides hold rounding noise
-      if err > 1e-5:
+      if err > 5e-5:   # fp32 rounding noise of a sum that is exactly 0 in real arithmetic (other gradients: 1e-3..1)
         bad.append((n, err, scale))
       continue
     if not flips:
