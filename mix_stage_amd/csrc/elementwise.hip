@@ -266,7 +266,12 @@ __global__ void lerp_time_bwd_kernel(const float* __restrict__ dy, float* __rest
   if (f == f1) wf += lf;
   float acc = 0.f;
   if (wf != 0.f) {
-    for (int d = 0; d < Tout; ++d) {
+    // outputs whose two source rows can include t: source coordinate (d + 0.5) * Tin/Tout - 0.5 in (t - 1, t + 1);
+    // one extra output on either side covers rounding and the clamped borders (the exact test stays inside)
+    const float r = (float)Tout / (float)Tin;
+    const int d_lo = t == 0 ? 0 : max(0, (int)floorf(((float)t - 0.5f) * r - 0.5f) - 1);
+    const int d_hi = t == Tin - 1 ? Tout - 1 : min(Tout - 1, (int)ceilf(((float)t + 1.5f) * r - 0.5f) + 1);
+    for (int d = d_lo; d <= d_hi; ++d) {
       int t0, t1;
       float lt;
       lerp_coords(d, Tin, Tout, t0, t1, lt);
@@ -285,11 +290,13 @@ __global__ void lerp_time_bwd_kernel(const float* __restrict__ dy, float* __rest
 #define MIX_TT 64
 __global__ __launch_bounds__(256) void softmax_mix_fwd_kernel(const float* __restrict__ z, const float* __restrict__ score,
                                                               float* __restrict__ soft, float* __restrict__ out, int M,
-                                                              int P, int T) {
-  extern __shared__ float sm[];  // wsm[M][64] | tile[64][P+1]
+                                                              int P, int T, int FC) {
+  // blockIdx.z: chunk of FC pose features (so the launch fills the chip); every chunk recomputes the softmax weights
+  extern __shared__ float sm[];  // wsm[M][64] | tile[64][FC+1]
   float* wsm = sm;
   float* tile = sm + (size_t)M * MIX_TT;
   const int b = blockIdx.y, t0 = blockIdx.x * MIX_TT, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int f_beg = blockIdx.z * FC, nf = min(FC, P - f_beg);
   const int tt = t0 + lane;
   const bool tv = tt < T;
   if (w == 0) {
@@ -305,31 +312,33 @@ __global__ __launch_bounds__(256) void softmax_mix_fwd_kernel(const float* __res
     for (int m = 0; m < M; ++m) {
       const float v = wsm[m * MIX_TT + lane] * inv;
       wsm[m * MIX_TT + lane] = v;
-      if (tv) soft[((size_t)b * T + tt) * M + m] = v;
+      if (tv && blockIdx.z == 0) soft[((size_t)b * T + tt) * M + m] = v;
     }
   }
   __syncthreads();
-  for (int f = w; f < P; f += 4) {
+  for (int fl = w; fl < nf; fl += 4) {
     float acc = 0.f;
     for (int m = 0; m < M; ++m)
-      acc += wsm[m * MIX_TT + lane] * (tv ? z[((size_t)b * M * P + (size_t)m * P + f) * T + tt] : 0.f);
-    tile[lane * (P + 1) + f] = acc;
+      acc += wsm[m * MIX_TT + lane] * (tv ? z[((size_t)b * M * P + (size_t)m * P + f_beg + fl) * T + tt] : 0.f);
+    tile[lane * (FC + 1) + fl] = acc;
   }
   __syncthreads();
   const int nt = min(MIX_TT, T - t0);
-  for (int e = t; e < nt * P; e += 256) {
-    const int r = e / P, f = e - r * P;
-    out[((size_t)b * T + t0 + r) * P + f] = tile[r * (P + 1) + f];
+  for (int e = t; e < nt * nf; e += 256) {
+    const int r = e / nf, fl = e - r * nf;
+    out[((size_t)b * T + t0 + r) * P + f_beg + fl] = tile[r * (FC + 1) + fl];
   }
 }
 
+// backward, stage 1: one workgroup per (time tile, b, sub-generator m); the 4 waves split the pose features.
+//   dz[b,m,f,t] = soft[b,t,m] * dout[b,t,f];   dscore[b,m,t] <- ds[m] = sum_f dout[b,t,f] * z[b,m,f,t]  (raw, stage 2 finishes)
 __global__ __launch_bounds__(256) void softmax_mix_bwd_kernel(const float* __restrict__ z, const float* __restrict__ soft,
                                                               const float* __restrict__ dout, float* __restrict__ dz,
                                                               float* __restrict__ dscore, int M, int P, int T) {
-  extern __shared__ float sm[];  // dso[M][64] | tile[64][P+1]
+  extern __shared__ float sm[];  // dso[4][64] | tile[64][P+1]
   float* dso = sm;
-  float* tile = sm + (size_t)M * MIX_TT;
-  const int b = blockIdx.y, t0 = blockIdx.x * MIX_TT, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  float* tile = sm + 4 * MIX_TT;
+  const int b = blockIdx.y, m = blockIdx.z, t0 = blockIdx.x * MIX_TT, t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int tt = t0 + lane;
   const bool tv = tt < T;
   const int nt = min(MIX_TT, T - t0);
@@ -338,25 +347,32 @@ __global__ __launch_bounds__(256) void softmax_mix_bwd_kernel(const float* __res
     tile[r * (P + 1) + f] = dout[((size_t)b * T + t0 + r) * P + f];
   }
   __syncthreads();
-  for (int m = w; m < M; m += 4) {
-    const float sw = tv ? soft[((size_t)b * T + tt) * M + m] : 0.f;
-    float ds = 0.f;
-    for (int f = 0; f < P; ++f) {
+  const float sw = tv ? soft[((size_t)b * T + tt) * M + m] : 0.f;
+  const int fq = (P + 3) / 4, f0 = w * fq, f1 = min(P, f0 + fq);
+  float ds = 0.f;
+  if (tv)
+    for (int f = f0; f < f1; ++f) {
       const size_t off = ((size_t)b * M * P + (size_t)m * P + f) * T + tt;
-      const float g = tv ? tile[lane * (P + 1) + f] : 0.f;
-      if (tv) {
-        ds += g * z[off];
-        dz[off] = sw * g;
-      }
+      const float g = tile[lane * (P + 1) + f];
+      ds += g * z[off];
+      dz[off] = sw * g;
     }
-    dso[m * MIX_TT + lane] = ds;
-  }
+  dso[w * MIX_TT + lane] = ds;
   __syncthreads();
-  if (w == 0 && tv) {
-    float dot = 0.f;
-    for (int m = 0; m < M; ++m) dot += soft[((size_t)b * T + tt) * M + m] * dso[m * MIX_TT + lane];
-    for (int m = 0; m < M; ++m)
-      dscore[((size_t)b * M + m) * T + tt] = soft[((size_t)b * T + tt) * M + m] * (dso[m * MIX_TT + lane] - dot);
+  if (w == 0 && tv)
+    dscore[((size_t)b * M + m) * T + tt] = (dso[lane] + dso[MIX_TT + lane]) + (dso[2 * MIX_TT + lane] + dso[3 * MIX_TT + lane]);
+}
+
+// stage 2, in place: dscore[b,m,t] = soft[m] * (ds[m] - sum_m' soft[m'] ds[m'])
+__global__ void softmax_mix_bwd_finish_kernel(const float* __restrict__ soft, float* __restrict__ dscore, int B, int M, int T) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * T) return;
+  const int b = i / T, tt = i - b * T;
+  float dot = 0.f;
+  for (int m = 0; m < M; ++m) dot += soft[((size_t)b * T + tt) * M + m] * dscore[((size_t)b * M + m) * T + tt];
+  for (int m = 0; m < M; ++m) {
+    const size_t o = ((size_t)b * M + m) * T + tt;
+    dscore[o] = soft[((size_t)b * T + tt) * M + m] * (dscore[o] - dot);
   }
 }
 
@@ -503,13 +519,13 @@ __global__ __launch_bounds__(256) void concat_style_bwd_emb_kernel(const float* 
 
 // ----------------------------------------------------------------------------------------------
 // cross entropy (mean over rows); single workgroup, fixed order
-__global__ __launch_bounds__(256) void cross_entropy_fwd_kernel(const float* __restrict__ score, const int64_t* __restrict__ target,
-                                                                float* __restrict__ loss, int n_outer, int n_inner, int C,
-                                                                int so, int sc, int si) {
-  __shared__ float red[4];
+__global__ __launch_bounds__(1024) void cross_entropy_fwd_kernel(const float* __restrict__ score, const int64_t* __restrict__ target,
+                                                                 float* __restrict__ loss, int n_outer, int n_inner, int C,
+                                                                 int so, int sc, int si) {
+  __shared__ float red[16];
   const int rows = n_outer * n_inner;
   float acc = 0.f;
-  for (int r = threadIdx.x; r < rows; r += 256) {
+  for (int r = threadIdx.x; r < rows; r += 1024) {
     const int o = r / n_inner, i = r - o * n_inner;
     const float* sp = score + (size_t)o * so + (size_t)i * si;
     float mx = -INFINITY;
@@ -518,8 +534,14 @@ __global__ __launch_bounds__(256) void cross_entropy_fwd_kernel(const float* __r
     for (int c = 0; c < C; ++c) den += expf(sp[(size_t)c * sc] - mx);
     acc += (logf(den) + mx) - sp[(size_t)target[r] * sc];
   }
-  acc = block_sum_256(acc, red);
-  if (threadIdx.x == 0) loss[0] = acc / (float)rows;
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int w = 0; w < 16; ++w) s += red[w];          // fixed order
+    loss[0] = s / (float)rows;
+  }
 }
 
 __global__ void cross_entropy_bwd_kernel(const float* __restrict__ score, const int64_t* __restrict__ target,
@@ -818,20 +840,29 @@ int ms_lerp_time_bwd(const float* dy, float* dx, int B, int C, int Tin, int F, i
 }
 
 int ms_softmax_mix_fwd(const float* z, const float* score, float* soft, float* out, int B, int M, int P, int T, void* stream) {
-  const size_t lds = ((size_t)M * MIX_TT + (size_t)MIX_TT * (P + 1)) * sizeof(float);
+  // feature chunks: enough workgroups for the chip (B=32, T=64 alone gives 32)
+  const int tiles = cdiv(T, MIX_TT) * B;
+  int nch = std::max(1, std::min(P, 512 / std::max(1, tiles)));
+  const int fc = cdiv(P, nch);
+  nch = cdiv(P, fc);
+  const size_t lds = ((size_t)M * MIX_TT + (size_t)MIX_TT * (fc + 1)) * sizeof(float);
   if (lds > 160 * 1024) return set_error("ms_softmax_mix_fwd: M=%d P=%d needs %zu B of LDS", M, P, lds);
-  hipLaunchKernelGGL(softmax_mix_fwd_kernel, dim3(cdiv(T, MIX_TT), B), dim3(256), lds, (hipStream_t)stream, z, score, soft, out,
-                     M, P, T);
+  hipLaunchKernelGGL(softmax_mix_fwd_kernel, dim3(cdiv(T, MIX_TT), B, nch), dim3(256), lds, (hipStream_t)stream, z, score, soft,
+                     out, M, P, T, fc);
   return check_launch("softmax_mix_fwd_kernel");
 }
 
 int ms_softmax_mix_bwd(const float* z, const float* soft, const float* dout, float* dz, float* dscore, int B, int M, int P,
                        int T, void* stream) {
-  const size_t lds = ((size_t)M * MIX_TT + (size_t)MIX_TT * (P + 1)) * sizeof(float);
+  const size_t lds = ((size_t)4 * MIX_TT + (size_t)MIX_TT * (P + 1)) * sizeof(float);
   if (lds > 160 * 1024) return set_error("ms_softmax_mix_bwd: M=%d P=%d needs %zu B of LDS", M, P, lds);
-  hipLaunchKernelGGL(softmax_mix_bwd_kernel, dim3(cdiv(T, MIX_TT), B), dim3(256), lds, (hipStream_t)stream, z, soft, dout, dz,
+  if (M > 65535) return set_error("ms_softmax_mix_bwd: M=%d", M);
+  hipLaunchKernelGGL(softmax_mix_bwd_kernel, dim3(cdiv(T, MIX_TT), B, M), dim3(256), lds, (hipStream_t)stream, z, soft, dout, dz,
                      dscore, M, P, T);
-  return check_launch("softmax_mix_bwd_kernel");
+  int rc = check_launch("softmax_mix_bwd_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(softmax_mix_bwd_finish_kernel, dim3(cdiv(B * T, 256)), dim3(256), 0, (hipStream_t)stream, soft, dscore, B, M, T);
+  return check_launch("softmax_mix_bwd_finish_kernel");
 }
 
 int ms_kmeans_labels(const float* pose, const int32_t* keep, const double* centers, int64_t* labels, int B, int T, int P,
@@ -888,7 +919,7 @@ int ms_concat_style_bwd(const float* dout, const int64_t* ids, int ids_stride_b,
 int ms_cross_entropy_fwd(const float* score, const int64_t* target, float* loss, float* row_scratch, int n_outer, int n_inner,
                          int C, int stride_outer, int stride_c, int stride_inner, void* stream) {
   (void)row_scratch;
-  hipLaunchKernelGGL(cross_entropy_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, score, target, loss, n_outer, n_inner,
+  hipLaunchKernelGGL(cross_entropy_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, score, target, loss, n_outer, n_inner,
                      C, stride_outer, stride_c, stride_inner);
   return check_launch("cross_entropy_fwd_kernel");
 }
