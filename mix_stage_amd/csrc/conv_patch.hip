@@ -393,7 +393,9 @@ PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH,
     pl.splitk = cdiv(nchunks, pl.chunks_per_split);
   } else if (pl.ok && base < 384 && nchunks >= 4) {
     const long base32 = (long)pl.n_tiles * cdiv(Mg, 32) * groups;
-    if (g_patch_intra && KH == 1 && KW == 3 && S == 1 && tw >= 32 && base32 >= 192) {
+    // (short reductions only: with a long K -- the 2048-channel data gradient of the first decoder layer -- slices over
+    // workgroups keep more of the chip busy: 91 vs 152 us)
+    if (g_patch_intra && KH == 1 && KW == 3 && S == 1 && tw >= 32 && base32 >= 192 && nchunks <= 16) {
       // 1-D k3 layers with few tiles: 32-channel tiles, every K chunk split over 4 wave groups INSIDE the workgroup
       // (no partial tiles in HBM, no reduction kernel)
       pl.wm = 1; pl.ksi = 4;
