@@ -84,7 +84,7 @@ size_t ms_conv_block_bwd_workspace(const ms_conv_desc* d) {
     const int tg2 = bc ? 1 : d->groups, tcog2 = bc ? d->groups * d->Cout : d->Cout;
     const bool one_d2 = d->H == 1 && d->KH == 1;
     const PatchPlan pq = plan_patch(one_d2 ? 1 : 2, d->Cin, tg2, tcog2, cdiv(d->KH, d->SH), cdiv(d->KW, d->SW), 1, 1, d->B,
-                                    cdiv(d->H, d->SH), cdiv(d->W, d->SW));
+                                    cdiv(d->H, d->SH), cdiv(d->W, d->SW), d->SH * d->SW);
     if (pq.ok && pq.splitk > 1) bytes += align_up((size_t)pq.splitk * d->B * tg2 * d->Cin * d->H * d->W * sizeof(float), 256);
   }
   const GatherPlan pl = dgrad_plan(d);
@@ -195,7 +195,8 @@ static DgradWeights dgrad_weights_of(const ms_conv_desc* d, const float* w) {
   r.tcog = bcast ? d->groups * d->Cout : d->Cout;
   const int jh = cdiv(d->KH, d->SH), jw = cdiv(d->KW, d->SW);
   const bool one_d = d->H == 1 && d->KH == 1;
-  const PatchPlan pp0 = plan_patch(one_d ? 1 : 2, d->Cin, r.tg, r.tcog, jh, jw, 1, 1, d->B, cdiv(d->H, d->SH), cdiv(d->W, d->SW));
+  const PatchPlan pp0 = plan_patch(one_d ? 1 : 2, d->Cin, r.tg, r.tcog, jh, jw, 1, 1, d->B, cdiv(d->H, d->SH), cdiv(d->W, d->SW),
+                                   d->SH * d->SW);
   const bool direct = pp0.ok && patch_dgrad_direct_ok(w, d->Cin, d->KH, d->KW, d->SH, d->SW, bcast);
   r.need = direct ? 0 : 1;
   r.flip = pp0.ok ? 1 : 0;
@@ -375,7 +376,7 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
     const int ncls = d->SH * d->SW;
     // patch-staged path: each output-parity class is a dense stride-1 forward conv of dy_raw with the class's taps
     // reversed (weights prepared by transpose_weight_kernel(flip=1)); outputs are scattered with stride (SH, SW)
-    const PatchPlan pp0 = plan_patch(one_d ? 1 : 2, d->Cin, tg, tcog, jh, jw, 1, 1, d->B, cdiv(d->H, d->SH), cdiv(d->W, d->SW));
+    const PatchPlan pp0 = plan_patch(one_d ? 1 : 2, d->Cin, tg, tcog, jh, jw, 1, 1, d->B, cdiv(d->H, d->SH), cdiv(d->W, d->SW), ncls);
     // stride-1 convs with whole 64-channel tiles: the patch kernel reads w in place, no transposed copy
     const bool direct = pp0.ok && patch_dgrad_direct_ok(w, d->Cin, d->KH, d->KW, d->SH, d->SW, bcast != 0);
     if (wt_prepared) {
@@ -387,49 +388,43 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
     if (pp0.ok) {
       const int Kg2 = tcog * jh * jw;
       const int cin_tot = tg * d->Cin;
+      // all output-parity classes in ONE launch (class 0 has the largest extent: its tiling serves the others)
+      PatchArgs q = {};
+      q.A = wt; q.src = g; q.out = dx; q.out2 = dx2;
+      q.Mg = d->Cin; q.Kg = Kg2; q.groups = tg; q.Kc = tcog; q.bcast = 0; q.a_vec = (Kg2 % 4 == 0);
+      if (direct) { q.A = w; q.a_vec = 2; }
+      q.ep = up2 ? EP_DGRAD_UP2 : EP_BARE; q.is_dgrad = 1;
+      q.ncls = ncls; q.cls_a_stride = (unsigned)((size_t)tg * d->Cin * Kg2);
+      double flops = 0, bytes = 4.0 * ((double)ncls * tg * d->Cin * Kg2 + (double)d->B * C * hw);
       for (int cls = 0; cls < ncls; ++cls) {
         const int ry = cls / d->SW, rx = cls - ry * d->SW;
         const int kh0 = (ry + d->PH) % d->SH, kw0 = (rx + d->PW) % d->SW;
         const int cy = (ry + d->PH - kh0) / d->SH, cx = (rx + d->PW - kw0) / d->SW;
-        const int QH = (d->H - ry + d->SH - 1) / d->SH, QW = (d->W - rx + d->SW - 1) / d->SW;
-        if (QH <= 0 || QW <= 0) continue;
-        const PatchPlan pp = plan_patch(one_d ? 1 : 2, d->Cin, tg, tcog, jh, jw, 1, 1, d->B, QH, QW);
-        PatchPlan use = pp;
-        use.splitk = pp0.splitk; use.chunks_per_split = pp0.chunks_per_split;   // one split factor for all classes
-        use.wm = pp0.wm; use.ksi = pp0.ksi;
-        if (!pp.ok || pp.tm != pp0.tm || pp.tw != pp0.tw || pp.tn != pp0.tn) {               // a smaller class than the planning one: reuse the plan geometry, recompute tiles
-          use = pp0;
-          const int rows = one_d ? d->B : QH, th = 64 * use.tn / use.tw;
-          use.tiles_y = cdiv(rows, th); use.tiles_x = cdiv(QW, use.tw);
-          use.n_tiles = (one_d ? 1 : d->B) * use.tiles_y * use.tiles_x;
-        }
-        PatchArgs q = {};
-        q.A = wt + (size_t)cls * tg * d->Cin * Kg2; q.src = g; q.out = dx; q.out2 = dx2;
-        q.Mg = d->Cin; q.Kg = Kg2; q.groups = tg; q.Kc = tcog; q.bcast = 0; q.a_vec = (Kg2 % 4 == 0);
-        if (direct) { q.A = w; q.a_vec = 2; }
-        q.ep = up2 ? EP_DGRAD_UP2 : EP_BARE; q.is_dgrad = 1;
-        if (one_d) {
-          q.SRCH = d->B; q.SRCW = d->OW; q.s_img = 0; q.s_chan = d->OW; q.s_row = C * d->OW;
-          q.OUTH = d->B; q.OUTW = QW; q.o_img = 0; q.o_chan = d->W; q.o_row = cin_tot * d->W;
-          q.PH = 0; q.o_sh = 1; q.o_ry = 0;
-        } else {
-          q.SRCH = d->OH; q.SRCW = d->OW; q.s_img = C * hw; q.s_chan = hw; q.s_row = d->OW;
-          q.OUTH = QH; q.OUTW = QW; q.o_img = cin_tot * d->H * d->W; q.o_chan = d->H * d->W; q.o_row = d->W;
-          q.PH = (jh - 1) - cy; q.o_sh = d->SH; q.o_ry = ry;
-        }
-        q.PW = (jw - 1) - cx; q.o_sw = d->SW; q.o_rx = rx;
-        q.tiles_x = use.tiles_x; q.tiles_y = use.tiles_y;
-        q.splitk = use.splitk; q.chunks_per_split = use.chunks_per_split;
-        q.src_elems = (size_t)d->B * C * hw; q.a_elems = (size_t)(cls + 1) * tg * d->Cin * Kg2;
-        if (use.splitk > 1) {
-          q.part = dg_part; q.part_stride = (size_t)d->B * cin_tot * d->H * d->W;
-          q.ep = EP_BARE;               // partial tiles: plain full-resolution layout, the reduce kernel splits UP2
-        }
-        const double flops = 2.0 * d->Cin * Kg2 * (double)d->B * QH * QW * tg;
-        const double bytes = 4.0 * ((double)tg * d->Cin * Kg2 + (double)d->B * C * hw / ncls + (double)d->B * cin_tot * QH * QW);
-        rc = launch_patch(q, use, jh, jw, 1, false, flops, bytes, s);
-        if (rc) return rc;
+        const int QH = std::max(0, (d->H - ry + d->SH - 1) / d->SH), QW = std::max(0, (d->W - rx + d->SW - 1) / d->SW);
+        q.cls_PH[cls] = one_d ? 0 : (jh - 1) - cy; q.cls_PW[cls] = (jw - 1) - cx;
+        q.cls_OUTH[cls] = one_d ? d->B : QH; q.cls_OUTW[cls] = QW;
+        q.cls_ry[cls] = one_d ? 0 : ry; q.cls_rx[cls] = rx;
+        flops += 2.0 * d->Cin * Kg2 * (double)d->B * (one_d ? 1 : QH) * QW * tg;
+        bytes += 4.0 * (double)d->B * cin_tot * (one_d ? 1 : QH) * QW;
       }
+      if (one_d) {
+        q.SRCH = d->B; q.SRCW = d->OW; q.s_img = 0; q.s_chan = d->OW; q.s_row = C * d->OW;
+        q.o_img = 0; q.o_chan = d->W; q.o_row = cin_tot * d->W; q.o_sh = 1;
+      } else {
+        q.SRCH = d->OH; q.SRCW = d->OW; q.s_img = C * hw; q.s_chan = hw; q.s_row = d->OW;
+        q.o_img = cin_tot * d->H * d->W; q.o_chan = d->H * d->W; q.o_row = d->W; q.o_sh = d->SH;
+      }
+      q.o_sw = d->SW;
+      q.PH = q.cls_PH[0]; q.PW = q.cls_PW[0]; q.OUTH = q.cls_OUTH[0]; q.OUTW = q.cls_OUTW[0]; q.o_ry = q.cls_ry[0]; q.o_rx = q.cls_rx[0];
+      q.tiles_x = pp0.tiles_x; q.tiles_y = pp0.tiles_y;
+      q.splitk = pp0.splitk; q.chunks_per_split = pp0.chunks_per_split;
+      q.src_elems = (size_t)d->B * C * hw; q.a_elems = (size_t)ncls * tg * d->Cin * Kg2;
+      if (pp0.splitk > 1) {
+        q.part = dg_part; q.part_stride = (size_t)d->B * cin_tot * d->H * d->W;
+        q.ep = EP_BARE;               // partial tiles: plain full-resolution layout, the reduce kernel splits UP2
+      }
+      rc = launch_patch(q, pp0, jh, jw, 1, false, flops, bytes, s);
+      if (rc) return rc;
       if (pp0.splitk > 1) {
         const size_t n = (size_t)d->B * cin_tot * d->H * d->W;
         rc = launch_splitk_dgrad_epilogue(dg_part, pp0.splitk, n, dx, dx2, n, d->W, up2 ? 1 : 0, s);

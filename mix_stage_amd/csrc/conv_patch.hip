@@ -71,13 +71,19 @@ void conv_patch_kernel(const PatchArgs p) {
   // channel tiles that share an input patch sit behind the same L2
   const int vid = xcd_remap(blockIdx.x, p.gx * p.gy * p.gz);
   const int by_ = vid % p.gy, bx_ = (vid / p.gy) % p.gx, bz_ = vid / (p.gy * p.gx);
-  const int g = bz_ / p.splitk, ks = bz_ - g * p.splitk, m0 = by_ * BM;
+  // (strided data gradient: the output-parity class comes first in z)
+  const int zz = p.groups * p.splitk;
+  const int cls = p.ncls > 1 ? bz_ / zz : 0, bzc = bz_ - cls * zz;
+  const int g = bzc / p.splitk, ks = bzc - g * p.splitk, m0 = by_ * BM;
+  const int PHc = p.ncls > 1 ? p.cls_PH[cls] : p.PH, PWc = p.ncls > 1 ? p.cls_PW[cls] : p.PW;
+  const int OUTHc = p.ncls > 1 ? p.cls_OUTH[cls] : p.OUTH, OUTWc = p.ncls > 1 ? p.cls_OUTW[cls] : p.OUTW;
+  const int o_ryc = p.ncls > 1 ? p.cls_ry[cls] : p.o_ry, o_rxc = p.ncls > 1 ? p.cls_rx[cls] : p.o_rx;
   const int tiles_per_img = p.tiles_y * p.tiles_x;
   const int img = bx_ / tiles_per_img;
   const int trem = bx_ - img * tiles_per_img;
   const int tyi = trem / p.tiles_x, txi = trem - tyi * p.tiles_x;
   const int oy0 = tyi * TH, ox0 = txi * TW;
-  const int iy0 = oy0 * SV - p.PH, ix0 = ox0 * S - p.PW;
+  const int iy0 = oy0 * SV - PHc, ix0 = ox0 * S - PWc;
   const int cbase = p.bcast ? 0 : g * p.Kc;
   const int Kg = p.Kg;
 
@@ -115,7 +121,7 @@ void conv_patch_kernel(const PatchArgs p) {
     }
   }
   const __amdgpu_buffer_rsrc_t rsA = buf_rsrc(p.A), rsS = buf_rsrc(p.src), rsS2 = buf_rsrc(UP2 ? p.src2 : p.src);
-  const unsigned a_group = (unsigned)g * p.Mg * Kg;     // (AM 2: Kg = Kc*KHW, so this is the group's first output channel)
+  const unsigned a_group = (unsigned)cls * p.cls_a_stride + (unsigned)g * p.Mg * Kg;     // (AM 2: Kg = Kc*KHW, so this is the group's first output channel)
   const int img_base = img * p.s_img;
 
   // two register sets: chunk c+2 is in flight from HBM/L2 while chunk c+1 waits in registers and chunk c computes
@@ -271,8 +277,8 @@ void conv_patch_kernel(const PatchArgs p) {
   const int ctot = p.groups * p.Mg;
   const int nloc = wn * 32 + (lane & 31);
   const int oy = oy0 + nloc / TW, ox = ox0 + nloc % TW;
-  const bool cval = lead & (oy < p.OUTH) & (ox < p.OUTW);
-  const int ooff = img * p.o_img + (oy * p.o_sh + p.o_ry) * p.o_row + ox * p.o_sw + p.o_rx;   // + channel * o_chan
+  const bool cval = lead & (oy < OUTHc) & (ox < OUTWc);
+  const int ooff = img * p.o_img + (oy * p.o_sh + o_ryc) * p.o_row + ox * p.o_sw + o_rxc;   // + channel * o_chan
   const int ep = p.ep;
   if (p.part) {                       // raw partial tile in the output layout; a split-K epilogue kernel finishes
     float* part = p.part + (size_t)ks * p.part_stride;
@@ -333,13 +339,13 @@ void conv_patch_kernel(const PatchArgs p) {
     }
     s += __shfl_xor(s, 1);
     s += __shfl_xor(s, 2);
-    const int cnt = min(TH, p.OUTH - oy0) * min(TW, p.OUTW - ox0);
+    const int cnt = min(TH, OUTHc - oy0) * min(TW, OUTWc - ox0);
     const float mean = s / (float)cnt;
     float m2 = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int nl = q + 4 * i;
-      const bool ok = (oy0 + nl / TW < p.OUTH) & (ox0 + nl % TW < p.OUTW);
+      const bool ok = (oy0 + nl / TW < OUTHc) & (ox0 + nl % TW < OUTWc);
       const float dlt = v[i] - mean;
       m2 += ok ? dlt * dlt : 0.f;
     }
@@ -364,7 +370,7 @@ int patch_chunk_channels(int KH, int KW) {
   return khw == 1 ? 32 : khw == 2 ? 16 : khw == 3 ? 16 : khw == 4 ? 16 : khw == 9 ? 4 : khw == 16 ? 4 : khw == 24 ? 2 : 4;
 }
 
-PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH, int SW, int B, int OH, int OW) {
+PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH, int SW, int B, int OH, int OW, int zmul) {
   PatchPlan pl = {0, 1, 64, 0, 0, 0, 1, 1 << 30, 1, 2, 1};
   const int S = SW;
   if (nd == 2 && SH != SW) return pl;
@@ -383,7 +389,7 @@ PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH,
   pl.ok = 1; pl.tm = tm; pl.tw = tw; pl.tn = tn;
   pl.tiles_y = cdiv(rows, th); pl.tiles_x = cdiv(OW, tw);
   pl.n_tiles = imgs * pl.tiles_y * pl.tiles_x;
-  const long base = (long)pl.n_tiles * cdiv(Mg, 64 * tm) * groups;
+  const long base = (long)pl.n_tiles * cdiv(Mg, 64 * tm) * groups * zmul;   // zmul: parity classes sharing the launch
   // too few workgroups: the split-K im2col path spreads the weight stream better
   if (base < g_patch_min_wgs) pl.ok = 0;
   // fewer workgroups than 1.5 per CU and a long reduction: slice the channel chunks over workgroups
@@ -392,7 +398,7 @@ PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH,
     pl.chunks_per_split = cdiv(nchunks, g_patch_force_splitk);
     pl.splitk = cdiv(nchunks, pl.chunks_per_split);
   } else if (pl.ok && base < 384 && nchunks >= 4) {
-    const long base32 = (long)pl.n_tiles * cdiv(Mg, 32) * groups;
+    const long base32 = (long)pl.n_tiles * cdiv(Mg, 32) * groups * zmul;
     // (short reductions only: with a long K -- the 2048-channel data gradient of the first decoder layer -- slices over
     // workgroups keep more of the chip busy: 91 vs 152 us)
     if (g_patch_intra && KH == 1 && KW == 3 && S == 1 && tw >= 32 && base32 >= 192 && nchunks <= 16) {
@@ -472,7 +478,8 @@ int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S,
                  hipStream_t s) {
   const int bm = 32 * pl.wm;
   PatchArgs b = a;
-  b.gx = pl.n_tiles; b.gy = cdiv(a.Mg, bm); b.gz = a.groups * a.splitk;
+  if (a.ncls > 4) return set_error("patch conv: more than 4 parity classes");
+  b.gx = pl.n_tiles; b.gy = cdiv(a.Mg, bm); b.gz = a.groups * a.splitk * std::max(1, a.ncls);
   if ((double)b.gx * b.gy * b.gz > 2.0e9) return set_error("conv grid too large");
   dim3 grid(b.gx * b.gy * b.gz);
   if (a.splitk < 1 || (a.splitk > 1 && !a.part)) return set_error("patch conv: bad split-K setup");

@@ -72,9 +72,13 @@ struct PatchArgs {
   int PH, PW, tiles_x, tiles_y;
   float slope, eps;
   size_t src_elems, a_elems;    // extents of src (UP2: of src2) and A, for the 32-bit buffer offsets
+  // data gradient of a strided conv: all SH*SW output-parity classes in ONE launch (blockIdx also enumerates the class);
+  // per class: padding, output extent, scatter phase; weights of class c start at A + c*cls_a_stride
+  int ncls, cls_PH[4], cls_PW[4], cls_OUTH[4], cls_OUTW[4], cls_ry[4], cls_rx[4];
+  unsigned cls_a_stride;
 };
 struct PatchPlan { int ok, tm, tw, tiles_y, tiles_x, n_tiles, splitk, chunks_per_split, tn, wm, ksi; };   // wm: 32-row wave tiles per tile; ksi: intra-workgroup K split
-PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH, int SW, int B, int OH, int OW);
+PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH, int SW, int B, int OH, int OW, int zmul = 1);
 int patch_chunk_channels(int KH, int KW);
 bool patch_dgrad_direct_ok(const float* w, int Cin_g, int KH, int KW, int SH, int SW, bool up2_or_bcast);
 int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S, bool up2, double flops, double bytes,

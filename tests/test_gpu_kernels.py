@@ -60,6 +60,8 @@ BLOCK_CASES = [
     ('ae5', '2d', 256, 256, 4, 2, 1, (16, 32), 'plain'),
     ('ae7', '2d', 256, 256, (3, 8), 1, 1, (8, 16), 'plain'),
     ('ragged2d', '2d', 3, 6, (3, 8), 1, 1, (5, 11), 'plain'),
+    ('odd_s2_2d', '2d', 5, 7, 4, 2, 1, (9, 37), 'plain'),      # stride-2 parity classes of different extents
+    ('odd_s2_1d', '1d', 6, 10, 4, 2, 1, (37,), 'plain'),
 ]
 
 
