@@ -168,6 +168,15 @@ def _prepared_for(w, d):
   return e['wt']
 
 
+def drop_trainer_caches(storage_ptrs):
+  """Forget the prepared weights and partial-gradient buffers of parameters living in these storages (a trainer that goes
+  away calls this; the buffers are referenced by its captured graphs until then)."""
+  for sp in storage_ptrs:
+    for e in _prepared['by_storage'].pop(sp, ()):
+      _prepared['entries'] = {k: v for k, v in _prepared['entries'].items() if v is not e}
+  _deferred['bufs'] = {k: v for k, v in _deferred['bufs'].items() if v[2] not in storage_ptrs}
+
+
 def refresh_prepared_weights(flat_params):
   """Rebuild every prepared buffer whose weight lives in `flat_params`' storage: one launch (per 48 blocks).  Call after
   each update of that storage that torch cannot see (the HIP Adam kernels write through raw pointers)."""
@@ -209,7 +218,8 @@ def _wgrad_partials_for(w, d):
   key = (w.data_ptr(), id(d))
   buf = _deferred['bufs'].get(key)
   if buf is None or buf[0].numel() != info[0]:
-    buf = _deferred['bufs'][key] = (torch.empty(info[0], dtype=torch.float32, device=w.device), d)   # d: keeps id(d) unique
+    buf = _deferred['bufs'][key] = (torch.empty(info[0], dtype=torch.float32, device=w.device), d,   # d: keeps id(d) unique
+                                    w.untyped_storage().data_ptr())
   return buf[0], info[1]
 
 

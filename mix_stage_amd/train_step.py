@@ -15,6 +15,8 @@ MI355X-first structure:
     (bn_sync='local'); host-side random decisions come from identically seeded CPU generators so all
     ranks take the same D-vs-G branch (gan.py:105) and curriculum branch (JL:127).
 """
+import weakref
+
 import torch
 import torch.distributed as dist
 
@@ -192,6 +194,8 @@ class MixStageTrainStep:
       broadcast_from_rank0([self.optim_G.flat_p, self.optim_D.flat_p] + [b for b in model.buffers()], process_group)
     self._graphs = {}
     self._static = None
+    weakref.finalize(self, ops.drop_trainer_caches, [self.optim_G.flat_p.untyped_storage().data_ptr(),
+                                                     self.optim_D.flat_p.untyped_storage().data_ptr()])
     self.losses = None       # list of 0-dim device tensors of the last step (reference order)
     self.fake_pose = None
 
