@@ -1,0 +1,43 @@
+"""Worker of tests/test_gpu_dp.py: one data-parallel rank (gloo, all ranks on cuda:0).  Prints one JSON line."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import torch
+import torch.distributed as dist
+
+from oracle import mixstage_oracle as O
+
+
+def main():
+  rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  torch.cuda.set_device(0)
+  from test_gpu_model import build_hip_gan
+  from mix_stage_amd.train_step import MixStageTrainStep
+  torch.manual_seed(1234)                      # same host generator on every rank: same D/G decisions
+  model = build_hip_gan(4, 4)
+  if rank == 1:                                # rank 1 starts from different weights: the broadcast must fix that
+    with torch.no_grad():
+      for p in model.parameters():
+        p.mul_(1.5)
+  ts = MixStageTrainStep(model, use_graphs=True)
+  kinds = []
+  losses = []
+  for i in range(6):
+    audio, pose, labels, style = O.synthetic_batch(4, M=4, S=4, seed=100 + 10 * i + rank)   # a different shard per rank
+    kinds.append(ts.step(audio.cuda(), labels.cuda(), pose.cuda(), style.cuda()))
+    losses.append([float(l.detach()) for l in ts.losses])
+  torch.cuda.synchronize()
+  print('DPRESULT ' + json.dumps(dict(rank=rank, kinds=kinds, sums=ts.state_checksums(), losses=losses,
+                                      g_step=ts.optim_G.step_count, d_step=ts.optim_D.step_count)), flush=True)
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()
