@@ -23,6 +23,7 @@ if ROOT not in sys.path:
 B_PER_GPU, T, F_MEL, P, M, S = 32, 64, 128, 104, 8, 8
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16
 
 
 def parse():
@@ -34,6 +35,9 @@ def parse():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-kernel-timing', action='store_true')
   ap.add_argument('--seed', type=int, default=4321)
+  ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16x6'],
+                  help='fp32: exact fp32 matrix products (default, the headline); bf16x6: both operands split exactly into 3 bf16 '
+                       'parts, 6 of 9 partial products on the bf16 pipe, fp32 accumulate (same measured accuracy)')
   ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL over xGMI); gloo only for smoke-testing the DP path')
   ap.add_argument('--same-device', action='store_true', help='smoke test: all ranks share cuda:0 (needs --dist-backend gloo)')
   return ap.parse_args()
@@ -120,8 +124,11 @@ def kernel_roofline(ts, batch, kinds):
   top = syms[0]
   avg_s = top['total_ms'] / top['count'] * 1e-3
   achieved = top['flops'] / (top['total_ms'] * 1e-3) / 1e12
-  roof = dict(bound='mfma', achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-              frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None, kernel=top['sym'],
+  # bf16x6 kernels do 6 bf16 MFMA products per algorithmic fp32 product: their ceiling in algorithmic flops is 1/6 of the dense
+  # bf16 peak (MI355X_MICROARCH.md: 2.5 PFLOP/s)
+  peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if 'patch6' in top['sym'] else FP32_MFMA_PEAK_TFLOPS
+  roof = dict(bound='mfma', achieved=round(achieved, 2), peak=round(peak, 1), unit='TFLOP/s',
+              frac=round(achieved / peak, 4), traffic=None, kernel=top['sym'],
               avg_us=round(avg_s * 1e6, 2), launches=top['count'],
               algorithmic_flops_per_launch=round(top['flops'] / top['count']),
               algorithmic_bytes_per_launch=round(top['bytes'] / top['count']),
@@ -150,6 +157,8 @@ def main():
     if world == 1 and args.gpus > 1:
       raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr '
                        '127.0.0.1 bench.py --gpus %d ...' % (args.gpus, args.gpus))
+  if args.precision == 'bf16x6':
+    os.environ['MS_PRECISION'] = 'bf16x6'       # read when the library is loaded
   if args.same_device:
     local_rank = 0
   torch.cuda.set_device(local_rank)
@@ -199,7 +208,7 @@ def main():
         'metric': 'train-step clips/sec (B=32, T=64, M=8)', 'value': round(world * B_PER_GPU * args.steps / elapsed, 2),
         'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else 'f32 via bf16x6 (exact 3-way bf16 split of both operands, 6 of 9 products, fp32 accumulate)', 'data': 'synthetic',
         'config': {'workload': 'Mix-StAGE GAN train step (reference D/G coin flip, seed %d: %d G + %d D steps), '
                                'B=%d clips per GPU, T=%d, %d-mel, %d-dim pose, M=S=%d, audio branch pinned'
                                % (args.seed, n_g, args.steps - n_g, B_PER_GPU, T, F_MEL, P, M),

@@ -85,6 +85,20 @@ int ms_conv_block_fwd(const ms_conv_desc* d, const float* x, const float* x2, co
                       float* running_var, float* y_raw, float* y, float* save, void* workspace,
                       size_t workspace_bytes, void* stream);
 
+/* Full form of the forward.  w_planes: this block's buffer from ms_fwd_weights_prepare (bf16x6 mode: the weights split into
+ * three bf16 planes); NULL = split them per call into the scratch. */
+typedef struct ms_fwd_options {
+  const void* w_planes;
+} ms_fwd_options;
+int ms_conv_block_fwd_ex(const ms_conv_desc* d, const float* x, const float* x2, const float* w,
+                         const float* bias, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, float* y_raw, float* y, float* save, void* workspace,
+                         size_t workspace_bytes, void* stream, const ms_fwd_options* opt);
+/* bf16x6 mode (ms_set_precision): bytes of the block's split weight planes (0: the block runs the fp32 kernels), and their
+ * batched construction for n blocks in one launch -- once per optimizer update, like ms_dgrad_weights_prepare. */
+size_t ms_fwd_weights_bytes(const ms_conv_desc* d);
+int ms_fwd_weights_prepare(int n, const ms_conv_desc* descs, const float* const* w, void* const* planes, void* stream);
+
 /* Backward of the same block (what autograd derives for layers.py:78 in the reference).
  *   dy       grad wrt y.
  *   y_raw/save as produced by the forward (BN_TRAIN); y (LRELU mode mask); BN_EVAL uses running stats.
@@ -134,6 +148,12 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
  *   ms_dgrad_weights_elems   floats the block's copy needs; 0 = its data gradient reads w in place, nothing to prepare
  *   ms_dgrad_weights_prepare descs[n], w[n], wt[n] (wt[i] may be NULL where elems == 0) */
 size_t ms_dgrad_weights_elems(const ms_conv_desc* d, const float* w);
+/* Arithmetic of the patch-staged conv kernels.  0 (default): exact fp32 products on v_mfma_f32_32x32x2_f32.
+ * 1 ("bf16x6"): both fp32 operands split exactly into three bf16 parts, 6 of the 9 partial products on
+ * v_mfma_f32_32x32x16_bf16, fp32 accumulation -- the dropped products are <= 2^-24 relative (one fp32 rounding error), measured
+ * error against fp64 equals the fp32 kernels'; 16/6 of the fp32 matrix rate.  Returns the previous mode. */
+int ms_set_precision(int mode);
+int ms_get_precision(void);
 int ms_tuning_epoch(void);   /* bumped by the ms_debug_set_* knobs: prepared weights built under another value are stale */
 int ms_dgrad_weights_prepare(int n, const ms_conv_desc* descs, const float* const* w, float* const* wt, void* stream);
 

@@ -19,6 +19,11 @@ class BwdOptions(ctypes.Structure):
               ('wt_prepared', ctypes.c_void_p), ('wgrad_partials', ctypes.c_void_p)]
 
 
+class FwdOptions(ctypes.Structure):
+  """struct ms_fwd_options"""
+  _fields_ = [('w_planes', ctypes.c_void_p)]
+
+
 class ConvDesc(ctypes.Structure):
   """struct ms_conv_desc"""
   _fields_ = [(n, ctypes.c_int32) for n in
@@ -47,6 +52,11 @@ SIGNATURES = {
     'ms_dgrad_weights_elems': (c_size_t, [_DESC, _P]),
     'ms_dgrad_weights_prepare': (c_int, [c_int, _P, _P, _P, _P]),
     'ms_tuning_epoch': (c_int, []),
+    'ms_conv_block_fwd_ex': (c_int, [_DESC] + [_P] * 11 + [_P, c_size_t, _P, _P]),
+    'ms_fwd_weights_bytes': (c_size_t, [_DESC]),
+    'ms_fwd_weights_prepare': (c_int, [c_int, _P, _P, _P, _P]),
+    'ms_set_precision': (c_int, [c_int]),
+    'ms_get_precision': (c_int, []),
     'ms_wgrad_partials_elems': (c_size_t, [_DESC, _P]),
     'ms_wgrad_reduce_multi': (c_int, [c_int, _P, _P, _P, _P, _P]),
     'ms_lerp_time_fwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
@@ -95,6 +105,11 @@ def lib():
     for name, (res, args) in SIGNATURES.items():
       fn = getattr(handle, name)          # AttributeError here = header/library drift
       fn.restype, fn.argtypes = res, args
+    mode = os.environ.get('MS_PRECISION', '')
+    if mode:                            # 'fp32' | 'bf16x6' (see ms_set_precision)
+      if mode not in ('fp32', 'bf16x6'):
+        raise MixStageLibError('MS_PRECISION=%s: expected fp32 or bf16x6' % mode)
+      handle.ms_set_precision(1 if mode == 'bf16x6' else 0)
     _lib = handle
   return _lib
 

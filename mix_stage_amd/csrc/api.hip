@@ -65,7 +65,9 @@ size_t ms_conv_block_fwd_workspace(const ms_conv_desc* d) {
     bytes = std::max(bytes, align_up((size_t)pp.n_tiles * ctot_of(d) * 2 * sizeof(float), 256) + (size_t)pp.n_tiles * sizeof(float));
   if (pp.ok && (pp.splitk > 1 || pp.ksi > 1)) bytes = std::max(bytes, (size_t)pp.splitk * npix * ctot_of(d) * sizeof(float));
   if (pl.splitk > 1) bytes = std::max(bytes, (size_t)pl.splitk * npix * ctot_of(d) * sizeof(float));
-  return align_up(bytes, 256) + 256;
+  bytes = align_up(bytes, 256) + 256;
+  if (pp.ok && pp.p6) bytes += align_up((size_t)3 * ctot_of(d) * patch6_row_elems(d->Cin, d->KH, d->KW) * 2, 256);   // split weights
+  return bytes;
 }
 
 size_t ms_conv_block_bwd_workspace(const ms_conv_desc* d) {
@@ -86,6 +88,8 @@ size_t ms_conv_block_bwd_workspace(const ms_conv_desc* d) {
     const PatchPlan pq = plan_patch(one_d2 ? 1 : 2, d->Cin, tg2, tcog2, cdiv(d->KH, d->SH), cdiv(d->KW, d->SW), 1, 1, d->B,
                                     cdiv(d->H, d->SH), cdiv(d->W, d->SW), d->SH * d->SW);
     if (pq.ok && pq.splitk > 1) bytes += align_up((size_t)pq.splitk * d->B * tg2 * d->Cin * d->H * d->W * sizeof(float), 256);
+    if (pq.ok && pq.p6)   // bf16x6 data gradient: split planes of the transposed weights
+      bytes += align_up((size_t)3 * d->SH * d->SW * tg2 * d->Cin * patch6_row_elems(tcog2, cdiv(d->KH, d->SH), cdiv(d->KW, d->SW)) * 2, 256);
   }
   const GatherPlan pl = dgrad_plan(d);
   if (pl.splitk > 1)
@@ -94,8 +98,17 @@ size_t ms_conv_block_bwd_workspace(const ms_conv_desc* d) {
 }
 
 int ms_conv_block_fwd(const ms_conv_desc* d, const float* x, const float* x2, const float* w, const float* bias,
-                      const float* gamma, const float* beta, float* running_mean, float* running_var, float* y_raw,
-                      float* y, float* save, void* workspace, size_t workspace_bytes, void* stream) {
+                      const float* gamma, const float* beta, float* running_mean, float* running_var, float* y_raw, float* y,
+                      float* save, void* workspace, size_t workspace_bytes, void* stream) {
+  return ms_conv_block_fwd_ex(d, x, x2, w, bias, gamma, beta, running_mean, running_var, y_raw, y, save, workspace,
+                              workspace_bytes, stream, nullptr);
+}
+
+int ms_conv_block_fwd_ex(const ms_conv_desc* d, const float* x, const float* x2, const float* w, const float* bias,
+                         const float* gamma, const float* beta, float* running_mean, float* running_var, float* y_raw,
+                         float* y, float* save, void* workspace, size_t workspace_bytes, void* stream,
+                         const ms_fwd_options* opt) {
+  const unsigned short* w_planes = opt ? (const unsigned short*)opt->w_planes : nullptr;
   int rc = validate(d, "ms_conv_block_fwd");
   if (rc) return rc;
   if (!x || !w || !y) return set_error("ms_conv_block_fwd: null tensor");
@@ -150,7 +163,22 @@ int ms_conv_block_fwd(const ms_conv_desc* d, const float* x, const float* x2, co
     if (raw_out) { q.part = (float*)workspace; q.part_stride = (size_t)npix * C; }
     const double flops = 2.0 * d->Cout * a.Kg * (double)npix * d->groups;
     const double bytes = 4.0 * ((double)C * a.Kg + (double)d->B * cin_tot * d->H * d->W + (double)npix * C);
-    rc = launch_patch(q, pp, d->KH, d->KW, d->SW, d->in_mode == MS_IN_UP2ADD, flops, bytes, s);
+    if (pp.p6) {
+      // bf16x6: three bf16 planes of the weights -- the trainer's (ms_fwd_options.w_planes) or built here behind the other scratch
+      const int re = patch6_row_elems(d->Cin, d->KH, d->KW);
+      const unsigned short* planes = w_planes;
+      if (!planes) {
+        const size_t planes_bytes = align_up((size_t)3 * C * re * 2, 256);
+        unsigned short* mine = (unsigned short*)((char*)workspace + (ms_conv_block_fwd_workspace(d) - planes_bytes));
+        rc = launch_split_weights(w, mine, C, d->Cin, d->KH, d->KW, s);
+        if (rc) return rc;
+        planes = mine;
+      }
+      q.Aplanes = planes; q.plane_stride = (unsigned)((size_t)C * re); q.a_row_elems = re;
+      rc = launch_patch6(q, pp, d->KH, d->KW, d->SW, d->in_mode == MS_IN_UP2ADD, flops, bytes, s);
+    } else {
+      rc = launch_patch(q, pp, d->KH, d->KW, d->SW, d->in_mode == MS_IN_UP2ADD, flops, bytes, s);
+    }
     if (rc) return rc;
     if (raw_out)
       return launch_splitk_fwd_epilogue(q.part, pp.splitk, q.part_stride, bias, gamma, beta, running_mean, running_var, y_raw,
@@ -187,7 +215,7 @@ int ms_conv_block_fwd(const ms_conv_desc* d, const float* x, const float* x2, co
 // The data-gradient weights of block d: none (the patch kernel reads w in place), or the transposed / parity-class-split
 // copy, with the taps reversed when the patch-staged kernels will consume it.  Shared by the backward and the prepare
 // entry points so that both take the same decision.
-struct DgradWeights { int need, flip, tg, tcog; size_t elems; };
+struct DgradWeights { int need, flip, tg, tcog, p6; size_t elems; };
 static DgradWeights dgrad_weights_of(const ms_conv_desc* d, const float* w) {
   const bool bcast = d->in_mode == MS_IN_BCAST;
   DgradWeights r;
@@ -197,9 +225,10 @@ static DgradWeights dgrad_weights_of(const ms_conv_desc* d, const float* w) {
   const bool one_d = d->H == 1 && d->KH == 1;
   const PatchPlan pp0 = plan_patch(one_d ? 1 : 2, d->Cin, r.tg, r.tcog, jh, jw, 1, 1, d->B, cdiv(d->H, d->SH), cdiv(d->W, d->SW),
                                    d->SH * d->SW);
-  const bool direct = pp0.ok && patch_dgrad_direct_ok(w, d->Cin, d->KH, d->KW, d->SH, d->SW, bcast);
+  const bool direct = pp0.ok && !pp0.p6 && patch_dgrad_direct_ok(w, d->Cin, d->KH, d->KW, d->SH, d->SW, bcast);
   r.need = direct ? 0 : 1;
   r.flip = pp0.ok ? 1 : 0;
+  r.p6 = (pp0.ok && pp0.p6) ? 1 : 0;
   r.elems = dgrad_weight_elems(d->groups, d->Cout, d->Cin, d->KH, d->KW, d->SH, d->SW);
   return r;
 }
@@ -237,10 +266,45 @@ int ms_wgrad_reduce_multi(int n, const float* const* partials, float* const* dw,
   return rb.n ? launch_reduce_splits_multi(rb, (hipStream_t)stream) : 0;
 }
 
+// bf16x6 data gradient: bytes of the three planes of the transposed class slabs (0: the fp32 kernels run)
+static size_t dgrad_planes_bytes(const ms_conv_desc* d, const DgradWeights& dw) {
+  if (!dw.p6) return 0;
+  const int jh = cdiv(d->KH, d->SH), jw = cdiv(d->KW, d->SW);
+  return (size_t)3 * d->SH * d->SW * dw.tg * d->Cin * patch6_row_elems(dw.tcog, jh, jw) * 2;
+}
+
 size_t ms_dgrad_weights_elems(const ms_conv_desc* d, const float* w) {
   if (validate(d, "ms_dgrad_weights_elems")) return 0;
   const DgradWeights dw = dgrad_weights_of(d, w);
-  return dw.need ? dw.elems : 0;
+  if (!dw.need) return 0;
+  return align_up(dw.elems, 64) + (dgrad_planes_bytes(d, dw) + 3) / 4;      // fp32 copy | bf16 planes (bf16x6 mode)
+}
+
+size_t ms_fwd_weights_bytes(const ms_conv_desc* d) {
+  if (validate(d, "ms_fwd_weights_bytes")) return 0;
+  const PatchPlan pp = fwd_patch_plan(d);
+  return (pp.ok && pp.p6) ? (size_t)3 * ctot_of(d) * patch6_row_elems(d->Cin, d->KH, d->KW) * 2 : 0;
+}
+
+int ms_fwd_weights_prepare(int n, const ms_conv_desc* descs, const float* const* w, void* const* planes, void* stream) {
+  if (n < 0 || (n && (!descs || !w || !planes))) return set_error("ms_fwd_weights_prepare: null argument");
+  SplitBatch sb;
+  sb.n = 0;
+  for (int i = 0; i < n; ++i) {
+    const ms_conv_desc* d = descs + i;
+    int rc = validate(d, "ms_fwd_weights_prepare");
+    if (rc) return rc;
+    if (!ms_fwd_weights_bytes(d)) continue;
+    if (!planes[i]) return set_error("ms_fwd_weights_prepare: block %d needs a buffer of ms_fwd_weights_bytes bytes", i);
+    SplitJob jb = {w[i], (unsigned short*)planes[i], ctot_of(d), d->Cin, d->KH * d->KW, 0, 0, 0};
+    sb.job[sb.n++] = jb;
+    if (sb.n == SPLIT_BATCH_MAX) {
+      rc = launch_split_weights_multi(sb, (hipStream_t)stream);
+      if (rc) return rc;
+      sb.n = 0;
+    }
+  }
+  return sb.n ? launch_split_weights_multi(sb, (hipStream_t)stream) : 0;
 }
 
 int ms_dgrad_weights_prepare(int n, const ms_conv_desc* descs, const float* const* w, float* const* wt, void* stream) {
@@ -256,14 +320,33 @@ int ms_dgrad_weights_prepare(int n, const ms_conv_desc* descs, const float* cons
     if (!wt[i]) return set_error("ms_dgrad_weights_prepare: block %d needs a buffer of ms_dgrad_weights_elems floats", i);
     TransposeJob jb = {w[i], wt[i], dw.tg, dw.tcog, d->Cin, d->KH, d->KW, d->SH, d->SW, d->PH, d->PW, dw.flip, 0};
     tb.job[tb.n++] = jb;
-    if (tb.n == TRANSPOSE_BATCH_MAX || i == n - 1) {
+    if (tb.n == TRANSPOSE_BATCH_MAX) {
       rc = launch_transpose_weight_multi(tb, (hipStream_t)stream);
       if (rc) return rc;
       tb.n = 0;
     }
   }
-  if (tb.n) return launch_transpose_weight_multi(tb, (hipStream_t)stream);
-  return 0;
+  if (tb.n) {
+    const int rc = launch_transpose_weight_multi(tb, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  // bf16x6 mode: the planes of the fp32 copies just built, behind them
+  SplitBatch sb;
+  sb.n = 0;
+  for (int i = 0; i < n; ++i) {
+    const ms_conv_desc* d = descs + i;
+    const DgradWeights dw = dgrad_weights_of(d, w[i]);
+    if (!dw.need || !dw.p6) continue;
+    SplitJob jb = {wt[i], (unsigned short*)(wt[i] + align_up(dw.elems, 64)), d->SH * d->SW * dw.tg * d->Cin, dw.tcog,
+                   cdiv(d->KH, d->SH) * cdiv(d->KW, d->SW), 0, 0, 0};
+    sb.job[sb.n++] = jb;
+    if (sb.n == SPLIT_BATCH_MAX) {
+      const int rc = launch_split_weights_multi(sb, (hipStream_t)stream);
+      if (rc) return rc;
+      sb.n = 0;
+    }
+  }
+  return sb.n ? launch_split_weights_multi(sb, (hipStream_t)stream) : 0;
 }
 
 int ms_conv_block_bwd(const ms_conv_desc* d, const float* x, const float* x2, const float* w, const float* gamma,
@@ -378,7 +461,7 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
     // reversed (weights prepared by transpose_weight_kernel(flip=1)); outputs are scattered with stride (SH, SW)
     const PatchPlan pp0 = plan_patch(one_d ? 1 : 2, d->Cin, tg, tcog, jh, jw, 1, 1, d->B, cdiv(d->H, d->SH), cdiv(d->W, d->SW), ncls);
     // stride-1 convs with whole 64-channel tiles: the patch kernel reads w in place, no transposed copy
-    const bool direct = pp0.ok && patch_dgrad_direct_ok(w, d->Cin, d->KH, d->KW, d->SH, d->SW, bcast != 0);
+    const bool direct = pp0.ok && !pp0.p6 && patch_dgrad_direct_ok(w, d->Cin, d->KH, d->KW, d->SH, d->SW, bcast != 0);
     if (wt_prepared) {
       wt = const_cast<float*>(wt_prepared);      // built by ms_dgrad_weights_prepare for this very descriptor
     } else if (!direct) {
@@ -423,7 +506,26 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
         q.part = dg_part; q.part_stride = (size_t)d->B * cin_tot * d->H * d->W;
         q.ep = EP_BARE;               // partial tiles: plain full-resolution layout, the reduce kernel splits UP2
       }
-      rc = launch_patch(q, pp0, jh, jw, 1, false, flops, bytes, s);
+      if (pp0.p6) {
+        // bf16x6: planes of the transposed class slabs -- behind the prepared fp32 copy when the trainer built them
+        // (ms_dgrad_weights_prepare), else split here
+        const int re = patch6_row_elems(tcog, jh, jw), rows = ncls * tg * d->Cin;
+        const unsigned short* planes;
+        if (wt_prepared) {
+          planes = (const unsigned short*)(wt_prepared + align_up(dgrad_weight_elems(d->groups, d->Cout, d->Cin, d->KH, d->KW, d->SH, d->SW), 64));
+        } else {
+          unsigned short* mine = (unsigned short*)((char*)dg_part + (pp0.splitk > 1 ? align_up((size_t)pp0.splitk * d->B * cin_tot *
+                                                                                                  d->H * d->W * sizeof(float), 256) : 0));
+          rc = launch_split_weights(wt, mine, rows, tcog, jh, jw, s);
+          if (rc) return rc;
+          planes = mine;
+        }
+        q.Aplanes = planes; q.plane_stride = (unsigned)((size_t)rows * re); q.a_row_elems = re;
+        q.cls_a_stride = (unsigned)(tg * d->Cin);
+        rc = launch_patch6(q, pp0, jh, jw, 1, false, flops, bytes, s);
+      } else {
+        rc = launch_patch(q, pp0, jh, jw, 1, false, flops, bytes, s);
+      }
       if (rc) return rc;
       if (pp0.splitk > 1) {
         const size_t n = (size_t)d->B * cin_tot * d->H * d->W;
@@ -476,11 +578,12 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
       q.tiles_per_split = wp.tiles_per_split; q.splits = wp.splits;
       const double flops = 2.0 * d->Cout * q.Kg * (double)npix * d->groups;
       const double bytes = 4.0 * ((double)npix * C + (double)d->B * cin_tot * d->H * d->W + (double)C * q.Kg);
-      if (wp.splits > 1 && !defer_wgrad) {
+      if (wp.splits > 1 && !defer_wgrad && !wp.p6) {
         q.counters = counter_region(CNT_WGRAD, cdiv(q.Kg, 64) * cdiv(d->Cout, 64) * d->groups);
         q.final_out = dw;
       }
-      rc = launch_wgrad_patch(q, wp, d->KH, d->KW, d->SW, up2, flops, bytes, ws_stream);
+      rc = wp.p6 ? launch_wgrad_patch6(q, wp, d->KH, d->KW, d->SW, up2, flops, bytes, ws_stream)
+                 : launch_wgrad_patch(q, wp, d->KH, d->KW, d->SW, up2, flops, bytes, ws_stream);
       if (rc) return rc;
       if (wp.splits > 1 && !q.counters && !defer_wgrad) rc = launch_reduce_splits(wg_part, dw, C * q.Kg, wp.splits, ws_stream);
     } else {

@@ -364,6 +364,7 @@ void conv_patch_kernel(const PatchArgs p) {
 // dispatch
 int g_patch_min_wgs = 96;      // below this many workgroups the split-K im2col path is used instead
 int g_patch_force_splitk = 0;   // tuning knob: > 0 forces this split-K factor in the patch kernel
+int g_precision = 0;
 int g_patch_intra = 1;          // tuning knob: intra-workgroup K split for small 1-D k3 layers
 int patch_chunk_channels(int KH, int KW) {
   const int khw = KH * KW;
@@ -371,7 +372,7 @@ int patch_chunk_channels(int KH, int KW) {
 }
 
 PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH, int SW, int B, int OH, int OW, int zmul) {
-  PatchPlan pl = {0, 1, 64, 0, 0, 0, 1, 1 << 30, 1, 2, 1};
+  PatchPlan pl = {0, 1, 64, 0, 0, 0, 1, 1 << 30, 1, 2, 1, 0};
   const int S = SW;
   if (nd == 2 && SH != SW) return pl;
   const bool known = (KH == 1 && KW == 2 && S == 1) || (KH == 2 && KW == 2 && S == 1) || (KH == 1 && KW == 3 && S == 1) ||
@@ -384,16 +385,17 @@ PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH,
   int tw;
   if (nd == 1) tw = OW > 32 ? 64 : OW > 16 ? 32 : 16;
   else tw = OW > 16 ? 32 : 16;
-  const int tm = 1, tn = 1;
+  const bool p6 = g_precision == 1 && patch6_supported(KH, KW, S);   // bf16x6 kernels: 64 x 128 tiles
+  const int tm = 1, tn = p6 ? 2 : 1;
   const int th = 64 * tn / tw;
-  pl.ok = 1; pl.tm = tm; pl.tw = tw; pl.tn = tn;
+  pl.ok = 1; pl.tm = tm; pl.tw = tw; pl.tn = tn; pl.p6 = p6 ? 1 : 0;
   pl.tiles_y = cdiv(rows, th); pl.tiles_x = cdiv(OW, tw);
   pl.n_tiles = imgs * pl.tiles_y * pl.tiles_x;
   const long base = (long)pl.n_tiles * cdiv(Mg, 64 * tm) * groups * zmul;   // zmul: parity classes sharing the launch
   // too few workgroups: the split-K im2col path spreads the weight stream better
-  if (base < g_patch_min_wgs) pl.ok = 0;
+  if (base * tn < g_patch_min_wgs) pl.ok = 0;   // (bf16x6: 128-pixel tiles, half as many workgroups for the same layer)
   // fewer workgroups than 1.5 per CU and a long reduction: slice the channel chunks over workgroups
-  const int nchunks = cdiv(Kc, patch_chunk_channels(KH, KW));
+  const int nchunks = cdiv(Kc, p6 ? 16 : patch_chunk_channels(KH, KW));   // (the bf16x6 kernels step 16 channels)
   if (pl.ok && g_patch_force_splitk > 0 && nchunks >= g_patch_force_splitk) {
     pl.chunks_per_split = cdiv(nchunks, g_patch_force_splitk);
     pl.splitk = cdiv(nchunks, pl.chunks_per_split);
@@ -401,7 +403,7 @@ PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH,
     const long base32 = (long)pl.n_tiles * cdiv(Mg, 32) * groups * zmul;
     // (short reductions only: with a long K -- the 2048-channel data gradient of the first decoder layer -- slices over
     // workgroups keep more of the chip busy: 91 vs 152 us)
-    if (g_patch_intra && KH == 1 && KW == 3 && S == 1 && tw >= 32 && base32 >= 192 && nchunks <= 16) {
+    if (!p6 && g_patch_intra && KH == 1 && KW == 3 && S == 1 && tw >= 32 && base32 >= 192 && nchunks <= 16) {
       // 1-D k3 layers with few tiles: 32-channel tiles, every K chunk split over 4 wave groups INSIDE the workgroup
       // (no partial tiles in HBM, no reduction kernel)
       pl.wm = 1; pl.ksi = 4;
@@ -506,6 +508,14 @@ int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S,
 
 static int g_tuning_epoch = 0;
 extern "C" int ms_tuning_epoch(void) { return g_tuning_epoch; }
+extern "C" int ms_set_precision(int mode) {
+  if (mode != 0 && mode != 1) return ms::set_error("ms_set_precision: mode %d", mode);
+  const int old = ms::g_precision;
+  if (old != mode) ++g_tuning_epoch;
+  ms::g_precision = mode;
+  return old;
+}
+extern "C" int ms_get_precision(void) { return ms::g_precision; }
 
 extern "C" int ms_debug_set_patch_tuning(int intra_split, int force_splitk) {
   ++g_tuning_epoch;

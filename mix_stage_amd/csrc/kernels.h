@@ -76,8 +76,12 @@ struct PatchArgs {
   // per class: padding, output extent, scatter phase; weights of class c start at A + c*cls_a_stride
   int ncls, cls_PH[4], cls_PW[4], cls_OUTH[4], cls_OUTW[4], cls_ry[4], cls_rx[4];
   unsigned cls_a_stride;
+  // bf16x6 kernels (conv_patch6.hip): pre-split weight planes [3][rows][a_row_elems] bf16; cls_a_stride counts ROWS there
+  const unsigned short* Aplanes;
+  unsigned plane_stride;       // elements per plane
+  int a_row_elems;
 };
-struct PatchPlan { int ok, tm, tw, tiles_y, tiles_x, n_tiles, splitk, chunks_per_split, tn, wm, ksi; };   // wm: 32-row wave tiles per tile; ksi: intra-workgroup K split
+struct PatchPlan { int ok, tm, tw, tiles_y, tiles_x, n_tiles, splitk, chunks_per_split, tn, wm, ksi, p6; };   // wm: 32-row wave tiles per tile; ksi: intra-workgroup K split
 PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH, int SW, int B, int OH, int OW, int zmul = 1);
 int patch_chunk_channels(int KH, int KW);
 bool patch_dgrad_direct_ok(const float* w, int Cin_g, int KH, int KW, int SH, int SW, bool up2_or_bcast);
@@ -85,6 +89,20 @@ int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S,
                  hipStream_t s);
 
 extern int g_patch_intra;
+extern int g_precision;        // 0: exact-fp32 MFMA kernels; 1: bf16x6 split-operand kernels where they exist (conv_patch6.hip)
+bool patch6_supported(int KH, int KW, int S);
+int patch6_row_elems(int Kc, int KH, int KW);
+int launch_split_weights(const float* w, unsigned short* planes, int rows, int Kc, int KH, int KW, hipStream_t s);
+struct SplitJob {
+  const float* w;            // [rows][Kc][KHW] fp32
+  unsigned short* planes;    // [3][rows][row_elems] bf16
+  int rows, Kc, KHW, CK, row_elems, block_end;
+};
+enum { SPLIT_BATCH_MAX = 64 };
+struct SplitBatch { int n; SplitJob job[SPLIT_BATCH_MAX]; };
+int launch_split_weights_multi(SplitBatch& sb, hipStream_t s);
+int launch_patch6(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S, bool up2, double flops, double bytes,
+                  hipStream_t s);
 extern int g_patch_min_wgs;   // test knob (ms_debug_set_patch_min_workgroups): 0 forces the patch kernels
 
 // ---- patch-staged weight gradient (wgrad_patch.hip)
@@ -101,7 +119,10 @@ struct WgradPatchArgs {
   int* counters;       // per (group, channel tile, column tile) arrival counters: the last split sums the slabs in-launch
   float* final_out;    // dw, written by the last arriver
 };
-struct WgradPatchPlan { int ok, tw, tiles_y, tiles_x, n_tiles, splits, tiles_per_split; };
+struct WgradPatchPlan { int ok, tw, tiles_y, tiles_x, n_tiles, splits, tiles_per_split, p6; };
+bool wgrad6_supported(int KH, int KW, int S);
+int launch_wgrad_patch6(const WgradPatchArgs& a, const WgradPatchPlan& pl, int KH, int KW, int S, bool up2, double flops,
+                        double bytes, hipStream_t s);
 WgradPatchPlan plan_wgrad_patch(int nd, int Cog, int Kg, int groups, int KH, int KW, int SH, int SW, int B, int OH, int OW);
 int launch_wgrad_patch(const WgradPatchArgs& a, const WgradPatchPlan& pl, int KH, int KW, int S, bool up2, double flops,
                        double bytes, hipStream_t s);

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void wgrad_patch_kernel(const WgradPatchArgs p
 
 // ---------------------------------------------------------------------------------------------
 WgradPatchPlan plan_wgrad_patch(int nd, int Cog, int Kg, int groups, int KH, int KW, int SH, int SW, int B, int OH, int OW) {
-  WgradPatchPlan pl = {0, 64, 0, 0, 0, 1, 0};
+  WgradPatchPlan pl = {0, 64, 0, 0, 0, 1, 0, 0};
   const int S = SW;
   if (nd == 2 && SH != SW) return pl;
   const bool known = (KH == 1 && KW == 3 && S == 1) || (KH == 1 && KW == 4 && S == 2) || (KH == 1 && KW == 4 && S == 1) ||
@@ -189,9 +189,11 @@ WgradPatchPlan plan_wgrad_patch(int nd, int Cog, int Kg, int groups, int KH, int
   pl.tiles_y = cdiv(rows, th); pl.tiles_x = cdiv(OW, pl.tw);
   pl.n_tiles = imgs * pl.tiles_y * pl.tiles_x;
   if (pl.n_tiles < (g_patch_min_wgs > 0 ? 4 : 1)) return pl;
-  const long base = (long)cdiv(Cog, 64) * cdiv(Kg, 64) * groups;
+  pl.p6 = (g_precision == 1 && wgrad6_supported(KH, KW, S)) ? 1 : 0;     // bf16x6 kernel: 64 x 128 tiles
+  const long base = (long)cdiv(Cog, 64) * cdiv(Kg, pl.p6 ? 128 : 64) * groups;
   int splits = 1;
   if (base < 512) splits = (int)((512 + base - 1) / base);
+  if (pl.p6 && base < 512) splits = std::max(1, (int)(512 / base));   // 2 workgroups per CU: stay within one round of 512
   splits = std::min(splits, std::max(1, pl.n_tiles / 4));      // at least 4 pixel tiles (128 k-pairs) per split
   pl.tiles_per_split = cdiv(pl.n_tiles, splits);
   pl.splits = cdiv(pl.n_tiles, pl.tiles_per_split);

@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import (BwdOptions, ConvDesc, MS_BARE, MS_BN_EVAL, MS_BN_TRAIN, MS_IN_BCAST, MS_IN_PLAIN,
+from ._lib import (BwdOptions, ConvDesc, FwdOptions, MS_BARE, MS_BN_EVAL, MS_BN_TRAIN, MS_IN_BCAST, MS_IN_PLAIN,
                    MS_IN_UP2ADD, MS_LRELU, check, lib)
 
 _vp = ctypes.c_void_p
@@ -61,9 +61,14 @@ def workspace(nbytes, device):
   ws = _workspaces.get(key)
   if ws is None or ws.numel() < nbytes:
     size = max(int(nbytes * 1.5), 1 << 22)
+    if ws is not None:
+      _retired_workspaces.append(ws)       # captured HIP graphs may still launch kernels that point into it
     ws = torch.empty(size, dtype=torch.uint8, device=device)
     _workspaces[key] = ws
   return ws
+
+
+_retired_workspaces = []
 
 
 _side_workspaces = {}
@@ -131,29 +136,37 @@ def _prepare_entries(entries):
   if not entries:
     return
   L = lib()
-  n = len(entries)
-  descs = (ConvDesc * n)(*[e['d'] for e in entries])
-  ws = (ctypes.c_void_p * n)(*[e['w'].data_ptr() for e in entries])
-  wts = (ctypes.c_void_p * n)(*[e['wt'].data_ptr() for e in entries])
-  check(L.ms_dgrad_weights_prepare(n, descs, ws, wts, _stream()), 'ms_dgrad_weights_prepare')
   tune = L.ms_tuning_epoch()
-  for e in entries:
-    e['version'], e['tune'] = e['w']._version, tune
+  for kind, fn in (('dgrad', L.ms_dgrad_weights_prepare), ('fwd', L.ms_fwd_weights_prepare)):
+    es = [e for e in entries if e['kind'] == kind]
+    if not es:
+      continue
+    n = len(es)
+    descs = (ConvDesc * n)(*[e['d'] for e in es])
+    ws = (ctypes.c_void_p * n)(*[e['w'].data_ptr() for e in es])
+    outs = (ctypes.c_void_p * n)(*[e['wt'].data_ptr() for e in es])
+    check(fn(n, descs, ws, outs, _stream()), 'ms_%s_weights_prepare' % kind)
+    for e in es:
+      e['version'], e['tune'] = e['w']._version, tune
 
 
-def _prepared_for(w, d):
-  """The block's prepared buffer (None: not needed / feature off).  Builds or rebuilds it when w was modified in place
-  by anything torch knows about (w._version) or a tuning knob moved."""
+def _prepared_for(w, d, kind='dgrad'):
+  """The block's prepared buffer (None: not needed / feature off): kind 'dgrad' = the transposed (class-split) copy of w for
+  the data gradient (+ its bf16 planes in bf16x6 mode), kind 'fwd' = the bf16 planes of w (bf16x6 mode only).  Builds or
+  rebuilds it when w was modified in place by anything torch knows about (w._version) or a tuning knob moved."""
   if not _prepared['on']:
     return None
   L = lib()
-  key = (w.data_ptr(), id(d))
+  key = (w.data_ptr(), id(d), kind)
   tune = L.ms_tuning_epoch()
   e = _prepared['entries'].get(key)
   if e is None or e['tune'] != tune:
-    n = L.ms_dgrad_weights_elems(ctypes.byref(d), _ptr(w))
+    if kind == 'dgrad':
+      n = L.ms_dgrad_weights_elems(ctypes.byref(d), _ptr(w))           # floats
+    else:
+      n = (L.ms_fwd_weights_bytes(ctypes.byref(d)) + 3) // 4           # bytes -> floats
     if e is None:
-      e = dict(w=w, d=d, n=0, wt=None, version=-1, tune=-1)
+      e = dict(w=w, d=d, n=0, wt=None, version=-1, tune=-1, kind=kind)
       _prepared['entries'][key] = e
       _prepared['by_storage'].setdefault(w.untyped_storage().data_ptr(), []).append(e)
     if n != e['n']:
@@ -270,10 +283,14 @@ class ConvGeom:
         raise RuntimeError('conv block: input (%d,%d) too small for kernel (%d,%d)' % (H, W, self.KH, self.KW))
       d = ConvDesc(B, Cin_g, H, W, Cout_g, self.groups, self.KH, self.KW, self.SH, self.SW, self.PH, self.PW,
                    OH, OW, mode, in_mode, self.slope, self.eps, self.momentum, 0)
-      L = lib()
+      d._tune = -1
+      self._cache[key] = d
+    L = lib()
+    tune = L.ms_tuning_epoch()
+    if d._tune != tune:          # scratch needs follow the kernel choice (precision mode, test knobs)
       d._fwd_ws = L.ms_conv_block_fwd_workspace(ctypes.byref(d))
       d._bwd_ws = L.ms_conv_block_bwd_workspace(ctypes.byref(d))
-      self._cache[key] = d
+      d._tune = tune
     return d
 
 
@@ -318,9 +335,16 @@ class _ConvBlockFn(torch.autograd.Function):
       y_raw = torch.empty_like(y)
       save = torch.empty(4 * ctot, dtype=torch.float32, device=x.device)
     ws = workspace(d._fwd_ws, x.device)
-    check(lib().ms_conv_block_fwd(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(bias), _ptr(gamma), _ptr(beta),
-                                  _ptr(rm), _ptr(rv), _ptr(y_raw), _ptr(y), _ptr(save), _ptr(ws), ws.numel(),
-                                  _stream()), 'ms_conv_block_fwd')
+    planes = _prepared_for(w, d, 'fwd')
+    if planes is not None:
+      opt = FwdOptions(planes.data_ptr())
+      check(lib().ms_conv_block_fwd_ex(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(bias), _ptr(gamma), _ptr(beta),
+                                       _ptr(rm), _ptr(rv), _ptr(y_raw), _ptr(y), _ptr(save), _ptr(ws), ws.numel(),
+                                       _stream(), ctypes.byref(opt)), 'ms_conv_block_fwd_ex')
+    else:
+      check(lib().ms_conv_block_fwd(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(bias), _ptr(gamma), _ptr(beta),
+                                    _ptr(rm), _ptr(rv), _ptr(y_raw), _ptr(y), _ptr(save), _ptr(ws), ws.numel(),
+                                    _stream()), 'ms_conv_block_fwd')
     ctx.geom_desc = d
     ctx.mode, ctx.in_mode = mode, in_mode
     ctx.has_bias = bias is not None

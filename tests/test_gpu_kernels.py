@@ -304,3 +304,37 @@ def test_cpu_tensor_fails_loudly():
     ops.velocity_cm(torch.zeros(1, 4, 3))
   with pytest.raises(TypeError):
     ops.velocity_cm(torch.zeros(1, 4, 3, dtype=torch.float64, device=DEV))
+
+
+def test_bf16x6_mode_matches_fp32_accuracy():
+  """ms_set_precision(1): the patch-staged kernels run on the bf16 matrix pipe with both operands split exactly into three
+  bf16 parts (6 of 9 partial products, fp32 accumulation).  Its error against fp64 must stay at the fp32 kernels' level --
+  for the forward, the data gradient (stride 1, stride 2 classes, grouped) and the weight gradient."""
+  from mix_stage_amd import _lib, ops
+  from mix_stage_amd._lib import MS_BARE
+  L = _lib.lib()
+  geoms = [(4, 256, 256, 64, 3, 1, 1, 1), (2, 256, 104, 64, 3, 1, 1, 8), (4, 64, 128, 32, 4, 2, 1, 1), (3, 6, 10, 37, 4, 2, 1, 1),
+           (2, 256, 104, 64, 1, 1, 0, 1)]
+  old_wg = L.ms_debug_set_patch_min_workgroups(0)
+  try:
+    for B, cin, cout, T, k, s, p, groups in geoms:
+      gen = torch.Generator().manual_seed(7)
+      x = torch.randn(B, cin, T, generator=gen).to(DEV).requires_grad_()
+      w = (torch.randn(cout, cin // groups, k, generator=gen) * 0.1).to(DEV).requires_grad_()
+      b = torch.randn(cout, generator=gen).to(DEV).requires_grad_()
+      geom = ops.ConvGeom(1, groups, k, s, p)
+      ref = F.conv1d(x.double(), w.double(), b.double(), stride=s, padding=p, groups=groups)
+      gy = torch.randn(ref.shape, generator=torch.Generator().manual_seed(8), dtype=torch.float64).to(DEV)
+      assert ref.is_cuda
+      gx_ref, gw_ref = torch.autograd.grad(ref, (x, w), gy)
+      errs = {}
+      for mode in (0, 1):
+        L.ms_set_precision(mode)
+        y = ops.conv_block(x, w, b, geom, MS_BARE)
+        gx, gw = torch.autograd.grad(y, (x, w), gy.float())
+        errs[mode] = [rel_err(y, ref), rel_err(gx, gx_ref), rel_err(gw, gw_ref)]
+      for e0, e1 in zip(errs[0], errs[1]):
+        assert e1 < 2e-5 and e1 < 3 * e0 + 1e-7, (errs, (B, cin, cout, T, k, s, groups))
+  finally:
+    L.ms_set_precision(0)
+    L.ms_debug_set_patch_min_workgroups(old_wg)
