@@ -395,11 +395,11 @@ PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH,
   // too few workgroups: the split-K im2col path spreads the weight stream better
   if (base * tn < g_patch_min_wgs) pl.ok = 0;   // (bf16x6: 128-pixel tiles, half as many workgroups for the same layer)
   // fewer workgroups than 1.5 per CU and a long reduction: slice the channel chunks over workgroups
-  const int nchunks = cdiv(Kc, p6 ? 16 : patch_chunk_channels(KH, KW));   // (the bf16x6 kernels step 16 channels)
+  const int nchunks = cdiv(Kc, p6 ? (KH * KW <= 4 ? 16 : 8) : patch_chunk_channels(KH, KW));   // (bf16x6: 16 / 8 channels)
   if (pl.ok && g_patch_force_splitk > 0 && nchunks >= g_patch_force_splitk) {
     pl.chunks_per_split = cdiv(nchunks, g_patch_force_splitk);
     pl.splitk = cdiv(nchunks, pl.chunks_per_split);
-  } else if (pl.ok && base < 384 && nchunks >= 4) {
+  } else if (pl.ok && base < (p6 ? 192 : 384) && nchunks >= 4) {   // (bf16x6: 128-pixel tiles, 2 workgroups per CU)
     const long base32 = (long)pl.n_tiles * cdiv(Mg, 32) * groups * zmul;
     // (short reductions only: with a long K -- the 2048-channel data gradient of the first decoder layer -- slices over
     // workgroups keep more of the chip busy: 91 vs 152 us)

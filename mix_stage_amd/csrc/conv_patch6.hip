@@ -37,9 +37,9 @@ constexpr int p6_nkb(int khw) { return (p6_nhb(khw) + 1) / 2; }         // 16-de
 bool patch6_supported(int KH, int KW, int S) {
   const int khw = KH * KW;
   const bool known = (KH == 1 && KW == 2 && S == 1) || (KH == 2 && KW == 2 && S == 1) || (KH == 1 && KW == 3 && S == 1) ||
-                     (KH == 1 && KW == 4 && S == 2) || (KH == 1 && KW == 4 && S == 1) || (KH == 1 && KW == 1 && S == 1) ||
-                     (KH == 3 && KW == 3 && S == 1);
-  return known && khw <= 4;   // 3x3 and larger: the split weight planes of a chunk do not leave room for 2 workgroups per CU yet
+                     (KH == 1 && KW == 4 && S == 1) || (KH == 1 && KW == 1 && S == 1) ||
+                     (KH == 3 && KW == 3 && S == 1) || (KH == 4 && KW == 4 && S == 2);   // (k1x4 s2: 89 KB of LDS -> fp32 kernel)
+  return known;   // (3x8: 77 KB of weight planes per chunk -- stays on the fp32 kernel)
 }
 int patch6_row_elems(int Kc, int KH, int KW) {
   const int khw = KH * KW;
@@ -156,12 +156,14 @@ __global__ __launch_bounds__(256, 2) void conv_patch6_kernel(const PatchArgs p) 
   constexpr int SLOTS = NKB * 2;                        // 16-byte slots per row and plane
   constexpr int NAV = 3 * BM * SLOTS, NA = (NAV + 255) / 256;
   constexpr int LP = BN + 4;                            // pitch of the epilogue's [channel][pixel] tile
-  constexpr int SMEM_BYTES = 2 * A_STAGE * 2 + 2 * P_STAGE * 4;
+  // taps > 4: one LDS stage (the three weight planes of a chunk take 34-52 KB), two barriers per chunk; else double-buffered
+  constexpr int NST = KHW > 4 ? 1 : 2;
+  constexpr int SMEM_BYTES = NST * A_STAGE * 2 + NST * P_STAGE * 4;
   static_assert(SMEM_BYTES >= BM * LP * 4, "epilogue tile does not fit");
   static_assert(BN % TW == 0, "bad tile");
   __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
   unsigned short* sA = reinterpret_cast<unsigned short*>(smem_raw);
-  float* sP = reinterpret_cast<float*>(smem_raw + 2 * A_STAGE * 2);
+  float* sP = reinterpret_cast<float*>(smem_raw + NST * A_STAGE * 2);
 
   const int t = threadIdx.x, lane = t & 63, wn = t >> 6, kb = lane >> 5;
   const int vid = xcd_remap(blockIdx.x, p.gx * p.gy * p.gz);
@@ -283,20 +285,35 @@ __global__ __launch_bounds__(256, 2) void conv_patch6_kernel(const PatchArgs p) 
       }
     }
   };
-  load_chunk(chunk_beg, ra0, rb0);
-  if (nchunks > 1) load_chunk(chunk_beg + 1, ra1, rb1);
-  store_chunk(0, ra0, rb0);
-  __syncthreads();
-  for (int ch = 0; ch < nchunks; ch += 2) {
-    if (ch + 2 < nchunks) load_chunk(chunk_beg + ch + 2, ra0, rb0);
-    compute_chunk(0);
-    if (ch + 1 < nchunks) store_chunk(1, ra1, rb1);
+  if (NST == 2) {
+    load_chunk(chunk_beg, ra0, rb0);
+    if (nchunks > 1) load_chunk(chunk_beg + 1, ra1, rb1);
+    store_chunk(0, ra0, rb0);
     __syncthreads();
-    if (ch + 1 >= nchunks) break;
-    if (ch + 3 < nchunks) load_chunk(chunk_beg + ch + 3, ra1, rb1);
-    compute_chunk(1);
-    if (ch + 2 < nchunks) store_chunk(0, ra0, rb0);
+    for (int ch = 0; ch < nchunks; ch += 2) {
+      if (ch + 2 < nchunks) load_chunk(chunk_beg + ch + 2, ra0, rb0);
+      compute_chunk(0);
+      if (ch + 1 < nchunks) store_chunk(1, ra1, rb1);
+      __syncthreads();
+      if (ch + 1 >= nchunks) break;
+      if (ch + 3 < nchunks) load_chunk(chunk_beg + ch + 3, ra1, rb1);
+      compute_chunk(1);
+      if (ch + 2 < nchunks) store_chunk(0, ra0, rb0);
+      __syncthreads();
+    }
+  } else {
+    load_chunk(chunk_beg, ra0, rb0);
+    store_chunk(0, ra0, rb0);
     __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+      if (ch + 1 < nchunks) load_chunk(chunk_beg + ch + 1, ra0, rb0);     // in flight while this chunk computes
+      compute_chunk(0);
+      __syncthreads();
+      if (ch + 1 < nchunks) {
+        store_chunk(0, ra0, rb0);
+        __syncthreads();
+      }
+    }
   }
 
   // ---------------- epilogue ----------------
@@ -421,7 +438,8 @@ int launch_patch6(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S
   else if (KH == 1 && KW == 1 && S == 1) launch_p6_tw<1, 1, 1, false>(b, pl.tw, grid, s);
   else if (KH == 1 && KW == 2 && S == 1) launch_p6_tw<1, 2, 1, false>(b, pl.tw, grid, s);
   else if (KH == 2 && KW == 2 && S == 1) launch_p6_tw<2, 2, 1, false>(b, pl.tw, grid, s);
-  else launch_p6_tw<3, 3, 1, false>(b, pl.tw, grid, s);
+  else if (KH == 3 && KW == 3 && S == 1) launch_p6_tw<3, 3, 1, false>(b, pl.tw, grid, s);
+  else launch_p6_tw<4, 4, 2, false>(b, pl.tw, grid, s);
   return check_launch("conv_patch6_kernel");
 }
 
@@ -442,7 +460,7 @@ constexpr int pitch_mod32_6(int at_least, int want_mod) {
 }
 
 template <int KH, int KW, int S, int TW, bool UP2>
-__global__ __launch_bounds__(256, 2) void wgrad_patch6_kernel(const WgradPatchArgs p) {
+__global__ __launch_bounds__(256, 3) void wgrad_patch6_kernel(const WgradPatchArgs p) {
   constexpr int BM = 64, BN = 128, NPIX = 64, TH = NPIX / TW;
   constexpr int SV = (KH == 1) ? 1 : S;
   constexpr int KHW = KH * KW;
@@ -456,8 +474,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch6_kernel(const WgradPatchAr
   constexpr int NA = BM * (NPIX / 8) / 256;              // 8-pixel slots of the dy tile per thread (= 2)
   constexpr int NKB = NPIX / 16;                         // 16-pixel MFMA k-blocks per tile
   static_assert(TW % 8 == 0 && NA * 256 == BM * (NPIX / 8), "bad wgrad6 configuration");
-  __shared__ __attribute__((aligned(16))) unsigned short sA[2 * A_STAGE];
-  __shared__ float sP[2 * P_STAGE];
+  // ONE LDS stage (the next tile waits in registers; two barriers per 48-MFMA tile step): 40-45 KB, three workgroups per CU
+  __shared__ __attribute__((aligned(16))) unsigned short sA[A_STAGE];
+  __shared__ float sP[P_STAGE];
 
   const int t = threadIdx.x, lane = t & 63, wn = t >> 6, kb = lane >> 5;
   const int vid = xcd_remap(blockIdx.x, p.gx * p.gy * p.gz);
@@ -518,9 +537,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch6_kernel(const WgradPatchAr
       else rb[i] = buf_load(rsS, ok ? 4u * (unsigned)(o + ix) : BUF_OOB, 0);
     }
   };
-  auto store_tile = [&](int buf) {
-    unsigned short* As = sA + buf * A_STAGE;
-    float* Ps = sP + buf * P_STAGE;
+  auto store_tile = [&]() {
+    unsigned short* As = sA;
+    float* Ps = sP;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       bf16x8 h, m, l;
@@ -551,14 +570,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch6_kernel(const WgradPatchAr
   const int nsteps = tile_end - tile_beg;
   if (nsteps > 0) {
     load_tile(tile_beg);
-    store_tile(0);
+    store_tile();
   }
   __syncthreads();
   for (int st = 0; st < nsteps; ++st) {
-    const int cur = st & 1;
     if (st + 1 < nsteps) load_tile(tile_beg + st + 1);
-    const unsigned short* As = sA + cur * A_STAGE;
-    const float* Ps = sP + cur * P_STAGE;
+    const unsigned short* As = sA;
+    const float* Ps = sP;
 #pragma unroll
     for (int b = 0; b < NKB; ++b) {
       // pixels b*16 + kb*8 + j of the tile: row (b*16)/TW, columns (b*16)%TW + kb*8 + j
@@ -581,8 +599,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_patch6_kernel(const WgradPatchAr
         acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mi], 0, 0, 0);
       }
     }
-    if (st + 1 < nsteps) store_tile(cur ^ 1);
     __syncthreads();
+    if (st + 1 < nsteps) {
+      store_tile();
+      __syncthreads();
+    }
   }
 
   float* outp = p.out + (size_t)sp * ctot * p.Kg;
@@ -612,7 +633,8 @@ static void launch_wg6_tw(const WgradPatchArgs& a, int tw, dim3 grid, hipStream_
 
 bool wgrad6_supported(int KH, int KW, int S) {
   // (the others would need > 80 KB of LDS per workgroup with these tiles: they stay on the fp32 kernel)
-  return (KH == 1 && KW == 3 && S == 1) || (KH == 3 && KW == 3 && S == 1) || (KH == 3 && KW == 8 && S == 1);
+  return (KH == 1 && KW == 3 && S == 1) || (KH == 3 && KW == 3 && S == 1) || (KH == 3 && KW == 8 && S == 1) ||
+         (KH == 4 && KW == 4 && S == 2);
 }
 
 int launch_wgrad_patch6(const WgradPatchArgs& a, const WgradPatchPlan& pl, int KH, int KW, int S, bool up2, double flops,
@@ -628,6 +650,7 @@ int launch_wgrad_patch6(const WgradPatchArgs& a, const WgradPatchPlan& pl, int K
     if (up2) launch_wg6_tw<1, 3, 1, true>(b, pl.tw, grid, s);
     else launch_wg6_tw<1, 3, 1, false>(b, pl.tw, grid, s);
   } else if (KH == 3 && KW == 3 && S == 1) launch_wg6_tw<3, 3, 1, false>(b, pl.tw, grid, s);
+  else if (KH == 4 && KW == 4 && S == 2) launch_wg6_tw<4, 4, 2, false>(b, pl.tw, grid, s);
   else launch_wg6_tw<3, 8, 1, false>(b, pl.tw, grid, s);
   return check_launch("wgrad_patch6_kernel");
 }

@@ -193,7 +193,7 @@ WgradPatchPlan plan_wgrad_patch(int nd, int Cog, int Kg, int groups, int KH, int
   const long base = (long)cdiv(Cog, 64) * cdiv(Kg, pl.p6 ? 128 : 64) * groups;
   int splits = 1;
   if (base < 512) splits = (int)((512 + base - 1) / base);
-  if (pl.p6 && base < 512) splits = std::max(1, (int)(512 / base));   // 2 workgroups per CU: stay within one round of 512
+  if (pl.p6 && base < 768) splits = std::max(1, (int)(768 / base));   // 3 workgroups per CU: stay within one round of 768
   splits = std::min(splits, std::max(1, pl.n_tiles / 4));      // at least 4 pixel tiles (128 k-pairs) per split
   pl.tiles_per_split = cdiv(pl.n_tiles, splits);
   pl.splits = cdiv(pl.n_tiles, pl.tiles_per_split);

@@ -37,3 +37,25 @@ run(2, 256, 104, 64, 3, 1, 1, 8)
 run(4, 256, 256, 64, 3, 1, 1, 1)
 run(4, 64, 128, 32, 4, 2, 1, 1)
 run(3, 6, 10, 37, 4, 2, 1, 1)
+
+def run2d(B, cin, cout, H, W, k, s, p):
+  torch.manual_seed(0)
+  x = torch.randn(B, cin, H, W, device=dev, requires_grad=True)
+  w = (torch.randn(cout, cin, k, k, device=dev) * 0.1).requires_grad_()
+  b = torch.randn(cout, device=dev, requires_grad=True)
+  geom = ops.ConvGeom(2, 1, k, s, p)
+  ref = F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=p)
+  gy = torch.randn_like(ref)
+  gx_ref, gw_ref = torch.autograd.grad(ref, (x, w), gy)
+  res = {}
+  for mode in (0, 1):
+    L.ms_set_precision(mode); L.ms_debug_set_patch_min_workgroups(0)
+    y = ops.conv_block(x, w, b, geom, MS_BARE)
+    gx, gw = torch.autograd.grad(y, (x, w), gy.float())
+    res[mode] = [((a.double() - r).abs().max() / r.abs().max()).item() for a, r in ((y, ref), (gx, gx_ref), (gw, gw_ref))]
+  print('2d B%d cin%d cout%d %dx%d k%d s%d : fp32 %s   bf16x6 %s' % (B, cin, cout, H, W, k, s, ['%.1e' % v for v in res[0]], ['%.1e' % v for v in res[1]]))
+run2d(2, 64, 128, 16, 32, 3, 1, 1)
+run2d(2, 5, 7, 9, 37, 3, 1, 1)
+run2d(2, 64, 64, 32, 48, 4, 2, 1)
+run2d(2, 5, 7, 9, 37, 4, 2, 1)
+run2d(2, 256, 256, 16, 32, 4, 2, 1)
