@@ -190,11 +190,19 @@ def drop_trainer_caches(storage_ptrs):
   _deferred['bufs'] = {k: v for k, v in _deferred['bufs'].items() if v[2] not in storage_ptrs}
 
 
-def refresh_prepared_weights(flat_params):
+def refresh_prepared_weights(flat_params, start=0):
   """Rebuild every prepared buffer whose weight lives in `flat_params`' storage: one launch (per 48 blocks).  Call after
-  each update of that storage that torch cannot see (the HIP Adam kernels write through raw pointers)."""
+  each update of that storage that torch cannot see (the HIP Adam kernels write through raw pointers).  start: skip the
+  first `start` buffers of that storage (those a captured graph already rebuilds, see prepared_count)."""
   if _prepared['on']:
-    _prepare_entries(_prepared['by_storage'].get(flat_params.untyped_storage().data_ptr(), ()))
+    _prepare_entries(_prepared['by_storage'].get(flat_params.untyped_storage().data_ptr(), ())[start:])
+
+
+def prepared_count(flat_params):
+  """Number of prepared buffers registered for this storage so far (the list only grows): a graph captured now rebuilds
+  exactly these; buffers that appear later (another step kind runs other blocks of the same network) need an eager
+  refresh_prepared_weights(flat_params, start=count) after each replay."""
+  return len(_prepared['by_storage'].get(flat_params.untyped_storage().data_ptr(), ()))
 
 
 # ------------------------------------------------------------------------------------------------

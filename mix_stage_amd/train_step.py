@@ -284,6 +284,8 @@ class MixStageTrainStep:
       self._all_reduce(opt)
       entry['opt'].replay()
     opt.host_step += 1
+    # prepared weights that did not exist when this graph was captured (blocks only the other step kind runs)
+    ops.refresh_prepared_weights(opt.flat_p, start=entry['n_prepared'])
     self.fake_pose, self.losses = entry['fake'], entry['losses']
 
   def _capture(self, key, k, st, opt):
@@ -331,7 +333,8 @@ class MixStageTrainStep:
       g2 = torch.cuda.CUDAGraph()
       with torch.cuda.graph(g2, capture_error_mode=mode):
         opt.clip_and_step(count=False)
-    entry = dict(fwd_bwd=g1, opt=g2, fake=fake, losses=losses, bn_tape=tape, active=active)
+    entry = dict(fwd_bwd=g1, opt=g2, fake=fake, losses=losses, bn_tape=tape, active=active,
+                 n_prepared=ops.prepared_count(opt.flat_p))
     self._graphs[key] = entry
     return entry
 

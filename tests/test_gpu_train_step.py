@@ -209,3 +209,29 @@ def test_prepared_dgrad_weights_and_deferred_wgrad_reductions_change_nothing():
     got = run(True, use_graphs)
     assert got[2] > 0 and got[3] > 0, 'no block used prepared weights / deferred reductions'
     assert torch.equal(got[0], base[0]) and torch.equal(got[1], base[1]), 'prepared weights changed the result'
+
+
+@pytest.mark.parametrize('precision', [0, 1], ids=['fp32', 'bf16x6'])
+def test_prepared_weights_created_after_a_graph_was_captured(precision):
+  """A step kind captured first cannot rebuild prepared buffers that only appear later (D's data-gradient weights for the
+  G-step's batch shape, G's forward planes for blocks only the D-step runs): they are refreshed eagerly after each replay.
+  D-first order, graph replay vs eager, bit for bit, in both arithmetic modes."""
+  from mix_stage_amd import _lib
+  from mix_stage_amd.train_step import MixStageTrainStep
+  M = S = 4
+  batches = [O.synthetic_batch(4, M=M, S=S, seed=90 + i) for i in range(6)]
+  kinds = ['D', 'G', 'D', 'G', 'G', 'D']
+  old = _lib.lib().ms_set_precision(precision)
+  try:
+    out = {}
+    for use_graphs in (False, True):
+      torch.manual_seed(11)
+      model = _hip(M, S)
+      ts = MixStageTrainStep(model, use_graphs=use_graphs)
+      for (audio, pose, labels, style), k in zip(batches, kinds):
+        ts.step(audio.to(DEV), labels.to(DEV), pose.to(DEV), style.to(DEV), kind=k)
+      torch.cuda.synchronize()
+      out[use_graphs] = (ts.optim_G.flat_p.clone(), ts.optim_D.flat_p.clone())
+    assert torch.equal(out[False][0], out[True][0]) and torch.equal(out[False][1], out[True][1])
+  finally:
+    _lib.lib().ms_set_precision(old)
