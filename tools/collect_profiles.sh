@@ -15,3 +15,9 @@ cp $OUT/stats/*/*kernel_stats.csv $OUT/kernel_stats.csv
 # keep the merge small: drop the raw traces
 rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write
 cut -c1-400 $OUT/bench.json
+# the opt-in bf16x6 arithmetic mode: bench line + kernel stats
+cd $R && python bench.py --precision bf16x6 --no-cpu-baseline > $OUT/bench_bf16x6_full.log 2>&1
+grep -o '{"metric.*' $OUT/bench_bf16x6_full.log > $OUT/bench_bf16x6.json
+cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats6 -- python3 $R/bench.py --precision bf16x6 --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1
+cp $OUT/stats6/*/*kernel_stats.csv $OUT/kernel_stats_bf16x6.csv; rm -rf $OUT/stats6
+cut -c1-200 $OUT/bench_bf16x6.json
