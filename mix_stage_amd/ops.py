@@ -72,22 +72,6 @@ _retired_workspaces = []
 
 
 _side_workspaces = {}
-_counters = {}
-# In-launch "last arriver" reduction of split-K / split-pixel slabs (ms_set_counter_buffer).  Correct and bitwise
-# reproducible, but measured SLOWER on MI355X (5609 vs 6878 clips/s): every workgroup pays an agent-scope release fence
-# (L2 write-back, 2-6 us) at its tail, more than the ~5 us reduce kernel it saves.  Off.
-USE_IN_LAUNCH_SPLIT_REDUCTION = False
-
-
-def _ensure_counters(device):
-  """Persistent zeroed arrival counters for the in-launch split reductions (ms_set_counter_buffer)."""
-  key = (device.type, device.index)
-  if key not in _counters:
-    buf = torch.zeros(1 << 16, dtype=torch.int32, device=device)
-    check(lib().ms_set_counter_buffer(_ptr(buf), buf.numel()), 'ms_set_counter_buffer')
-    _counters[key] = buf
-  return _counters[key]
-
 
 
 def side_workspace(nbytes, device):
