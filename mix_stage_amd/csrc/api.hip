@@ -65,6 +65,10 @@ size_t ms_conv_block_fwd_workspace(const ms_conv_desc* d) {
     bytes = std::max(bytes, align_up((size_t)pp.n_tiles * ctot_of(d) * 2 * sizeof(float), 256) + (size_t)pp.n_tiles * sizeof(float));
   if (pp.ok && (pp.splitk > 1 || pp.ksi > 1)) bytes = std::max(bytes, (size_t)pp.splitk * npix * ctot_of(d) * sizeof(float));
   if (pl.splitk > 1) bytes = std::max(bytes, (size_t)pl.splitk * npix * ctot_of(d) * sizeof(float));
+  if (conv_c1_ok(d->groups, d->Cin, d->Cout, d->KH, d->KW, d->SH, d->SW, d->PH, d->PW, d->H, d->in_mode == MS_IN_PLAIN)) {
+    const int nt = conv_c1_tiles(d->B, d->H, d->W);
+    bytes = std::max(bytes, align_up((size_t)nt * ctot_of(d) * 2 * sizeof(float), 256) + (size_t)nt * sizeof(float));
+  }
   bytes = align_up(bytes, 256) + 256;
   if (pp.ok && pp.p6) bytes += align_up((size_t)3 * ctot_of(d) * patch6_row_elems(d->Cin, d->KH, d->KW) * 2, 256);   // split weights
   return bytes;
@@ -133,6 +137,21 @@ int ms_conv_block_fwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
   a.a_vec = (a.Kg % 4 == 0) && (((uintptr_t)w & 15) == 0);
   a.ep = d->mode == MS_BARE ? EP_BARE : d->mode == MS_LRELU ? EP_LRELU : d->mode == MS_BN_EVAL ? EP_BN_EVAL : EP_RAW_STATS;
   a.slope = d->slope; a.eps = d->eps;
+  if (conv_c1_ok(d->groups, d->Cin, d->Cout, d->KH, d->KW, d->SH, d->SW, d->PH, d->PW, d->H, d->in_mode == MS_IN_PLAIN)) {
+    // one input channel (the AudioEncoder's first block): VALU kernel bound by the output write
+    const int nt = conv_c1_tiles(d->B, d->H, d->W);
+    float* stats = (float*)workspace;
+    float* counts = (float*)((char*)workspace + align_up((size_t)nt * C * 2 * sizeof(float), 256));
+    rc = launch_conv_c1(x, w, bias, a.out, gamma, beta, running_mean, running_var, stats, counts, d->B, d->H, d->W, a.ep, d->slope,
+                        d->eps, s);
+    if (rc) return rc;
+    if (d->mode == MS_BN_TRAIN) {
+      rc = launch_bn_finalize(stats, counts, nt, 0, npix, C, gamma, beta, running_mean, running_var, save, d->eps, d->momentum, s);
+      if (rc) return rc;
+      rc = launch_bn_apply(y_raw, y, save, C, hw, (size_t)npix * C, d->slope, s);
+    }
+    return rc;
+  }
   const PatchPlan pp = fwd_patch_plan(d);
   if (pp.ok) {
     // rows >= 16 wide: patch-staged kernel (raw input patch in LDS, no im2col address math in the K loop)

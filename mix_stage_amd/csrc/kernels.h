@@ -88,6 +88,12 @@ bool patch_dgrad_direct_ok(const float* w, int Cin_g, int KH, int KW, int SH, in
 int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S, bool up2, double flops, double bytes,
                  hipStream_t s);
 
+// single-input-channel 3x3 conv on the VALU (conv_c1.hip)
+bool conv_c1_ok(int groups, int Cin, int Cout, int KH, int KW, int SH, int SW, int PH, int PW, int H, int in_plain);
+int conv_c1_tiles(int B, int H, int W);
+int launch_conv_c1(const float* x, const float* w, const float* bias, float* out, const float* bn_g, const float* bn_b,
+                   const float* bn_m, const float* bn_v, float* stats, float* counts, int B, int H, int W, int ep, float slope,
+                   float eps, hipStream_t s);
 extern int g_patch_intra;
 extern int g_precision;        // 0: exact-fp32 MFMA kernels; 1: bf16x6 split-operand kernels where they exist (conv_patch6.hip)
 bool patch6_supported(int KH, int KW, int S);
