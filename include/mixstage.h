@@ -259,7 +259,7 @@ size_t ms_reduce_partials_count(size_t n); /* floats needed in `partials` of ms_
 int ms_timing_enable(int on);
 size_t ms_timing_report(char* buf, size_t cap);
 
-/* Test aid: the patch-staged conv kernel is used when a launch has at least this many workgroups (default 96);
+/* Test aid: the patch-staged conv kernel is used when a launch has at least this many workgroups (default 32);
  * tests set 0 to exercise it at small sizes.  Returns the previous value. */
 int ms_debug_set_patch_min_workgroups(int n);
 /* Tuning aid for the patch-staged conv kernel: intra_split < 0 switches the intra-workgroup K split of small 1-D k3

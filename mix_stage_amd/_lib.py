@@ -110,6 +110,8 @@ def lib():
       if mode not in ('fp32', 'bf16x6'):
         raise MixStageLibError('MS_PRECISION=%s: expected fp32 or bf16x6' % mode)
       handle.ms_set_precision(1 if mode == 'bf16x6' else 0)
+    if os.environ.get('MS_PATCH_MIN_WGS'):      # tuning experiments only (ms_debug_set_patch_min_workgroups)
+      handle.ms_debug_set_patch_min_workgroups(int(os.environ['MS_PATCH_MIN_WGS']))
     _lib = handle
   return _lib
 

@@ -362,7 +362,8 @@ void conv_patch_kernel(const PatchArgs p) {
 
 // ---------------------------------------------------------------------------------------------
 // dispatch
-int g_patch_min_wgs = 96;      // below this many workgroups the split-K im2col path is used instead
+int g_patch_min_wgs = 32;      // below this many workgroups the split-K im2col path is used instead (swept 8..192: flat from 8
+                               // to 128, best at 32; 192 loses 11 %)
 int g_patch_force_splitk = 0;   // tuning knob: > 0 forces this split-K factor in the patch kernel
 int g_precision = 0;
 int g_patch_intra = 1;          // tuning knob: intra-workgroup K split for small 1-D k3 layers

@@ -80,10 +80,10 @@ def _mk_block(mod, case, seed=0):
 @pytest.fixture(params=['auto', 'patch', 'gather'])
 def kernel_path(request):
   """'auto': the production dispatch (at these sizes mostly the one-workgroup-per-channel small-conv kernel); 'patch'
-  forces the patch-staged MFMA kernels wherever their geometry allows (normally chosen for launches with >= 96
+  forces the patch-staged MFMA kernels wherever their geometry allows (normally chosen for launches with >= 32
   workgroups); 'gather' forces the im2col-gather MFMA kernels with split-K (normally the fallback)."""
   from mix_stage_amd import _lib
-  old = _lib.lib().ms_debug_set_patch_min_workgroups({'patch': 0, 'gather': 1 << 30}.get(request.param, 96))
+  old = _lib.lib().ms_debug_set_patch_min_workgroups({'patch': 0, 'gather': 1 << 30}.get(request.param, 32))
   yield request.param
   _lib.lib().ms_debug_set_patch_min_workgroups(old)
 
