@@ -778,7 +778,7 @@ int wgrad_splits(int Cog, int Kg, int groups, int Npix) {
   const long tiles = (long)cdiv(Cog, 64) * cdiv(Kg, 64) * groups;
   int splits = 1;
   if (tiles < 512) splits = (int)((512 + tiles - 1) / tiles);
-  const int max_splits = cdiv(Npix, 256);  // at least 8 reduction steps per split
+  const int max_splits = cdiv(Npix, 64);   // at least 2 reduction steps (32 pixels each) per split: the deep UNet levels have 64-256 pixels
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   return splits;
