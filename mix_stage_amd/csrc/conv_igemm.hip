@@ -413,6 +413,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     }
 }
 
+// sum over the split slabs in ascending order (bitwise the same as the plain loop), 8 loads in flight at a time
+__device__ inline float sum_splits_in_order(const float* __restrict__ p, size_t stride, int splits) {
+  float s = 0.f;
+  int k = 0;
+  for (; k + 8 <= splits; k += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = p[(size_t)(k + j) * stride];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+  }
+  for (; k < splits; ++k) s += p[(size_t)k * stride];
+  return s;
+}
+
 // many splits, few outputs: one wave per output element, lanes stride over the splits, fixed-order wave reduction
 __global__ __launch_bounds__(256) void reduce_splits_wave_kernel(const float* __restrict__ part, float* __restrict__ out, int n,
                                                                  int splits) {
@@ -428,9 +443,7 @@ __global__ __launch_bounds__(256) void reduce_splits_wave_kernel(const float* __
 // out[i] = sum_s part[s][i]   (fixed order -> bitwise reproducible)
 __global__ void reduce_splits_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int splits) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += part[(size_t)k * n + i];
-    out[i] = s;
+    out[i] = sum_splits_in_order(part + i, (size_t)n, splits);
   }
 }
 
@@ -452,9 +465,7 @@ __global__ __launch_bounds__(256) void reduce_splits_multi_kernel(const ReduceBa
     if (lane == 0) jb.out[i] += s;
   } else {
     for (int i = b * 256 + threadIdx.x; i < jb.n; i += nb * 256) {
-      float s = 0.f;
-      for (int k = 0; k < jb.splits; ++k) s += jb.part[(size_t)k * jb.n + i];
-      jb.out[i] += s;
+      jb.out[i] += sum_splits_in_order(jb.part + i, (size_t)jb.n, jb.splits);
     }
   }
 }
