@@ -195,7 +195,7 @@ WgradPatchPlan plan_wgrad_patch(int nd, int Cog, int Kg, int groups, int KH, int
   // 3 workgroups share a CU: fill one round of 768 (the decoder layer: 384 tiles x 2); layers with few tiles take as many
   // pixel splits as that allows -- measured: 512 -> 768 target
   if (base < 768) splits = std::max(1, (int)(768 / base));
-  splits = std::min(splits, std::max(1, pl.n_tiles / 4));      // at least 4 pixel tiles (128 k-pairs) per split
+  splits = std::min(splits, std::max(1, pl.n_tiles / 1));      // at least 1 pixel tile per split
   pl.tiles_per_split = cdiv(pl.n_tiles, splits);
   pl.splits = cdiv(pl.n_tiles, pl.tiles_per_split);
   pl.ok = 1;
