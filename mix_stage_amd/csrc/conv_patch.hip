@@ -400,7 +400,7 @@ PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH,
   if (pl.ok && g_patch_force_splitk > 0 && nchunks >= g_patch_force_splitk) {
     pl.chunks_per_split = cdiv(nchunks, g_patch_force_splitk);
     pl.splitk = cdiv(nchunks, pl.chunks_per_split);
-  } else if (pl.ok && base < (p6 ? 192 : 384) && nchunks >= 4) {   // (bf16x6: 128-pixel tiles, 2 workgroups per CU)
+  } else if (pl.ok && base < (p6 ? 256 : 384) && nchunks >= 4) {   // (bf16x6: 128-pixel tiles, 2 workgroups per CU)
     const long base32 = (long)pl.n_tiles * cdiv(Mg, 32) * groups * zmul;
     // (short reductions only: with a long K -- the 2048-channel data gradient of the first decoder layer -- slices over
     // workgroups keep more of the chip busy: 91 vs 152 us)
