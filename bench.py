@@ -216,6 +216,9 @@ def main():
                    'bn_sync': 'local'},
         'last_losses': [round(l, 5) for l in losses], 'losses_finite': finite,
     }
+  if rank == 0 and world > 1:     # measured at N=1 only (per-kernel events / the CPU oracle would distort the ranks' lockstep)
+    out['roofline'] = None
+    out['cpu_baseline'] = None
   if rank == 0 and world == 1:
     roof, rows = (None, [])
     if not args.no_kernel_timing:
