@@ -1,18 +1,26 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Mix-StAGE train-step clips/sec (B=32 per GPU, T=64, 128-mel, 104-dim pose, M=S=8), fp32.
+"""Headline benchmark: Mix-StAGE train-step clips/sec (B=32 per GPU, T=64, 128-mel, 104-dim pose, M=S=8).
 
-    python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W [--precision fp32|bf16x6|bf16]
+
+With N > 1 and no launcher in the environment the script starts the N ranks itself (fresh child processes of
+`python -m torch.distributed.run`, started BEFORE this process touches the GPU); under a launcher (RANK / WORLD_SIZE set) it
+is one rank.  One rank per GPU, RCCL (`nccl`) over xGMI.
 
 One "step" = one reference train step (trainer.py:604-674 contract, see mix_stage_amd/train_step.py): zero_grad ->
 GAN.forward (D-step or G-step by the reference's seeded host coin flip, gan.py:105) -> backward -> gradient all-reduce
 (N>1) -> clip_grad_norm_(.,1) -> Adam(1e-4).  Inputs are synthetic, resident in HBM before the timed region; weights are
 the name-keyed deterministic fill.  The curriculum is pinned to the audio branch (thresh = 1), as stated in
-BASELINE.md.  Prints ONE JSON line on rank 0.
+BASELINE.md.  Prints ONE JSON line on rank 0: `value` over exactly K timed steps of the coin-flip sequence, plus (outside
+the timed region) G-step and D-step times measured separately and their 50/50 blend.
 """
 import argparse
+import hashlib
 import json
 import os
+import re
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,9 +29,11 @@ if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
 B_PER_GPU, T, F_MEL, P, M, S = 32, 64, 128, 104, 8, 8
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16
+# forward GFLOP per 32 clips: a G-step is ~3x the generator+D forward, a D-step ~1x G forward + 3x (2 D passes)
+G_STEP_GFLOP, D_STEP_GFLOP = 3 * 99.0, 99.0 + 3 * 2 * 0.215
 
 
 def parse():
@@ -34,16 +44,34 @@ def parse():
   ap.add_argument('--no-graphs', action='store_true', help='eager launches instead of HIP-graph replay')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-kernel-timing', action='store_true')
+  ap.add_argument('--no-per-kind', action='store_true', help='skip the separate G-step / D-step timing')
   ap.add_argument('--seed', type=int, default=4321)
-  ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16x6'],
-                  help='fp32: exact fp32 matrix products (default, the headline); bf16x6: both operands split exactly into 3 bf16 '
-                       'parts, 6 of 9 partial products on the bf16 pipe, fp32 accumulate (same measured accuracy)')
+  ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16x6', 'bf16'],
+                  help='fp32: exact fp32 matrix products (default, the parity headline); bf16x6: both operands split exactly '
+                       'into 3 bf16 parts, 6 of 9 partial products on the bf16 pipe, fp32 accumulate (same measured accuracy); '
+                       'bf16: native bf16 operands and bf16 activations in HBM, fp32 accumulate and BN statistics '
+                       '(BASELINE configs[1]/[3] arithmetic; pose L1 is reported, not gated at 1e-4)')
+  ap.add_argument('--bn-sync', default='local', choices=['local', 'global'])
   ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL over xGMI); gloo only for smoke-testing the DP path')
   ap.add_argument('--same-device', action='store_true', help='smoke test: all ranks share cuda:0 (needs --dist-backend gloo)')
   return ap.parse_args()
 
 
-def build_model(dev):
+def self_launch(args):
+  """--gpus N without a launcher: start the N ranks as fresh children.  Nothing in this process has touched the GPU yet
+  (argparse only), so no initialised HIP state is inherited or exec'd over."""
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+  env = dict(os.environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // args.gpus)))
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+         '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+  return subprocess.run(cmd, env=env).returncode
+
+
+def build_model(dev, precision='fp32'):
   import torch
   import mix_stage_amd as A
   from oracle import mixstage_oracle as O     # deterministic weight fill + synthetic inputs (shared with the tests)
@@ -53,7 +81,10 @@ def build_model(dev):
   model = A.GAN(G, D, criterion='L1Loss', input_modalities=['audio/log_mel_400'], update_D_prob_flag=0, no_grad=0)
   model.load_state_dict(O.deterministic_state(model.state_dict()))
   model.G.thresh.value, model.G.thresh.iters = 1, 10 ** 9
-  return model.to(dev)
+  model = model.to(dev)
+  if precision == 'bf16':
+    A.set_compute_dtype(model, 'bf16')
+  return model
 
 
 def usable_cores():
@@ -69,35 +100,60 @@ def usable_cores():
 
 
 def cpu_baseline(seed):
-  """The oracle (pure PyTorch on the host cores, fp32) on a bounded sample of the same workload: G-steps and D-steps
-  at B=32 after one untimed step of each kind (2 timed steps per kind, 1 if a step takes longer than 8 s)."""
+  """The oracle (pure PyTorch on the host cores) on a bounded sample of the same workload: fp32 G-steps and D-steps at
+  B=32 after one untimed step of each kind (2 timed steps per kind, 1 if a step takes longer than 8 s); plus ONE step of each
+  kind in fp64, the reference's own training dtype (trainer.py:138)."""
   import torch
   from oracle import mixstage_oracle as O
   cores = min(usable_cores(), 32)       # oversubscribed intra-op threads make PyTorch CPU convs much slower
   torch.set_num_threads(cores)
-  model = O.build_gan(M=M, S=S, T=T, P=P)
-  og = torch.optim.Adam(model.G.parameters(), lr=1e-4)
-  od = torch.optim.Adam(model.D.parameters(), lr=1e-4)
-  audio, pose, labels, style = O.synthetic_batch(B_PER_GPU, T=T, F_=F_MEL, P=P, M=M, S=S, seed=1234)
-  times, reps = {}, {}
-  for kind in ('G', 'D'):
-    t0 = time.perf_counter()
-    O.oracle_train_step(model, og, od, audio, pose, labels, style, kind, T=T)
-    warm = time.perf_counter() - t0
-    n = 2 if warm < 8.0 else 1
-    t0 = time.perf_counter()
-    for _ in range(n):
+  res = {}
+  for name, dtype, n_max in (('fp32', torch.float32, 2), ('fp64', torch.float64, 1)):
+    model = O.build_gan(M=M, S=S, T=T, P=P, dtype=dtype)
+    og = torch.optim.Adam(model.G.parameters(), lr=1e-4)
+    od = torch.optim.Adam(model.D.parameters(), lr=1e-4)
+    audio, pose, labels, style = O.synthetic_batch(B_PER_GPU, T=T, F_=F_MEL, P=P, M=M, S=S, seed=1234, dtype=dtype)
+    times, reps = {}, {}
+    for kind in ('G', 'D'):
+      t0 = time.perf_counter()
       O.oracle_train_step(model, og, od, audio, pose, labels, style, kind, T=T)
-    times[kind], reps[kind] = (time.perf_counter() - t0) / n, n
-  blended = 0.5 * (times['G'] + times['D'])       # D_prob = 0.5 (gan.py:27)
-  return dict(value=round(B_PER_GPU / blended, 2), unit='clips/s', cores=cores, kind='port',
+      warm = time.perf_counter() - t0
+      n = n_max if warm < 8.0 else 1
+      t0 = time.perf_counter()
+      for _ in range(n):
+        O.oracle_train_step(model, og, od, audio, pose, labels, style, kind, T=T)
+      times[kind], reps[kind] = (time.perf_counter() - t0) / n, n
+    res[name] = (times, reps)
+  (t32, r32), (t64, r64) = res['fp32'], res['fp64']
+  blend32 = 0.5 * (t32['G'] + t32['D'])       # D_prob = 0.5 (gan.py:27)
+  blend64 = 0.5 * (t64['G'] + t64['D'])
+  return dict(value=round(B_PER_GPU / blend32, 2), unit='clips/s', cores=cores, kind='port',
               sample='oracle (PyTorch CPU fp32, %d threads): %d G-steps + %d D-steps at B=32 after 1 warm-up each; '
-                     'G %.3f s, D %.3f s per step, 50/50 blend' % (cores, reps['G'], reps['D'], times['G'], times['D']))
+                     'G %.3f s, D %.3f s per step, 50/50 blend' % (cores, r32['G'], r32['D'], t32['G'], t32['D']),
+              fp64=dict(value=round(B_PER_GPU / blend64, 2), unit='clips/s',
+                        sample='same oracle in float64 (the reference trains in fp64): %d G + %d D step(s) after 1 warm-up each; '
+                               'G %.3f s, D %.3f s' % (r64['G'], r64['D'], t64['G'], t64['D'])))
 
 
-def kernel_roofline(ts, batch, kinds):
+def source_hash():
+  """Hash of the kernel sources: PMC files record it so that a traffic figure is only quoted for the code that produced it."""
+  h = hashlib.sha256()
+  d = os.path.join(ROOT, 'mix_stage_amd', 'csrc')
+  for f in sorted(os.listdir(d)):
+    if f.endswith(('.hip', '.h', '.cpp')):
+      h.update(f.encode()); h.update(open(os.path.join(d, f), 'rb').read())
+  return h.hexdigest()[:16]
+
+
+def decoder_label_re(precision):
+  # forward + BN statistics of decoder.1-3 (JL:69-77): grouped k3 conv, 256 -> 256 channels per group, M groups
+  return re.compile(r'conv_fwd\S* k1x3 s1 Mg256 Kg768 g%d .*\+bnstats' % M)
+
+
+def kernel_roofline(ts, batch, kinds, precision):
   """Per-kernel launch durations from HIP events recorded on the launch stream by the library itself
-  (ms_timing_*), over eager replays of the same steps as the timed region."""
+  (ms_timing_*), over eager replays of the same steps as the timed region.  The roofline entry is the north-star kernel
+  BY LABEL: the grouped decoder block forward (+ BN statistics), one layer = one launch."""
   import torch
   from mix_stage_amd import ops
   ops.timing_enable(True)
@@ -113,50 +169,76 @@ def kernel_roofline(ts, batch, kinds):
     ts.use_graphs = saved
   if not rows:
     return None, []
-  # aggregate by kernel symbol (what rocprofv3 --stats reports); launches without a symbol keep their label
-  by_sym = {}
-  for r in rows:
-    sym = r['label'].split('|')[0]
-    a = by_sym.setdefault(sym, dict(sym=sym, count=0, total_ms=0.0, flops=0.0, bytes=0.0))
-    a['count'] += r['count']; a['total_ms'] += r['total_ms']
-    a['flops'] += r['flops'] * r['count']; a['bytes'] += r['bytes'] * r['count']
-  syms = sorted(by_sym.values(), key=lambda a: -a['total_ms'])
-  top = syms[0]
-  avg_s = top['total_ms'] / top['count'] * 1e-3
-  achieved = top['flops'] / (top['total_ms'] * 1e-3) / 1e12
-  # bf16x6 kernels do 6 bf16 MFMA products per algorithmic fp32 product: their ceiling in algorithmic flops is 1/6 of the dense
-  # bf16 peak (MI355X_MICROARCH.md: 2.5 PFLOP/s)
-  peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if 'patch6' in top['sym'] else FP32_MFMA_PEAK_TFLOPS
-  roof = dict(bound='mfma', achieved=round(achieved, 2), peak=round(peak, 1), unit='TFLOP/s',
-              frac=round(achieved / peak, 4), traffic=None, kernel=top['sym'],
-              avg_us=round(avg_s * 1e6, 2), launches=top['count'],
-              algorithmic_flops_per_launch=round(top['flops'] / top['count']),
-              algorithmic_bytes_per_launch=round(top['bytes'] / top['count']),
-              note='dominant kernel symbol by total time over 2 G-steps + 2 D-steps; avg over all its launches (all layer '
-                   'shapes), HIP events on the launch stream; same aggregation as rocprofv3 --kernel-trace --stats')
-  # HBM traffic of that kernel from the committed PMC passes (tools/pmc_summary.py; rocprofv3 cannot run inside bench.py)
+  rows.sort(key=lambda r: -r['total_ms'])
+  pat = decoder_label_re(precision)
+  dec = [r for r in rows if pat.search(r['label'])]
+  if not dec:
+    return None, rows
+  r = dec[0]
+  avg_s = r['total_ms'] / r['count'] * 1e-3
+  native16 = precision == 'bf16'
+  peak_tf = BF16_MFMA_PEAK_TFLOPS if native16 else (BF16_MFMA_PEAK_TFLOPS / 6.0 if 'patch6' in r['label'] else FP32_MFMA_PEAK_TFLOPS)
+  tf = r['flops'] / avg_s / 1e12
+  gbs = r['bytes'] / avg_s / 1e9
+  t_mfma, t_hbm = r['flops'] / (peak_tf * 1e12), r['bytes'] / (HBM_PEAK_GBS * 1e9)
+  bound = 'hbm' if t_hbm >= t_mfma else 'mfma'
+  roof = dict(bound=bound,
+              achieved=round(gbs if bound == 'hbm' else tf, 2), peak=HBM_PEAK_GBS if bound == 'hbm' else round(peak_tf, 1),
+              unit='GB/s' if bound == 'hbm' else 'TFLOP/s',
+              frac=round((gbs / HBM_PEAK_GBS) if bound == 'hbm' else (tf / peak_tf), 4), traffic=None,
+              kernel=r['label'].split('|')[0], label=r['label'].split('|')[-1], avg_us=round(avg_s * 1e6, 2), launches=r['count'],
+              algorithmic_flops_per_launch=round(r['flops']), algorithmic_bytes_per_launch=round(r['bytes']),
+              frac_mfma=round(tf / peak_tf, 4), frac_hbm=round(gbs / HBM_PEAK_GBS, 4),
+              achieved_tflops=round(tf, 2), achieved_gbs=round(gbs, 1),
+              time_lower_bound_us=round(max(t_mfma, t_hbm) * 1e6, 2),
+              frac_of_lower_bound=round(max(t_mfma, t_hbm) / avg_s, 4),
+              note='north-star kernel by label: grouped decoder block forward + BN statistics (decoder.1-3: k3, %d groups, '
+                   '256->256 channels per group, B*T = %d pixels), one launch per layer; HIP events on the launch stream over '
+                   '2 G-steps + 2 D-steps (eager); bound = the larger of flops/peak and bytes/HBM-peak' % (M, B_PER_GPU * T))
+  # HBM traffic of that launch from the committed PMC passes (tools/pmc_decoder.sh; rocprofv3 cannot run inside bench.py):
+  # quoted only when the file was produced by these very kernel sources
   try:
-    pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))['kernels'].get(top['sym'])
-    if pmc:
-      roof['traffic'] = pmc['hbm_bytes_per_launch']
-      roof['traffic_note'] = 'HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r01_pmc_traffic.json'
+    pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_decoder.json')))
+    ent = pmc.get(precision)
+    if ent and ent.get('src_hash') == source_hash():
+      roof['traffic'] = ent['hbm_bytes_per_launch']
+      roof['traffic_note'] = 'HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, profiles/r02_pmc_decoder.json (same sources: %s)' % ent['src_hash']
   except (OSError, ValueError, KeyError):
     pass
-  rows.sort(key=lambda r: -r['total_ms'])
   return roof, rows
+
+
+def time_steps(ts, batch, n, kind, world, dist, dev):
+  import torch
+  torch.cuda.synchronize()
+  if world > 1:
+    dist.barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  kinds = [ts.step(*batch, kind=kind) for _ in range(n)]
+  torch.cuda.synchronize()
+  if world > 1:
+    dist.barrier()
+  torch.cuda.synchronize()
+  elapsed = time.perf_counter() - t0
+  if world > 1:
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+  return elapsed, kinds
 
 
 def main():
   args = parse()
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  if args.gpus > 1 and 'RANK' not in os.environ:
+    sys.exit(self_launch(args))
+  if world != args.gpus:
+    raise SystemExit('WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
   import torch
   import torch.distributed as dist
-  world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-  if world != args.gpus:
-    if world == 1 and args.gpus > 1:
-      raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr '
-                       '127.0.0.1 bench.py --gpus %d ...' % (args.gpus, args.gpus))
   if args.precision == 'bf16x6':
     os.environ['MS_PRECISION'] = 'bf16x6'       # read when the library is loaded
   if args.same_device:
@@ -172,57 +254,61 @@ def main():
 
   from oracle import mixstage_oracle as O
   from mix_stage_amd.train_step import MixStageTrainStep
-  model = build_model(dev)
-  ts = MixStageTrainStep(model, use_graphs=not args.no_graphs, time_steps=T)
+  model = build_model(dev, args.precision)
+  ts = MixStageTrainStep(model, use_graphs=not args.no_graphs, time_steps=T, bn_sync=args.bn_sync)
   # every rank gets its own shard of synthetic clips (pure data parallel, weak scaling: 32 clips per GPU)
   audio, pose, labels, style = O.synthetic_batch(B_PER_GPU, T=T, F_=F_MEL, P=P, M=M, S=S, seed=1234 + rank)
   batch = [t.to(dev) for t in (audio, labels, pose, style)]
   torch.manual_seed(args.seed)          # identical host generators on all ranks -> identical D/G decisions
 
-  kinds = []
   for _ in range(args.warmup):
     ts.step(*batch)
-  torch.cuda.synchronize()
-  if world > 1:
-    dist.barrier()
-  torch.cuda.synchronize()
-  t0 = time.perf_counter()
-  for _ in range(args.steps):
-    kinds.append(ts.step(*batch))
-  torch.cuda.synchronize()
-  if world > 1:
-    dist.barrier()
-  torch.cuda.synchronize()
-  elapsed = time.perf_counter() - t0
-  if world > 1:
-    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    elapsed = float(tt.item())
+  elapsed, kinds = time_steps(ts, batch, args.steps, None, world, dist, dev)
   losses = [float(l.detach()) for l in ts.losses]
   finite = all(l == l and abs(l) < 1e6 for l in losses)
+  per_kind = None
+  if not args.no_per_kind:
+    n_k = max(5, min(20, args.steps))
+    per_kind = {}
+    for kind in ('G', 'D'):
+      for _ in range(2):
+        ts.step(*batch, kind=kind)
+      per_kind[kind] = time_steps(ts, batch, n_k, kind, world, dist, dev)[0] / n_k
 
   out = None
   if rank == 0:
     n_g = sum(k == 'G' for k in kinds)
+    dtype = {'fp32': 'f32', 'bf16x6': 'f32 via bf16x6 (exact 3-way bf16 split of both operands, 6 of 9 products, fp32 accumulate)',
+             'bf16': 'bf16 (fp32 accumulate, fp32 BN statistics, fp32 master weights)'}[args.precision]
     out = {
         'metric': 'train-step clips/sec (B=32, T=64, M=8)', 'value': round(world * B_PER_GPU * args.steps / elapsed, 2),
         'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else 'f32 via bf16x6 (exact 3-way bf16 split of both operands, 6 of 9 products, fp32 accumulate)', 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
         'config': {'workload': 'Mix-StAGE GAN train step (reference D/G coin flip, seed %d: %d G + %d D steps), '
                                'B=%d clips per GPU, T=%d, %d-mel, %d-dim pose, M=S=%d, audio branch pinned'
                                % (args.seed, n_g, args.steps - n_g, B_PER_GPU, T, F_MEL, P, M),
                    'global_batch': world * B_PER_GPU, 'parallelism': 'dp%d' % world, 'hip_graphs': not args.no_graphs,
-                   'bn_sync': 'local'},
+                   'bn_sync': args.bn_sync},
         'last_losses': [round(l, 5) for l in losses], 'losses_finite': finite,
     }
+    if per_kind:
+      g_ms, d_ms = 1e3 * per_kind['G'], 1e3 * per_kind['D']
+      peak = {'fp32': FP32_MFMA_PEAK_TFLOPS, 'bf16x6': FP32_MFMA_PEAK_TFLOPS, 'bf16': BF16_MFMA_PEAK_TFLOPS}[args.precision]
+      out.update(g_step_ms=round(g_ms, 4), d_step_ms=round(d_ms, 4),
+                 value_blend_50_50=round(world * B_PER_GPU / (0.5e-3 * (g_ms + d_ms)), 2),
+                 whole_step={'g_step_tflops': round(G_STEP_GFLOP / g_ms, 2), 'd_step_tflops': round(D_STEP_GFLOP / d_ms, 2),
+                             'mfma_frac_g_step': round(G_STEP_GFLOP / g_ms / peak, 4),
+                             'mfma_frac_d_step': round(D_STEP_GFLOP / d_ms / peak, 4),
+                             'note': 'per-rank algorithmic GFLOP of a whole step (G: 3 x 99.0, D: 99.0 + 6 x 0.215; SURVEY A.3) '
+                                     '/ measured step time, against the matrix peak of the arithmetic mode (%.1f TF)' % peak})
   if rank == 0 and world > 1:     # measured at N=1 only (per-kernel events / the CPU oracle would distort the ranks' lockstep)
     out['roofline'] = None
     out['cpu_baseline'] = None
   if rank == 0 and world == 1:
     roof, rows = (None, [])
     if not args.no_kernel_timing:
-      roof, rows = kernel_roofline(ts, batch, ['G', 'D', 'G', 'D'])
+      roof, rows = kernel_roofline(ts, batch, ['G', 'D', 'G', 'D'], args.precision)
     out['roofline'] = roof
     out['kernel_table'] = [dict(label=r['label'].split('|')[-1], count=r['count'], avg_us=round(1e3 * r['total_ms'] / r['count'], 2),
                                 total_ms=round(r['total_ms'], 3),

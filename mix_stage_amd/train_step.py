@@ -176,8 +176,12 @@ class FlatAdam:
 class MixStageTrainStep:
   """Runs reference-equivalent training steps for GAN(G, D) on one GPU or data-parallel over ranks."""
 
-  def __init__(self, model, lr=1e-4, clip=1.0, use_graphs=True, process_group=None, time_steps=64, overlap_wgrad=False):
+  def __init__(self, model, lr=1e-4, clip=1.0, use_graphs=True, process_group=None, time_steps=64, overlap_wgrad=False,
+               bn_sync='local'):
     self.model = model
+    if bn_sync not in ('local', 'global'):
+      raise ValueError("bn_sync must be 'local' or 'global'")
+    self.bn_sync = bn_sync
     # overlap_wgrad: weight gradients on a side HIP stream (ms_conv_block_bwd_overlap).  Measured on MI355X / ROCm 7.2
     # inside the captured step it is SLOWER (5.01 vs 4.67 ms/step: cross-stream edges in the HIP graph cost more than the
     # concurrency buys), so it is off by default.

@@ -143,6 +143,54 @@ def test_gan_step_matches_oracle(M, S, B, kind):
   _compare_step(M, S, B, kind, F_=128, seed=1234, strict=False)
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x6'])
+@pytest.mark.parametrize('kind', ['G', 'D'])
+def test_headline_size_step_matches_oracle(kind, precision):
+  """The size bench.py times (B=32, T=64, 128-mel, M=S=8: 1024-workgroup launches, 4 workgroups per CU, full-grid XCD
+  remap) against the fp64 oracle: pose, losses, softmax, every parameter gradient, BN running statistics -- in both
+  arithmetic modes of the fp32 path."""
+  from mix_stage_amd import _lib
+  prev = _lib.lib().ms_set_precision(1 if precision == 'bf16x6' else 0)
+  try:
+    _compare_step(8, 8, 32, kind, F_=128, seed=1234, strict=False)
+  finally:
+    _lib.lib().ms_set_precision(prev)
+
+
+@pytest.mark.parametrize('name', ['c1_fp32', 'c2r_fp32', 'c3r_fp32'])
+def test_golden_gradients_from_reference(golden_dir, name):
+  """Every parameter gradient of the HIP path against the vectors the REFERENCE produced (make_golden.py: L2 norm and
+  a 16-element strided sample of each gradient, recorded after clip_grad_norm_ rescaled them in place)."""
+  z = np.load(os.path.join(golden_dir, name + '.npz'))
+  B, T, M, S = [int(v) for v in z['meta']]
+  batch = [torch.from_numpy(z[k]) for k in ('audio', 'pose', 'labels', 'style')]
+  for kind in ('G', 'D'):
+    hip = build_hip_gan(M, S)
+    _step(hip, batch, kind, DEV)
+    k = kind + '/'
+    mod = hip.G if kind == 'G' else hip.D
+    grads = {kind + '.' + n: p.grad.detach().double().reshape(-1).cpu() for n, p in mod.named_parameters()
+             if p.grad is not None}
+    total = float(torch.sqrt(sum((g * g).sum() for g in grads.values())))
+    ref_total = float(z[k + 'total_grad_norm'])
+    assert abs(total - ref_total) <= 1e-3 * ref_total, (total, ref_total)
+    coef = min(1.0, 1.0 / (ref_total + 1e-6))          # the reference probed its gradients after the clip
+    worst = 0.0
+    for n, g in grads.items():
+      if k + 'gnorm/' + n not in z.files:
+        assert float(g.abs().max()) == 0.0, n            # the reference left this parameter without a gradient
+        continue
+      gn, gs = float(z[k + 'gnorm/' + n]), z[k + 'gsamp/' + n]
+      stride = max(1, g.numel() // 16)
+      mine = (g[::stride][:16] * coef).numpy()
+      if n.endswith('conv.bias') and gn < 1e-4 * ref_total * coef:
+        continue                                         # conv bias in front of BN: exactly 0 in real arithmetic
+      scale = gn / np.sqrt(g.numel()) + 1e-12            # rms of the gradient: the per-element yardstick
+      assert abs(float(g.norm()) * coef - gn) <= 2e-3 * gn + 1e-9, (n, float(g.norm()) * coef, gn)
+      worst = max(worst, float(np.abs(mine - gs).max() / scale))
+    assert worst <= 5e-2, worst                          # sampled elements within 5 % of the gradient's rms
+
+
 @pytest.mark.parametrize('name', ['c1_fp32', 'c2r_fp32', 'c3r_fp32'])
 def test_golden_vectors_from_reference(golden_dir, name):
   z = np.load(os.path.join(golden_dir, name + '.npz'))

@@ -1,7 +1,8 @@
 #!/bin/bash
 # GPU box: the round's measurement artifacts -> gpurun_out/final_<tag>/ (copy the summaries into profiles/ afterwards)
+set -eu
 TAG=${1:-e}
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/final_$TAG
 mkdir -p $OUT
 cd $R && python bench.py > $OUT/bench_full.log 2>&1
