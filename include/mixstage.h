@@ -9,7 +9,9 @@
  * Conventions
  *   - plain C: device pointers (HBM), sizes, one POD descriptor; no torch types.
  *   - all tensors are dense row-major fp32 in the reference's (B, C, T) / (B, C, H, W) layout:
- *     the time (or frequency) axis is contiguous.
+ *     the time (or frequency) axis is contiguous.  Blocks whose descriptor says dtype = MS_BF16 / MS_F16 take their
+ *     activation tensors (x, x2, y_raw, y, dy, dyr, dx, dx2) as 16-bit "cb8" buffers through the same pointer
+ *     parameters (see ms_dtype); parameters, statistics and parameter gradients stay fp32.
  *   - `stream` is a hipStream_t passed as void*; kernels are enqueued, never synchronised;
  *     nothing is allocated inside (callers pass outputs and workspace) -> graph-capturable.
  *   - return 0 on success, negative on error; ms_last_error() gives the text (thread-local).
@@ -24,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MS_ABI_VERSION 1
+#define MS_ABI_VERSION 2
 
 /* epilogue of a conv block */
 enum ms_block_mode {
@@ -41,6 +43,23 @@ enum ms_input_mode {
   MS_IN_UP2ADD = 2 /* 1-D only: x = nearest_up2(a) + r, replaces layers.py:151 upconv(x)+residual        */
 };
 
+/* Arithmetic / storage type of a conv block (ms_conv_desc.dtype, low byte).
+ *   MS_F32   fp32 tensors in the reference's (B, C, T) / (B, C, H, W) layout, exact fp32 matrix products (the parity path).
+ *   MS_BF16  / MS_F16: 16-bit operands on v_mfma_f32_32x32x16_{bf16,f16}, fp32 accumulation, fp32 BatchNorm statistics,
+ *            fp32 master weights, biases, BN parameters and weight gradients.  Activations and their gradients live in HBM
+ *            in the channel-blocked layout "cb8": [B][ceil(C/8)][H][W][8] 16-bit elements (one 16-byte vector = 8
+ *            consecutive channels of one pixel, pad channels zero; grouped blocks need channels-per-group % 8 == 0).
+ *            What trainer.py:138 selects by casting the model (`.double()` there; the reference runs any dtype its modules
+ *            are cast to) -- BASELINE configs[1], [3] (bf16) and [4] (fp16, eval).
+ * MS_DT_OUT_F32 (flag): the block's OUTPUT y is a plain fp32 (B, C, OH, OW) tensor (score-producing blocks whose consumers
+ *            are the fp32 loss kernels); dy of its backward then is plain fp32 too.  y_raw stays cb8.
+ * MS_DT_BN_FOLDED (flag, BN_EVAL blocks): inference form -- the eval BatchNorm is folded into the prepared forward weights
+ *            (w * gamma/sqrt(var+eps)) and bias; valid while the running statistics do not change (sampling).  Without it the
+ *            epilogue applies the running statistics as they are at launch time. */
+enum ms_dtype { MS_F32 = 0, MS_BF16 = 1, MS_F16 = 2 };
+#define MS_DT_OUT_F32 0x100
+#define MS_DT_BN_FOLDED 0x200
+
 /* Geometry of one conv block (1-D convs use H = KH = SH = 1, PH = 0). */
 typedef struct ms_conv_desc {
   int32_t B;          /* batch                                                   */
@@ -55,7 +74,7 @@ typedef struct ms_conv_desc {
   float slope;        /* LeakyReLU negative slope (0.2 on the path, 0 = ReLU)    */
   float eps;          /* BatchNorm eps                                           */
   float momentum;     /* BatchNorm momentum                                      */
-  int32_t reserved;
+  int32_t dtype;      /* ms_dtype | flags; 0 = fp32                              */
 } ms_conv_desc;
 
 const char* ms_last_error(void);
@@ -140,6 +159,33 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
                          const float* y_raw, const float* y, const float* save, const float* dy, float* dyr,
                          float* dx, float* dx2, float* dw, float* dbias, float* dgamma, float* dbeta,
                          void* workspace, size_t workspace_bytes, void* stream, const ms_bwd_options* opt);
+
+/* 16-bit modes: the matrix operands of a block's forward (which = 0; eval BatchNorm folded in: w*scale, and the folded
+ * scale | bias behind them) and data gradient (which = 1), converted from the fp32 master weights into the kernels' staging
+ * order.  A trainer builds them once per optimizer update, for many blocks in one launch, and passes them back through
+ * ms_fwd_options.w_planes / ms_bwd_options.wt_prepared; without them every call converts into its scratch. */
+typedef struct ms_prep16_item {
+  const ms_conv_desc* desc;
+  const float* w;
+  const float* bias;            /* BN_EVAL folding only (may be NULL) */
+  const float* gamma;
+  const float* beta;
+  const float* running_mean;
+  const float* running_var;
+  void* fwd;                    /* ms_weights16_bytes(desc, 0) bytes, or NULL: skip */
+  void* dgrad;                  /* ms_weights16_bytes(desc, 1) bytes, or NULL: skip */
+} ms_prep16_item;
+size_t ms_weights16_bytes(const ms_conv_desc* d, int which);
+int ms_weights16_prepare(int n, const ms_prep16_item* items, void* stream);
+
+/* cb8 <-> fp32 at the boundaries of the 16-bit path (dtype = MS_BF16 / MS_F16):
+ *   plain: fp32 (B, C, HW) channel-major, the layout of the fp32 kernels;  btc: fp32 (B, T, C) time-major, the layout of the
+ *   reference's pose tensors (layers.py:229,280).  velocity: v[t] = x[t] - x[t-1], v[0] = 0 (gan.py:47-52) fused into the
+ *   conversion; velocity_bwd: its adjoint fused into the conversion back. */
+int ms_cb8_from_plain(int dtype, const float* x, void* y, int B, int C, int HW, void* stream);
+int ms_cb8_to_plain(int dtype, const void* x, float* y, int B, int C, int HW, void* stream);
+int ms_cb8_from_btc(int dtype, const float* x, void* y, int B, int T, int C, int velocity, void* stream);
+int ms_cb8_to_btc(int dtype, const void* x, float* y, int B, int T, int C, int velocity_bwd, void* stream);
 
 /* Data-gradient weights.  The data gradient of a block multiplies by w transposed (split into stride-parity classes for
  * strided convs); ms_conv_block_bwd builds that copy in its scratch on every call.  It depends on w and the descriptor

@@ -29,11 +29,18 @@ class ConvDesc(ctypes.Structure):
   _fields_ = [(n, ctypes.c_int32) for n in
               ('B', 'Cin', 'H', 'W', 'Cout', 'groups', 'KH', 'KW', 'SH', 'SW', 'PH', 'PW', 'OH', 'OW',
                'mode', 'in_mode')] + \
-             [('slope', c_float), ('eps', c_float), ('momentum', c_float), ('reserved', ctypes.c_int32)]
+             [('slope', c_float), ('eps', c_float), ('momentum', c_float), ('dtype', ctypes.c_int32)]
+
+
+class Prep16Item(ctypes.Structure):
+  """struct ms_prep16_item"""
+  _fields_ = [('desc', ctypes.POINTER(ConvDesc))] + [(n, ctypes.c_void_p) for n in
+             ('w', 'bias', 'gamma', 'beta', 'running_mean', 'running_var', 'fwd', 'dgrad')]
 
 
 MS_BARE, MS_LRELU, MS_BN_TRAIN, MS_BN_EVAL = 0, 1, 2, 3
 MS_IN_PLAIN, MS_IN_BCAST, MS_IN_UP2ADD = 0, 1, 2
+MS_F32, MS_BF16, MS_F16, MS_DT_OUT_F32, MS_DT_BN_FOLDED = 0, 1, 2, 0x100, 0x200
 
 _P = c_void_p
 _DESC = ctypes.POINTER(ConvDesc)
@@ -59,6 +66,12 @@ SIGNATURES = {
     'ms_get_precision': (c_int, []),
     'ms_wgrad_partials_elems': (c_size_t, [_DESC, _P]),
     'ms_wgrad_reduce_multi': (c_int, [c_int, _P, _P, _P, _P, _P]),
+    'ms_weights16_bytes': (c_size_t, [_DESC, c_int]),
+    'ms_weights16_prepare': (c_int, [c_int, _P, _P]),
+    'ms_cb8_from_plain': (c_int, [c_int, _P, _P, c_int, c_int, c_int, _P]),
+    'ms_cb8_to_plain': (c_int, [c_int, _P, _P, c_int, c_int, c_int, _P]),
+    'ms_cb8_from_btc': (c_int, [c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    'ms_cb8_to_btc': (c_int, [c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),
     'ms_lerp_time_fwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'ms_lerp_time_bwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'ms_softmax_mix_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

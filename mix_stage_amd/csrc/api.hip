@@ -2,7 +2,7 @@
 // Orchestrates the kernels of conv_igemm.hip and elementwise.hip on the caller's stream.
 #include <algorithm>
 
-#include "kernels.h"
+#include "conv16.h"
 
 namespace ms {
 
@@ -18,6 +18,8 @@ static int validate(const ms_conv_desc* d, const char* who) {
   if (d->in_mode < MS_IN_PLAIN || d->in_mode > MS_IN_UP2ADD) return set_error("%s: bad in_mode %d", who, d->in_mode);
   if (d->in_mode == MS_IN_UP2ADD && (d->H != 1 || d->KH != 1 || (d->W & 1)))
     return set_error("%s: UP2ADD needs a 1-D block with even W", who);
+  if (dt_of(d) > DT_F16 || (d->dtype & ~(0xff | MS_DT_OUT_F32 | MS_DT_BN_FOLDED))) return set_error("%s: bad dtype 0x%x", who, d->dtype);
+  if (dt_of(d) == DT_F32 && (d->dtype & ~0xff)) return set_error("%s: MS_DT_OUT_F32 is a flag of the 16-bit modes", who);
   const double out_elems = (double)d->B * d->groups * d->Cout * d->OH * d->OW;
   const double in_elems = (double)d->B * d->groups * d->Cin * d->H * d->W;
   if (out_elems >= 2147483648.0 || in_elems >= 2147483648.0) return set_error("%s: tensor exceeds 2^31 elements", who);
@@ -56,6 +58,7 @@ extern "C" {
 
 size_t ms_conv_block_fwd_workspace(const ms_conv_desc* d) {
   if (!d) return 256;
+  if (dt_of(d) != DT_F32) return block_fwd16_workspace(d);
   const int npix = d->B * d->OH * d->OW;
   const GatherPlan pl = plan_gather(d->Cout, npix, d->groups, d->Cin * d->KH * d->KW);
   const PatchPlan pp = fwd_patch_plan(d);
@@ -76,6 +79,7 @@ size_t ms_conv_block_fwd_workspace(const ms_conv_desc* d) {
 
 size_t ms_conv_block_bwd_workspace(const ms_conv_desc* d) {
   if (!d) return 256;
+  if (dt_of(d) != DT_F32) return block_bwd16_workspace(d);
   int bpc;
   const int nchunk = bwd_chunks(d->B, ctot_of(d), &bpc);
   const int npix = d->B * d->OH * d->OW;
@@ -120,6 +124,9 @@ int ms_conv_block_fwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
   if (bn && (!gamma || !beta || !running_mean || !running_var)) return set_error("ms_conv_block_fwd: BN tensors missing");
   if (d->mode == MS_BN_TRAIN && (!y_raw || !save || !workspace)) return set_error("ms_conv_block_fwd: y_raw/save/workspace missing");
   if (d->in_mode == MS_IN_UP2ADD && !x2) return set_error("ms_conv_block_fwd: UP2ADD needs x2");
+  if (dt_of(d) != DT_F32)     // 16-bit modes: the tensor pointers are cb8 buffers (include/mixstage.h, ms_dtype)
+    return block_fwd16(d, x, x2, w, bias, gamma, beta, running_mean, running_var, y_raw, y, save, workspace, workspace_bytes,
+                       (hipStream_t)stream, w_planes);
   if (workspace_bytes < ms_conv_block_fwd_workspace(d)) return set_error("ms_conv_block_fwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   const int C = ctot_of(d), npix = d->B * d->OH * d->OW, hw = d->OH * d->OW;
@@ -262,7 +269,7 @@ static int wgrad_splits_used(const ms_conv_desc* d) {
 
 size_t ms_wgrad_partials_elems(const ms_conv_desc* d, int* splits) {
   if (validate(d, "ms_wgrad_partials_elems")) return 0;
-  const int sp = wgrad_splits_used(d);
+  const int sp = dt_of(d) != DT_F32 ? wgrad16_splits(d) : wgrad_splits_used(d);
   if (splits) *splits = sp;
   return sp > 1 ? (size_t)sp * wsize_of(d) : 0;
 }
@@ -294,6 +301,7 @@ static size_t dgrad_planes_bytes(const ms_conv_desc* d, const DgradWeights& dw) 
 
 size_t ms_dgrad_weights_elems(const ms_conv_desc* d, const float* w) {
   if (validate(d, "ms_dgrad_weights_elems")) return 0;
+  if (dt_of(d) != DT_F32) return 0;          // 16-bit modes: ms_weights16_bytes / ms_weights16_prepare
   const DgradWeights dw = dgrad_weights_of(d, w);
   if (!dw.need) return 0;
   return align_up(dw.elems, 64) + (dgrad_planes_bytes(d, dw) + 3) / 4;      // fp32 copy | bf16 planes (bf16x6 mode)
@@ -301,6 +309,7 @@ size_t ms_dgrad_weights_elems(const ms_conv_desc* d, const float* w) {
 
 size_t ms_fwd_weights_bytes(const ms_conv_desc* d) {
   if (validate(d, "ms_fwd_weights_bytes")) return 0;
+  if (dt_of(d) != DT_F32) return 0;          // 16-bit modes: ms_weights16_bytes / ms_weights16_prepare
   const PatchPlan pp = fwd_patch_plan(d);
   return (pp.ok && pp.p6) ? (size_t)3 * ctot_of(d) * patch6_row_elems(d->Cin, d->KH, d->KW) * 2 : 0;
 }
@@ -415,6 +424,12 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
   if (d->mode == MS_LRELU && (!y || !dyr)) return set_error("ms_conv_block_bwd: LRELU needs y/dyr");
   if (dw && !x) return set_error("ms_conv_block_bwd: dw needs x");
   if (d->in_mode == MS_IN_UP2ADD && ((dw && !x2) || (dx && !dx2))) return set_error("ms_conv_block_bwd: UP2ADD needs x2/dx2");
+  if (dt_of(d) != DT_F32) {
+    if (side_stream) return set_error("ms_conv_block_bwd: no side-stream form in the 16-bit modes");
+    if (d->mode == MS_BARE && out_f32_of(d) && !dyr) return set_error("ms_conv_block_bwd: fp32 dy needs the dyr scratch");
+    return block_bwd16(d, x, x2, w, gamma, y_raw, y, save, dy, dyr, dx, dx2, dw, dbias, dgamma, dbeta, workspace, workspace_bytes,
+                       (hipStream_t)stream, wt_prepared, opt->wgrad_partials);
+  }
   if (workspace_bytes < ms_conv_block_bwd_workspace(d)) return set_error("ms_conv_block_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   const int C = ctot_of(d), npix = d->B * d->OH * d->OW, hw = d->OH * d->OW;

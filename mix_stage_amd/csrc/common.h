@@ -30,6 +30,7 @@ inline int check_launch(const char* what) {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ inline int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 
 // wave-level sum over the 32 lanes that share (lane>>5); xor masks < 32 never cross the halves
 __device__ inline float half_wave_sum(float v) {

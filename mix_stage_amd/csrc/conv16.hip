@@ -1,0 +1,209 @@
+// 16-bit arithmetic mode: tile planning, weight preparation and dispatch of conv16_kernel (conv16_kernel.h).
+#include <algorithm>
+
+#include "conv16_kernel.h"
+
+namespace ms {
+
+// ---------------------------------------------------------------------------------------------
+// planning
+static int pow2_at_least(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+static int ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+Conv16Plan plan_conv16(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH, int SW, int B, int OH, int OW, int zmul,
+                       bool up2) {
+  Conv16Plan pl = {};
+  if (!(KW == 1 || KW == 2 || KW == 3 || KW == 4 || KW == 8)) return pl;
+  if (nd == 2 && SH != SW) return pl;
+  if (up2 && !(KW == 3 && SW == 1 && nd == 1)) return pl;
+  const int rows = nd == 1 ? B : OH, imgs = nd == 1 ? 1 : B;
+  const int S = SW, SV = nd == 1 ? 1 : SH;
+  const int ck8 = conv16_ck8(KW);
+  // candidate tiles, largest first: the first one that fills the chip (>= 192 workgroups), else the smallest
+  const int cand[3][2] = {{2, 2}, {1, 2}, {1, 1}};
+  for (int c = 0; c < 3; ++c) {
+    const int wm = cand[c][0], wn = cand[c][1];
+    const int bm = 64 * wm, bn = 64 * wn;
+    if (c == 0 && Mg < 128) continue;          // 128-row tiles only for layers with >= 128 rows per group
+    const int tw = std::min(pow2_at_least(OW), bn), th = bn / tw;
+    const int pc = (tw - 1) * S + KW;
+    const int tiles_y = cdiv(rows, th), tiles_x = cdiv(OW, tw);
+    const long nwg = (long)imgs * tiles_y * tiles_x * cdiv(Mg, bm) * groups * zmul;
+    const bool fits = ck8 * th * pc <= CONV16_NP * 256;
+    if (!fits) continue;
+    if (nwg >= 192 || c == 2) {
+      pl.ok = 1; pl.wm = wm; pl.wn = wn; pl.tw = tw; pl.th = th; pl.tiles_y = tiles_y; pl.tiles_x = tiles_x;
+      pl.n_tiles = imgs * tiles_y * tiles_x;
+      pl.ck8 = ck8; pl.nchunks = cdiv(c8_of(Kc), ck8); pl.pc = pc;
+      pl.lds_bytes = 2 * (KW * ck8 * bm + ck8 * th * pc + 1) * 16;
+      (void)SV;
+      return pl;
+    }
+  }
+  return pl;
+}
+
+size_t conv16_weight_bytes(const Conv16Plan& pl, int Mg, int groups, int Kc, int KH, int KW, int ncls) {
+  (void)Kc;
+  const int bm = 64 * pl.wm;
+  return (size_t)ncls * groups * cdiv(Mg, bm) * pl.nchunks * KH * KW * pl.ck8 * bm * 16;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight preparation.  One thread per 16-byte vector of the A operand:
+//   out[cls][g][mt][ch][kh][kw][ks][h][row] = 8 consecutive reduction channels (ch*CK8*8 + (2*ks+h)*8 + j) of row mt*BM+row
+// forward:       row = output channel of group g, reduction channel = input channel, tap (kh, kw)
+// data gradient: row = input channel, reduction channel = output channel (bcast: of ANY group, all groups sum into the
+//                shared input), class (ry, rx) of a strided conv keeps taps kh0 + SH*jh, kw0 + SW*jw, reversed -- the
+//                same slabs transpose_weight_kernel(flip=1) builds for the fp32 kernels.
+template <typename DT>
+__device__ inline void prep16_vec(const Prep16Job& jb, size_t v) {
+  const int KS = jb.CK8 / 2, BM = jb.BM;
+  const bool dg = jb.dgrad != 0;
+  const int KHs = dg ? cdiv_dev(jb.KH, jb.SH) : jb.KH, KWs = dg ? cdiv_dev(jb.KW, jb.SW) : jb.KW;
+  const int tg = (dg && jb.bcast) ? 1 : jb.groups;
+  size_t x = v;
+  const int row = (int)(x % BM); x /= BM;
+  const int h = (int)(x % 2); x /= 2;
+  const int ks = (int)(x % KS); x /= KS;
+  const int kw = (int)(x % KWs); x /= KWs;
+  const int kh = (int)(x % KHs); x /= KHs;
+  const int ch = (int)(x % jb.nchunks); x /= jb.nchunks;
+  const int mt = (int)(x % jb.n_mt); x /= jb.n_mt;
+  const int g = (int)(x % tg); x /= tg;
+  const int cls = (int)x;
+  const int m = mt * BM + row;
+  const int k0 = ch * jb.CK8 * 8 + (2 * ks + h) * 8;
+  float f[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = k0 + j;
+    float val = 0.f;
+    if (!dg) {
+      if (m < jb.Cog && k < jb.Cig) {
+        const int co = g * jb.Cog + m;
+        val = jb.w[(((size_t)co * jb.Cig + k) * jb.KH + kh) * jb.KW + kw];
+        if (jb.scale) val *= jb.scale[co];
+      }
+    } else {
+      const int tcog = jb.bcast ? jb.groups * jb.Cog : jb.Cog;
+      if (m < jb.Cig && k < tcog) {
+        const int gg = jb.bcast ? k / jb.Cog : g, co = jb.bcast ? k - gg * jb.Cog : k;
+        const int ry = cls / jb.SW, rx = cls - ry * jb.SW;
+        const int jh = KHs - 1 - kh, jw = KWs - 1 - kw;                 // taps reversed: the data gradient is a forward conv
+        const int okh = (ry + jb.PH) % jb.SH + jb.SH * jh, okw = (rx + jb.PW) % jb.SW + jb.SW * jw;
+        if (okh < jb.KH && okw < jb.KW)
+          val = jb.w[((((size_t)(gg * jb.Cog + co)) * jb.Cig + m) * jb.KH + okh) * jb.KW + okw];
+      }
+    }
+    f[j] = val;
+  }
+  reinterpret_cast<u32x4*>(jb.out)[v] = pack8<DT>(f);
+}
+
+__device__ inline size_t prep16_total(const Prep16Job& jb) {
+  const bool dg = jb.dgrad != 0;
+  const int KHs = dg ? cdiv_dev(jb.KH, jb.SH) : jb.KH, KWs = dg ? cdiv_dev(jb.KW, jb.SW) : jb.KW;
+  const int tg = (dg && jb.bcast) ? 1 : jb.groups, ncls = dg ? jb.SH * jb.SW : 1;
+  return (size_t)ncls * tg * jb.n_mt * jb.nchunks * KHs * KWs * jb.CK8 * jb.BM;
+}
+
+__global__ __launch_bounds__(256) void prep16_multi_kernel(const Prep16Batch pb) {
+  int j = 0;
+  while (j + 1 < pb.n && (int)blockIdx.x >= pb.job[j].block_end) ++j;
+  const Prep16Job& jb = pb.job[j];
+  const int b0 = j ? pb.job[j - 1].block_end : 0, nb = jb.block_end - b0;
+  const size_t total = prep16_total(jb);
+  for (size_t v = (size_t)((int)blockIdx.x - b0) * 256 + threadIdx.x; v < total; v += (size_t)nb * 256) {
+    if (jb.dt == DT_BF16) prep16_vec<BF16>(jb, v);
+    else prep16_vec<F16>(jb, v);
+  }
+}
+
+int launch_prep16_multi(Prep16Batch& pb, hipStream_t s) {
+  if (pb.n <= 0) return 0;
+  int blocks = 0;
+  double total = 0;
+  for (int i = 0; i < pb.n; ++i) {
+    Prep16Job& jb = pb.job[i];
+    const bool dg = jb.dgrad != 0;
+    const int KHs = dg ? cdiv(jb.KH, jb.SH) : jb.KH, KWs = dg ? cdiv(jb.KW, jb.SW) : jb.KW;
+    const int tg = (dg && jb.bcast) ? 1 : jb.groups, ncls = dg ? jb.SH * jb.SW : 1;
+    const double n = (double)ncls * tg * jb.n_mt * jb.nchunks * KHs * KWs * jb.CK8 * jb.BM;
+    total += n;
+    blocks += (int)std::min<double>(2048.0, std::max(1.0, n / 1024.0));
+    jb.block_end = blocks;
+  }
+  TimingScope ts(s, 0, 48.0 * total, "prep16_multi_kernel|prep16_multi jobs%d", pb.n);
+  hipLaunchKernelGGL(prep16_multi_kernel, dim3(blocks), dim3(256), 0, s, pb);
+  return check_launch("prep16_multi_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------
+// dispatch
+template <typename DT, int KW, int WM, int WN, bool UP2>
+static int launch_one(const Conv16Args& a, int lds_bytes, int nwg, hipStream_t s) {
+  static bool attr_done = false;          // kernels that stage more than 64 KiB need the limit raised once
+  auto fn = conv16_kernel<DT, KW, WM, WN, UP2>;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return set_error("conv16: cannot raise the dynamic LDS limit");
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(fn, dim3(nwg), dim3(256), lds_bytes, s, a);
+  return 0;
+}
+
+template <typename DT, int KW, bool UP2>
+static int launch_tile(const Conv16Args& a, const Conv16Plan& pl, int nwg, hipStream_t s) {
+  if (pl.wm == 2 && pl.wn == 2) return launch_one<DT, KW, 2, 2, UP2>(a, pl.lds_bytes, nwg, s);
+  if (pl.wm == 1 && pl.wn == 2) return launch_one<DT, KW, 1, 2, UP2>(a, pl.lds_bytes, nwg, s);
+  return launch_one<DT, KW, 1, 1, UP2>(a, pl.lds_bytes, nwg, s);
+}
+
+template <typename DT>
+static int launch_kw(const Conv16Args& a, const Conv16Plan& pl, int KW, bool up2, int nwg, hipStream_t s) {
+  if (up2) return launch_tile<DT, 3, true>(a, pl, nwg, s);
+  switch (KW) {
+    case 1: return launch_tile<DT, 1, false>(a, pl, nwg, s);
+    case 2: return launch_tile<DT, 2, false>(a, pl, nwg, s);
+    case 3: return launch_tile<DT, 3, false>(a, pl, nwg, s);
+    case 4: return launch_tile<DT, 4, false>(a, pl, nwg, s);
+    case 8: return launch_tile<DT, 8, false>(a, pl, nwg, s);
+  }
+  return set_error("conv16: no kernel for %d taps per row", KW);
+}
+
+int launch_conv16(int dt, const Conv16Args& a, const Conv16Plan& pl, int KW, bool up2, double flops, double bytes,
+                  hipStream_t s) {
+  if (!pl.ok) return set_error("conv16: geometry not supported (taps per row %d)", KW);
+  if (a.ncls > 4) return set_error("conv16: more than 4 parity classes");
+  const int bm = 64 * pl.wm;
+  Conv16Args b = a;
+  b.ltw = ilog2(pl.tw); b.TH = pl.th; b.PC = pl.pc; b.nchunks = pl.nchunks; b.tiles_x = pl.tiles_x; b.tiles_y = pl.tiles_y;
+  b.gx = pl.n_tiles; b.gy = cdiv(a.Mg, bm); b.gz = a.groups * std::max(1, a.ncls);
+  const unsigned nav = (unsigned)(KW * pl.ck8 * bm);
+  b.a_mt_stride = (unsigned)(pl.nchunks * a.KH) * nav;
+  b.a_group_stride = (unsigned)b.gy * b.a_mt_stride;
+  b.a_cls_stride = (unsigned)a.groups * b.a_group_stride;
+  if ((double)b.gx * b.gy * b.gz > 2.0e9) return set_error("conv16: grid too large");
+  if ((double)b.a_cls_stride * std::max(1, a.ncls) * 16.0 >= 4.0e9) return set_error("conv16: prepared weights of 4 GB or more");
+  if (a.groups > 1 && (a.Mg & 7)) return set_error("conv16: grouped blocks need a multiple of 8 output channels per group");
+  const int nwg = b.gx * b.gy * b.gz;
+  TimingScope ts(s, flops, bytes, "conv16_kernel<%s,%d,%d,%d,%d>|conv_%s_cb8 k%dx%d s%d Mg%d Kg%d g%d tiles%d tile%dx%d tw%d%s",
+                 dt == DT_BF16 ? "bf16" : "f16", KW, pl.wm, pl.wn, up2 ? 1 : 0, a.is_dgrad ? "dgrad" : "fwd", a.KH, KW, a.S, a.Mg,
+                 a.Kc8g * 8 * a.KH * KW, a.groups, pl.n_tiles, bm, 64 * pl.wn, pl.tw, a.ep == EP_RAW_STATS ? " +bnstats" : "");
+  const int rc = dt == DT_BF16 ? launch_kw<BF16>(b, pl, KW, up2, nwg, s) : launch_kw<F16>(b, pl, KW, up2, nwg, s);
+  if (rc) return rc;
+  return check_launch("conv16_kernel");
+}
+
+}  // namespace ms

@@ -1,0 +1,331 @@
+// conv16_kernel<DT, KW, WM, WN, UP2>: forward conv / data gradient on v_mfma_f32_32x32x16_{bf16,f16}, fp32 accumulate.
+//
+// A workgroup (4 waves, 2 x 2) owns BM = 64*WM output channels x BN = 64*WN output pixels (a TH x TW block of one image;
+// 1-D convs use the batch axis as the row axis).  The K loop runs over stages (channel chunk of CK8 blocks, kernel row kh):
+// a stage holds the weight slice [KW][CK8*8 channels][BM rows] and the raw input rows [CK8][TH][(TW-1)*S + KW] in LDS, both
+// as 16-byte vectors of 8 consecutive channels -- what one lane feeds to one MFMA:
+//   A (weights):      lane (r, h) reads slot [kw][ks][h][row r]                    (32 lanes = 512 contiguous bytes)
+//   B (activations):  lane (r, h) reads block 2*ks+h, pixel (ty, tx*S + kw)        (32 lanes = consecutive pixels)
+// so the inner loop is ds_read_b128 + MFMA only.  Staging is global -> registers -> LDS with raw buffer loads (padding and
+// ragged edges by an out-of-range offset that the hardware answers with zeros); the next stage's loads are in flight while
+// the current one computes.  Weights arrive pre-arranged per (m tile, stage) by prep16_kernel, so their staging is a linear copy.
+#pragma once
+#include "conv16.h"
+
+namespace ms {
+
+struct BF16 {
+  typedef __bf16 v8 __attribute__((ext_vector_type(8)));
+  typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+  static constexpr const char* name = "bf16";
+  __device__ static inline f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
+  }
+  __device__ static inline unsigned pack2(float lo, float hi) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f2){lo, hi}, v2));
+  }
+  __device__ static inline float lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+  __device__ static inline float hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+};
+struct F16 {
+  typedef _Float16 v8 __attribute__((ext_vector_type(8)));
+  typedef _Float16 v2 __attribute__((ext_vector_type(2)));
+  static constexpr const char* name = "f16";
+  __device__ static inline f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
+  }
+  __device__ static inline unsigned pack2(float lo, float hi) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f2){lo, hi}, v2));
+  }
+  __device__ static inline float lo(unsigned u) {
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu));
+  }
+  __device__ static inline float hi(unsigned u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16)); }
+};
+
+template <typename DT>
+__device__ inline void unpack8(u32x4 v, float (&f)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { f[2 * i] = DT::lo(v[i]); f[2 * i + 1] = DT::hi(v[i]); }
+}
+template <typename DT>
+__device__ inline u32x4 pack8(const float (&f)[8]) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = DT::pack2(f[2 * i], f[2 * i + 1]);
+  return v;
+}
+
+__device__ inline u32x4 buf_load_v(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+
+constexpr int conv16_ck8(int KW) { return KW == 8 ? 2 : 4; }
+constexpr int CONV16_NP = 6;      // patch vectors a thread stages per stage at most (plan_conv16 keeps CK8*TH*PC <= 6*256)
+
+template <typename DT, int KW, int WM, int WN, bool UP2>
+__global__ __launch_bounds__(256) void conv16_kernel(const Conv16Args p) {
+  constexpr int CK8 = conv16_ck8(KW), KS = CK8 / 2;
+  constexpr int BM = 64 * WM;
+  constexpr int NAV = KW * CK8 * BM, NA = (NAV + 255) / 256;
+  constexpr int NP = CONV16_NP;
+  extern __shared__ u32x4 smem[];
+
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int wm = wid >> 1, wn = wid & 1, r = lane & 31, h = lane >> 5;
+  const int TW = 1 << p.ltw, TH = p.TH, PC = p.PC, S = p.S, SV = p.SV, KH = p.KH;
+  const int thpc = TH * PC, pv = CK8 * thpc;
+  const int stage_vecs = NAV + pv + 1;           // + one dummy vector: out-of-range staging stores land there
+
+  // logical block id: channel tile fastest, then pixel tile, then (class, group); one contiguous range per XCD
+  const int vid = xcd_remap(blockIdx.x, p.gx * p.gy * p.gz);
+  const int by_ = vid % p.gy, bx_ = (vid / p.gy) % p.gx, bz_ = vid / (p.gy * p.gx);
+  const int cls = p.ncls > 1 ? bz_ / p.groups : 0, g = bz_ - cls * p.groups, m0 = by_ * BM;
+  const int PHc = p.ncls > 1 ? p.cls_PH[cls] : p.PH, PWc = p.ncls > 1 ? p.cls_PW[cls] : p.PW;
+  const int OUTHc = p.ncls > 1 ? p.cls_OUTH[cls] : p.OUTH, OUTWc = p.ncls > 1 ? p.cls_OUTW[cls] : p.OUTW;
+  const int o_ryc = p.ncls > 1 ? p.cls_ry[cls] : p.o_ry, o_rxc = p.ncls > 1 ? p.cls_rx[cls] : p.o_rx;
+  const int tiles_per_img = p.tiles_y * p.tiles_x;
+  const int img = bx_ / tiles_per_img;
+  const int trem = bx_ - img * tiles_per_img;
+  const int tyi = trem / p.tiles_x, txi = trem - tyi * p.tiles_x;
+  const int oy0 = tyi * TH, ox0 = txi << p.ltw;
+  const int iy0 = oy0 * SV - PHc, ix0 = ox0 * S - PWc;
+  const int cbase8 = p.bcast ? 0 : g * p.Kc8g;
+
+  // ---- stage-invariant staging offsets of the input rows
+  int poff[NP], prow[NP], plds[NP], pcb[NP], pix[UP2 ? NP : 1];
+  bool pcol[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int e = t + i * 256;
+    const int cb = e / thpc, rem = e - cb * thpc, ty = rem / PC, c = rem - ty * PC;
+    const int iy = iy0 + ty * SV, ix = ix0 + c;
+    pcol[i] = (e < pv) & ((unsigned)ix < (unsigned)p.SRCW);
+    prow[i] = iy;
+    pcb[i] = cb;
+    poff[i] = cb * p.s_cblk + iy * p.s_row + ix;
+    if (UP2) pix[i] = ix;
+    plds[i] = e < pv ? NAV + e : NAV + pv;
+  }
+  const __amdgpu_buffer_rsrc_t rsA = buf_rsrc(p.A), rsS = buf_rsrc(p.src), rsS2 = buf_rsrc(UP2 ? p.src2 : p.src);
+  const unsigned a_wg = (unsigned)cls * p.a_cls_stride + (unsigned)g * p.a_group_stride + (unsigned)by_ * p.a_mt_stride;
+  const int nstages = p.nchunks * KH;
+
+  u32x4 ra[NA], rb[NP], rb2[UP2 ? NP : 1];
+  auto load_stage = [&](int st) {
+    const int ch = st / KH, kh = st - ch * KH;
+    const unsigned sa = __builtin_amdgcn_readfirstlane(16u * (a_wg + (unsigned)st * NAV));
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int idx = t + i * 256;
+      ra[i] = buf_load_v(rsA, (NAV % 256 == 0 || idx < NAV) ? 16u * (unsigned)idx : BUF_OOB, sa);
+    }
+    const int cb0 = ch * CK8;
+    const int sbase = __builtin_amdgcn_readfirstlane(img * p.s_img + (cbase8 + cb0) * p.s_cblk);
+    const int khrow = kh * p.s_row;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const bool ok = pcol[i] & ((unsigned)(prow[i] + kh) < (unsigned)p.SRCH) & (cb0 + pcb[i] < p.Kc8g);
+      if (UP2) {
+        // x = nearest_up2(a) + r: a has half the row length, hence half of every stride (all strides are even)
+        const int o = poff[i] + khrow, c = pix[UP2 ? i : 0];
+        rb[i] = buf_load_v(rsS, ok ? 16u * (unsigned)(((o - c) >> 1) + (c >> 1)) : BUF_OOB, 16u * (unsigned)(sbase >> 1));
+        rb2[UP2 ? i : 0] = buf_load_v(rsS2, ok ? 16u * (unsigned)o : BUF_OOB, 16u * (unsigned)sbase);
+      } else {
+        rb[i] = buf_load_v(rsS, ok ? 16u * (unsigned)(poff[i] + khrow) : BUF_OOB, 16u * (unsigned)sbase);
+      }
+    }
+  };
+  auto store_stage = [&](int buf) {
+    u32x4* st = smem + buf * stage_vecs;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int idx = t + i * 256;
+      if (NAV % 256 == 0 || idx < NAV) st[idx] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      if (UP2) {                       // the sum is formed here, after the stage's MFMAs: the loads stay in flight meanwhile
+        float fa[8], fr[8];
+        unpack8<DT>(rb[i], fa);
+        unpack8<DT>(rb2[UP2 ? i : 0], fr);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fa[j] += fr[j];
+        st[plds[i]] = pack8<DT>(fa);
+      } else {
+        st[plds[i]] = rb[i];
+      }
+    }
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  // ---- per-lane operand bases
+  const int a_base = h * BM + wm * 32 * WM + r;
+  int b_base[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int n = (wn * WN + j) * 32 + r;
+    b_base[j] = NAV + h * thpc + (n >> p.ltw) * PC + (n & (TW - 1)) * S;
+  }
+
+  auto compute_stage = [&](int cur) {
+    const u32x4* st = smem + cur * stage_vecs;
+#pragma unroll
+    for (int kw = 0; kw < KW; ++kw) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        u32x4 av[WM], bv[WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) av[i] = st[a_base + ((kw * KS + ks) * 2) * BM + i * 32];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) bv[j] = st[b_base[j] + 2 * ks * thpc + kw];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j) acc[i][j] = DT::mfma(av[i], bv[j], acc[i][j]);
+      }
+    }
+  };
+
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+  for (int st = 0; st < nstages; ++st) {
+    const int cur = st & 1;
+    if (st + 1 < nstages) load_stage(st + 1);
+    compute_stage(cur);
+    if (st + 1 < nstages) store_stage(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---------------- epilogue ----------------
+  const int ep = p.ep;
+  const int ctot = p.groups * p.Mg;
+  float s1[WM][16], s2[WM][16];
+  if (ep == EP_RAW_STATS) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { s1[i][q] = 0.f; s2[i][q] = 0.f; }
+  }
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    // per-row epilogue constants of this lane's 16 rows
+    float bsv[16], scv[16], shv[16];
+    bool mvl[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int m = m0 + (wm * WM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+      mvl[q] = m < p.Mg;
+      const int chn = g * p.Mg + (mvl[q] ? m : 0);
+      bsv[q] = (p.bias && mvl[q]) ? p.bias[chn] : 0.f;
+      scv[q] = 1.f; shv[q] = 0.f;
+      if (ep == EP_BN_EVAL) {
+        const float inv = 1.0f / sqrtf(p.bn_v[chn] + p.eps);
+        scv[q] = p.bn_g[chn] * inv;
+        shv[q] = p.bn_b[chn] - p.bn_m[chn] * scv[q];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int n = (wn * WN + j) * 32 + r;
+      const int oy = oy0 + (n >> p.ltw), ox = ox0 + (n & (TW - 1));
+      const bool cval = (oy < OUTHc) & (ox < OUTWc);
+      // (plain array, not an ext_vector: this clang miscompiles constant-index writes followed by reads on a local f32x16)
+      float c[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        float v = acc[i][j][q] + bsv[q];
+        if (ep == EP_RAW_STATS) {
+          const float vm = (cval & mvl[q]) ? v : 0.f;
+          s1[i][q] += vm;
+          s2[i][q] = fmaf(vm, vm, s2[i][q]);
+        }
+        if (ep == EP_BN_EVAL) v = lrelu(fmaf(v, scv[q], shv[q]), p.slope);
+        if (ep == EP_LRELU) v = lrelu(v, p.slope);
+        c[q] = mvl[q] ? v : 0.f;
+      }
+      if (p.out_f32) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int m = m0 + (wm * WM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+          if (mvl[q] && cval)
+            p.out_f32[(size_t)img * p.of_img + (size_t)(g * p.Mg + m) * p.of_chan + (size_t)oy * p.of_row + ox] = c[q];
+        }
+        continue;
+      }
+      // 8 consecutive channels of a pixel sit in two lanes (l, l+32): v_permlane32_swap pairs register groups so that the
+      // lower lane ends up with blocks 0,1 and the upper lane with blocks 2,3 of this 32-row tile, one 16-byte store each
+      float vec[2][8];
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned x = __builtin_bit_cast(unsigned, c[4 * pr + e]), y = __builtin_bit_cast(unsigned, c[4 * (pr + 2) + e]);
+          const unsigned long long sw = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_permlane32_swap(x, y, false, false));
+          vec[pr][e] = __builtin_bit_cast(float, (unsigned)sw);
+          vec[pr][4 + e] = __builtin_bit_cast(float, (unsigned)(sw >> 32));
+        }
+      const int cb_tile = (g * p.Mg + m0 + (wm * WM + i) * 32) >> 3;
+      const int cb_end = (g * p.Mg + p.Mg + 7) >> 3;
+      const size_t obase = (size_t)img * p.o_img + (size_t)(oy * p.o_sh + o_ryc) * p.o_row + (size_t)(ox * p.o_sw + o_rxc);
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const int cb = cb_tile + pr + 2 * h;
+        if (ep == EP_DGRAD_UP2) {
+          // 1-D stride-1 data gradient of an upsample-add input: out2 = grad of the residual (full resolution),
+          // out = grad of the half-resolution tensor = sum over the pair of columns (adjacent lanes)
+          float pair[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pair[e] = vec[pr][e] + __shfl_xor(vec[pr][e], 1);
+          if (cval && cb < cb_end) {
+            reinterpret_cast<u32x4*>(p.out2)[obase + (size_t)cb * p.o_cblk] = pack8<DT>(vec[pr]);
+            if (!(lane & 1)) {
+              const size_t hb = (size_t)img * (p.o_img >> 1) + (size_t)oy * (p.o_row >> 1) + (size_t)(ox >> 1);
+              reinterpret_cast<u32x4*>(p.out)[hb + (size_t)cb * (p.o_cblk >> 1)] = pack8<DT>(pair);
+            }
+          }
+        } else if (cval && cb < cb_end) {
+          reinterpret_cast<u32x4*>(p.out)[obase + (size_t)cb * p.o_cblk] = pack8<DT>(vec[pr]);
+        }
+      }
+    }
+  }
+
+  if (ep == EP_RAW_STATS) {
+    // per-channel (sum, sum of squares) of the tile: over the 32 pixels of a lane half in registers, over the two pixel
+    // waves through LDS in a fixed order; stored as (sum, M2 about the tile mean) like the fp32 kernels
+    float* red = reinterpret_cast<float*>(smem);     // [2 waves][BM][2]
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float a = half_wave_sum(s1[i][q]), b = half_wave_sum(s2[i][q]);
+        if (r == 0) {
+          const int ml = (wm * WM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+          red[(wn * BM + ml) * 2] = a;
+          red[(wn * BM + ml) * 2 + 1] = b;
+        }
+      }
+    __syncthreads();
+    if (t < BM && m0 + t < p.Mg) {
+      const float sa = red[t * 2] + red[(BM + t) * 2], sb = red[t * 2 + 1] + red[(BM + t) * 2 + 1];
+      const int cnt = min(TH, OUTHc - oy0) * min(TW, OUTWc - ox0);
+      float* stp = p.stats + ((size_t)bx_ * ctot + g * p.Mg + m0 + t) * 2;
+      stp[0] = sa;
+      stp[1] = fmaxf(sb - sa * sa / (float)cnt, 0.f);
+    }
+    if (t == 0 && by_ == 0 && g == 0) p.counts[bx_] = (float)(min(TH, OUTHc - oy0) * min(TW, OUTWc - ox0));
+  }
+}
+
+}  // namespace ms

@@ -1,0 +1,422 @@
+// 16-bit arithmetic mode: the HBM-bound kernels around the convs, on cb8 tensors ([B][C8][HW][8] 16-bit, conv16.h):
+// BatchNorm apply / backward, activation backward, eval-BN folding, and the layout converters at the path's fp32 boundaries.
+// One thread moves one 16-byte vector (8 channels of a pixel); consecutive lanes take consecutive pixels, so every access
+// is a 1 KiB wave transaction along the time axis.  All reductions run in a fixed order (no float atomics).
+#include <algorithm>
+
+#include "conv16_kernel.h"
+
+namespace ms {
+
+// y = lrelu(y_raw * scale[c] + shift[c]); y cb8, or plain fp32 (B, C, HW) when y_f32 != NULL
+template <typename DT>
+__global__ __launch_bounds__(256) void bn_apply16_kernel(const u32x4* __restrict__ y_raw, u32x4* __restrict__ y,
+                                                         float* __restrict__ y_f32, const float* __restrict__ save, int C,
+                                                         int C8, int HW, size_t total, float slope) {
+  const float* scale = save + 2 * (size_t)C;
+  const float* shift = save + 3 * (size_t)C;
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (size_t)gridDim.x * 256) {
+    const size_t bc = v / HW;
+    const int cb = (int)(bc % C8), pix = (int)(v - bc * HW);
+    const size_t b = bc / C8;
+    float f[8];
+    unpack8<DT>(y_raw[v], f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cb * 8 + j;
+      f[j] = c < C ? lrelu(fmaf(f[j], scale[c], shift[c]), slope) : 0.f;
+    }
+    if (y_f32) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (cb * 8 + j < C) y_f32[(b * C + cb * 8 + j) * HW + pix] = f[j];
+    } else {
+      y[v] = pack8<DT>(f);
+    }
+  }
+}
+
+int launch_bn_apply16(int dt, const void* y_raw, void* y, float* y_f32, const float* save, int B, int C, int HW, float slope,
+                      hipStream_t s) {
+  const int C8 = c8_of(C);
+  const size_t total = (size_t)B * C8 * HW;
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
+  TimingScope ts(s, 0, (y_f32 ? 2.0 + 4.0 : 4.0) * 8.0 * total, "bn_apply16_kernel|bn_apply16 C%d N%d", C, B * HW);
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL(bn_apply16_kernel<BF16>, dim3(blocks), dim3(256), 0, s, (const u32x4*)y_raw, (u32x4*)y, y_f32, save, C, C8, HW,
+                       total, slope);
+  else
+    hipLaunchKernelGGL(bn_apply16_kernel<F16>, dim3(blocks), dim3(256), 0, s, (const u32x4*)y_raw, (u32x4*)y, y_f32, save, C, C8, HW,
+                       total, slope);
+  return check_launch("bn_apply16_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------
+// block-wide sums of 8 values per thread; result valid in thread 0.  red: 4*8 floats of LDS.
+__device__ inline void block_sum8(float (&v)[8], float* red) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = wave_sum(v[j]);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[(threadIdx.x >> 6) * 8 + j] = v[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = red[j] + red[8 + j] + red[16 + j] + red[24 + j];
+}
+
+template <typename DT, bool DYF32>
+__device__ inline void load_dy8(const u32x4* dy, const float* dy_f32, size_t v, size_t b, int cb, int pix, int C, int HW,
+                                float (&f)[8]) {
+  if (DYF32) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = cb * 8 + j < C ? dy_f32[(b * C + cb * 8 + j) * HW + pix] : 0.f;
+  } else {
+    unpack8<DT>(dy[v], f);
+  }
+}
+
+// BatchNorm + LeakyReLU backward, pass 1.  grid (C8, nchunk); chunk = contiguous range of batch items.
+//   dz = dy * lrelu'(z), z = y_raw*scale+shift;  xh = (y_raw-mean)*invstd;  partial[c][chunk] = (sum dz, sum dz*xh)
+template <typename DT, bool DYF32>
+__global__ __launch_bounds__(256) void bn_bwd16_reduce_kernel(const u32x4* __restrict__ dy, const float* __restrict__ dy_f32,
+                                                              const u32x4* __restrict__ y_raw, const float* __restrict__ save,
+                                                              float* __restrict__ partial, int B, int C, int C8, int HW,
+                                                              int b_per_chunk, float slope) {
+  __shared__ float red[32];
+  const int cb = blockIdx.x, ch = blockIdx.y, t = threadIdx.x, nchunk = gridDim.y;
+  const int b0 = ch * b_per_chunk, nb = min(b_per_chunk, B - b0);
+  float mean[8], invstd[8], sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = min(cb * 8 + j, C - 1);
+    mean[j] = save[c]; invstd[j] = save[C + c]; sc[j] = save[2 * C + c]; sh[j] = save[3 * C + c];
+  }
+  float s1[8] = {}, s2[8] = {};
+  const int n = nb * HW;
+  for (int e = t; e < n; e += 256) {
+    const int bl = e / HW, pix = e - bl * HW;
+    const size_t b = b0 + bl, v = (b * C8 + cb) * HW + pix;
+    float g[8], yr[8];
+    load_dy8<DT, DYF32>(dy, dy_f32, v, b, cb, pix, C, HW, g);
+    unpack8<DT>(y_raw[v], yr);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float z = fmaf(yr[j], sc[j], sh[j]);
+      const float dz = g[j] * (z > 0.f ? 1.f : slope);
+      s1[j] += dz;
+      s2[j] = fmaf(dz, (yr[j] - mean[j]) * invstd[j], s2[j]);
+    }
+  }
+  block_sum8(s1, red);
+  block_sum8(s2, red);
+  if (t == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cb * 8 + j;
+      if (c < C) {
+        partial[((size_t)c * nchunk + ch) * 2] = s1[j];
+        partial[((size_t)c * nchunk + ch) * 2 + 1] = s2[j];
+      }
+    }
+  }
+}
+
+//   pass 2: dyr = gamma*invstd*(dz - s1/N - xh*s2/N); colsum partial of dyr; dgamma = s2, dbeta = s1
+template <typename DT, bool DYF32>
+__global__ __launch_bounds__(256) void bn_bwd16_apply_kernel(const u32x4* __restrict__ dy, const float* __restrict__ dy_f32,
+                                                             const u32x4* __restrict__ y_raw, const float* __restrict__ save,
+                                                             const float* __restrict__ gamma, const float* __restrict__ partial,
+                                                             u32x4* __restrict__ dyr, float* __restrict__ colpart, float* dgamma,
+                                                             float* dbeta, int B, int C, int C8, int HW, int b_per_chunk,
+                                                             float slope) {
+  __shared__ float red[32];
+  const int cb = blockIdx.x, ch = blockIdx.y, t = threadIdx.x, nchunk = gridDim.y;
+  const float invN = 1.0f / (float)((size_t)B * HW);
+  float mean[8], invstd[8], sc[8], sh[8], gi[8], m1[8], m2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = min(cb * 8 + j, C - 1);
+    const bool cv = cb * 8 + j < C;
+    float a = 0.f, b2 = 0.f;
+    for (int k = 0; k < nchunk; ++k) {
+      a += partial[((size_t)c * nchunk + k) * 2];
+      b2 += partial[((size_t)c * nchunk + k) * 2 + 1];
+    }
+    mean[j] = save[c]; invstd[j] = save[C + c]; sc[j] = save[2 * C + c]; sh[j] = save[3 * C + c];
+    gi[j] = cv ? gamma[c] * invstd[j] : 0.f;
+    m1[j] = a * invN; m2[j] = b2 * invN;
+    if (t == 0 && ch == 0 && cv && dgamma) { dgamma[c] = b2; dbeta[c] = a; }
+  }
+  const int b0 = ch * b_per_chunk, nb = min(b_per_chunk, B - b0);
+  const int n = nb * HW;
+  float cs[8] = {};
+  for (int e = t; e < n; e += 256) {
+    const int bl = e / HW, pix = e - bl * HW;
+    const size_t b = b0 + bl, v = (b * C8 + cb) * HW + pix;
+    float g[8], yr[8], o[8];
+    load_dy8<DT, DYF32>(dy, dy_f32, v, b, cb, pix, C, HW, g);
+    unpack8<DT>(y_raw[v], yr);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float z = fmaf(yr[j], sc[j], sh[j]);
+      const float dz = g[j] * (z > 0.f ? 1.f : slope);
+      const float xh = (yr[j] - mean[j]) * invstd[j];
+      o[j] = gi[j] * (dz - m1[j] - xh * m2[j]);
+      cs[j] += o[j];
+    }
+    dyr[v] = pack8<DT>(o);
+  }
+  block_sum8(cs, red);
+  if (t == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (cb * 8 + j < C) colpart[(size_t)(cb * 8 + j) * nchunk + ch] = cs[j];
+  }
+}
+
+int bwd16_chunks(int B, int C8, int HW, int* b_per_chunk) {
+  (void)HW;
+  int nchunk = std::min(B, std::max(1, 768 / std::max(1, C8)));
+  const int bpc = cdiv(B, nchunk);
+  nchunk = cdiv(B, bpc);
+  if (b_per_chunk) *b_per_chunk = bpc;
+  return nchunk;
+}
+
+int launch_bn_bwd16(int dt, const void* dy, const float* dy_f32, const void* y_raw, const float* save, const float* gamma,
+                    float* partial, void* dyr, float* colpart, float* dgamma, float* dbeta, int B, int C, int HW, float slope,
+                    hipStream_t s) {
+  const int C8 = c8_of(C);
+  int bpc;
+  const int nchunk = bwd16_chunks(B, C8, HW, &bpc);
+  const dim3 grid(C8, nchunk);
+  const double vec = (double)B * C8 * HW;
+  TimingScope ts(s, 0, 16.0 * (dy_f32 ? 4.0 + 2.0 + 1.0 : 5.0) * vec, "bn_bwd16_kernels|bn_bwd16 C%d N%d", C, B * HW);
+#define MS_BNB(DT, F)                                                                                                              \
+  do {                                                                                                                             \
+    hipLaunchKernelGGL((bn_bwd16_reduce_kernel<DT, F>), grid, dim3(256), 0, s, (const u32x4*)dy, dy_f32, (const u32x4*)y_raw, save,   \
+                       partial, B, C, C8, HW, bpc, slope);                                                                         \
+    hipLaunchKernelGGL((bn_bwd16_apply_kernel<DT, F>), grid, dim3(256), 0, s, (const u32x4*)dy, dy_f32, (const u32x4*)y_raw, save,    \
+                       gamma, partial, (u32x4*)dyr, colpart, dgamma, dbeta, B, C, C8, HW, bpc, slope);                             \
+  } while (0)
+  if (dt == DT_BF16) { if (dy_f32) MS_BNB(BF16, true); else MS_BNB(BF16, false); }
+  else { if (dy_f32) MS_BNB(F16, true); else MS_BNB(F16, false); }
+#undef MS_BNB
+  return check_launch("bn_bwd16 kernels");
+}
+
+// activation backward for blocks without BN: mode 1 (LRELU): dyr = dy * (y>0 ? 1 : slope); mode 0 (BARE): dyr = dy,
+// written only when dy arrives as plain fp32 (it is then also the conversion to cb8).  Per-channel colsum partials always.
+template <typename DT, bool DYF32>
+__global__ __launch_bounds__(256) void act_bwd16_kernel(const u32x4* __restrict__ dy, const float* __restrict__ dy_f32,
+                                                        const u32x4* __restrict__ y, u32x4* __restrict__ dyr,
+                                                        float* __restrict__ colpart, int B, int C, int C8, int HW, int b_per_chunk,
+                                                        int mode, float slope) {
+  __shared__ float red[32];
+  const int cb = blockIdx.x, ch = blockIdx.y, t = threadIdx.x, nchunk = gridDim.y;
+  const int b0 = ch * b_per_chunk, nb = min(b_per_chunk, B - b0);
+  const int n = nb * HW;
+  float cs[8] = {};
+  for (int e = t; e < n; e += 256) {
+    const int bl = e / HW, pix = e - bl * HW;
+    const size_t b = b0 + bl, v = (b * C8 + cb) * HW + pix;
+    float g[8];
+    load_dy8<DT, DYF32>(dy, dy_f32, v, b, cb, pix, C, HW, g);
+    if (mode == 1) {
+      float yy[8];
+      unpack8<DT>(y[v], yy);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] *= (yy[j] > 0.f ? 1.f : slope);
+    }
+    if (mode == 1 || DYF32) dyr[v] = pack8<DT>(g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cs[j] += g[j];
+  }
+  block_sum8(cs, red);
+  if (t == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (cb * 8 + j < C) colpart[(size_t)(cb * 8 + j) * nchunk + ch] = cs[j];
+  }
+}
+
+int launch_act_bwd16(int dt, const void* dy, const float* dy_f32, const void* y, void* dyr, float* colpart, int B, int C, int HW,
+                     int mode, float slope, hipStream_t s) {
+  const int C8 = c8_of(C);
+  int bpc;
+  const int nchunk = bwd16_chunks(B, C8, HW, &bpc);
+  const dim3 grid(C8, nchunk);
+  TimingScope ts(s, 0, 16.0 * 3.0 * (double)B * C8 * HW, "act_bwd16_kernel|act_bwd16 C%d N%d mode%d", C, B * HW, mode);
+#define MS_ACT(DT, F)                                                                                                          \
+  hipLaunchKernelGGL((act_bwd16_kernel<DT, F>), grid, dim3(256), 0, s, (const u32x4*)dy, dy_f32, (const u32x4*)y, (u32x4*)dyr,   \
+                     colpart, B, C, C8, HW, bpc, mode, slope)
+  if (dt == DT_BF16) { if (dy_f32) MS_ACT(BF16, true); else MS_ACT(BF16, false); }
+  else { if (dy_f32) MS_ACT(F16, true); else MS_ACT(F16, false); }
+#undef MS_ACT
+  return check_launch("act_bwd16_kernel");
+}
+
+__global__ void colsum16_kernel(const float* __restrict__ colpart, float* __restrict__ out, int C, int nchunk) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int k = 0; k < nchunk; ++k) s += colpart[(size_t)c * nchunk + k];
+  out[c] = s;
+}
+
+int launch_colsum16(const float* colpart, float* out, int C, int nchunk, hipStream_t s) {
+  hipLaunchKernelGGL(colsum16_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, colpart, out, C, nchunk);
+  return check_launch("colsum16_kernel");
+}
+
+// eval BatchNorm folded into the conv: scale[c] = gamma/sqrt(var+eps), bias'[c] = (bias - mean)*scale + beta
+__global__ void bn_fold_kernel(const float* __restrict__ bias, const float* __restrict__ g, const float* __restrict__ b,
+                               const float* __restrict__ m, const float* __restrict__ v, float* __restrict__ scale,
+                               float* __restrict__ bias_out, int C, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = g[c] * (1.0f / sqrtf(v[c] + eps));
+  scale[c] = sc;
+  bias_out[c] = fmaf((bias ? bias[c] : 0.f) - m[c], sc, b[c]);
+}
+
+int launch_bn_fold(const float* bias, const float* g, const float* b, const float* m, const float* v, float* scale,
+                   float* bias_out, int C, float eps, hipStream_t s) {
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, bias, g, b, m, v, scale, bias_out, C, eps);
+  return check_launch("bn_fold_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------
+// layout converters at the fp32 boundaries of the path
+template <typename DT>
+__global__ __launch_bounds__(256) void cb8_from_plain_kernel(const float* __restrict__ x, u32x4* __restrict__ y, int C, int C8,
+                                                             int HW, size_t total) {
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (size_t)gridDim.x * 256) {
+    const size_t bc = v / HW;
+    const int cb = (int)(bc % C8), pix = (int)(v - bc * HW);
+    const size_t b = bc / C8;
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = cb * 8 + j < C ? x[(b * C + cb * 8 + j) * HW + pix] : 0.f;
+    y[v] = pack8<DT>(f);
+  }
+}
+
+template <typename DT>
+__global__ __launch_bounds__(256) void cb8_to_plain_kernel(const u32x4* __restrict__ x, float* __restrict__ y, int C, int C8, int HW,
+                                                           size_t total) {
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (size_t)gridDim.x * 256) {
+    const size_t bc = v / HW;
+    const int cb = (int)(bc % C8), pix = (int)(v - bc * HW);
+    const size_t b = bc / C8;
+    float f[8];
+    unpack8<DT>(x[v], f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (cb * 8 + j < C) y[(b * C + cb * 8 + j) * HW + pix] = f[j];
+  }
+}
+
+// time-major fp32 (B, T, C) -> cb8 (B, C8, T); velocity: v[t] = x[t] - x[t-1], v[0] = 0 (gan.py:47-52)
+template <typename DT>
+__global__ __launch_bounds__(256) void cb8_from_btc_kernel(const float* __restrict__ x, u32x4* __restrict__ y, int T, int C, int C8,
+                                                           size_t total, int velocity) {
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (size_t)gridDim.x * 256) {
+    const size_t bc = v / T;
+    const int cb = (int)(bc % C8), t = (int)(v - bc * T);
+    const size_t b = bc / C8;
+    const float* row = x + (b * T + t) * C + cb * 8;
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float val = 0.f;
+      if (cb * 8 + j < C) {
+        val = row[j];
+        if (velocity) val = t > 0 ? val - row[j - C] : 0.f;
+      }
+      f[j] = val;
+    }
+    y[v] = pack8<DT>(f);
+  }
+}
+
+// cb8 (B, C8, T) -> time-major fp32 (B, T, C); velocity_bwd: dx[t] = dv[t] - dv[t+1] (dv[0] does not reach x: v[0] = 0)
+template <typename DT>
+__global__ __launch_bounds__(256) void cb8_to_btc_kernel(const u32x4* __restrict__ x, float* __restrict__ y, int T, int C, int C8,
+                                                         size_t total, int velocity_bwd) {
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (size_t)gridDim.x * 256) {
+    const size_t bc = v / T;
+    const int cb = (int)(bc % C8), t = (int)(v - bc * T);
+    const size_t b = bc / C8;
+    float f[8];
+    unpack8<DT>(x[v], f);
+    if (velocity_bwd) {
+      float nx[8] = {};
+      if (t + 1 < T) unpack8<DT>(x[v + 1], nx);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = (t > 0 ? f[j] : 0.f) - nx[j];
+    }
+    float* row = y + (b * T + t) * C + cb * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (cb * 8 + j < C) row[j] = f[j];
+  }
+}
+
+}  // namespace ms
+
+using namespace ms;
+
+extern "C" {
+
+static int conv_blocks(size_t total) { return (int)std::min<size_t>((total + 255) / 256, 8192); }
+
+int ms_cb8_from_plain(int dtype, const float* x, void* y, int B, int C, int HW, void* stream) {
+  if (dtype != MS_BF16 && dtype != MS_F16) return set_error("ms_cb8_from_plain: dtype %d", dtype);
+  if (!x || !y || B < 1 || C < 1 || HW < 1) return set_error("ms_cb8_from_plain: bad argument");
+  const int C8 = c8_of(C);
+  const size_t total = (size_t)B * C8 * HW;
+  hipStream_t s = (hipStream_t)stream;
+  TimingScope ts(s, 0, 6.0 * 8.0 * total, "cb8_from_plain_kernel|cb8_from_plain C%d N%d", C, B * HW);
+  if (dtype == MS_BF16) hipLaunchKernelGGL(cb8_from_plain_kernel<BF16>, dim3(conv_blocks(total)), dim3(256), 0, s, x, (u32x4*)y, C, C8, HW, total);
+  else hipLaunchKernelGGL(cb8_from_plain_kernel<F16>, dim3(conv_blocks(total)), dim3(256), 0, s, x, (u32x4*)y, C, C8, HW, total);
+  return check_launch("cb8_from_plain_kernel");
+}
+
+int ms_cb8_to_plain(int dtype, const void* x, float* y, int B, int C, int HW, void* stream) {
+  if (dtype != MS_BF16 && dtype != MS_F16) return set_error("ms_cb8_to_plain: dtype %d", dtype);
+  if (!x || !y || B < 1 || C < 1 || HW < 1) return set_error("ms_cb8_to_plain: bad argument");
+  const int C8 = c8_of(C);
+  const size_t total = (size_t)B * C8 * HW;
+  hipStream_t s = (hipStream_t)stream;
+  TimingScope ts(s, 0, 6.0 * 8.0 * total, "cb8_to_plain_kernel|cb8_to_plain C%d N%d", C, B * HW);
+  if (dtype == MS_BF16) hipLaunchKernelGGL(cb8_to_plain_kernel<BF16>, dim3(conv_blocks(total)), dim3(256), 0, s, (const u32x4*)x, y, C, C8, HW, total);
+  else hipLaunchKernelGGL(cb8_to_plain_kernel<F16>, dim3(conv_blocks(total)), dim3(256), 0, s, (const u32x4*)x, y, C, C8, HW, total);
+  return check_launch("cb8_to_plain_kernel");
+}
+
+int ms_cb8_from_btc(int dtype, const float* x, void* y, int B, int T, int C, int velocity, void* stream) {
+  if (dtype != MS_BF16 && dtype != MS_F16) return set_error("ms_cb8_from_btc: dtype %d", dtype);
+  if (!x || !y || B < 1 || C < 1 || T < 1) return set_error("ms_cb8_from_btc: bad argument");
+  const int C8 = c8_of(C);
+  const size_t total = (size_t)B * C8 * T;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MS_BF16) hipLaunchKernelGGL(cb8_from_btc_kernel<BF16>, dim3(conv_blocks(total)), dim3(256), 0, s, x, (u32x4*)y, T, C, C8, total, velocity);
+  else hipLaunchKernelGGL(cb8_from_btc_kernel<F16>, dim3(conv_blocks(total)), dim3(256), 0, s, x, (u32x4*)y, T, C, C8, total, velocity);
+  return check_launch("cb8_from_btc_kernel");
+}
+
+int ms_cb8_to_btc(int dtype, const void* x, float* y, int B, int T, int C, int velocity_bwd, void* stream) {
+  if (dtype != MS_BF16 && dtype != MS_F16) return set_error("ms_cb8_to_btc: dtype %d", dtype);
+  if (!x || !y || B < 1 || C < 1 || T < 1) return set_error("ms_cb8_to_btc: bad argument");
+  const int C8 = c8_of(C);
+  const size_t total = (size_t)B * C8 * T;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MS_BF16) hipLaunchKernelGGL(cb8_to_btc_kernel<BF16>, dim3(conv_blocks(total)), dim3(256), 0, s, (const u32x4*)x, y, T, C, C8, total, velocity_bwd);
+  else hipLaunchKernelGGL(cb8_to_btc_kernel<F16>, dim3(conv_blocks(total)), dim3(256), 0, s, (const u32x4*)x, y, T, C, C8, total, velocity_bwd);
+  return check_launch("cb8_to_btc_kernel");
+}
+
+}  // extern "C"

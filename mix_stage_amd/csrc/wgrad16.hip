@@ -1,0 +1,270 @@
+// 16-bit arithmetic mode: weight gradient on v_mfma_f32_32x32x16_{bf16,f16}.
+//
+//   dw[co][ci][kh][kw] = sum over pixels p of dy[co][p] * x[ci][p*S + (kh, kw) - pad]
+//
+// is a GEMM whose reduction index is the PIXEL, while the cb8 layout keeps 8 CHANNELS of one pixel together.  The MFMA
+// operands (8 consecutive reduction indices per lane = 8 pixels of ONE channel) are therefore transposed on their way out of
+// LDS by ds_read_b64_tr_b16: per group of 16 lanes it reads 4 rows (pixels) x 16 columns (channels, two cb8 vectors) and
+// hands lane i column i -- four consecutive pixels of its channel.  Two such reads make one MFMA operand; no data is
+// re-laid out anywhere, every lane supplies its own row address, so tap and stride offsets are free.
+//
+// A workgroup (4 waves, 2 x 2) owns 64 output channels x 64 input channels x TP taps (kw0 .. kw0+TP-1 of one kernel row) of
+// one group and a range of 64-pixel tiles; per tile it stages dy [8 blocks][64 px] and the input rows
+// [8 blocks][TH][(TW-1)*S + TP] as 16-byte vectors.  Pixel splits leave fp32 partial slabs that are summed in a fixed order
+// by the caller (ms_wgrad_reduce_multi), like the fp32 kernels'.
+#include <algorithm>
+
+#include "conv16_kernel.h"
+
+namespace ms {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ inline u32x4 tr_read2(const u32x4* base, int vec0, int vec1, int sub8) {
+  // vecN: index of the cb8 vector (row of the 4x16 block this lane addresses), sub8: 0/8 byte offset inside it
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const char* b = reinterpret_cast<const char*>(base);
+  // (whole-value bit casts: element access on a builtin's vector result is miscompiled by this clang)
+  const unsigned long long lo = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(b + (size_t)vec0 * 16 + sub8)));
+  const unsigned long long hi = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(b + (size_t)vec1 * 16 + sub8)));
+  u32x4 v;
+  v[0] = (unsigned)lo;
+  v[1] = (unsigned)(lo >> 32);
+  v[2] = (unsigned)hi;
+  v[3] = (unsigned)(hi >> 32);
+  return v;
+}
+
+constexpr int WG16_NPX = 8;   // input-row vectors a thread stages per tile at most (plan_wgrad16 keeps 8*TH*PCX <= 8*256)
+
+template <typename DT, int TP, bool UP2>
+__global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args p) {
+  extern __shared__ u32x4 smem[];
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int wm = wid >> 1, wn = wid & 1, h = lane >> 5;
+  const int TW = 1 << p.ltw, TH = p.TH, PCX = p.PCX, S = p.S, SV = p.SV;
+  const int xv = 8 * TH * PCX;                 // input-row vectors per tile
+  const int stage_vecs = 512 + xv + 1;
+
+  const int vid = xcd_remap(blockIdx.x, p.gx * p.gy * p.gz);
+  const int bx_ = vid % p.gx, by_ = (vid / p.gx) % p.gy, bz_ = vid / (p.gx * p.gy);
+  // z = ((group * KH + kh) * ktg + tap group) * splits + split
+  const int split = bz_ % p.splits;
+  int zz = bz_ / p.splits;
+  const int tgi = zz % p.ktg; zz /= p.ktg;
+  const int kh = zz % p.KH;
+  const int g = zz / p.KH;
+  const int kw0 = tgi * TP;
+  const int co0 = by_ * 64, ci0 = bx_ * 64;     // channel offsets inside the group (multiples of 8)
+  const int cog8 = (p.Cog + 7) >> 3, cig8 = (p.Cig + 7) >> 3;
+  const int dy_cb0 = ((g * p.Cog) >> 3) + (co0 >> 3);
+  const int x_cb0 = (p.bcast ? 0 : ((g * p.Cig) >> 3)) + (ci0 >> 3);
+  const int tile_beg = split * p.tiles_per_split, tile_end = min(p.n_tiles, tile_beg + p.tiles_per_split);
+  const int tiles_per_img = p.tiles_y * p.tiles_x;
+
+  const __amdgpu_buffer_rsrc_t rsD = buf_rsrc(p.dyr), rsS = buf_rsrc(p.src), rsS2 = buf_rsrc(UP2 ? p.src2 : p.src);
+
+  // ---- tile-invariant parts of the staging offsets
+  // dy: vector e = cb*64 + n, n = ty*TW + tx
+  int d_cb[2], d_ty[2], d_tx[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = t + i * 256;
+    d_cb[i] = e >> 6;
+    const int n = e & 63;
+    d_ty[i] = n >> p.ltw; d_tx[i] = n & (TW - 1);
+  }
+  int x_cb[WG16_NPX], x_ty[WG16_NPX], x_c[WG16_NPX], x_lds[WG16_NPX];
+#pragma unroll
+  for (int i = 0; i < WG16_NPX; ++i) {
+    const int e = t + i * 256;
+    const int cb = e / (TH * PCX), rem = e - cb * TH * PCX, ty = rem / PCX;
+    x_cb[i] = cb; x_ty[i] = ty; x_c[i] = rem - ty * PCX;
+    x_lds[i] = e < xv ? 512 + e : 512 + xv;
+  }
+
+  u32x4 rd[2], rx[WG16_NPX], rx2[UP2 ? WG16_NPX : 1];
+  auto load_tile = [&](int tile) {
+    const int img = tile / tiles_per_img, trem = tile - img * tiles_per_img;
+    const int tyi = trem / p.tiles_x, txi = trem - tyi * p.tiles_x;
+    const int oy0 = tyi * TH, ox0 = txi << p.ltw;
+    const int dbase = __builtin_amdgcn_readfirstlane(img * p.o_img + dy_cb0 * p.o_cblk);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int oy = oy0 + d_ty[i], ox = ox0 + d_tx[i];
+      const bool ok = (oy < p.OUTH) & (ox < p.OUTW) & ((co0 >> 3) + d_cb[i] < cog8);
+      rd[i] = buf_load_v(rsD, ok ? 16u * (unsigned)(d_cb[i] * p.o_cblk + oy * p.o_row + ox) : BUF_OOB, 16u * (unsigned)dbase);
+    }
+    const int iy0 = oy0 * SV - p.PH + kh, ix0 = ox0 * S - p.PW + kw0;
+    const int sbase = __builtin_amdgcn_readfirstlane(img * p.s_img + x_cb0 * p.s_cblk);
+#pragma unroll
+    for (int i = 0; i < WG16_NPX; ++i) {
+      const int iy = iy0 + x_ty[i] * SV, ix = ix0 + x_c[i];
+      const bool ok = (x_lds[i] < 512 + xv) & ((unsigned)iy < (unsigned)p.SRCH) & ((unsigned)ix < (unsigned)p.SRCW) &
+                      ((ci0 >> 3) + x_cb[i] < cig8);
+      const int o = x_cb[i] * p.s_cblk + iy * p.s_row;
+      if (UP2) {
+        rx[i] = buf_load_v(rsS, ok ? 16u * (unsigned)((o >> 1) + (ix >> 1)) : BUF_OOB, 16u * (unsigned)(sbase >> 1));
+        rx2[UP2 ? i : 0] = buf_load_v(rsS2, ok ? 16u * (unsigned)(o + ix) : BUF_OOB, 16u * (unsigned)sbase);
+      } else {
+        rx[i] = buf_load_v(rsS, ok ? 16u * (unsigned)(o + ix) : BUF_OOB, 16u * (unsigned)sbase);
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    u32x4* st = smem + buf * stage_vecs;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) st[t + i * 256] = rd[i];
+#pragma unroll
+    for (int i = 0; i < WG16_NPX; ++i) {
+      if (UP2) {
+        float fa[8], fr[8];
+        unpack8<DT>(rx[i], fa);
+        unpack8<DT>(rx2[UP2 ? i : 0], fr);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fa[j] += fr[j];
+        st[x_lds[i]] = pack8<DT>(fa);
+      } else {
+        st[x_lds[i]] = rx[i];
+      }
+    }
+  };
+
+  f32x16 acc[TP];
+#pragma unroll
+  for (int q = 0; q < TP; ++q)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+
+  // ---- transposed-read lane roles: group of 16 lanes = 16 channels (2 blocks); lane 4q+pp addresses row q, 4 channels pp
+  const int li = lane & 15, q4 = li >> 2, pp = li & 3, half16 = (lane >> 4) & 1;
+  const int sub8 = (pp & 1) * 8;
+  const int a_blk = wm * 4 + half16 * 2 + (pp >> 1);     // dy block inside the 64-channel tile
+  const int b_blk = wn * 4 + half16 * 2 + (pp >> 1);     // x block inside the 64-channel tile
+  const int thpcx = TH * PCX;
+
+  auto compute_tile = [&](int cur) {
+    const u32x4* st = smem + cur * stage_vecs;
+    const u32x4* xs = st + 512;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int p0 = 16 * kk + 8 * h + q4, p1 = p0 + 4;           // this lane's rows (pixels) of the two 4-row reads
+      const u32x4 av = tr_read2(st, a_blk * 64 + p0, a_blk * 64 + p1, sub8);
+      const int x0 = b_blk * thpcx + (p0 >> p.ltw) * PCX + (p0 & (TW - 1)) * S;
+      const int x1 = b_blk * thpcx + (p1 >> p.ltw) * PCX + (p1 & (TW - 1)) * S;
+#pragma unroll
+      for (int q = 0; q < TP; ++q) {
+        const u32x4 bv = tr_read2(xs, x0 + q, x1 + q, sub8);
+        acc[q] = DT::mfma(av, bv, acc[q]);
+      }
+    }
+  };
+
+  if (tile_beg < tile_end) {
+    load_tile(tile_beg);
+    store_tile(0);
+    __syncthreads();
+    for (int tile = tile_beg; tile < tile_end; ++tile) {
+      const int cur = (tile - tile_beg) & 1;
+      if (tile + 1 < tile_end) load_tile(tile + 1);
+      compute_tile(cur);
+      if (tile + 1 < tile_end) store_tile(cur ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- store: D[row = co][col = ci] per tap; dw is (groups*Cog, Cig, KH, KW) fp32
+  const int r = lane & 31;
+  float* out = p.out + (size_t)split * p.out_split_stride;
+  const int ci = ci0 + wn * 32 + r;
+#pragma unroll
+  for (int q = 0; q < TP; ++q) {
+    const int kw = kw0 + q;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int co = co0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (co < p.Cog && ci < p.Cig && kw < p.KW)
+        out[(((size_t)(g * p.Cog + co) * p.Cig + ci) * p.KH + kh) * p.KW + kw] = acc[q][e];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+static int pow2_at_least(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+static int ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+Wgrad16Plan plan_wgrad16(int nd, int Cog, int Cig, int groups, int KH, int KW, int SH, int SW, int B, int OH, int OW) {
+  Wgrad16Plan pl = {};
+  const int rows = nd == 1 ? B : OH, imgs = nd == 1 ? 1 : B;
+  pl.tp = KW == 1 ? 1 : KW == 3 ? 3 : (KW % 4 == 0) ? 4 : (KW == 2 ? 2 : 0);
+  if (!pl.tp) return pl;
+  pl.ktg = KW / pl.tp;
+  pl.tw = std::min(pow2_at_least(OW), 64);
+  pl.th = 64 / pl.tw;
+  pl.pcx = (pl.tw - 1) * SW + pl.tp;
+  if (8 * pl.th * pl.pcx > WG16_NPX * 256) return (pl.tp = 0, pl);
+  pl.tiles_y = cdiv(rows, pl.th); pl.tiles_x = cdiv(OW, pl.tw);
+  pl.n_tiles = imgs * pl.tiles_y * pl.tiles_x;
+  // pixel splits: fill ~2 workgroups per CU, at least 2 tiles per workgroup
+  const long base = (long)cdiv(Cog, 64) * cdiv(Cig, 64) * groups * KH * pl.ktg;
+  int splits = (int)std::max<long>(1, std::min<long>((512 + base - 1) / base, pl.n_tiles / 2));
+  splits = std::min(splits, 64);
+  pl.tiles_per_split = cdiv(pl.n_tiles, std::max(1, splits));
+  pl.splits = cdiv(pl.n_tiles, pl.tiles_per_split);
+  pl.lds_bytes = 2 * (512 + 8 * pl.th * pl.pcx + 1) * 16;
+  (void)SH;
+  return pl;
+}
+
+template <typename DT, int TP, bool UP2>
+static int launch_w(const Wgrad16Args& a, int lds, int nwg, hipStream_t s) {
+  static bool attr_done = false;
+  auto fn = wgrad16_kernel<DT, TP, UP2>;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return set_error("wgrad16: cannot raise the dynamic LDS limit");
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(fn, dim3(nwg), dim3(256), lds, s, a);
+  return 0;
+}
+
+template <typename DT>
+static int launch_tp(const Wgrad16Args& a, const Wgrad16Plan& pl, bool up2, int nwg, hipStream_t s) {
+  if (up2) return launch_w<DT, 3, true>(a, pl.lds_bytes, nwg, s);
+  switch (pl.tp) {
+    case 1: return launch_w<DT, 1, false>(a, pl.lds_bytes, nwg, s);
+    case 2: return launch_w<DT, 2, false>(a, pl.lds_bytes, nwg, s);
+    case 3: return launch_w<DT, 3, false>(a, pl.lds_bytes, nwg, s);
+    case 4: return launch_w<DT, 4, false>(a, pl.lds_bytes, nwg, s);
+  }
+  return set_error("wgrad16: no kernel for %d taps", pl.tp);
+}
+
+int launch_wgrad16(int dt, const Wgrad16Args& a, const Wgrad16Plan& pl, bool up2, double flops, double bytes, hipStream_t s) {
+  if (!pl.tp) return set_error("wgrad16: geometry not supported");
+  if (up2 && pl.tp != 3) return set_error("wgrad16: the upsample-add input needs a k3 block");
+  if ((a.groups > 1) && ((a.Cog & 7) || (!a.bcast && (a.Cig & 7)))) return set_error("wgrad16: grouped blocks need channels per group % 8 == 0");
+  Wgrad16Args b = a;
+  b.ltw = ilog2(pl.tw); b.TH = pl.th; b.PCX = pl.pcx; b.tiles_x = pl.tiles_x; b.tiles_y = pl.tiles_y; b.n_tiles = pl.n_tiles;
+  b.tiles_per_split = pl.tiles_per_split; b.splits = pl.splits; b.ktg = pl.ktg;
+  b.gx = cdiv(a.Cig, 64); b.gy = cdiv(a.Cog, 64); b.gz = a.groups * a.KH * pl.ktg * pl.splits;
+  const double nwg = (double)b.gx * b.gy * b.gz;
+  if (nwg > 2.0e9) return set_error("wgrad16: grid too large");
+  TimingScope ts(s, flops, bytes, "wgrad16_kernel<%s,%d,%d>|conv_wgrad_cb8 k%dx%d s%d Cog%d Kg%d g%d tiles%d tw%d splits%d",
+                 dt == DT_BF16 ? "bf16" : "f16", pl.tp, up2 ? 1 : 0, a.KH, a.KW, a.S, a.Cog, a.Cig * a.KH * a.KW, a.groups, pl.n_tiles,
+                 pl.tw, pl.splits);
+  const int rc = dt == DT_BF16 ? launch_tp<BF16>(b, pl, up2, (int)nwg, s) : launch_tp<F16>(b, pl, up2, (int)nwg, s);
+  if (rc) return rc;
+  return check_launch("wgrad16_kernel");
+}
+
+}  // namespace ms

@@ -121,6 +121,10 @@ def _prepare_entries(entries):
     return
   L = lib()
   tune = L.ms_tuning_epoch()
+  e16 = [e for e in entries if e['kind'].endswith('16')]
+  if e16:                                # 16-bit mode operands (ops16): one ms_weights16_prepare launch per 24 blocks
+    from . import ops16
+    ops16._prepare16(e16)
   for kind, fn in (('dgrad', L.ms_dgrad_weights_prepare), ('fwd', L.ms_fwd_weights_prepare)):
     es = [e for e in entries if e['kind'] == kind]
     if not es:
@@ -265,8 +269,8 @@ class ConvGeom:
     self.slope, self.eps, self.momentum = float(slope), float(eps), float(momentum)
     self._cache = {}
 
-  def desc(self, B, Cin_g, H, W, Cout_g, mode, in_mode):
-    key = (B, Cin_g, H, W, Cout_g, mode, in_mode)
+  def desc(self, B, Cin_g, H, W, Cout_g, mode, in_mode, dtype=0):
+    key = (B, Cin_g, H, W, Cout_g, mode, in_mode, dtype)
     d = self._cache.get(key)
     if d is None:
       OH = (H + 2 * self.PH - self.KH) // self.SH + 1
@@ -274,7 +278,7 @@ class ConvGeom:
       if OH < 1 or OW < 1:
         raise RuntimeError('conv block: input (%d,%d) too small for kernel (%d,%d)' % (H, W, self.KH, self.KW))
       d = ConvDesc(B, Cin_g, H, W, Cout_g, self.groups, self.KH, self.KW, self.SH, self.SW, self.PH, self.PW,
-                   OH, OW, mode, in_mode, self.slope, self.eps, self.momentum, 0)
+                   OH, OW, mode, in_mode, self.slope, self.eps, self.momentum, dtype)
       d._tune = -1
       self._cache[key] = d
     L = lib()

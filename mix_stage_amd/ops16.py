@@ -1,0 +1,275 @@
+"""torch.autograd bindings of the 16-bit arithmetic mode (bf16 / fp16 operands, fp32 accumulate; include/mixstage.h: ms_dtype).
+
+Activations travel between the blocks as "cb8" tensors: torch tensors of dtype bfloat16 / float16 and shape
+(B, C8, T, 8) or (B, C8, H, W, 8), C8 = ceil(C/8) -- [channel block][pixel][8 channels], pad channels zero -- the layout the
+matrix cores consume without transposition (mix_stage_amd/csrc/conv16.h).  Parameters, BatchNorm statistics, losses and
+parameter gradients stay fp32.  The converters below sit at the fp32 boundaries of the path (inputs, scores, poses).
+"""
+import ctypes
+
+import torch
+
+from . import ops
+from ._lib import (BwdOptions, ConvDesc, FwdOptions, MS_BARE, MS_BF16, MS_BN_EVAL, MS_BN_TRAIN, MS_DT_BN_FOLDED, MS_DT_OUT_F32,
+                   MS_F16, MS_IN_BCAST, MS_IN_PLAIN, MS_IN_UP2ADD, MS_LRELU, Prep16Item, check, lib)
+from .ops import _grad_slot, _ptr, _stream, workspace
+
+TORCH_DT = {MS_BF16: torch.bfloat16, MS_F16: torch.float16}
+MS_DT = {torch.bfloat16: MS_BF16, torch.float16: MS_F16}
+NAME_DT = {'bf16': MS_BF16, 'bfloat16': MS_BF16, 'fp16': MS_F16, 'f16': MS_F16, 'float16': MS_F16, 'half': MS_F16}
+
+
+def is_cb8(t):
+  return t is not None and t.dtype in MS_DT and t.dim() in (4, 5) and t.shape[-1] == 8
+
+
+def _need16(*tensors):
+  for t in tensors:
+    if t is not None and not t.is_cuda:
+      raise ops._lib.MixStageLibError('mix_stage_amd ops run on the MI355X only (got a %s tensor)' % t.device)
+
+
+# ------------------------------------------------------------------------------------------------
+# layout converters
+class _ToCb8Fn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x, dt):
+    _need16(x)
+    if x.dtype != torch.float32:
+      raise TypeError('to_cb8 expects a float32 (B, C, ...) tensor, got %s' % x.dtype)
+    x = x.contiguous()
+    B, C = x.shape[0], x.shape[1]
+    sp = tuple(x.shape[2:])
+    hw = 1
+    for v in sp:
+      hw *= v
+    y = torch.empty((B, (C + 7) // 8) + sp + (8,), dtype=TORCH_DT[dt], device=x.device)
+    check(lib().ms_cb8_from_plain(dt, _ptr(x), _ptr(y), B, C, hw, _stream()), 'ms_cb8_from_plain')
+    ctx.meta = (dt, B, C, sp, hw)
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    dt, B, C, sp, hw = ctx.meta
+    dy = dy.contiguous()
+    dx = torch.empty((B, C) + sp, dtype=torch.float32, device=dy.device)
+    check(lib().ms_cb8_to_plain(dt, _ptr(dy), _ptr(dx), B, C, hw, _stream()), 'ms_cb8_to_plain')
+    return dx, None
+
+
+class _FromCb8Fn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x, C):
+    _need16(x)
+    x = x.contiguous()
+    dt = MS_DT[x.dtype]
+    B = x.shape[0]
+    sp = tuple(x.shape[2:-1])
+    hw = 1
+    for v in sp:
+      hw *= v
+    y = torch.empty((B, C) + sp, dtype=torch.float32, device=x.device)
+    check(lib().ms_cb8_to_plain(dt, _ptr(x), _ptr(y), B, C, hw, _stream()), 'ms_cb8_to_plain')
+    ctx.meta = (dt, B, C, sp, hw, tuple(x.shape))
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    dt, B, C, sp, hw, shape = ctx.meta
+    dy = dy.contiguous()
+    dx = torch.empty(shape, dtype=TORCH_DT[dt], device=dy.device)
+    check(lib().ms_cb8_from_plain(dt, _ptr(dy), _ptr(dx), B, C, hw, _stream()), 'ms_cb8_from_plain')
+    return dx, None
+
+
+class _BtcToCb8Fn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x, dt, velocity):
+    _need16(x)
+    if x.dtype != torch.float32:
+      raise TypeError('btc_to_cb8 expects a float32 (B, T, C) tensor, got %s' % x.dtype)
+    x = x.contiguous()
+    B, T, C = x.shape
+    y = torch.empty((B, (C + 7) // 8, T, 8), dtype=TORCH_DT[dt], device=x.device)
+    check(lib().ms_cb8_from_btc(dt, _ptr(x), _ptr(y), B, T, C, 1 if velocity else 0, _stream()), 'ms_cb8_from_btc')
+    ctx.meta = (dt, B, T, C, velocity)
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    dt, B, T, C, velocity = ctx.meta
+    dy = dy.contiguous()
+    dx = torch.empty((B, T, C), dtype=torch.float32, device=dy.device)
+    check(lib().ms_cb8_to_btc(dt, _ptr(dy), _ptr(dx), B, T, C, 1 if velocity else 0, _stream()), 'ms_cb8_to_btc')
+    return dx, None, None
+
+
+def to_cb8(x, dt):
+  """fp32 (B, C, ...) channel-major -> cb8 (B, C8, ..., 8)."""
+  return _ToCb8Fn.apply(x, int(dt))
+
+
+def from_cb8(x, C):
+  """cb8 (B, C8, ..., 8) -> fp32 (B, C, ...) channel-major."""
+  return _FromCb8Fn.apply(x, int(C))
+
+
+def btc_to_cb8(x, dt, velocity=False):
+  """fp32 time-major (B, T, C) -> cb8 (B, C8, T, 8); velocity=True fuses GAN.get_velocity (gan.py:47-52)."""
+  return _BtcToCb8Fn.apply(x, int(dt), bool(velocity))
+
+
+# ------------------------------------------------------------------------------------------------
+# prepared operands (ms_weights16_prepare): once per optimizer update for all blocks of a network in one launch
+def _prepare16(entries):
+  entries = [e for e in entries if e['n']]
+  if not entries:
+    return
+  n = len(entries)
+  items = (Prep16Item * n)()
+  for it, e in zip(items, entries):
+    it.desc = ctypes.pointer(e['d'])
+    it.w = e['w'].data_ptr()
+    for k in ('bias', 'gamma', 'beta', 'running_mean', 'running_var'):
+      t = e.get(k)
+      setattr(it, k, t.data_ptr() if t is not None else None)
+    it.fwd = e['wt'].data_ptr() if e['kind'] == 'fwd16' else None
+    it.dgrad = e['wt'].data_ptr() if e['kind'] == 'dgrad16' else None
+  check(lib().ms_weights16_prepare(n, items, _stream()), 'ms_weights16_prepare')
+  tune = lib().ms_tuning_epoch()
+  for e in entries:
+    e['version'], e['tune'] = e['w']._version, tune
+
+
+def _prepared16_for(w, d, kind, bn=None):
+  """The block's prepared 16-bit operand (None: feature off): kind 'fwd16' / 'dgrad16'."""
+  P = ops._prepared
+  if not P['on']:
+    return None
+  if kind == 'fwd16' and d.mode == MS_BN_EVAL and not (d.dtype & MS_DT_BN_FOLDED):
+    pass      # unfolded eval blocks share the training weights: the epilogue applies the running statistics
+  key = (w.data_ptr(), id(d), kind)
+  e = P['entries'].get(key)
+  if e is None:
+    n = lib().ms_weights16_bytes(ctypes.byref(d), 0 if kind == 'fwd16' else 1)
+    e = dict(w=w, d=d, n=(n + 3) // 4, wt=None, version=-1, tune=-1, kind=kind)
+    if bn is not None:
+      e.update(bn)
+    if e['n']:
+      e['wt'] = torch.empty(e['n'], dtype=torch.float32, device=w.device)
+    P['entries'][key] = e
+    P['by_storage'].setdefault(w.untyped_storage().data_ptr(), []).append(e)
+  if not e['n']:
+    return None
+  if e['version'] != w._version:
+    _prepare16([e])
+  return e['wt']
+
+
+# ------------------------------------------------------------------------------------------------
+class _ConvBlock16Fn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x, x2, w, bias, gamma, beta, geom, mode, in_mode, stats, dt_flags):
+    rm, rv = stats if stats is not None else (None, None)
+    _need16(x, x2, w, bias, gamma, beta, rm, rv)
+    if not is_cb8(x) or (x2 is not None and not is_cb8(x2)):
+      raise TypeError('16-bit conv block expects cb8 inputs (ops16.to_cb8), got %s %s' % (x.dtype, tuple(x.shape)))
+    dt = MS_DT[x.dtype]
+    if (dt_flags & 0xff) != dt:
+      raise TypeError('block is set to dtype %d but the input is %s' % (dt_flags & 0xff, x.dtype))
+    x = x.contiguous()
+    x2 = x2.contiguous() if x2 is not None else None
+    nd = geom.nd
+    if x.dim() != nd + 3:
+      raise RuntimeError('conv block expects a %d-D cb8 input, got %s' % (nd + 3, tuple(x.shape)))
+    B = x.shape[0]
+    ref = x2 if in_mode == MS_IN_UP2ADD else x
+    H, W = (ref.shape[2], ref.shape[3]) if nd == 2 else (1, ref.shape[2])
+    ctot = w.shape[0]
+    Cout_g = ctot // geom.groups
+    Cin_g = w.shape[1]
+    exp_c = Cin_g if in_mode == MS_IN_BCAST else Cin_g * geom.groups
+    if x.shape[1] != (exp_c + 7) // 8:
+      raise RuntimeError('conv block: expected %d input channel blocks, got %d' % ((exp_c + 7) // 8, x.shape[1]))
+    if in_mode == MS_IN_UP2ADD and (x.shape[2] * 2 != W or x2.shape[1] != x.shape[1]):
+      raise RuntimeError('UP2ADD: a %s and residual %s do not match' % (tuple(x.shape), tuple(x2.shape)))
+    d = geom.desc(B, Cin_g, H, W, Cout_g, mode, in_mode, dt_flags)
+    out_f32 = bool(dt_flags & MS_DT_OUT_F32)
+    sp = (d.OH, d.OW) if nd == 2 else (d.OW,)
+    c8 = (ctot + 7) // 8
+    if out_f32:
+      y = torch.empty((B, ctot) + sp, dtype=torch.float32, device=x.device)
+    else:
+      y = torch.empty((B, c8) + sp + (8,), dtype=x.dtype, device=x.device)
+    y_raw = save = None
+    if mode == MS_BN_TRAIN:
+      y_raw = torch.empty((B, c8) + sp + (8,), dtype=x.dtype, device=x.device)
+      save = torch.empty(4 * ctot, dtype=torch.float32, device=x.device)
+    ws = workspace(d._fwd_ws, x.device)
+    folded = mode == MS_BN_EVAL and bool(dt_flags & MS_DT_BN_FOLDED)
+    planes = _prepared16_for(w, d, 'fwd16', dict(bias=bias, gamma=gamma, beta=beta, running_mean=rm, running_var=rv)
+                             if folded else None)
+    opt = FwdOptions(planes.data_ptr() if planes is not None else None)
+    check(lib().ms_conv_block_fwd_ex(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(bias), _ptr(gamma), _ptr(beta),
+                                     _ptr(rm), _ptr(rv), _ptr(y_raw), _ptr(y), _ptr(save), _ptr(ws), ws.numel(),
+                                     _stream(), ctypes.byref(opt)), 'ms_conv_block_fwd_ex')
+    ctx.geom_desc = d
+    ctx.mode, ctx.in_mode = mode, in_mode
+    ctx.has_bias = bias is not None
+    ctx.params = (w, bias, gamma, beta)
+    ctx.raw_shape = (B, c8) + sp + (8,)
+    ctx.save_for_backward(x, x2, w, gamma, y_raw, y if mode == MS_LRELU else None, save)
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    x, x2, w, gamma, y_raw, y, save = ctx.saved_tensors
+    d, mode, in_mode = ctx.geom_desc, ctx.mode, ctx.in_mode
+    if mode == MS_BN_EVAL:
+      raise RuntimeError('backward through an eval-mode (running-stats) ConvNormRelu is not on the path')
+    need_x, need_x2, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+    need_bn = mode == MS_BN_TRAIN and ctx.needs_input_grad[4]
+    dy = dy.contiguous()
+    dev = dy.device
+    out_f32 = bool(d.dtype & MS_DT_OUT_F32)
+    dyr = torch.empty(ctx.raw_shape, dtype=x.dtype, device=dev) if (mode != MS_BARE or out_f32) else None
+    up2 = in_mode == MS_IN_UP2ADD
+    want_dx = need_x or (up2 and need_x2)
+    dx = torch.empty_like(x) if want_dx else None
+    dx2 = torch.empty_like(x2) if (want_dx and up2) else None
+    pw, pbias, pgamma, pbeta = ctx.params
+    dw = dbias = dgamma = dbeta = None
+    direct_w = direct_b = direct_g = direct_be = False
+    if need_w:
+      dw, direct_w = _grad_slot(pw, w)
+      if ctx.has_bias:
+        dbias, direct_b = _grad_slot(pbias, pbias)
+    if need_bn:
+      dgamma, direct_g = _grad_slot(pgamma, gamma)
+      dbeta, direct_be = _grad_slot(pbeta, gamma)
+    ws = workspace(d._bwd_ws, dev)
+    wt = _prepared16_for(w, d, 'dgrad16') if want_dx else None
+    part, nsplit = (None, 1)
+    D = ops._deferred
+    if D['on'] and direct_w:
+      part, nsplit = ops._wgrad_partials_for(w, d)
+    opt = BwdOptions(None, None, 0, wt.data_ptr() if wt is not None else None, part.data_ptr() if part is not None else None)
+    check(lib().ms_conv_block_bwd_ex(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(gamma), None, None, _ptr(y_raw),
+                                     _ptr(y), _ptr(save), _ptr(dy), _ptr(dyr), _ptr(dx), _ptr(dx2), _ptr(dw),
+                                     _ptr(dbias), _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), _stream(),
+                                     ctypes.byref(opt)), 'ms_conv_block_bwd_ex')
+    if part is not None:
+      D['jobs'].append((part, dw, nsplit))
+      if not D['queued']:
+        D['queued'] = True
+        torch.autograd.Variable._execution_engine.queue_callback(ops._flush_deferred_wgrad)
+    return (dx, dx2, None if direct_w else dw, None if direct_b else dbias, None if direct_g else dgamma,
+            None if direct_be else dbeta, None, None, None, None, None)
+
+
+def conv_block16(x, w, bias, geom, mode, gamma=None, beta=None, running_mean=None, running_var=None, x2=None,
+                 in_mode=MS_IN_PLAIN, out_f32=False, bn_folded=False):
+  """One conv block in the 16-bit mode: x (and x2) cb8, result cb8 -- or plain fp32 (B, C, ...) with out_f32."""
+  stats = (running_mean, running_var) if running_mean is not None else None
+  flags = MS_DT[x.dtype] | (MS_DT_OUT_F32 if out_f32 else 0) | (MS_DT_BN_FOLDED if (bn_folded and mode == MS_BN_EVAL) else 0)
+  return _ConvBlock16Fn.apply(x, x2, w, bias, gamma, beta, geom, mode, in_mode, stats, flags)

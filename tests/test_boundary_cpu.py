@@ -16,7 +16,7 @@ def test_library_exports_every_declared_symbol():
   declared = set(re.findall(r'\b(ms_[a-z0-9_]+)\s*\(', hdr))
   assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
   L = _lib.lib()                                   # raises if the .so is missing or a symbol is absent
-  assert L.ms_abi_version() == 1
+  assert L.ms_abi_version() == 2
   d = _lib.ConvDesc(32, 256, 1, 64, 256, 8, 1, 3, 1, 1, 0, 1, 1, 64, _lib.MS_BN_TRAIN, _lib.MS_IN_PLAIN, 0.2, 1e-5,
                     0.1, 0)
   import ctypes

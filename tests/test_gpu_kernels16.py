@@ -1,0 +1,195 @@
+"""GPU: the 16-bit arithmetic mode (bf16 / fp16 operands on v_mfma_f32_32x32x16, fp32 accumulate; cb8 tensors) block by
+block through the C-ABI, against an fp64 reference evaluated on the SAME 16-bit-rounded operands -- what is left is the
+accumulation order, so the fp32 outputs (scores, weight gradients, statistics) are checked tightly and the 16-bit outputs to
+one rounding of the output type."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+BARE, LRELU, BN_TRAIN, BN_EVAL = 0, 1, 2, 3
+PLAIN, BCAST, UP2 = 0, 1, 2
+
+
+def _round(t, dt):
+  return t.to(dt).to(torch.float64)
+
+
+def _case(nd, B, cin, cout, groups, k, s, p, H, W, mode, in_mode=PLAIN, out_f32=False, dt=torch.bfloat16, seed=0):
+  from mix_stage_amd import ops, ops16
+  from mix_stage_amd._lib import MS_BF16, MS_F16
+  msdt = MS_BF16 if dt == torch.bfloat16 else MS_F16
+  g = torch.Generator().manual_seed(seed)
+  sp = (H, W) if nd == 2 else (W,)
+  cin_tot = cin if in_mode == BCAST else cin * groups
+  kk = (k, k) if (nd == 2 and not isinstance(k, tuple)) else k
+  kt = tuple(kk) if isinstance(kk, tuple) else (kk,)
+  fan = cin
+  for v in kt:
+    fan *= v
+  w = (torch.randn((cout * groups, cin) + kt, generator=g) * fan ** -0.5).to(DEV)
+  bias = (torch.randn(cout * groups, generator=g) * 0.1).to(DEV)
+  gamma = (0.5 + torch.rand(cout * groups, generator=g)).to(DEV)
+  beta = (torch.randn(cout * groups, generator=g) * 0.1).to(DEV)
+  rm = (torch.randn(cout * groups, generator=g) * 0.1).to(DEV)
+  rv = (0.5 + torch.rand(cout * groups, generator=g)).to(DEV)
+  if in_mode == UP2:
+    a = torch.randn((B, cin_tot, W // 2), generator=g).to(DEV).requires_grad_()
+    r = torch.randn((B, cin_tot, W), generator=g).to(DEV).requires_grad_()
+    xa, xr = ops16.to_cb8(a, msdt), ops16.to_cb8(r, msdt)
+  else:
+    x = torch.randn((B, cin_tot) + sp, generator=g).to(DEV).requires_grad_()
+    xc = ops16.to_cb8(x, msdt)
+  wp = w.clone().requires_grad_(); bp = bias.clone().requires_grad_()
+  gp = gamma.clone().requires_grad_(); bep = beta.clone().requires_grad_()
+  rm_h, rv_h = rm.clone(), rv.clone()
+  geom = ops.ConvGeom(nd, groups, k, s, p)
+  bn = mode in (BN_TRAIN, BN_EVAL)
+  kw = dict(gamma=gp if bn else None, beta=bep if bn else None, running_mean=rm_h if bn else None,
+            running_var=rv_h if bn else None, out_f32=out_f32)
+  if in_mode == UP2:
+    y = ops16.conv_block16(xa, wp, bp, geom, mode, x2=xr, in_mode=UP2, **kw)
+  else:
+    y = ops16.conv_block16(xc, wp, bp, geom, mode, in_mode=in_mode, **kw)
+  ctot = cout * groups
+  y32 = y if out_f32 else ops16.from_cb8(y, ctot)
+  dyv = torch.randn(y32.shape, generator=g).to(DEV)
+  if mode != BN_EVAL:
+    (y32 * dyv).sum().backward()
+
+  # ---- fp64 reference on the rounded operands
+  w64 = _round(w.cpu(), dt).requires_grad_()
+  b64 = bias.cpu().double().requires_grad_()
+  if in_mode == UP2:
+    a64, r64 = _round(a.detach().cpu(), dt), _round(r.detach().cpu(), dt)
+    xin = _round((a64.repeat_interleave(2, dim=-1) + r64).float(), dt).requires_grad_()
+  else:
+    xin = _round(x.detach().cpu(), dt).requires_grad_()
+  xcat = torch.cat([xin] * groups, 1) if in_mode == BCAST else xin
+  conv = F.conv2d if nd == 2 else F.conv1d
+  raw = conv(xcat, w64, b64, stride=s, padding=p, groups=groups)
+  g64 = gamma.cpu().double().requires_grad_(); be64 = beta.cpu().double().requires_grad_()
+  dims = (0, 2, 3) if nd == 2 else (0, 2)
+  shape = (1, -1, 1, 1) if nd == 2 else (1, -1, 1)
+  if mode == BN_TRAIN:
+    # statistics come from the fp32 accumulators, the normalisation (and, in the backward pass, x_hat and the LeakyReLU mask)
+    # from the 16-bit y_raw the block keeps: mirror that with a straight-through rounding of raw
+    mean, var = raw.mean(dims), raw.var(dims, unbiased=False)
+    raw_r = raw + (_round(raw.detach().float(), dt) - raw.detach())
+    z = (raw_r - mean.view(shape)) / torch.sqrt(var.view(shape) + 1e-5) * g64.view(shape) + be64.view(shape)
+    ref = F.leaky_relu(z, 0.2)
+  elif mode == BN_EVAL:
+    z = (raw - rm.cpu().double().view(shape)) / torch.sqrt(rv.cpu().double().view(shape) + 1e-5) * g64.view(shape) + be64.view(shape)
+    ref = F.leaky_relu(z, 0.2)
+  elif mode == LRELU:
+    ref = F.leaky_relu(raw, 0.2)
+  else:
+    ref = raw
+  if mode != BN_EVAL:
+    dy_used = dyv.cpu().double() if out_f32 else _round(dyv.cpu(), dt)      # cb8 outputs receive a 16-bit gradient
+    (ref * dy_used).sum().backward()
+
+  out_tol = 2e-5 if (out_f32 and mode != BN_TRAIN) else 1.2e-2      # fp32 from the accumulators vs one 16-bit rounding
+  scale = ref.abs().max().item() + 1e-6
+  err = (y32.detach().cpu().double() - ref.detach()).abs().max().item()
+  assert err <= out_tol * scale, ('forward', err, scale)
+  if mode == BN_TRAIN:
+    n = raw.numel() // ctot
+    new_rm = 0.9 * rm.cpu().double() + 0.1 * mean.detach()
+    new_rv = 0.9 * rv.cpu().double() + 0.1 * raw.detach().var(dims, unbiased=True) if n > 1 else None
+    assert (rm_h.cpu().double() - new_rm).abs().max().item() <= 1e-4
+    if new_rv is not None:
+      assert (rv_h.cpu().double() - new_rv).abs().max().item() <= 2e-3 * (1 + new_rv.abs().max().item())
+  # gradients: dy went through a 16-bit rounding (cb8 outputs) and BN backward rounds dy_raw again
+  gt = 2e-2 if mode in (BN_TRAIN, LRELU) or not out_f32 else 1e-2
+  def close(a, b, what, tol=gt):
+    sc = b.abs().max().item() + 1e-9
+    e = (a.detach().cpu().double() - b).abs().max().item()
+    l2 = (a.detach().cpu().double() - b).norm().item() / (b.norm().item() + 1e-12)
+    assert e <= 2 * tol * sc + 1e-6 and l2 <= tol, (what, e, sc, l2)
+  if mode != BN_EVAL:
+    close(wp.grad, w64.grad, 'dw')
+    if mode != BN_TRAIN:
+      close(bp.grad, b64.grad, 'dbias')
+    else:
+      close(gp.grad, g64.grad, 'dgamma'); close(bep.grad, be64.grad, 'dbeta')
+    if in_mode == UP2:
+      dxin = xin.grad
+      close(r.grad, dxin, 'dx2')
+      close(a.grad, dxin.reshape(dxin.shape[0], dxin.shape[1], -1, 2).sum(-1), 'dx')
+    else:
+      close(x.grad, xin.grad, 'dx')
+
+
+CASES_1D = [
+    # name, B, cin, cout, groups, k, s, p, W, mode, in_mode, out_f32
+    ('dec1', 8, 128, 128, 4, 3, 1, 1, 64, BN_TRAIN, PLAIN, False),
+    ('dec0_bcast', 8, 74, 128, 4, 3, 1, 1, 64, BN_TRAIN, BCAST, False),
+    ('unet_pre', 4, 256, 256, 1, 3, 1, 1, 64, BN_TRAIN, PLAIN, False),
+    ('unet_down', 4, 64, 64, 1, 4, 2, 1, 64, BN_TRAIN, PLAIN, False),
+    ('unet_deep', 6, 64, 64, 1, 4, 2, 1, 4, BN_TRAIN, PLAIN, False),
+    ('unet_up2', 4, 64, 64, 1, 3, 1, 1, 16, BN_TRAIN, UP2, False),
+    ('unet_up2_t2', 4, 64, 64, 1, 3, 1, 1, 2, BN_TRAIN, UP2, False),
+    ('pse0', 4, 104, 64, 1, 3, 1, 1, 64, BN_TRAIN, PLAIN, False),
+    ('pse_last', 6, 64, 5, 1, 4, 2, 1, 2, BN_TRAIN, PLAIN, True),
+    ('cls0', 4, 266, 256, 1, 3, 1, 1, 64, BN_TRAIN, PLAIN, False),
+    ('cls_logits', 4, 256, 8, 1, 1, 1, 0, 64, BARE, PLAIN, True),
+    ('logits_g', 4, 64, 104, 4, 1, 1, 0, 64, BARE, PLAIN, True),
+    ('d_conv1', 4, 104, 64, 1, 4, 2, 1, 64, LRELU, PLAIN, False),
+    ('d_conv3', 4, 128, 256, 1, 4, 1, 1, 16, BN_TRAIN, PLAIN, False),
+    ('d_logits', 4, 256, 1, 1, 4, 1, 0, 15, BARE, PLAIN, True),
+    ('eval_k3', 4, 64, 64, 1, 3, 1, 1, 64, BN_EVAL, PLAIN, False),
+    ('bare_cb8', 4, 64, 64, 1, 3, 1, 1, 32, BARE, PLAIN, False),
+    ('t256', 2, 64, 128, 2, 3, 1, 1, 256, BN_TRAIN, PLAIN, False),
+]
+
+
+@pytest.mark.parametrize('case', CASES_1D, ids=[c[0] for c in CASES_1D])
+def test_block16_1d(case):
+  _, B, cin, cout, groups, k, s, p, W, mode, in_mode, out_f32 = case
+  _case(1, B, cin, cout, groups, k, s, p, 1, W, mode, in_mode, out_f32)
+
+
+CASES_2D = [
+    # name, B, cin, cout, k, s, p, H, W
+    ('ae0', 2, 1, 64, 3, 1, 1, 16, 32),
+    ('ae1', 2, 64, 64, 4, 2, 1, 16, 32),
+    ('ae2', 2, 64, 128, 3, 1, 1, 8, 16),
+    ('ae7', 3, 64, 128, (3, 8), 1, (1, 3), 8, 16),
+    ('odd', 2, 16, 32, 4, 2, 1, 10, 14),
+]
+
+
+@pytest.mark.parametrize('case', CASES_2D, ids=[c[0] for c in CASES_2D])
+def test_block16_2d(case):
+  _, B, cin, cout, k, s, p, H, W = case
+  _case(2, B, cin, cout, 1, k, s, p, H, W, BN_TRAIN)
+
+
+def test_block16_fp16_eval():
+  _case(1, 4, 64, 64, 1, 3, 1, 1, 1, 64, BN_EVAL, dt=torch.float16)
+  _case(1, 4, 128, 128, 2, 3, 1, 1, 1, 64, LRELU, dt=torch.float16)
+
+
+def test_converters_roundtrip():
+  from mix_stage_amd import ops16
+  from mix_stage_amd._lib import MS_BF16
+  x = torch.randn(3, 13, 7, device=DEV)
+  c = ops16.to_cb8(x, MS_BF16)
+  assert c.shape == (3, 2, 7, 8) and c.dtype == torch.bfloat16
+  back = ops16.from_cb8(c, 13)
+  assert torch.equal(back, x.bfloat16().float())
+  assert float(c[:, 1, :, 5:].abs().max()) == 0.0                   # pad channels are zero
+  p = torch.randn(2, 9, 20, device=DEV)                              # (B, T, C)
+  v = ops16.btc_to_cb8(p, MS_BF16, velocity=True)
+  ref = torch.zeros_like(p); ref[:, 1:] = p[:, 1:] - p[:, :-1]
+  got = ops16.from_cb8(v, 20).transpose(1, 2)
+  assert torch.equal(got, ref.bfloat16().float())
+  p2 = p.clone().requires_grad_()
+  w = torch.randn(2, 9, 20, device=DEV)
+  (ops16.from_cb8(ops16.btc_to_cb8(p2, MS_BF16, velocity=True), 20).transpose(1, 2) * w).sum().backward()
+  wr = w.bfloat16().float()
+  exp = torch.zeros_like(p); exp[:, 1:] += wr[:, 1:]; exp[:, :-1] -= wr[:, 1:]
+  assert (p2.grad - exp).abs().max().item() <= 1e-6
