@@ -6,7 +6,7 @@ import contextlib
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, ops16
 
 
 class ConstantLambdaScheduler:
@@ -91,6 +91,9 @@ class GAN(nn.Module):
 
   def _score(self, pose):
     """D(get_velocity(pose)) with the velocity produced channel-major for D's first conv."""
+    dt = getattr(self.D, '_ms_dt', 0)
+    if dt and hasattr(self.D, 'forward_channel_major'):
+      return self.D.forward_channel_major(ops16.btc_to_cb8(pose, dt, velocity=True))[0]
     v = ops.velocity_cm(pose)
     if hasattr(self.D, 'forward_channel_major'):
       return self.D.forward_channel_major(v)[0]

@@ -14,7 +14,7 @@ import contextlib
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, ops16
 from .layers import (AudioEncoder, ClusterClassify, ConvNormRelu, Curriculum, EmbLin, Group, PoseEncoder,
                      PoseStyleEncoder, TextEncoder1D, UNet1D, bare_conv)
 from .speech2gesture import Speech2Gesture_D
@@ -130,8 +130,11 @@ class JointLateClusterSoftStyle4_G(nn.Module):
       else:
         x = x[0]
 
+    dt = getattr(self, '_ms_dt', 0)       # 16-bit modes: cb8 tensors between the conv blocks, fp32 at the boundaries
+    if dt:
+      x = ops16.to_cb8(x, dt)
     x = self.unet(x)                                            # (B, 256, T) channel-major throughout
-    B, _, T = x.shape
+    B, T = x.shape[0], x.shape[2]
 
     ## Pose Style
     style = kwargs['style']
@@ -158,6 +161,8 @@ class JointLateClusterSoftStyle4_G(nn.Module):
       id_in_loss = torch.zeros(1)[0]
     if mode == 'emb' and pose_style.dim() == 2 and pose_style.shape != (B, T) and pose_style.numel() == B * T:
       pose_style = pose_style.reshape(B, T)                  # windows concatenated into one long sequence (TR:779-786)
+    if dt:
+      x = ops16.from_cb8(x, self.unet.conv2[-1].conv.weight.shape[0])     # the style concat runs on the fp32 kernel
     if mode == 'emb' and pose_style.dim() == 2 and pose_style.shape[1] == T:
       ## content || style embedding, channel-major, one kernel (JL:175-180)
       self.pose_style_ids = pose_style
@@ -168,6 +173,8 @@ class JointLateClusterSoftStyle4_G(nn.Module):
         labels_style = labels_style.view(B, -1, labels_style.shape[-1])
       x = torch.cat([x, labels_style.transpose(2, 1)], dim=1)  # (B, 256+style_dim, T)
 
+    if dt:
+      x = ops16.to_cb8(x, dt)
     ## cluster scores from content+style (JL:183-187)
     labels_score = self.classify_cluster(x)                     # (B, M, T)
     internal_losses.append(ops.cross_entropy(labels_score, labels, layout='bct'))
@@ -176,7 +183,7 @@ class JointLateClusterSoftStyle4_G(nn.Module):
     z = self.decoder[0].forward_broadcast(x)
     for m in list(self.decoder)[1:]:
       z = m(z)
-    z = bare_conv(self.logits, z)                               # (B, M*P, T)
+    z = bare_conv(self.logits, z, out_f32=True)                 # (B, M*P, T), fp32 in every mode
     x, self.labels_cap_soft = ops.softmax_mix(z, labels_score, self.out_feats)   # (B,T,P), (B,T,M)
 
     if pose_style_encoder_flag:

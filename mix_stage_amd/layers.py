@@ -16,8 +16,33 @@ the arithmetic runs in libmixstage_hip.so (ops.conv_block).
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, ops16
 from ._lib import MS_BARE, MS_BN_EVAL, MS_BN_TRAIN, MS_IN_BCAST, MS_IN_PLAIN, MS_IN_UP2ADD, MS_LRELU
+
+
+def set_compute_dtype(module, dtype):
+  """Arithmetic mode of every conv block under `module`: 'fp32' (default: exact fp32 matrix products, the parity path),
+  'bf16' or 'fp16' (16-bit operands and activations, fp32 accumulate / BatchNorm statistics / parameters; what casting the
+  reference model selects, trainer.py:138).  Parameters and buffers stay fp32 tensors; the modules keep accepting and
+  returning fp32 tensors at their public boundaries."""
+  code = 0 if dtype in (None, 'fp32', 'f32', 'float32', torch.float32) else (
+      ops16.MS_DT[dtype] if isinstance(dtype, torch.dtype) else ops16.NAME_DT[dtype])
+  for m in module.modules():
+    m._ms_dt = code
+  return module
+
+
+def set_inference_folding(module, on=True):
+  """16-bit modes, eval only: fold every eval-mode BatchNorm into the prepared conv weights and bias (valid while the
+  running statistics do not change: sampling / style transfer)."""
+  for m in module.modules():
+    if isinstance(m, ConvNormRelu):
+      m._bn_folded = bool(on)
+  return module
+
+
+def compute_dtype(module):
+  return getattr(module, '_ms_dt', 0)
 
 
 # set to a list while a training step is being graph-captured: the ConvNormRelu blocks that ran with batch
@@ -57,15 +82,24 @@ def _default_padding(kernel_size, stride):
   return int((kernel_size - stride) / 2)
 
 
-def bare_conv(conv, x, lrelu_slope=None):
-  """An nn.Conv1d/2d container evaluated on the HIP kernels (JL:83 logits, layers.py:459, S2G:50-51,63)."""
+def bare_conv(conv, x, lrelu_slope=None, out_f32=False):
+  """An nn.Conv1d/2d container evaluated on the HIP kernels (JL:83 logits, layers.py:459, S2G:50-51,63).
+  16-bit modes: x cb8 (a plain fp32 tensor is converted), result cb8 -- or plain fp32 with out_f32 (score outputs)."""
   geom = getattr(conv, '_ms_geom', None)
   if geom is None:
     nd = 1 if isinstance(conv, nn.Conv1d) else 2
     geom = ops.ConvGeom(nd, conv.groups, conv.kernel_size, conv.stride, conv.padding,
                         slope=0.0 if lrelu_slope is None else lrelu_slope)
     conv._ms_geom = geom
-  return ops.conv_block(x, conv.weight, conv.bias, geom, MS_BARE if lrelu_slope is None else MS_LRELU)
+  mode = MS_BARE if lrelu_slope is None else MS_LRELU
+  dt = getattr(conv, '_ms_dt', 0)
+  if dt:
+    was_plain = not ops16.is_cb8(x)
+    if was_plain:
+      x = ops16.to_cb8(x, dt)
+    y = ops16.conv_block16(x, conv.weight, conv.bias, geom, mode, out_f32=out_f32)
+    return ops16.from_cb8(y, conv.weight.shape[0]) if (was_plain and not out_f32) else y
+  return ops.conv_block(x, conv.weight, conv.bias, geom, mode)
 
 
 class ConvNormRelu(nn.Module):
@@ -115,7 +149,7 @@ class ConvNormRelu(nn.Module):
                                 eps=n.eps, momentum=0.1 if n.momentum is None else n.momentum)
     return self._geom
 
-  def _run(self, x, x2=None, in_mode=MS_IN_PLAIN):
+  def _run(self, x, x2=None, in_mode=MS_IN_PLAIN, out_f32=False):
     if self._p and self.training:
       raise NotImplementedError('dropout p>0 is not on the Mix-StAGE path (p=0 everywhere, JL:26)')
     n = self.norm
@@ -126,18 +160,30 @@ class ConvNormRelu(nn.Module):
         _train_tape.append(self)
     else:
       mode = MS_BN_EVAL
+    dt = getattr(self, '_ms_dt', 0)
+    if dt:
+      # 16-bit mode: cb8 in, cb8 out; a plain fp32 caller (the public module boundary) is converted both ways
+      was_plain = not ops16.is_cb8(x)
+      if was_plain:
+        x = ops16.to_cb8(x, dt)
+        x2 = ops16.to_cb8(x2, dt) if x2 is not None else None
+      y = ops16.conv_block16(x, self.conv.weight, self.conv.bias, self._geometry(), mode, n.weight, n.bias, n.running_mean,
+                             n.running_var, x2=x2, in_mode=in_mode, out_f32=out_f32,
+                             bn_folded=getattr(self, '_bn_folded', False))
+      return ops16.from_cb8(y, self.conv.weight.shape[0]) if (was_plain and not out_f32) else y
     return ops.conv_block(x, self.conv.weight, self.conv.bias, self._geometry(), mode, n.weight, n.bias,
                           n.running_mean, n.running_var, x2=x2, in_mode=in_mode)
 
   def forward(self, x, **kwargs):
-    # `_residual` / `_broadcast` select the fused input forms below (package-internal; the reference's
+    # `_residual` / `_broadcast` / `_out_f32` select the fused forms below (package-internal; the reference's
     # forward(x, **kwargs) ignores its kwargs)
     residual = kwargs.get('_residual')
+    out_f32 = bool(kwargs.get('_out_f32'))
     if residual is not None:
-      return self._run(x, x2=residual, in_mode=MS_IN_UP2ADD)
+      return self._run(x, x2=residual, in_mode=MS_IN_UP2ADD, out_f32=out_f32)
     if kwargs.get('_broadcast'):
-      return self._run(x, in_mode=MS_IN_BCAST)
-    return self._run(x)
+      return self._run(x, in_mode=MS_IN_BCAST, out_f32=out_f32)
+    return self._run(x, out_f32=out_f32)
 
   def forward_upsample_add(self, a, residual):
     """== self(upsample_nearest2(a) + residual) without materialising the sum (layers.py:151)."""
@@ -166,12 +212,17 @@ class UNet1D(nn.Module):
       self.conv2.append(ConvNormRelu(output_channels, output_channels, downsample=False, **common))
 
   def forward(self, x, return_bottleneck=False):
-    input_size = x.shape[-1]
+    input_size = x.shape[2] if ops16.is_cb8(x) else x.shape[-1]
     assert input_size / (2 ** (self.max_depth - 1)) >= 1, \
         'Input size is {}. It must be >= {}'.format(input_size, 2 ** (self.max_depth - 1))
     assert num_powers_of_two(input_size) >= self.max_depth, \
         'Input size is {}. It must be a multiple of 2^(max_depth) = 2^{} = {}'.format(
             input_size, self.max_depth, 2 ** self.max_depth)
+    dt = getattr(self, '_ms_dt', 0)
+    was_plain = bool(dt) and not ops16.is_cb8(x)
+    if was_plain:
+      x = ops16.to_cb8(x, dt)
+    channels = self.conv2[-1].conv.weight.shape[0]
     for m in self.pre_downsampling_conv:
       x = m(x)
     residuals = [x]
@@ -182,6 +233,8 @@ class UNet1D(nn.Module):
     bn = x
     for i, up in enumerate(self.conv2):
       x = up.forward_upsample_add(x, residuals[self.max_depth - i - 1])
+    if was_plain:
+      x, bn = ops16.from_cb8(x, channels), ops16.from_cb8(bn, channels)
     return (x, bn) if return_bottleneck else x
 
 
@@ -204,8 +257,13 @@ class AudioEncoder(nn.Module):
   def forward(self, x, time_steps=None):
     if time_steps is None:
       time_steps = x.shape[-2]
+    dt = getattr(self, '_ms_dt', 0)
+    if dt:
+      x = ops16.to_cb8(x, dt)
     for m in self.conv:
       x = m(x)
+    if dt:
+      x = ops16.from_cb8(x, self.conv[-1].conv.weight.shape[0])      # the resize runs on the fp32 kernel
     return ops.lerp_time(x, time_steps)
 
 
@@ -218,7 +276,17 @@ class _TimeMajorStack(nn.Module):
       self.conv.append(ConvNormRelu(cin, cout, type='1d', leaky=True, downsample=down, kernel_size=kernel_size,
                                     stride=stride, p=p, groups=groups))
 
-  def _chain(self, x):
+  def _chain(self, x, last_f32=False):
+    """16-bit modes: the result is a plain fp32 (B, C, T') tensor either way (converted, or written so by the last block)."""
+    dt = getattr(self, '_ms_dt', 0)
+    if dt:
+      x = ops16.btc_to_cb8(x, dt)
+      mods = list(self.conv)
+      for m in mods[:-1]:
+        x = m(x)
+      if last_f32:
+        return mods[-1](x, _out_f32=True)
+      return ops16.from_cb8(mods[-1](x), mods[-1].conv.weight.shape[0])
     x = ops.to_channel_major(x)
     for m in self.conv:
       x = m(x)
@@ -271,7 +339,7 @@ class PoseStyleEncoder(_TimeMajorStack):
                  (256, 256, True), (256, num_speakers, True)), kernel_size, stride, p, groups)
 
   def forward(self, x, time_steps=None):
-    x = self._chain(x)
+    x = self._chain(x, last_f32=True)
     x = x.mean(-1) if x.shape[-1] > 1 else x.squeeze(-1)   # mean over a length-1 axis is the identity
     return x.squeeze(dim=-1)
 
@@ -291,9 +359,12 @@ class ClusterClassify(nn.Module):
     self.logits = nn.Conv1d(256 * groups, num_clusters * groups, kernel_size=1, stride=1, groups=groups)
 
   def forward(self, x, time_steps=None):
+    dt = getattr(self, '_ms_dt', 0)
+    if dt and not ops16.is_cb8(x):
+      x = ops16.to_cb8(x, dt)
     for m in self.conv:
       x = m(x)
-    return bare_conv(self.logits, x)
+    return bare_conv(self.logits, x, out_f32=True)        # scores (B, M, T) are fp32 in every mode
 
 
 class Group(nn.Module):

@@ -3,7 +3,7 @@ on the HIP kernels.  Same constructor, forward(x) -> (scores, []), attribute nam
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, ops16
 from .layers import ConvNormRelu, bare_conv
 
 
@@ -37,8 +37,11 @@ class Speech2Gesture_D(nn.Module):
     for m in self.conv2:
       x = m(x)
     x = self.conv3(x)
-    x = bare_conv(self.logits, x)
+    x = bare_conv(self.logits, x, out_f32=True)                 # scores are fp32 in every mode
     return x.transpose(-1, -2).squeeze(dim=-1), []
 
   def forward(self, x):
+    dt = getattr(self, '_ms_dt', 0)
+    if dt:
+      return self.forward_channel_major(ops16.btc_to_cb8(x, dt))
     return self.forward_channel_major(ops.to_channel_major(x))

@@ -1,0 +1,185 @@
+"""GPU: BASELINE configs[1], [3] and [4] in their stated arithmetic (bf16 training, fp16 BN-folded graph-replayed inference)
+against the fp64 oracle.  BASELINE.md section 2: reduced-precision runs REPORT their measured pose L1 and style-id argmax
+agreement (bf16 autocast of the reference itself is at 6e-3 in train mode); the 1e-4 bar belongs to the fp32 path
+(tests/test_gpu_model.py).  The bounds asserted here are sanity rails around the measured values, which are printed and
+written to gpurun_out/precision_report.json."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mixstage_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPORT = {}
+
+
+def _report(key, **vals):
+  REPORT[key] = {k: (float(v) if not isinstance(v, (str, bool, int)) else v) for k, v in vals.items()}
+  out = os.path.join(ROOT, 'gpurun_out')
+  os.makedirs(out, exist_ok=True)
+  path = os.path.join(out, 'precision_report.json')
+  try:
+    old = json.load(open(path))
+  except (OSError, ValueError):
+    old = {}
+  old.update(REPORT)
+  json.dump(old, open(path, 'w'), indent=1)
+  print(key, REPORT[key])
+
+
+def _hip_gan(M, S, T=64, dtype='bf16'):
+  import mix_stage_amd as A
+  G = A.JointLateClusterSoftStyle4_G(time_steps=T, out_feats=104, num_clusters=M, style_dict={i: i for i in range(S)},
+                                     style_dim=10, lambda_id=0.1, argmax=1, some_grad_flag=1, train_only=1, shape={})
+  D = A.Speech2Gesture_D(in_channels=104)
+  model = A.GAN(G, D, criterion='L1Loss', input_modalities=['audio/log_mel_400'], update_D_prob_flag=0, no_grad=0)
+  model.load_state_dict(O.deterministic_state(model.state_dict()))
+  model.G.thresh.value, model.G.thresh.iters = 1, 10 ** 9
+  model = model.to(DEV)
+  A.set_compute_dtype(model, dtype)
+  return model
+
+
+def _step(model, batch, kind, dev, T=64):
+  audio, pose, labels, style = [t.to(dev) for t in batch]
+  model.train(); model.zero_grad()
+  model.D_prob = 1.1 if kind == 'D' else -1.0
+  fake, losses, _ = model([audio, labels], pose, **O.model_kwargs(style, T))
+  sum(l for l in losses if l.requires_grad).backward()
+  return fake.detach(), [float(l) for l in losses]
+
+
+def _train_compare(tag, M, S, B, T):
+  batch = O.synthetic_batch(B, T=T, M=M, S=S)
+  batch64 = [t.double() if t.is_floating_point() else t for t in batch]
+  for kind in ('G', 'D'):
+    ref = O.build_gan(M=M, S=S, T=T, dtype=torch.float64)
+    hip = _hip_gan(M, S, T)
+    seen = {}
+    def grab(k):
+      def hook(mod, i, o):          # (a hook must return None: a value would replace the module's output)
+        seen.setdefault(k, o.detach())
+      return hook
+    hks = [m.G.pose_style_encoder.register_forward_hook(grab(k)) for k, m in (('ref', ref), ('hip', hip))]
+    f_ref, l_ref = _step(ref, batch64, kind, 'cpu', T)
+    f_hip, l_hip = _step(hip, batch, kind, DEV, T)
+    for h in hks:
+      h.remove()
+    l1 = (f_hip.cpu().double() - f_ref).abs().mean().item()
+    dl = max(abs(a - b) for a, b in zip(l_hip, l_ref))
+    soft = (hip.G.labels_cap_soft.cpu().double() - ref.G.labels_cap_soft.detach()).abs().max().item()
+    mix_agree = (hip.G.labels_cap_soft.argmax(-1).cpu() == ref.G.labels_cap_soft.argmax(-1)).float().mean().item()
+    vals = dict(pose_l1=l1, max_loss_diff=dl, softmax_max_diff=soft, mixture_argmax_agreement=mix_agree)
+    if 'ref' in seen:
+      vals['style_argmax_equal'] = bool(torch.equal(seen['hip'].argmax(-1).cpu(), seen['ref'].argmax(-1)))
+      top2 = seen['ref'].topk(2, -1).values
+      vals['style_top2_margin_min'] = (top2[:, 0] - top2[:, 1]).min().item()
+    # gradient agreement (cosine).  The pose and GAN losses are L1: their gradient is sign(fake - target)/n, and a pose that
+    # moved by ~2e-2 flips ~1.5 % of those signs (a 24 % relative change of the incoming gradient all by itself), so the
+    # main path can only be sanity-checked.  The style encoder is reached through the smooth cross-entropy (id_in) alone
+    # and is the tight probe of the 16-bit backward kernels end to end (block-level: tests/test_gpu_kernels16.py).
+    mod_h, mod_r = (hip.G, ref.G) if kind == 'G' else (hip.D, ref.D)
+    acc = {'main': [0.0, 0.0, 0.0], 'style_encoder': [0.0, 0.0, 0.0]}
+    for (n, p), (_, q) in zip(mod_h.named_parameters(), mod_r.named_parameters()):
+      if q.grad is None or p.grad is None or n.endswith('conv.bias'):
+        continue
+      a, b = p.grad.cpu().double(), q.grad
+      s = acc['style_encoder' if n.startswith('pose_style_encoder') else 'main']
+      s[0] += float((a * b).sum()); s[1] += float(a.pow(2).sum()); s[2] += float(b.pow(2).sum())
+    for k, (dot, na, nb) in acc.items():
+      if nb > 0:
+        vals['grad_cosine_' + k] = dot / (na * nb) ** 0.5
+    _report('%s/%s-step' % (tag, kind), **vals)
+    assert np.isfinite(l1) and l1 <= 5e-2, vals
+    assert dl <= 5e-2, vals
+    assert vals['grad_cosine_main'] >= 0.6, vals
+    if 'grad_cosine_style_encoder' in vals:
+      assert vals['grad_cosine_style_encoder'] >= 0.98, vals
+    if 'style_argmax_equal' in vals and vals['style_top2_margin_min'] > 2e-2:
+      assert vals['style_argmax_equal'], vals            # (smaller margins than the 16-bit noise: reported only)
+
+
+def test_config1_bf16_train_step_m4_b32():
+  """BASELINE configs[1]: M=4 speakers, B=32, T=64, bf16 (grouped-decoder kernel), one G-step and one D-step."""
+  _train_compare('configs[1] M=4 B=32 T=64 bf16', 4, 4, 32, 64)
+
+
+def test_config3_bf16_train_step_m25_t256():
+  """BASELINE configs[3]: M=S=25 (full PATS speaker set), T=256, bf16; batch reduced so the fp64 oracle finishes in seconds."""
+  _train_compare('configs[3] M=25 T=256 B=2 bf16', 25, 25, 2, 256)
+
+
+def test_headline_bf16_train_step_m8_b32():
+  _train_compare('headline M=8 B=32 T=64 bf16', 8, 8, 32, 64)
+
+
+def test_bf16_train_steps_graph_equals_eager_and_learns():
+  """The captured step replays bit-identically in the 16-bit mode too, and a few steps of training move the pose loss down."""
+  from mix_stage_amd.train_step import MixStageTrainStep
+  M = S = 4
+  batch = [t.to(DEV) for t in O.synthetic_batch(8, M=M, S=S)]
+  audio, pose, labels, style = batch
+  results = {}
+  for use_graphs in (False, True):
+    torch.manual_seed(5)
+    model = _hip_gan(M, S)
+    ts = MixStageTrainStep(model, use_graphs=use_graphs)
+    hist = []
+    for i in range(8):
+      k = ts.step(audio, labels, pose, style, kind='G' if i % 2 == 0 else 'D')
+      hist.append((k, [float(l) for l in ts.losses]))
+    results[use_graphs] = (hist, {k: v.clone() for k, v in model.state_dict().items()})
+  assert results[False][0] == results[True][0]
+  for k, v in results[False][1].items():
+    assert torch.equal(v, results[True][1][k]), k
+  g_losses = [h[1][0] for h in results[True][0] if h[0] == 'G']
+  assert all(np.isfinite(g_losses)) and g_losses[-1] < g_losses[0], g_losses
+
+
+def test_config4_fp16_inference_b1024_graph_folded():
+  """BASELINE configs[4]: inference-only style transfer, B=1024, M=8, fp16, eval BatchNorm folded into the prepared weights,
+  the forward captured in a HIP graph and replayed.  Eval-mode clips are independent, so the first 48 are checked against the
+  fp64 oracle run on those clips alone."""
+  import mix_stage_amd as A
+  B, M, S, NCHK = 1024, 8, 8, 48
+  audio, pose, labels, style = O.synthetic_batch(B, M=M, S=S)
+  style = (style + 3) % S                     # transfer to another speaker's style (trainer.py:1367-1386)
+  hip = _hip_gan(M, S, dtype='fp16').eval()
+  A.set_inference_folding(hip, True)
+  kw = O.model_kwargs(style.to(DEV)); kw['sample_flag'] = 1
+  st = [audio.to(DEV), labels.to(DEV), pose.to(DEV)]
+  with torch.no_grad():
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+      hip([st[0], st[1]], st[2], **kw)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+      y_cap, losses, _ = hip([st[0], st[1]], st[2], **kw)
+    g.replay()
+    torch.cuda.synchronize()
+    first = y_cap.clone()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+      g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    assert torch.equal(first, y_cap)
+  ms = e0.elapsed_time(e1) / 5
+  ref = O.build_gan(M=M, S=S, dtype=torch.float64).eval()
+  kw_r = O.model_kwargs(style[:NCHK]); kw_r['sample_flag'] = 1
+  with torch.no_grad():
+    f_ref, _, _ = ref([audio[:NCHK].double(), labels[:NCHK]], pose[:NCHK].double(), **kw_r)
+  l1 = (y_cap[:NCHK].cpu().double() - f_ref).abs().mean().item()
+  mix_agree = (hip.G.labels_cap_soft[:NCHK].argmax(-1).cpu() == ref.G.labels_cap_soft.argmax(-1)).float().mean().item()
+  _report('configs[4] inference B=1024 M=8 fp16 folded graph', pose_l1=l1, mixture_argmax_agreement=mix_agree,
+          ms_per_forward=ms, clips_per_s=B / ms * 1e3)
+  assert y_cap.shape == (B, 64, 104) and np.isfinite(l1) and l1 <= 2e-2
