@@ -312,6 +312,9 @@ int ms_debug_set_patch_min_workgroups(int n);
  * layers off (0 = planner's choice), and a forced split-K factor over workgroups (0 = planner's choice). */
 int ms_debug_set_patch_tuning(int intra_split, int force_splitk);
 
+/* Tuning aid for the 16-bit conv kernel: force the workgroup tile to 64*wm output channels x 64*wn pixels (0, 0: planner). */
+int ms_debug_set_conv16_tile(int wm, int wn);
+
 /* Self-test kernel: C(32x32) = A(32xK) * B(Kx32) through the fp32 MFMA path (checks fragment maps). */
 int ms_selftest_mfma(const float* A, const float* B, float* C, int K, void* stream);
 

@@ -98,6 +98,7 @@ SIGNATURES = {
     'ms_timing_report': (c_size_t, [ctypes.c_char_p, c_size_t]),
     'ms_debug_set_patch_min_workgroups': (c_int, [c_int]),
     'ms_debug_set_patch_tuning': (c_int, [c_int, c_int]),
+    'ms_debug_set_conv16_tile': (c_int, [c_int, c_int]),
     'ms_selftest_mfma': (c_int, [_P, _P, _P, c_int, _P]),
 }
 

@@ -202,9 +202,10 @@ int block_bwd16(const ms_conv_desc* d, const void* x, const void* x2, const floa
   // 1. gradient wrt the raw conv output (+ per-channel column sums = bias gradient)
   const void* gsrc = dy;
   const float* dyf = outf32 ? (const float*)dy : nullptr;
+  int bias_done = 0;
   if (d->mode == MS_BN_TRAIN) {
-    rc = launch_bn_bwd16(g.dt, outf32 ? nullptr : dy, dyf, y_raw, save, gamma, bn_part, dyr, colpart, dgamma, dbeta, d->B, g.C, g.hw,
-                         d->slope, s);
+    rc = launch_bn_bwd16(g.dt, outf32 ? nullptr : dy, dyf, y_raw, save, gamma, bn_part, dyr, colpart, dbias, dgamma, dbeta, d->B, g.C,
+                         g.hw, d->slope, &bias_done, s);
     gsrc = dyr;
   } else if (d->mode == MS_LRELU) {
     rc = launch_act_bwd16(g.dt, dy, nullptr, y, dyr, colpart, d->B, g.C, g.hw, 1, d->slope, s);
@@ -214,7 +215,7 @@ int block_bwd16(const ms_conv_desc* d, const void* x, const void* x2, const floa
     if (outf32) gsrc = dyr;
   }
   if (rc) return rc;
-  if (dbias) {
+  if (dbias && !bias_done) {
     rc = launch_colsum16(colpart, dbias, g.C, nchunk, s);
     if (rc) return rc;
   }

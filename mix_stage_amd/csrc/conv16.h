@@ -41,6 +41,7 @@ struct Conv16Args {
   int of_img, of_chan, of_row;         // out_f32 strides (elements)
   int PH, PW;
   int ltw, TH, PC, nchunks, tiles_x, tiles_y, gx, gy, gz;
+  int nstg;                            // LDS-DMA path: buffers in the ring (3 or 4)
   int ncls, cls_PH[4], cls_PW[4], cls_OUTH[4], cls_OUTW[4], cls_ry[4], cls_rx[4];
   unsigned a_mt_stride, a_group_stride, a_cls_stride;   // vectors
   float slope, eps;
@@ -48,7 +49,7 @@ struct Conv16Args {
 };
 
 struct Conv16Plan {
-  int ok, wm, wn, tw, th, tiles_y, tiles_x, n_tiles, ck8, nchunks, pc, lds_bytes;
+  int ok, wm, wn, tw, th, tiles_y, tiles_x, n_tiles, ck8, nchunks, pc, lds_bytes, dma, nstg;
 };
 Conv16Plan plan_conv16(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH, int SW, int B, int OH, int OW, int zmul,
                        bool up2);
@@ -96,8 +97,8 @@ int launch_bn_apply16(int dt, const void* y_raw, void* y, float* y_f32, const fl
 int bwd16_chunks(int B, int C8, int HW, int* b_per_chunk);
 // dy: cb8, or plain fp32 (B,C,HW) when dy_f32 != NULL
 int launch_bn_bwd16(int dt, const void* dy, const float* dy_f32, const void* y_raw, const float* save, const float* gamma,
-                    float* partial, void* dyr, float* colpart, float* dgamma, float* dbeta, int B, int C, int HW, float slope,
-                    hipStream_t s);
+                    float* partial, void* dyr, float* colpart, float* dbias, float* dgamma, float* dbeta, int B, int C, int HW,
+                    float slope, int* bias_done, hipStream_t s);
 // mode 1: dyr = dy * lrelu'(y); mode 0: dyr = dy (written only when dy arrives as fp32); colsum partials always
 int launch_act_bwd16(int dt, const void* dy, const float* dy_f32, const void* y, void* dyr, float* colpart, int B, int C, int HW,
                      int mode, float slope, hipStream_t s);

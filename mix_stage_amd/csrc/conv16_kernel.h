@@ -65,19 +65,204 @@ __device__ inline u32x4 buf_load_v(__amdgpu_buffer_rsrc_t r, unsigned voff, unsi
 constexpr int conv16_ck8(int KW) { return KW == 8 ? 2 : 4; }
 constexpr int CONV16_NP = 6;      // patch vectors a thread stages per stage at most (plan_conv16 keeps CK8*TH*PC <= 6*256)
 
-template <typename DT, int KW, int WM, int WN, bool UP2>
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
+__device__ inline void wait_vmcnt(int n) {
+#define MS_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+  switch (n) {
+    MS_VM(0) MS_VM(1) MS_VM(2) MS_VM(3) MS_VM(4) MS_VM(5) MS_VM(6) MS_VM(7) MS_VM(8) MS_VM(9) MS_VM(10) MS_VM(11) MS_VM(12)
+    MS_VM(13) MS_VM(14) MS_VM(15) MS_VM(16) MS_VM(17) MS_VM(18) MS_VM(19) MS_VM(20) MS_VM(21) MS_VM(22) MS_VM(23) MS_VM(24)
+    MS_VM(25) MS_VM(26) MS_VM(27) MS_VM(28) MS_VM(29) MS_VM(30) MS_VM(31) MS_VM(32) MS_VM(33) MS_VM(34) MS_VM(35) MS_VM(36)
+    MS_VM(37) MS_VM(38) MS_VM(39) MS_VM(40) MS_VM(41) MS_VM(42)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef MS_VM
+}
+
+// 16 bytes per lane from a buffer straight into LDS (buffer_load_dwordx4 ... lds): the destination is the wave-uniform
+// base `lds` + lane*16 -- the staging images below are laid out in exactly that order -- and out-of-range lanes store zeros
+__device__ inline void dma16(__amdgpu_buffer_rsrc_t r, u32x4* lds, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, (int)voff, (int)soff, 0, 0);
+}
+
+struct Tile16 { int g, m0, wm, wn, r, h, lane, t, img, oy0, ox0, OUTH, OUTW, o_ry, o_rx, bx, by; };
+
+// Sum each of v[0..15] over the 32 lanes that share lane>>5: at every step a lane hands half of its values to its partner and
+// keeps (and accumulates) the other half, so 16 values cost 8+4+2+1+1 exchanges in 5 dependent steps instead of 80.
+// Afterwards lane r holds in v[0] the total of value index (r >> 1) & 15.  All exchanges are VALU lane operations
+// (v_permlane16_swap between the two 16-lane rows of a half, DPP inside a row): __shfl_xor goes through ds_bpermute and
+// measured 14 us for the 64 exchanges of a 128 x 128 tile.
+template <int CTRL>
+__device__ inline float dpp_mov(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+__device__ inline void reduce16_over_half(float (&v)[16], int r) {
+  // rows 0/1 (2/3) of the wave = the two 16-lane halves of lane half h = 0 (1): swap odd rows of x with even rows of y
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const unsigned x = __builtin_bit_cast(unsigned, v[k]), y = __builtin_bit_cast(unsigned, v[k + 8]);
+    const unsigned long long sw = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_permlane16_swap(x, y, false, false));
+    // even rows now hold (value k of the even row, value k of the odd row), odd rows the same for value k + 8
+    v[k] = __builtin_bit_cast(float, (unsigned)sw) + __builtin_bit_cast(float, (unsigned)(sw >> 32));
+  }
+  {   // partner lane ^ 8: a rotation by 8 inside the row
+    const bool up = (r & 8) != 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float send = up ? v[k] : v[k + 4], keep = up ? v[k + 4] : v[k];
+      v[k] = keep + dpp_mov<0x128>(send);                  // row_ror:8
+    }
+  }
+  {   // partner lane ^ 4: row_half_mirror (i -> 7 - i) followed by the quad reversal (i -> i ^ 3)
+    const bool up = (r & 4) != 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float send = up ? v[k] : v[k + 2], keep = up ? v[k + 2] : v[k];
+      v[k] = keep + dpp_mov<0x1B>(dpp_mov<0x141>(send));   // quad_perm:[3,2,1,0] of row_half_mirror
+    }
+  }
+  {   // partner lane ^ 2
+    const bool up = (r & 2) != 0;
+    const float send = up ? v[0] : v[1], keep = up ? v[1] : v[0];
+    v[0] = keep + dpp_mov<0x4E>(send);                     // quad_perm:[2,3,0,1]
+  }
+  v[0] += dpp_mov<0xB1>(v[0]);                             // quad_perm:[1,0,3,2]
+}
+
+template <typename DT, int WM, int WN, int EP, bool OUTF32>
+__device__ __forceinline__ void conv16_epilogue(const Conv16Args& p, const f32x16 (&acc)[WM][WN], const Tile16& tl, u32x4* smem) {
+  constexpr int BM = 64 * WM;
+  const int TW = 1 << p.ltw;
+  const int ctot = p.groups * p.Mg;
+  float* red = reinterpret_cast<float*>(smem);     // EP_RAW_STATS: [2 pixel waves][BM][2]
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    const int mrow0 = tl.m0 + (tl.wm * WM + i) * 32 + 4 * tl.h;
+    float bsv[16], scv[EP == EP_BN_EVAL ? 16 : 1], shv[EP == EP_BN_EVAL ? 16 : 1];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int m = mrow0 + (q & 3) + 8 * (q >> 2);
+      const int chn = tl.g * p.Mg + min(m, p.Mg - 1);
+      bsv[q] = (p.bias && m < p.Mg) ? p.bias[chn] : 0.f;
+      if (EP == EP_BN_EVAL) {
+        const float sc = p.bn_g[chn] * (1.0f / sqrtf(p.bn_v[chn] + p.eps));
+        scv[q] = sc; shv[q] = p.bn_b[chn] - p.bn_m[chn] * sc;
+      }
+    }
+    float s1[16], s2[16];
+    if (EP == EP_RAW_STATS) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int n = (tl.wn * WN + j) * 32 + tl.r;
+      const int oy = tl.oy0 + (n >> p.ltw), ox = tl.ox0 + (n & (TW - 1));
+      const bool cval = (oy < tl.OUTH) & (ox < tl.OUTW);
+      // (plain array, not an ext_vector: this clang miscompiles constant-index writes followed by reads on a local f32x16)
+      float c[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        float v = acc[i][j][q] + bsv[q];
+        if (EP == EP_RAW_STATS) {
+          const float vm = cval ? v : 0.f;             // (rows beyond Mg: zero weights and zero bias -> v == 0)
+          s1[q] += vm;
+          s2[q] = fmaf(vm, vm, s2[q]);
+        }
+        if (EP == EP_BN_EVAL) v = lrelu(fmaf(v, scv[EP == EP_BN_EVAL ? q : 0], shv[EP == EP_BN_EVAL ? q : 0]), p.slope);
+        if (EP == EP_LRELU) v = lrelu(v, p.slope);
+        if (EP == EP_BN_EVAL) v = (mrow0 + (q & 3) + 8 * (q >> 2) < p.Mg) ? v : 0.f;     // shift of a pad row
+        c[q] = v;
+      }
+      if (OUTF32) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int m = mrow0 + (q & 3) + 8 * (q >> 2);
+          if (m < p.Mg && cval)
+            p.out_f32[(size_t)tl.img * p.of_img + (size_t)(tl.g * p.Mg + m) * p.of_chan + (size_t)oy * p.of_row + ox] = c[q];
+        }
+      } else {
+        // 8 consecutive channels of a pixel sit in two lanes (l, l+32): v_permlane32_swap pairs register groups so that the
+        // lower lane ends up with blocks 0,1 and the upper lane with blocks 2,3 of this 32-row tile, one 16-byte store each
+        float vec[2][8];
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned x = __builtin_bit_cast(unsigned, c[4 * pr + e]), y = __builtin_bit_cast(unsigned, c[4 * (pr + 2) + e]);
+            const unsigned long long sw = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_permlane32_swap(x, y, false, false));
+            vec[pr][e] = __builtin_bit_cast(float, (unsigned)sw);
+            vec[pr][4 + e] = __builtin_bit_cast(float, (unsigned)(sw >> 32));
+          }
+        const int cb_tile = (tl.g * p.Mg + tl.m0 + (tl.wm * WM + i) * 32) >> 3;
+        const int cb_end = (tl.g * p.Mg + p.Mg + 7) >> 3;
+        const size_t obase = (size_t)tl.img * p.o_img + (size_t)(oy * p.o_sh + tl.o_ry) * p.o_row + (size_t)(ox * p.o_sw + tl.o_rx);
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const int cb = cb_tile + pr + 2 * tl.h;
+          if (EP == EP_DGRAD_UP2) {
+            // 1-D stride-1 data gradient of an upsample-add input: out2 = grad of the residual (full resolution),
+            // out = grad of the half-resolution tensor = sum over the pair of columns (adjacent lanes)
+            float pair[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pair[e] = vec[pr][e] + __shfl_xor(vec[pr][e], 1);
+            if (cval && cb < cb_end) {
+              reinterpret_cast<u32x4*>(p.out2)[obase + (size_t)cb * p.o_cblk] = pack8<DT>(vec[pr]);
+              if (!(tl.lane & 1)) {
+                const size_t hb = (size_t)tl.img * (p.o_img >> 1) + (size_t)oy * (p.o_row >> 1) + (size_t)(ox >> 1);
+                reinterpret_cast<u32x4*>(p.out)[hb + (size_t)cb * (p.o_cblk >> 1)] = pack8<DT>(pair);
+              }
+            }
+          } else if (cval && cb < cb_end) {
+            reinterpret_cast<u32x4*>(p.out)[obase + (size_t)cb * p.o_cblk] = pack8<DT>(vec[pr]);
+          }
+        }
+      }
+    }
+    if (EP == EP_RAW_STATS) {
+      // per-channel (sum, sum of squares) over the 32 pixels of a lane half; the two pixel waves meet in LDS below
+      reduce16_over_half(s1, tl.r);
+      reduce16_over_half(s2, tl.r);
+      if (!(tl.r & 1)) {
+        const int q = (tl.r >> 1) & 15;
+        const int ml = (tl.wm * WM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * tl.h;
+        red[(tl.wn * BM + ml) * 2] = s1[0];
+        red[(tl.wn * BM + ml) * 2 + 1] = s2[0];
+      }
+    }
+  }
+  if (EP == EP_RAW_STATS) {
+    // fixed order over the two pixel waves; stored as (sum, M2 about the tile mean) like the fp32 kernels
+    __syncthreads();
+    const int th_v = min(p.TH, tl.OUTH - tl.oy0), tw_v = min(TW, tl.OUTW - tl.ox0);
+    if (tl.t < BM && tl.m0 + tl.t < p.Mg) {
+      const float sa = red[tl.t * 2] + red[(BM + tl.t) * 2], sb = red[tl.t * 2 + 1] + red[(BM + tl.t) * 2 + 1];
+      float* stp = p.stats + ((size_t)tl.bx * ctot + tl.g * p.Mg + tl.m0 + tl.t) * 2;
+      stp[0] = sa;
+      stp[1] = fmaxf(sb - sa * sa / (float)(th_v * tw_v), 0.f);
+    }
+    if (tl.t == 0 && tl.by == 0 && tl.g == 0) p.counts[tl.bx] = (float)(th_v * tw_v);
+  }
+}
+
+// DMA = true: the stages are filled by LDS-DMA loads into a ring of p.nstg buffers -- no staging registers, no ds_write, and
+// the loads of the next nstg-2 stages stay in flight behind the current stage's MFMAs (counted vmcnt, one raw barrier per
+// stage).  DMA = false: global -> registers -> LDS, two buffers (needed where the input is formed on the way: UP2).
+template <typename DT, int KW, int WM, int WN, bool UP2, bool DMA>
 __global__ __launch_bounds__(256) void conv16_kernel(const Conv16Args p) {
   constexpr int CK8 = conv16_ck8(KW), KS = CK8 / 2;
   constexpr int BM = 64 * WM;
   constexpr int NAV = KW * CK8 * BM, NA = (NAV + 255) / 256;
   constexpr int NP = CONV16_NP;
+  static_assert(!(UP2 && DMA), "the upsample-add input is formed in registers");
   extern __shared__ u32x4 smem[];
 
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wm = wid >> 1, wn = wid & 1, r = lane & 31, h = lane >> 5;
   const int TW = 1 << p.ltw, TH = p.TH, PC = p.PC, S = p.S, SV = p.SV, KH = p.KH;
   const int thpc = TH * PC, pv = CK8 * thpc;
-  const int stage_vecs = NAV + pv + 1;           // + one dummy vector: out-of-range staging stores land there
+  const int npd = (pv + 255) >> 8;               // DMA: 256-vector slabs of input rows per stage
+  // register path: + one dummy vector (out-of-range staging stores land there); DMA path: whole slabs
+  const int stage_vecs = DMA ? NAV + npd * 256 : NAV + pv + 1;
 
   // logical block id: channel tile fastest, then pixel tile, then (class, group); one contiguous range per XCD
   const int vid = xcd_remap(blockIdx.x, p.gx * p.gy * p.gz);
@@ -196,135 +381,67 @@ __global__ __launch_bounds__(256) void conv16_kernel(const Conv16Args p) {
     }
   };
 
-  load_stage(0);
-  store_stage(0);
-  __syncthreads();
-  for (int st = 0; st < nstages; ++st) {
-    const int cur = st & 1;
-    if (st + 1 < nstages) load_stage(st + 1);
-    compute_stage(cur);
-    if (st + 1 < nstages) store_stage(cur ^ 1);
+  if constexpr (DMA) {
+    const int wave = __builtin_amdgcn_readfirstlane(wid);
+    auto issue_stage = [&](int st) {
+      const int ch = st / KH, kh = st - ch * KH;
+      u32x4* dst = smem + (st % p.nstg) * stage_vecs + wave * 64;
+      const unsigned sa = __builtin_amdgcn_readfirstlane(16u * (a_wg + (unsigned)st * NAV));
+#pragma unroll
+      for (int i = 0; i < NA; ++i) dma16(rsA, dst + i * 256, 16u * (unsigned)(t + i * 256), sa);
+      const int cb0 = ch * CK8;
+      const int sbase = __builtin_amdgcn_readfirstlane(img * p.s_img + (cbase8 + cb0) * p.s_cblk);
+      const int khrow = kh * p.s_row;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        if (i < npd) {
+          const bool ok = pcol[i] & ((unsigned)(prow[i] + kh) < (unsigned)p.SRCH) & (cb0 + pcb[i] < p.Kc8g);
+          dma16(rsS, dst + NAV + i * 256, ok ? 16u * (unsigned)(poff[i] + khrow) : BUF_OOB, 16u * (unsigned)sbase);
+        }
+      }
+    };
+    const int per_stage = NA + npd;                    // LDS-DMA instructions a wave issues per stage
+    const int ahead = p.nstg - 2;                      // stages that stay in flight behind the one being computed
+    for (int st = 0; st < p.nstg - 1 && st < nstages; ++st) issue_stage(st);
+    for (int st = 0; st < nstages; ++st) {
+      // stage st has landed once at most `ahead` younger stages are outstanding (in the tail fewer are: drain)
+      wait_vmcnt(st + ahead < nstages ? ahead * per_stage : 0);
+      __builtin_amdgcn_s_barrier();                    // everyone's part of stage st is in LDS, everyone is done with stage st-1
+      asm volatile("" ::: "memory");
+      if (st + p.nstg - 1 < nstages) issue_stage(st + p.nstg - 1);    // refills the buffer of stage st-1
+      compute_stage(st % p.nstg);
+    }
+  } else {
+    load_stage(0);
+    store_stage(0);
     __syncthreads();
+    for (int st = 0; st < nstages; ++st) {
+      const int cur = st & 1;
+      if (st + 1 < nstages) load_stage(st + 1);
+      compute_stage(cur);
+      if (st + 1 < nstages) store_stage(cur ^ 1);
+      __syncthreads();
+    }
   }
 
   // ---------------- epilogue ----------------
-  const int ep = p.ep;
-  const int ctot = p.groups * p.Mg;
-  float s1[WM][16], s2[WM][16];
-  if (ep == EP_RAW_STATS) {
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) { s1[i][q] = 0.f; s2[i][q] = 0.f; }
-  }
-#pragma unroll
-  for (int i = 0; i < WM; ++i) {
-    // per-row epilogue constants of this lane's 16 rows
-    float bsv[16], scv[16], shv[16];
-    bool mvl[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int m = m0 + (wm * WM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-      mvl[q] = m < p.Mg;
-      const int chn = g * p.Mg + (mvl[q] ? m : 0);
-      bsv[q] = (p.bias && mvl[q]) ? p.bias[chn] : 0.f;
-      scv[q] = 1.f; shv[q] = 0.f;
-      if (ep == EP_BN_EVAL) {
-        const float inv = 1.0f / sqrtf(p.bn_v[chn] + p.eps);
-        scv[q] = p.bn_g[chn] * inv;
-        shv[q] = p.bn_b[chn] - p.bn_m[chn] * scv[q];
-      }
+  const Tile16 tl = {g, m0, wm, wn, r, h, lane, t, img, oy0, ox0, OUTHc, OUTWc, o_ryc, o_rxc, bx_, by_};
+  __syncthreads();                                   // the staging buffers become the statistics scratch
+  // one specialised instance per epilogue kind (wave-uniform switch): no per-element branching on the kind
+  if (p.out_f32) {
+    switch (p.ep) {
+      case EP_BARE: conv16_epilogue<DT, WM, WN, EP_BARE, true>(p, acc, tl, smem); break;
+      case EP_LRELU: conv16_epilogue<DT, WM, WN, EP_LRELU, true>(p, acc, tl, smem); break;
+      default: conv16_epilogue<DT, WM, WN, EP_BN_EVAL, true>(p, acc, tl, smem); break;
     }
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
-      const int n = (wn * WN + j) * 32 + r;
-      const int oy = oy0 + (n >> p.ltw), ox = ox0 + (n & (TW - 1));
-      const bool cval = (oy < OUTHc) & (ox < OUTWc);
-      // (plain array, not an ext_vector: this clang miscompiles constant-index writes followed by reads on a local f32x16)
-      float c[16];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        float v = acc[i][j][q] + bsv[q];
-        if (ep == EP_RAW_STATS) {
-          const float vm = (cval & mvl[q]) ? v : 0.f;
-          s1[i][q] += vm;
-          s2[i][q] = fmaf(vm, vm, s2[i][q]);
-        }
-        if (ep == EP_BN_EVAL) v = lrelu(fmaf(v, scv[q], shv[q]), p.slope);
-        if (ep == EP_LRELU) v = lrelu(v, p.slope);
-        c[q] = mvl[q] ? v : 0.f;
-      }
-      if (p.out_f32) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int m = m0 + (wm * WM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-          if (mvl[q] && cval)
-            p.out_f32[(size_t)img * p.of_img + (size_t)(g * p.Mg + m) * p.of_chan + (size_t)oy * p.of_row + ox] = c[q];
-        }
-        continue;
-      }
-      // 8 consecutive channels of a pixel sit in two lanes (l, l+32): v_permlane32_swap pairs register groups so that the
-      // lower lane ends up with blocks 0,1 and the upper lane with blocks 2,3 of this 32-row tile, one 16-byte store each
-      float vec[2][8];
-#pragma unroll
-      for (int pr = 0; pr < 2; ++pr)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const unsigned x = __builtin_bit_cast(unsigned, c[4 * pr + e]), y = __builtin_bit_cast(unsigned, c[4 * (pr + 2) + e]);
-          const unsigned long long sw = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_permlane32_swap(x, y, false, false));
-          vec[pr][e] = __builtin_bit_cast(float, (unsigned)sw);
-          vec[pr][4 + e] = __builtin_bit_cast(float, (unsigned)(sw >> 32));
-        }
-      const int cb_tile = (g * p.Mg + m0 + (wm * WM + i) * 32) >> 3;
-      const int cb_end = (g * p.Mg + p.Mg + 7) >> 3;
-      const size_t obase = (size_t)img * p.o_img + (size_t)(oy * p.o_sh + o_ryc) * p.o_row + (size_t)(ox * p.o_sw + o_rxc);
-#pragma unroll
-      for (int pr = 0; pr < 2; ++pr) {
-        const int cb = cb_tile + pr + 2 * h;
-        if (ep == EP_DGRAD_UP2) {
-          // 1-D stride-1 data gradient of an upsample-add input: out2 = grad of the residual (full resolution),
-          // out = grad of the half-resolution tensor = sum over the pair of columns (adjacent lanes)
-          float pair[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) pair[e] = vec[pr][e] + __shfl_xor(vec[pr][e], 1);
-          if (cval && cb < cb_end) {
-            reinterpret_cast<u32x4*>(p.out2)[obase + (size_t)cb * p.o_cblk] = pack8<DT>(vec[pr]);
-            if (!(lane & 1)) {
-              const size_t hb = (size_t)img * (p.o_img >> 1) + (size_t)oy * (p.o_row >> 1) + (size_t)(ox >> 1);
-              reinterpret_cast<u32x4*>(p.out)[hb + (size_t)cb * (p.o_cblk >> 1)] = pack8<DT>(pair);
-            }
-          }
-        } else if (cval && cb < cb_end) {
-          reinterpret_cast<u32x4*>(p.out)[obase + (size_t)cb * p.o_cblk] = pack8<DT>(vec[pr]);
-        }
-      }
+  } else {
+    switch (p.ep) {
+      case EP_BARE: conv16_epilogue<DT, WM, WN, EP_BARE, false>(p, acc, tl, smem); break;
+      case EP_LRELU: conv16_epilogue<DT, WM, WN, EP_LRELU, false>(p, acc, tl, smem); break;
+      case EP_BN_EVAL: conv16_epilogue<DT, WM, WN, EP_BN_EVAL, false>(p, acc, tl, smem); break;
+      case EP_RAW_STATS: conv16_epilogue<DT, WM, WN, EP_RAW_STATS, false>(p, acc, tl, smem); break;
+      default: conv16_epilogue<DT, WM, WN, EP_DGRAD_UP2, false>(p, acc, tl, smem); break;
     }
-  }
-
-  if (ep == EP_RAW_STATS) {
-    // per-channel (sum, sum of squares) of the tile: over the 32 pixels of a lane half in registers, over the two pixel
-    // waves through LDS in a fixed order; stored as (sum, M2 about the tile mean) like the fp32 kernels
-    float* red = reinterpret_cast<float*>(smem);     // [2 waves][BM][2]
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const float a = half_wave_sum(s1[i][q]), b = half_wave_sum(s2[i][q]);
-        if (r == 0) {
-          const int ml = (wm * WM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-          red[(wn * BM + ml) * 2] = a;
-          red[(wn * BM + ml) * 2 + 1] = b;
-        }
-      }
-    __syncthreads();
-    if (t < BM && m0 + t < p.Mg) {
-      const float sa = red[t * 2] + red[(BM + t) * 2], sb = red[t * 2 + 1] + red[(BM + t) * 2 + 1];
-      const int cnt = min(TH, OUTHc - oy0) * min(TW, OUTWc - ox0);
-      float* stp = p.stats + ((size_t)bx_ * ctot + g * p.Mg + m0 + t) * 2;
-      stp[0] = sa;
-      stp[1] = fmaxf(sb - sa * sa / (float)cnt, 0.f);
-    }
-    if (t == 0 && by_ == 0 && g == 0) p.counts[bx_] = (float)(min(TH, OUTHc - oy0) * min(TW, OUTWc - ox0));
   }
 }
 

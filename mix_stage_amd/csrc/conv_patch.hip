@@ -525,6 +525,15 @@ extern "C" int ms_debug_set_patch_tuning(int intra_split, int force_splitk) {
   return 0;
 }
 
+namespace ms { extern int g_conv16_force_wm, g_conv16_force_wn, g_conv16_dma; }
+extern "C" int ms_debug_set_conv16_tile(int wm, int wn) {
+  ++g_tuning_epoch;
+  ms::g_conv16_dma = wm >= 0 ? 1 : 0;          // negative wm: register-staged path (A/B against the LDS-DMA ring)
+  if (wm < 0) { wm = 0; wn = 0; }
+  ms::g_conv16_force_wm = wm; ms::g_conv16_force_wn = wn;
+  return 0;
+}
+
 extern "C" int ms_debug_set_patch_min_workgroups(int n) {
   const int old = ms::g_patch_min_wgs;
   ++g_tuning_epoch;

@@ -176,6 +176,78 @@ __global__ __launch_bounds__(256) void bn_bwd16_apply_kernel(const u32x4* __rest
   }
 }
 
+// Fused form for channel blocks with <= 256*NE vectors (every 1-D layer of the path at B*T <= 2048): one workgroup owns a
+// channel block, keeps dz / x_hat in registers across the reduction and writes dy_raw, dgamma, dbeta and the bias gradient
+// in ONE launch.
+template <typename DT, bool DYF32, int NE>
+__global__ __launch_bounds__(256) void bn_bwd16_fused_kernel(const u32x4* __restrict__ dy, const float* __restrict__ dy_f32,
+                                                             const u32x4* __restrict__ y_raw, const float* __restrict__ save,
+                                                             const float* __restrict__ gamma, u32x4* __restrict__ dyr, float* dbias,
+                                                             float* dgamma, float* dbeta, int B, int C, int C8, int HW, float slope) {
+  __shared__ float red[32];
+  const int cb = blockIdx.x, t = threadIdx.x;
+  const int n = B * HW;
+  float mean[8], invstd[8], sc[8], sh[8], gi[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = min(cb * 8 + j, C - 1);
+    mean[j] = save[c]; invstd[j] = save[C + c]; sc[j] = save[2 * C + c]; sh[j] = save[3 * C + c];
+    gi[j] = cb * 8 + j < C ? gamma[c] * invstd[j] : 0.f;
+  }
+  float dz[NE][8], xh[NE][8];
+  float s1[8] = {}, s2[8] = {};
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = t + i * 256;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dz[i][j] = 0.f; xh[i][j] = 0.f; }
+    if (e < n) {
+      const int bl = e / HW, pix = e - bl * HW;
+      const size_t v = ((size_t)bl * C8 + cb) * HW + pix;
+      float g[8], yr[8];
+      load_dy8<DT, DYF32>(dy, dy_f32, v, bl, cb, pix, C, HW, g);
+      unpack8<DT>(y_raw[v], yr);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float z = fmaf(yr[j], sc[j], sh[j]);
+        dz[i][j] = g[j] * (z > 0.f ? 1.f : slope);
+        xh[i][j] = (yr[j] - mean[j]) * invstd[j];
+        s1[j] += dz[i][j];
+        s2[j] = fmaf(dz[i][j], xh[i][j], s2[j]);
+      }
+    }
+  }
+  block_sum8(s1, red);
+  block_sum8(s2, red);
+  const float invN = 1.0f / (float)n;
+  float cs[8] = {};
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = t + i * 256;
+    if (e < n) {
+      const int bl = e / HW, pix = e - bl * HW;
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        o[j] = gi[j] * (dz[i][j] - s1[j] * invN - xh[i][j] * (s2[j] * invN));
+        cs[j] += o[j];
+      }
+      dyr[((size_t)bl * C8 + cb) * HW + pix] = pack8<DT>(o);
+    }
+  }
+  block_sum8(cs, red);
+  if (t == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cb * 8 + j;
+      if (c < C) {
+        if (dbias) dbias[c] = cs[j];
+        if (dgamma) { dgamma[c] = s2[j]; dbeta[c] = s1[j]; }
+      }
+    }
+  }
+}
+
 int bwd16_chunks(int B, int C8, int HW, int* b_per_chunk) {
   (void)HW;
   int nchunk = std::min(B, std::max(1, 768 / std::max(1, C8)));
@@ -186,9 +258,24 @@ int bwd16_chunks(int B, int C8, int HW, int* b_per_chunk) {
 }
 
 int launch_bn_bwd16(int dt, const void* dy, const float* dy_f32, const void* y_raw, const float* save, const float* gamma,
-                    float* partial, void* dyr, float* colpart, float* dgamma, float* dbeta, int B, int C, int HW, float slope,
-                    hipStream_t s) {
+                    float* partial, void* dyr, float* colpart, float* dbias, float* dgamma, float* dbeta, int B, int C, int HW,
+                    float slope, int* bias_done, hipStream_t s) {
   const int C8 = c8_of(C);
+  *bias_done = 0;
+  if ((long)B * HW <= 2048) {
+    *bias_done = 1;
+    const int ne = (B * HW + 255) / 256;
+    TimingScope ts(s, 0, 16.0 * (dy_f32 ? 4.0 + 1.0 + 1.0 : 3.0) * (double)B * C8 * HW, "bn_bwd16_fused_kernel|bn_bwd16 C%d N%d fused", C, B * HW);
+#define MS_BNF(DT, F, NE)                                                                                                        \
+    hipLaunchKernelGGL((bn_bwd16_fused_kernel<DT, F, NE>), dim3(C8), dim3(256), 0, s, (const u32x4*)dy, dy_f32, (const u32x4*)y_raw, \
+                       save, gamma, (u32x4*)dyr, dbias, dgamma, dbeta, B, C, C8, HW, slope)
+#define MS_BNF_NE(DT, F) do { if (ne <= 1) MS_BNF(DT, F, 1); else if (ne <= 2) MS_BNF(DT, F, 2); else if (ne <= 4) MS_BNF(DT, F, 4); else MS_BNF(DT, F, 8); } while (0)
+    if (dt == DT_BF16) { if (dy_f32) MS_BNF_NE(BF16, true); else MS_BNF_NE(BF16, false); }
+    else { if (dy_f32) MS_BNF_NE(F16, true); else MS_BNF_NE(F16, false); }
+#undef MS_BNF_NE
+#undef MS_BNF
+    return check_launch("bn_bwd16_fused_kernel");
+  }
   int bpc;
   const int nchunk = bwd16_chunks(B, C8, HW, &bpc);
   const dim3 grid(C8, nchunk);

@@ -173,18 +173,28 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args p) {
     }
   }
 
-  // ---- store: D[row = co][col = ci] per tap; dw is (groups*Cog, Cig, KH, KW) fp32
+  // ---- store: D[row = co][col = ci] per tap; dw is (groups*Cog, Cig, KH, KW) fp32.  For one (co, ci) the TP taps of this
+  // workgroup are adjacent in memory, and a lane holds all of them (same accumulator register of the TP accumulators): one
+  // TP-dword store per (lane, register); consecutive lanes = consecutive ci, KH*KW floats apart (1-D k3: a contiguous run)
   const int r = lane & 31;
   float* out = p.out + (size_t)split * p.out_split_stride;
   const int ci = ci0 + wn * 32 + r;
+  struct __attribute__((packed, aligned(4))) Taps { float v[TP]; };
 #pragma unroll
-  for (int q = 0; q < TP; ++q) {
-    const int kw = kw0 + q;
+  for (int e = 0; e < 16; ++e) {
+    const int co = co0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+    if (co < p.Cog && ci < p.Cig) {
+      float* dst = out + (((size_t)(g * p.Cog + co) * p.Cig + ci) * p.KH + kh) * p.KW + kw0;
+      if (kw0 + TP <= p.KW) {
+        Taps tv;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int co = co0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-      if (co < p.Cog && ci < p.Cig && kw < p.KW)
-        out[(((size_t)(g * p.Cog + co) * p.Cig + ci) * p.KH + kh) * p.KW + kw] = acc[q][e];
+        for (int q = 0; q < TP; ++q) tv.v[q] = acc[q][e];
+        *reinterpret_cast<Taps*>(dst) = tv;
+      } else {
+#pragma unroll
+        for (int q = 0; q < TP; ++q)
+          if (kw0 + q < p.KW) dst[q] = acc[q][e];
+      }
     }
   }
 }

@@ -18,7 +18,8 @@ x = torch.randn(32, 2048, 64, device=dev)
 if precision == 'bf16':
   A.set_compute_dtype(blk, 'bf16')
   from mix_stage_amd import ops16
-  x = ops16.to_cb8(x, torch.bfloat16)
+  from mix_stage_amd._lib import MS_BF16
+  x = ops16.to_cb8(x, MS_BF16)
 with torch.no_grad():
   for _ in range(iters):
     y = blk(x)

@@ -7,7 +7,8 @@ from mix_stage_amd import ops
 from mix_stage_amd.train_step import MixStageTrainStep
 from oracle import mixstage_oracle as O
 dev = torch.device('cuda:0')
-model = bench.build_model(dev)
+precision = sys.argv[1] if len(sys.argv) > 1 else 'fp32'
+model = bench.build_model(dev, precision)
 ts = MixStageTrainStep(model, use_graphs=False)
 audio, pose, labels, style = O.synthetic_batch(32, M=8, S=8)
 batch = [t.to(dev) for t in (audio, labels, pose, style)]
@@ -29,7 +30,7 @@ for kind in 'GD':
     ncat[c] = ncat.get(c, 0) + r['count']
   print('==== %s-step: eager wall %.2f ms, timed kernels %.2f ms, %d launches' % (kind, e0.elapsed_time(e1), tot, sum(r['count'] for r in rows)))
   print('  by category (ms, launches):', {k: (round(v, 3), ncat[k]) for k, v in sorted(cat.items(), key=lambda kv: -kv[1])})
-  for r in rows[:60]:
+  for r in rows[:int(sys.argv[2]) if len(sys.argv) > 2 else 60]:
     avg = r['total_ms'] / r['count'] * 1e3
     tf = r['flops'] / (avg * 1e-6) / 1e12 if r['flops'] else 0
     gb = r['bytes'] / (avg * 1e-6) / 1e9
