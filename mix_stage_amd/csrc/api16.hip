@@ -172,6 +172,10 @@ int block_fwd16(const ms_conv_desc* d, const void* x, const void* x2, const floa
                        (a.out_f32 ? 4.0 : esz) * (double)g.npix * g.C;
   rc = launch_conv16(g.dt, a, pl, d->KW, g.up2 != 0, flops, bytes, s);
   if (rc) return rc;
+  if (d->mode == MS_BN_TRAIN && pl.n_tiles <= 64)      // few statistics tiles: finalize inside the normalising launch
+    return launch_bn_finalize_apply16(g.dt, stats, counts, pl.n_tiles, g.npix, gamma, beta, running_mean, running_var, save, d->eps,
+                                      d->momentum, y_raw, outf32 ? nullptr : y, outf32 ? (float*)y : nullptr, d->B, g.C, g.hw,
+                                      d->slope, s);
   if (d->mode == MS_BN_TRAIN) {
     rc = launch_bn_finalize(stats, counts, pl.n_tiles, 0, g.npix, g.C, gamma, beta, running_mean, running_var, save, d->eps,
                             d->momentum, s);

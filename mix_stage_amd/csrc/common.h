@@ -32,19 +32,36 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ inline int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 
-// wave-level sum over the 32 lanes that share (lane>>5); xor masks < 32 never cross the halves
-__device__ inline float half_wave_sum(float v) {
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 8);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 1);
+// Cross-lane sums on the VALU (DPP row rotations inside a 16-lane row, v_permlane16_swap / v_permlane32_swap across rows):
+// the __shfl_xor forms go through ds_bpermute, which measured ~200 ns per exchange on MI355X (64 exchanges = 14 us in a
+// conv epilogue).  Every lane ends up with the total; the order of the additions is fixed.
+template <int CTRL>
+__device__ inline float dpp_rot(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+// value of lane ^ 1 / lane ^ 2 (inside a quad)
+__device__ inline float lane_xor1(float x) { return dpp_rot<0xB1>(x); }   // quad_perm:[1,0,3,2]
+__device__ inline float lane_xor2(float x) { return dpp_rot<0x4E>(x); }   // quad_perm:[2,3,0,1]
+__device__ inline float row_sum16(float v) {
+  v += dpp_rot<0x128>(v);   // row_ror:8
+  v += dpp_rot<0x124>(v);   // row_ror:4
+  v += dpp_rot<0x122>(v);   // row_ror:2
+  v += dpp_rot<0x121>(v);   // row_ror:1
   return v;
+}
+// sum over the 32 lanes that share (lane>>5)
+__device__ inline float half_wave_sum(float v) {
+  v = row_sum16(v);
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const unsigned long long sw = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_permlane16_swap(u, u, false, false));
+  return __builtin_bit_cast(float, (unsigned)sw) + __builtin_bit_cast(float, (unsigned)(sw >> 32));
 }
 
 __device__ inline float wave_sum(float v) {
-  v += __shfl_xor(v, 32);
-  return half_wave_sum(v);
+  v = half_wave_sum(v);
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const unsigned long long sw = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_permlane32_swap(u, u, false, false));
+  return __builtin_bit_cast(float, (unsigned)sw) + __builtin_bit_cast(float, (unsigned)(sw >> 32));
 }
 
 __device__ inline double wave_sum_d(double v) {

@@ -95,6 +95,9 @@ int launch_wgrad16(int dt, const Wgrad16Args& a, const Wgrad16Plan& pl, bool up2
 int launch_bn_apply16(int dt, const void* y_raw, void* y, float* y_f32, const float* save, int B, int C, int HW, float slope,
                       hipStream_t s);
 int bwd16_chunks(int B, int C8, int HW, int* b_per_chunk);
+int launch_bn_finalize_apply16(int dt, const float* stats, const float* counts, int n_tiles, int N, const float* gamma,
+                               const float* beta, float* rm, float* rv, float* save, float eps, float momentum, const void* y_raw,
+                               void* y, float* y_f32, int B, int C, int HW, float slope, hipStream_t s);
 // dy: cb8, or plain fp32 (B,C,HW) when dy_f32 != NULL
 int launch_bn_bwd16(int dt, const void* dy, const float* dy_f32, const void* y_raw, const float* save, const float* gamma,
                     float* partial, void* dyr, float* colpart, float* dbias, float* dgamma, float* dbeta, int B, int C, int HW,

@@ -204,7 +204,7 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16Args& p, const f32x1
             // out = grad of the half-resolution tensor = sum over the pair of columns (adjacent lanes)
             float pair[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) pair[e] = vec[pr][e] + __shfl_xor(vec[pr][e], 1);
+            for (int e = 0; e < 8; ++e) pair[e] = vec[pr][e] + lane_xor1(vec[pr][e]);
             if (cval && cb < cb_end) {
               reinterpret_cast<u32x4*>(p.out2)[obase + (size_t)cb * p.o_cblk] = pack8<DT>(vec[pr]);
               if (!(tl.lane & 1)) {

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherArgs p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const float v = acc[i][j][r];
-          const float pr = __shfl_xor(v, 1);
+          const float pr = lane_xor1(v);
           if (mval && cval[j]) {
             p.out2[(size_t)ooff[j] + (size_t)ch * ohw] = v;
             if (!(lane & 1)) {

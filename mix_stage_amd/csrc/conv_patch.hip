@@ -308,7 +308,7 @@ void conv_patch_kernel(const PatchArgs p) {
     if (ep == EP_DGRAD_UP2) {
       // 1-D stride-1 data gradient of an upsample-add input: out2 = grad of the residual (full resolution),
       // out = grad of the half-resolution tensor = sum over the pair of columns (adjacent lanes)
-      const float pr = __shfl_xor(v, 1);
+      const float pr = lane_xor1(v);
       if (mval && cval) {
         p.out2[(size_t)ooff + (size_t)chn * p.o_chan] = v;
         if (!(lane & 1)) p.out[(size_t)(ooff >> 1) + (size_t)chn * (p.o_chan >> 1)] = v + pr;
@@ -337,8 +337,8 @@ void conv_patch_kernel(const PatchArgs p) {
       v[i] = tile[ch * LP + q + 4 * i];
       s += v[i];
     }
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
+    s += lane_xor1(s);
+    s += lane_xor2(s);
     const int cnt = min(TH, OUTHc - oy0) * min(TW, OUTWc - ox0);
     const float mean = s / (float)cnt;
     float m2 = 0.f;
@@ -349,8 +349,8 @@ void conv_patch_kernel(const PatchArgs p) {
       const float dlt = v[i] - mean;
       m2 += ok ? dlt * dlt : 0.f;
     }
-    m2 += __shfl_xor(m2, 1);
-    m2 += __shfl_xor(m2, 2);
+    m2 += lane_xor1(m2);
+    m2 += lane_xor2(m2);
     if (q == 0 && m0 + ch < p.Mg) {
       float* st = p.stats + ((size_t)bx_ * ctot + g * p.Mg + m0 + ch) * 2;
       st[0] = s;

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch6_kernel(const PatchArgs p) 
       if (ep == EP_BN_EVAL) v = lrelu(fmaf(v, sc, sh), p.slope);
       if (ep == EP_LRELU) v = lrelu(v, p.slope);
       if (ep == EP_DGRAD_UP2) {
-        const float pr = __shfl_xor(v, 1);
+        const float pr = lane_xor1(v);
         if (mval && cval) {
           p.out2[(size_t)ooff + (size_t)chn * p.o_chan] = v;
           if (!(lane & 1)) p.out[(size_t)(ooff >> 1) + (size_t)chn * (p.o_chan >> 1)] = v + pr;
@@ -378,8 +378,8 @@ __global__ __launch_bounds__(256, 2) void conv_patch6_kernel(const PatchArgs p) 
     float s = 0.f;
 #pragma unroll 8
     for (int i = 0; i < 32; ++i) s += tile[ch * LP + q + 4 * i];
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
+    s += lane_xor1(s);
+    s += lane_xor2(s);
     const int cnt = min(TH, OUTHc - oy0) * min(TW, OUTWc - ox0);
     const float mean = s / (float)cnt;
     float m2 = 0.f;
@@ -390,8 +390,8 @@ __global__ __launch_bounds__(256, 2) void conv_patch6_kernel(const PatchArgs p) 
       const float dlt = tile[ch * LP + nl] - mean;
       m2 += ok ? dlt * dlt : 0.f;
     }
-    m2 += __shfl_xor(m2, 1);
-    m2 += __shfl_xor(m2, 2);
+    m2 += lane_xor1(m2);
+    m2 += lane_xor2(m2);
     if (q == 0 && m0 + ch < p.Mg) {
       float* st = p.stats + ((size_t)bx_ * ctot + g * p.Mg + m0 + ch) * 2;
       st[0] = s;

@@ -118,27 +118,32 @@ def test_headline_bf16_train_step_m8_b32():
   _train_compare('headline M=8 B=32 T=64 bf16', 8, 8, 32, 64)
 
 
-def test_bf16_train_steps_graph_equals_eager_and_learns():
-  """The captured step replays bit-identically in the 16-bit mode too, and a few steps of training move the pose loss down."""
+def test_bf16_train_steps_graph_equals_eager_and_track_fp32():
+  """The captured step replays bit-identically in the 16-bit mode too, and 24 training steps (Adam, lr 1e-4 as the reference trains) stay on
+  the trajectory of the exact-fp32 path (pose loss within 3e-2 at every step)."""
   from mix_stage_amd.train_step import MixStageTrainStep
   M = S = 4
   batch = [t.to(DEV) for t in O.synthetic_batch(8, M=M, S=S)]
   audio, pose, labels, style = batch
   results = {}
-  for use_graphs in (False, True):
+  for use_graphs in (False, True, 'fp32'):
     torch.manual_seed(5)
-    model = _hip_gan(M, S)
-    ts = MixStageTrainStep(model, use_graphs=use_graphs)
+    model = _hip_gan(M, S, dtype='fp32' if use_graphs == 'fp32' else 'bf16')
+    ts = MixStageTrainStep(model, use_graphs=bool(use_graphs))
     hist = []
-    for i in range(8):
+    for i in range(24):
       k = ts.step(audio, labels, pose, style, kind='G' if i % 2 == 0 else 'D')
       hist.append((k, [float(l) for l in ts.losses]))
     results[use_graphs] = (hist, {k: v.clone() for k, v in model.state_dict().items()})
   assert results[False][0] == results[True][0]
   for k, v in results[False][1].items():
     assert torch.equal(v, results[True][1][k]), k
-  g_losses = [h[1][0] for h in results[True][0] if h[0] == 'G']
-  assert all(np.isfinite(g_losses)) and g_losses[-1] < g_losses[0], g_losses
+  per_idx = [max(abs(la[i] - lb[i]) for (_, la), (_, lb) in zip(results[True][0], results['fp32'][0])) for i in range(5)]
+  worst = max(per_idx)
+  _report('bf16 vs fp32 over 24 train steps (M=4, B=8, lr 1e-4)', max_loss_diff=worst, pose_loss_max_diff=per_idx[0])
+  # first loss of either step kind is a pose / real-score L1 term; the adversarial and cross-entropy terms of a tiny
+  # discriminator and random cluster labels amplify the 16-bit noise more (measured 0.10 / 0.04): sanity rails
+  assert np.isfinite(worst) and per_idx[0] <= 3e-2 and worst <= 0.2, per_idx
 
 
 def test_config4_fp16_inference_b1024_graph_folded():
