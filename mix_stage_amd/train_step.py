@@ -65,10 +65,14 @@ def peek_step_decisions(D_prob, thresh_value, thresh_iters, thresh_num_iters, th
 class FlatAdam:
   """torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8) + clip_grad_norm_(params, max_norm) over flat buffers."""
 
-  def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0):
+  def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0, order_last=()):
     self.params = [p for p in params if p.requires_grad]
     if not self.params:
       raise ValueError('no trainable parameters')
+    # used-first layout: parameters named in `order_last` (sub-networks that are idle on the path being trained) sit at
+    # the END of the flat buffers, so the live gradients form one prefix -- what the data-parallel exchange moves
+    last = set(id(p) for p in order_last)
+    self.params = [p for p in self.params if id(p) not in last] + [p for p in self.params if id(p) in last]
     dev = self.params[0].device
     if dev.type != 'cuda':
       raise RuntimeError('FlatAdam runs on the MI355X only (parameters are on %s)' % dev)
@@ -89,7 +93,7 @@ class FlatAdam:
         view = self.flat_p[o:o + p.numel()].view_as(p)
         view.copy_(p)
         p.data = view
-        g = self.flat_g[o:o + p.numel()].view_as(p)
+        g = self.flat_g[o:o + p.numel()].view_as(p).data     # (.data: its own version counter, see gather_foreign_grads)
         p.grad = g
         p._ms_grad_slot = g            # kernels write the step's first gradient straight into the flat buffer
         p._ms_grad_fresh = False
@@ -108,15 +112,27 @@ class FlatAdam:
     self.seg_first = torch.full((len(self.params),), -1, dtype=torch.int32, device=dev)
     self.seg_scratch = torch.zeros(2 * len(self.params), dtype=torch.float32, device=dev)
     self.host_step = 0                                 # optimizer steps executed so far
+    self._grad_versions = [g._version for g in self._grad_views]
 
   def zero_grad(self):
     self.flat_g.zero_()
     for p in self.params:
       p._ms_grad_fresh = True
+    self._grad_versions = [g._version for g in self._grad_views]
 
   def active_params(self):
-    """Indices of the parameters that received a gradient since zero_grad() (their kernels wrote into the slot)."""
+    """Indices of the parameters that received a gradient since zero_grad(): their kernels wrote into the slot
+    (`_ms_grad_fresh` cleared), or plain torch autograd accumulated into the slot view / replaced p.grad (e.g. the 'lin'
+    style path: EmbLin's matmul, joint_late_cluster_soft_style.py:166) -- those are folded back first."""
+    self.gather_foreign_grads()
     return [i for i, p in enumerate(self.params) if not p._ms_grad_fresh]
+
+  def live_elems(self, active):
+    """Length of the flat-buffer prefix that holds every gradient of the parameters `active` (used-first layout)."""
+    end = 0
+    for i in active:
+      end = max(end, self.offsets[i] + (self.params[i].numel() + _ALIGN - 1) // _ALIGN * _ALIGN)
+    return end
 
   def mark_active(self, indices):
     """Record first-gradient steps for parameters that get a gradient in the step about to run."""
@@ -133,15 +149,18 @@ class FlatAdam:
     self.host_step = 0
 
   def gather_foreign_grads(self):
-    """If someone replaced p.grad (e.g. model.zero_grad(set_to_none=True) then backward), fold it back."""
+    """Gradients that did not come through the kernels' write-through: p.grad replaced (model.zero_grad(set_to_none=True)
+    then backward) is folded back; a slot view autograd ACCUMULATED into (version counter moved since zero_grad) is marked
+    as having a gradient, so its Adam segment runs."""
     with torch.no_grad():
-      for p, g in zip(self.params, self._grad_views):
+      for p, g, v0 in zip(self.params, self._grad_views, self._grad_versions):
         if p.grad is None:
-          g.zero_()
           p.grad = g
-        elif p.grad is not g:
+        elif p.grad.data_ptr() != g.data_ptr():
           g.copy_(p.grad)
           p.grad = g
+          p._ms_grad_fresh = False
+        elif p._ms_grad_fresh and g._version != v0:
           p._ms_grad_fresh = False
 
   def clip_and_step(self, count=True):
@@ -188,7 +207,10 @@ class MixStageTrainStep:
     self.side_stream = torch.cuda.Stream() if overlap_wgrad else None
     ops.enable_prepared_weights(True)
     ops.enable_deferred_wgrad(True)
-    self.optim_G = FlatAdam(model.G.parameters(), lr=lr, max_norm=clip)
+    # idle on the audio path: constructed for state_dict parity, trained only by other branches / never
+    idle = [p for n, p in model.G.named_parameters()
+            if n.split('.')[0] in ('text_encoder', 'pose_encoder', 'style_dec', 'style_dec_gr', 'concat_encoder', 'smoothen')]
+    self.optim_G = FlatAdam(model.G.parameters(), lr=lr, max_norm=clip, order_last=idle)
     self.optim_D = FlatAdam(model.D.parameters(), lr=lr, max_norm=clip)
     self.use_graphs = use_graphs
     self.time_steps = time_steps
@@ -223,9 +245,12 @@ class MixStageTrainStep:
       ops.set_backward_overlap(None)
     return fake, losses
 
-  def _all_reduce(self, opt):
+  def _all_reduce(self, opt, active=None):
+    """The exchange step: mean over ranks of the live prefix of the flat gradient buffer (used-first layout: 59.7 MB of
+    the generator's 80.6 MB on the audio branch; everything behind it is zero on every rank)."""
     if self.world > 1:
-      average_flat_gradients(opt.flat_g, self.pg)
+      n = opt.live_elems(active) if active is not None else opt.total
+      average_flat_gradients(opt.flat_g[:n] if n < opt.total else opt.flat_g, self.pg)
 
   def _peek_decisions(self):
     th = self.model.G.thresh
@@ -254,8 +279,9 @@ class MixStageTrainStep:
       if not self.use_graphs:
         self.fake_pose, self.losses = self._forward_backward(audio, labels, pose, style)
         opt = self.optim_G if m.G_flag else self.optim_D
-        opt.mark_active(opt.active_params())
-        self._all_reduce(opt)
+        active = opt.active_params()
+        opt.mark_active(active)
+        self._all_reduce(opt, active)
         opt.clip_and_step()
       else:
         self._graph_step(k, pose_branch, audio, labels, pose, style)
@@ -285,7 +311,7 @@ class MixStageTrainStep:
     opt.mark_active(entry['active'])
     entry['fwd_bwd'].replay()
     if self.world > 1:
-      self._all_reduce(opt)
+      self._all_reduce(opt, entry['active'])
       entry['opt'].replay()
     opt.host_step += 1
     # prepared weights that did not exist when this graph was captured (blocks only the other step kind runs)

@@ -117,8 +117,8 @@ def test_adam_per_parameter_step_origin_under_the_curriculum(use_graphs):
     torch.manual_seed(3)
     ts.step(audio.to(DEV), labels.to(DEV), pose.to(DEV), style.to(DEV), kind=kind)
   # first-gradient steps recorded per parameter: pose_encoder at step 1, audio_encoder at step 2 (G optimizer steps)
-  names = [n for n, p in hip.G.named_parameters() if p.requires_grad]
-  first = dict(zip(names, ts.optim_G.host_first))
+  index = {id(p): i for i, p in enumerate(ts.optim_G.params)}        # (the flat buffer is laid out used-first, not in module order)
+  first = {n: ts.optim_G.host_first[index[id(p)]] for n, p in hip.G.named_parameters() if p.requires_grad}
   assert first['pose_encoder.conv.0.conv.weight'] == 1 and first['audio_encoder.conv.0.conv.weight'] == 2
   assert first['text_encoder.conv.0.conv.weight'] == -1 and first['unet.conv1.0.conv.weight'] == 1
   ref_sd = ref.state_dict()
@@ -235,3 +235,30 @@ def test_prepared_weights_created_after_a_graph_was_captured(precision):
     assert torch.equal(out[False][0], out[True][0]) and torch.equal(out[False][1], out[True][1])
   finally:
     _lib.lib().ms_set_precision(old)
+
+
+@pytest.mark.parametrize('use_graphs', [False, True])
+def test_lin_style_path_trains_the_style_embedding(use_graphs):
+  """argmax=0 (joint_late_cluster_soft_style.py:160-166): the style embedding is reached through EmbLin's plain matmul, whose
+  gradient torch autograd accumulates into the flat-buffer slot behind the kernels' back.  The segmented Adam must still see
+  it: style_emb.emb.weight moves like torch.optim.Adam moves it in the oracle."""
+  from mix_stage_amd.train_step import MixStageTrainStep
+  M = S = 2
+  ref = O.build_gan(M=M, S=S)
+  hip = _hip(M, S)
+  ref.G.argmax = hip.G.argmax = 0
+  og = torch.optim.Adam(ref.G.parameters(), lr=1e-4)
+  od = torch.optim.Adam(ref.D.parameters(), lr=1e-4)
+  ts = MixStageTrainStep(hip, use_graphs=use_graphs)
+  w0 = hip.G.style_emb.emb.weight.detach().clone()
+  for i in range(3):
+    audio, pose, labels, style = O.synthetic_batch(3, M=M, S=S, seed=80 + i)
+    torch.manual_seed(9)
+    O.oracle_train_step(ref, og, od, audio, pose, labels, style, 'G')
+    torch.manual_seed(9)
+    ts.step(audio.to(DEV), labels.to(DEV), pose.to(DEV), style.to(DEV), kind='G')
+  w_hip, w_ref = hip.G.style_emb.emb.weight.detach().cpu(), ref.G.style_emb.emb.weight.detach()
+  assert (w_hip - w0.cpu()).abs().max().item() >= 1e-4          # it was updated at all (3 Adam steps of ~lr each)
+  assert (w_hip - w_ref).abs().max().item() <= 1.5e-4, (w_hip - w_ref).abs().max().item()
+  # a parameter that never receives a gradient keeps torch's "skipped" semantics: untouched bit for bit
+  assert torch.equal(hip.G.smoothen.conv.weight.detach().cpu(), ref.G.smoothen.conv.weight.detach())
