@@ -228,12 +228,14 @@ int ms_softmax_mix_bwd(const float* z, const float* soft, const float* dout, flo
                        int B, int M, int P, int T, void* stream);
 
 /* Pre-step in front of the path ("next" row N1; src/data/transform.py, src/model/trainer.py:1290-1308), on device:
- * ms_kmeans_labels: KMeans.predict (transform.py:352-410) on RemoveJoints(pose): features [x | velocity], fp64 squared
- *   distance to `centers` (M, 2*PK), first-minimum argmin -> labels (B,T) int64.  keep[PK] = surviving columns.
+ * ms_kmeans_labels: KMeans.predict (transform.py:352-410) on RemoveJoints(pose): the feature blocks of KMeans.get_feats
+ *   selected by `feats` (bit 0 pose (PK columns), bit 1 velocity (PK), bit 2 speed = |(vx, vy)| per kept joint (PK/2)), in
+ *   that order -- src/jobs/mix-stage.py trains with all three, argsUtils' default is pose|velocity -- fp64 squared distance
+ *   to `centers` (M, D), first-minimum argmin -> labels (B,T) int64.  keep[PK] = surviving columns (x block, then y block).
  * ms_znorm_select: ZNorm.znorm (transform.py:221-226) then RemoveJoints (transform.py:481-507):
  *   y[r][d] = (x[r][keep[d]] - mean[keep[d]]) * inv_std[keep[d]] in fp64 -> fp32; keep == NULL: all P columns. */
 int ms_kmeans_labels(const float* pose, const int32_t* keep, const double* centers, int64_t* labels, int B, int T, int P,
-                     int PK, int M, void* stream);
+                     int PK, int M, int feats, void* stream);
 int ms_znorm_select(const float* x, const int32_t* keep, const double* mean, const double* inv_std, float* y, size_t rows,
                     int P, int PK, void* stream);
 

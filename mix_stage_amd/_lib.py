@@ -76,7 +76,7 @@ SIGNATURES = {
     'ms_lerp_time_bwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'ms_softmax_mix_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     'ms_softmax_mix_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
-    'ms_kmeans_labels': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    'ms_kmeans_labels': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'ms_znorm_select': (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, _P]),
     'ms_step_metrics': (c_int, [_P] * 7 + [c_int, _P, c_int, c_int, c_int, c_int, _P]),
     'ms_concat_style_fwd': (c_int, [_P, _P, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P]),

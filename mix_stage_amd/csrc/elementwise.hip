@@ -382,7 +382,10 @@ __global__ void softmax_mix_bwd_finish_kernel(const float* __restrict__ soft, fl
 // reference (transform.py:395-410); first minimum wins.  One wave per (b,t).
 __global__ __launch_bounds__(256) void kmeans_labels_kernel(const float* __restrict__ pose, const int32_t* __restrict__ keep,
                                                             const double* __restrict__ centers, int64_t* __restrict__ labels,
-                                                            int BT, int T, int P, int PK, int M) {
+                                                            int BT, int T, int P, int PK, int M, int feats) {
+  // feature blocks of KMeans.get_feats (transform.py:352-378), in its order: pose (PK) | velocity (PK) | speed (PK/2)
+  const bool f_pose = feats & 1, f_vel = feats & 2, f_speed = feats & 4;
+  const int o_vel = f_pose ? PK : 0, o_speed = o_vel + (f_vel ? PK : 0), D = o_speed + (f_speed ? PK / 2 : 0);
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= BT) return;
@@ -391,14 +394,26 @@ __global__ __launch_bounds__(256) void kmeans_labels_kernel(const float* __restr
   int best = 0;
   double bestd = 0.0;
   for (int m = 0; m < M; ++m) {
-    const double* c = centers + (size_t)m * 2 * PK;
+    const double* c = centers + (size_t)m * D;
     double acc = 0.0;
-    for (int d = lane; d < PK; d += 64) {
-      const int col = keep[d];
-      const double x = (double)xr[col];
-      const double v = t > 0 ? x - (double)xr[col - P] : 0.0;
-      const double dx = c[d] - x, dv = c[PK + d] - v;
-      acc += dx * dx + dv * dv;
+    if (f_pose | f_vel) {
+      for (int d = lane; d < PK; d += 64) {
+        const int col = keep[d];
+        const double x = (double)xr[col];
+        const double v = t > 0 ? x - (double)xr[col - P] : 0.0;
+        if (f_pose) { const double dx = c[d] - x; acc += dx * dx; }
+        if (f_vel) { const double dv = c[o_vel + d] - v; acc += dv * dv; }
+      }
+    }
+    if (f_speed) {
+      // speed of a joint = |(vx, vy)|: the x block and the y block of the kept columns are PK/2 apart
+      for (int d = lane; d < PK / 2; d += 64) {
+        const int cx = keep[d], cy = keep[PK / 2 + d];
+        const double vx = t > 0 ? (double)xr[cx] - (double)xr[cx - P] : 0.0;
+        const double vy = t > 0 ? (double)xr[cy] - (double)xr[cy - P] : 0.0;
+        const double ds = c[o_speed + d] - sqrt(vx * vx + vy * vy);
+        acc += ds * ds;
+      }
     }
     acc = wave_sum_d(acc);
     if (m == 0 || acc < bestd) { bestd = acc; best = m; }
@@ -406,7 +421,6 @@ __global__ __launch_bounds__(256) void kmeans_labels_kernel(const float* __restr
   if (lane == 0) labels[r] = best;
 }
 
-// y[r][d] = (x[r][keep[d]] - mean[keep[d]]) * inv_std[keep[d]]  computed in fp64, stored fp32 (transform.py:221-226,481-507)
 __global__ __launch_bounds__(256) void znorm_select_kernel(const float* __restrict__ x, const int32_t* __restrict__ keep,
                                                            const double* __restrict__ mean, const double* __restrict__ inv_std,
                                                            float* __restrict__ y, size_t rows, int P, int PK) {
@@ -866,10 +880,12 @@ int ms_softmax_mix_bwd(const float* z, const float* soft, const float* dout, flo
 }
 
 int ms_kmeans_labels(const float* pose, const int32_t* keep, const double* centers, int64_t* labels, int B, int T, int P,
-                     int PK, int M, void* stream) {
+                     int PK, int M, int feats, void* stream) {
+  if (!pose || !keep || !centers || !labels || B < 1 || T < 1 || PK < 1 || M < 1) return set_error("ms_kmeans_labels: bad argument");
+  if (!(feats & 7) || (feats & ~7) || ((feats & 4) && (PK & 1))) return set_error("ms_kmeans_labels: feats must be a subset of pose|velocity|speed (1|2|4)");
   const int BT = B * T;
   hipLaunchKernelGGL(kmeans_labels_kernel, dim3(cdiv(BT, 4)), dim3(256), 0, (hipStream_t)stream, pose, keep, centers, labels, BT,
-                     T, P, PK, M);
+                     T, P, PK, M, feats);
   return check_launch("kmeans_labels_kernel");
 }
 

@@ -21,17 +21,28 @@ def _p(t):
 
 
 class DevicePreStep:
+  FEAT_BITS = {'pose': 1, 'velocity': 2, 'speed': 4}
+
   def __init__(self, centers, pose_mean, pose_var, audio_mean, audio_var, mask=(0, 7, 8, 9), num_feats=104, eps=1e-8,
-               device='cuda:0'):
+               device='cuda:0', feats=('pose', 'velocity')):
+    """feats: the k-means feature blocks (KMeans.get_feats, transform.py:352-378): argsUtils' default is
+    ['pose', 'velocity']; the Mix-StAGE job scripts (src/jobs/mix-stage.py) train with ['pose', 'velocity', 'speed'].
+    'acceleration' and 'spatial' are not offered."""
     dev = torch.device(device)
     J = num_feats // 2
     kept = [j for j in range(J) if j not in set(mask)]
     keep = [xy * J + j for xy in range(2) for j in kept]
     self.P, self.PK = num_feats, len(keep)
     self.keep = torch.tensor(keep, dtype=torch.int32, device=dev)
+    feats = tuple(feats)
+    unknown = [f for f in feats if f not in self.FEAT_BITS]
+    if unknown or list(feats) != [f for f in ('pose', 'velocity', 'speed') if f in feats]:
+      raise ValueError('feats must be a sub-list of [pose, velocity, speed] in that order, got %s' % (feats,))
+    self.feats = sum(self.FEAT_BITS[f] for f in feats)
+    width = sum({'pose': self.PK, 'velocity': self.PK, 'speed': self.PK // 2}[f] for f in feats)
     centers = torch.as_tensor(centers, dtype=torch.float64)
-    if centers.shape[1] != 2 * self.PK:
-      raise ValueError('centres must have %d columns ([pose | velocity] of the kept joints)' % (2 * self.PK))
+    if centers.shape[1] != width:
+      raise ValueError('centres must have %d columns (%s of the kept joints), got %d' % (width, ' | '.join(feats), centers.shape[1]))
     self.M = centers.shape[0]
     self.centers = centers.contiguous().to(dev)
 
@@ -56,7 +67,7 @@ class DevicePreStep:
     assert P == self.P and audio_raw.shape[:2] == (B, T) and F_ == self.audio_mean.numel()
     s = _vp(torch.cuda.current_stream().cuda_stream)
     labels = torch.empty((B, T), dtype=torch.int64, device=self.dev)
-    check(lib().ms_kmeans_labels(_p(pose_raw), _p(self.keep), _p(self.centers), _p(labels), B, T, P, self.PK, self.M, s),
+    check(lib().ms_kmeans_labels(_p(pose_raw), _p(self.keep), _p(self.centers), _p(labels), B, T, P, self.PK, self.M, self.feats, s),
           'ms_kmeans_labels')
     y = torch.empty((B, T, self.PK), dtype=torch.float32, device=self.dev)
     check(lib().ms_znorm_select(_p(pose_raw), _p(self.keep), _p(self.pose_mean), _p(self.pose_inv), _p(y), B * T, P, self.PK, s),

@@ -8,9 +8,10 @@ CPU after every step ("next" row N3 of SURVEY.md section 8f), restated from /roo
                                   poses, undo the normalisation, put the root joint at (0,0), PCK on (B*T, 2, J)
   data/transform.py:228-229       ZNorm.inv_znorm  x * var**0.5 + mean
 
-PARITY UNPINNED: metrics.py imports the trainer (circular, needs the dataset stack) and RemoveJoints(inv=True) delegates to
-pycasper.torchUtils.add_slices; "masked joints take the ground truth's values" (parents=None) is inferred from
-transform.py:483-497.
+PINNED for L1, VelL1 and PCK: tests/test_oracle_vs_reference.py runs the reference's own metrics.py (behind the stubs of
+oracle/refload.load_transform_and_metrics) and tests/golden/n1n3.npz holds values it produced.  PARITY UNPINNED for the
+glue around them (reinsert_joints / step_metrics): RemoveJoints(inv=True) delegates to pycasper.torchUtils.add_slices;
+"masked joints take the ground truth's values" (parents=None) is inferred from transform.py:483-497.
 """
 import numpy as np
 

@@ -83,6 +83,46 @@ def load():
   return ns
 
 
+def load_transform_and_metrics():
+  """The reference's src/data/transform.py and src/evaluation/metrics.py, executed where they lie, behind in-memory stand-ins
+  for the modules of the dataset / trainer stack they import at module level (h5py, pycasper, the trainer): none of those
+  is touched by the functions pinned here -- ZNorm.znorm (transform.py:221-226), KMeans.get_feats / predict
+  (transform.py:352-410), L1 / VelL1 / PCK (metrics.py:94-131,247-303).  RemoveJoints still rests on the un-vendored
+  pycasper.torchUtils.remove_slices (stays unpinned)."""
+  if 'tm' in _cache:
+    return _cache['tm']
+  assert available(), 'reference tree not present'
+  _install_pycasper_standin()
+
+  class _Absent:
+    def __init__(self, *a, **k):
+      raise RuntimeError('stand-in for a module of the reference dataset stack')
+
+  def stub(name, **attrs):
+    if name not in sys.modules:
+      m = types.ModuleType(name)
+      m.__dict__.update(attrs)
+      sys.modules[name] = m
+    return sys.modules[name]
+  stub('dataUtils', DummyData=_Absent)
+  stub('text', POStagging=_Absent)
+  stub('common', HDF5=_Absent)
+  stub('skeleton', Skeleton2D=_Absent)
+  stub('argsUtils', get_args_perm=lambda *a, **k: None)
+  stub('trainer_chooser')
+  bk = stub('pycasper.BookKeeper', BookKeeper=_Absent)
+  sys.modules['pycasper'].BookKeeper = bk
+  mods = {}
+  for name, rel in (('ref_transform', 'data/transform.py'), ('ref_metrics', 'evaluation/metrics.py')):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(os.path.dirname(REF_MODEL_DIR), rel))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    mods[name] = m
+  _cache['tm'] = types.SimpleNamespace(transform=mods['ref_transform'], metrics=mods['ref_metrics'])
+  return _cache['tm']
+
+
 def build_ref_gan(M=8, S=8, T=64, P=104, dtype=None, state=None, no_grad=0):
   """Reference GAN(G, D) in the job-script configuration (src/jobs/mix-stage.py:3)."""
   import torch

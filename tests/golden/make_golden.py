@@ -113,7 +113,48 @@ def run(name, B, T, M, S, dtype):
   print(name, 'ok', {k: (v.shape if hasattr(v, 'shape') else v) for k, v in list(rec.items())[:6]})
 
 
+def run_n1n3():
+  """Pre-step (N1) and step-metric (N3) vectors from the reference's own transform.py / metrics.py (refload stubs the
+  dataset stack they import): KMeans labels with the job scripts' features [pose, velocity, speed], ZNorm, L1 / VelL1 / PCK.
+  The joint removal in front of KMeans is the oracle's (pycasper.remove_slices is not in the reference tree)."""
+  import types
+  from oracle import prestep_oracle as PO
+  tm = refload.load_transform_and_metrics()
+  T, Mx = tm.transform, tm.metrics
+  rng = np.random.default_rng(2024)
+  B, Tn, P, M, mask = 6, 64, 104, 8, [0, 7, 8, 9]
+  pose = (rng.standard_normal((B, Tn, P)) * 40 + 100).astype(np.float32)
+  pose[:, 1:] = pose[:, :1] + np.cumsum(rng.standard_normal((B, Tn - 1, P)).astype(np.float32), axis=1)
+  PK = P - 2 * len(mask)
+  centers = np.concatenate([rng.standard_normal((M, PK)) * 40 + 100, rng.standard_normal((M, PK)),
+                            np.abs(rng.standard_normal((M, PK // 2))) * 1.5], axis=1)
+  mean, var = rng.standard_normal(P) * 10 + 100, rng.random(P) * 50 + 1
+  var[5], var[11] = 0.0, -1e-9
+  kept = torch.from_numpy(PO.remove_joints(pose, mask))
+  rec = dict(pose=pose, centers=centers, mean=mean, var=var, mask=np.array(mask))
+  for tag, feats, width in (('pvs', ['pose', 'velocity', 'speed'], 2 * PK + PK // 2), ('pv', ['pose', 'velocity'], 2 * PK)):
+    km = types.SimpleNamespace(feats=feats, centers=torch.from_numpy(centers[:, :width].copy()))
+    km.get_feats = lambda x, km=km: T.KMeans.get_feats(km, x)
+    rec['labels_' + tag] = T.KMeans.predict(km, kept).numpy()
+  rec['znorm'] = T.ZNorm.znorm(None, torch.from_numpy(pose).double(), [torch.from_numpy(mean), torch.from_numpy(var)]).numpy()
+  y = rng.standard_normal((B, Tn, P)); gt = y + 0.3 * rng.standard_normal((B, Tn, P))
+  l1, vl, pck = Mx.L1(), Mx.VelL1(), Mx.PCK(alphas=[0.1, 0.2], num_joints=52)
+  l1(torch.from_numpy(y), torch.from_numpy(gt), mask_idx=mask)
+  vl(torch.from_numpy(y), torch.from_numpy(gt), mask_idx=mask)
+  pck(torch.from_numpy(y).view(-1, 2, 52), torch.from_numpy(gt).view(-1, 2, 52), mask_idx=mask)
+  pa = pck.get_averages('t')
+  rec.update(m_y=y, m_gt=gt, L1=np.float64(l1.get_averages('t')['t_L1']), VelL1=np.float64(vl.get_averages('t')['t_VelL1']),
+             pck=np.array([[pa['t_pck_%s_%d' % (a, j)] for j in range(52)] for a in (0.1, 0.2)]),
+             pck_mean=np.array([pa['t_pck_0.1'], pa['t_pck_0.2']]))
+  np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'n1n3.npz'), **rec)
+  print('n1n3 ok', {k: getattr(v, 'shape', v) for k, v in rec.items()})
+
+
 if __name__ == '__main__':
   assert refload.available(), 'needs /root/reference'
+  if len(sys.argv) > 1 and sys.argv[1] == 'n1n3':
+    run_n1n3()
+    sys.exit(0)
   for name, cfg in CONFIGS.items():
     run(name, *cfg)
+  run_n1n3()

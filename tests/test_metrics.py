@@ -40,3 +40,16 @@ def test_hip_metrics_match_oracle():
     assert abs(got['pck'][a][1] - ref['pck'][a][1]) < 1e-12
   avg = m.averages('train')
   assert abs(avg['train_L1'] - ref['L1']) < 1e-9 and abs(avg['train_pck_0.1'] - ref['pck'][0.1][1]) < 1e-12
+
+
+def test_oracle_matches_reference_vectors():
+  """L1, VelL1 and PCK of tests/golden/n1n3.npz were computed by the reference's own metrics.py (make_golden.py n1n3)."""
+  import os
+  from oracle import metrics_oracle as MO
+  z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'n1n3.npz'))
+  mask = [int(v) for v in z['mask']]
+  assert abs(MO.l1(z['m_y'], z['m_gt'], mask) - float(z['L1'])) <= 1e-12
+  assert abs(MO.vel_l1(z['m_y'], z['m_gt'], mask) - float(z['VelL1'])) <= 1e-12
+  res = MO.pck(z['m_y'].reshape(-1, 2, 52), z['m_gt'].reshape(-1, 2, 52), mask, alphas=(0.1, 0.2))
+  for i, a in enumerate((0.1, 0.2)):
+    assert np.abs(res[a][0] - z['pck'][i]).max() <= 1e-6 and abs(res[a][1] - z['pck_mean'][i]) <= 1e-6

@@ -80,3 +80,59 @@ def test_oracle_pose_branch_vs_reference():
     # the pose branch trains pose_encoder and leaves audio_encoder untouched
     assert rm.G.pose_encoder.conv[0].conv.weight.grad is not None
     assert rm.G.audio_encoder.conv[0].conv.weight.grad is None
+
+
+def _n1_inputs(seed=3, B=3, T=16, P=104, M=5):
+  import numpy as np
+  rng = np.random.default_rng(seed)
+  pose = rng.standard_normal((B, T, P)) * 30 + 100
+  PK = P - 8
+  centers = rng.standard_normal((M, PK + PK + PK // 2)) * 30 + 50
+  mean, var = rng.standard_normal(P) * 10 + 100, rng.random(P) * 50 + 1
+  var[5], var[11] = 0.0, -1e-9
+  return pose, centers, mean, var
+
+
+def test_prestep_oracle_vs_reference_transform():
+  """N1: KMeans.get_feats / predict with the job scripts' feature list ['pose','velocity','speed'] (and the argsUtils default)
+  and ZNorm.znorm, executed from the reference's own transform.py."""
+  import types
+  import numpy as np
+  from oracle import prestep_oracle as PO
+  T = refload.load_transform_and_metrics().transform
+  pose, centers, mean, var = _n1_inputs()
+  kept = PO.remove_joints(pose, [0, 7, 8, 9])
+  for feats, width in ((['pose', 'velocity', 'speed'], 96 + 96 + 48), (['pose', 'velocity'], 192)):
+    km = types.SimpleNamespace(feats=feats, centers=torch.from_numpy(centers[:, :width].copy()))
+    km.get_feats = lambda x, km=km: T.KMeans.get_feats(km, x)
+    f_ref = T.KMeans.get_feats(km, torch.from_numpy(kept)).numpy()
+    assert np.abs(PO.kmeans_feats(kept, feats) - f_ref).max() <= 1e-12 * np.abs(f_ref).max()      # (x**0.5 vs sqrt: 1 ulp)
+    l_ref = T.KMeans.predict(km, torch.from_numpy(kept)).numpy()
+    assert np.array_equal(PO.kmeans_predict(kept, centers[:, :width], feats), l_ref)
+  z_ref = T.ZNorm.znorm(None, torch.from_numpy(pose), [torch.from_numpy(mean), torch.from_numpy(var)]).numpy()
+  assert np.abs(PO.znorm(pose, mean, var) - z_ref).max() <= 1e-12 * np.abs(z_ref).max()
+
+
+def test_metrics_oracle_vs_reference_metrics():
+  """N3: L1, VelL1 and PCK of the reference's own metrics.py on one batch (float64)."""
+  import numpy as np
+  from oracle import metrics_oracle as MO
+  Mx = refload.load_transform_and_metrics().metrics
+  rng = np.random.default_rng(11)
+  y, gt = rng.standard_normal((4, 16, 104)), rng.standard_normal((4, 16, 104))
+  mask = [0, 7, 8, 9]
+  l1, vl = Mx.L1(), Mx.VelL1()
+  l1(torch.from_numpy(y), torch.from_numpy(gt), mask_idx=mask); vl(torch.from_numpy(y), torch.from_numpy(gt), mask_idx=mask)
+  assert abs(MO.l1(y, gt, mask) - l1.get_averages('t')['t_L1']) <= 1e-12
+  assert abs(MO.vel_l1(y, gt, mask) - vl.get_averages('t')['t_VelL1']) <= 1e-12
+  pck = Mx.PCK(alphas=[0.1, 0.2], num_joints=52)
+  y3, g3 = y.reshape(-1, 2, 52) * 3, gt.reshape(-1, 2, 52) * 3 + 0.3 * rng.standard_normal((64, 2, 52))
+  y3 = g3 + 0.4 * rng.standard_normal(g3.shape)
+  pck(torch.from_numpy(y3), torch.from_numpy(g3), mask_idx=mask)
+  ref = pck.get_averages('t')
+  mine = MO.pck(y3, g3, mask, alphas=(0.1, 0.2))
+  for a in (0.1, 0.2):
+    per_joint, kept_mean = mine[a]
+    for j in range(52):
+      assert abs(per_joint[j] - ref['t_pck_%s_%d' % (a, j)]) <= 1e-6, (a, j)
+    assert abs(kept_mean - ref['t_pck_%s' % a]) <= 1e-6

@@ -47,3 +47,38 @@ def test_hip_prestep_matches_oracle():
     assert np.array_equal(labels.cpu().numpy(), l_ref)                       # index work: bit-exact
     np.testing.assert_allclose(y.cpu().numpy(), y_ref.astype(np.float32), rtol=2e-7, atol=0)
     np.testing.assert_allclose(a.cpu().numpy(), a_ref.astype(np.float32), rtol=2e-7, atol=0)
+
+
+def _fixture():
+  import os
+  return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'n1n3.npz'))
+
+
+def test_oracle_matches_reference_vectors():
+  """tests/golden/n1n3.npz holds KMeans labels (both feature lists) and ZNorm outputs computed by the reference's own
+  transform.py (tests/golden/make_golden.py n1n3)."""
+  z = _fixture()
+  mask = [int(v) for v in z['mask']]
+  kept = PO.remove_joints(z['pose'], mask)
+  assert np.array_equal(PO.kmeans_predict(kept, z['centers'], ('pose', 'velocity', 'speed')), z['labels_pvs'])
+  assert np.array_equal(PO.kmeans_predict(kept, z['centers'][:, :192], ('pose', 'velocity')), z['labels_pv'])
+  assert np.abs(PO.znorm(z['pose'], z['mean'], z['var']) - z['znorm']).max() <= 1e-9
+  assert len(np.unique(z['labels_pvs'])) > 2 and not np.array_equal(z['labels_pvs'], z['labels_pv'])
+
+
+@pytest.mark.gpu
+def test_hip_prestep_matches_reference_vectors():
+  """The on-device pre-step with the Mix-StAGE jobs' feature list [pose, velocity, speed] (src/jobs/mix-stage.py) and with
+  the argsUtils default, against labels produced by the reference: bit-exact."""
+  from mix_stage_amd.prestep import DevicePreStep
+  z = _fixture()
+  mask = [int(v) for v in z['mask']]
+  pose = torch.from_numpy(z['pose']).cuda()
+  audio = torch.zeros(pose.shape[0], pose.shape[1], 4, device='cuda')
+  for feats, width, key in ((('pose', 'velocity', 'speed'), 240, 'labels_pvs'), (('pose', 'velocity'), 192, 'labels_pv')):
+    pre = DevicePreStep(z['centers'][:, :width], z['mean'], z['var'], np.zeros(4), np.ones(4), mask=mask, feats=feats)
+    _, labels, y = pre(pose, audio)
+    assert np.array_equal(labels.cpu().numpy(), z[key])
+    np.testing.assert_allclose(y.cpu().numpy(), PO.remove_joints(z['znorm'], mask).astype(np.float32), rtol=3e-7, atol=0)
+  with pytest.raises(ValueError):
+    DevicePreStep(z['centers'], z['mean'], z['var'], np.zeros(4), np.ones(4), mask=mask)       # 240 columns need 'speed'
