@@ -80,12 +80,6 @@ typedef struct ms_conv_desc {
 const char* ms_last_error(void);
 int ms_abi_version(void);
 
-/* Optional: a persistent, ZERO-INITIALISED int32 buffer (n >= 4096 words recommended: 65536) for in-launch split-K
- * reductions: with it, the workgroup that arrives last on a tile sums the K slices inside the conv launch (fixed order,
- * bitwise reproducible) instead of a separate reduce kernel.  The buffer belongs to the caller, must stay zero between
- * launches (the kernels restore it) and serves one device.  NULL disables the in-launch form. */
-int ms_set_counter_buffer(int32_t* zeroed_counters, int n);
-
 /* Bytes of scratch the forward / backward of this block needs. */
 size_t ms_conv_block_fwd_workspace(const ms_conv_desc* d);
 size_t ms_conv_block_bwd_workspace(const ms_conv_desc* d);
@@ -131,17 +125,6 @@ int ms_conv_block_bwd(const ms_conv_desc* d, const float* x, const float* x2, co
                       const float* y_raw, const float* y, const float* save, const float* dy, float* dyr,
                       float* dx, float* dx2, float* dw, float* dbias, float* dgamma, float* dbeta,
                       void* workspace, size_t workspace_bytes, void* stream);
-
-/* Same, with the weight gradient (dw) enqueued on `side_stream` (forked from `stream` once dy_raw exists; NOT joined
- * here: the caller makes `stream` wait for `side_stream` before it reads dw, e.g. before the optimizer step).  The side
- * stream gets its own scratch of ms_conv_block_bwd_workspace(d) bytes.  side_stream == NULL: identical to
- * ms_conv_block_bwd.  x, x2, dy and dyr must stay valid until the streams are joined. */
-int ms_conv_block_bwd_overlap(const ms_conv_desc* d, const float* x, const float* x2, const float* w,
-                              const float* gamma, const float* running_mean, const float* running_var,
-                              const float* y_raw, const float* y, const float* save, const float* dy, float* dyr,
-                              float* dx, float* dx2, float* dw, float* dbias, float* dgamma, float* dbeta,
-                              void* workspace, size_t workspace_bytes, void* stream, void* side_stream,
-                              void* side_workspace, size_t side_workspace_bytes);
 
 /* Full form of the backward.  All fields optional (zero = the behaviour of ms_conv_block_bwd). */
 typedef struct ms_bwd_options {
@@ -200,7 +183,8 @@ size_t ms_dgrad_weights_elems(const ms_conv_desc* d, const float* w);
  * error against fp64 equals the fp32 kernels'; 16/6 of the fp32 matrix rate.  Returns the previous mode. */
 int ms_set_precision(int mode);
 int ms_get_precision(void);
-int ms_tuning_epoch(void);   /* bumped by the ms_debug_set_* knobs: prepared weights built under another value are stale */
+int ms_tuning_epoch(void);   /* bumped whenever the dispatch changes (precision mode, tuning aids): prepared weights built
+                              * under another value are stale */
 int ms_dgrad_weights_prepare(int n, const ms_conv_desc* descs, const float* const* w, float* const* wt, void* stream);
 
 /* Deferred weight-gradient reduction.  Small layers split the pixel reduction of dw over workgroups and sum the partial
@@ -283,6 +267,9 @@ int ms_l1_mean_fwd(const float* a, const float* b, float target, float* loss, fl
                    void* stream);
 int ms_l1_mean_bwd(const float* a, const float* b, float target, const float* gscale, float* da, size_t n,
                    void* stream);
+/* The same for criterion MSELoss, the GAN constructor's default (gan.py:21,40): mean (a-b)^2, da = gscale[0] * 2(a-b)/n. */
+int ms_l2_mean_fwd(const float* a, const float* b, float target, float* loss, float* partials, size_t n, void* stream);
+int ms_l2_mean_bwd(const float* a, const float* b, float target, const float* gscale, float* da, size_t n, void* stream);
 
 /* Trainer step tail (trainer.py:1138-1146): global L2 norm of a flat gradient buffer, then
  * clip_grad_norm_(., max_norm) folded into a fused Adam step (torch.optim.Adam defaults).
@@ -300,25 +287,6 @@ int ms_adam_step_segmented(float* p, const float* g, float* m, float* v, size_t 
                            const int32_t* seg_of_chunk, const int32_t* seg_first_step, float* seg_scratch, int n_seg,
                            void* stream);
 size_t ms_reduce_partials_count(size_t n); /* floats needed in `partials` of ms_sqnorm / ms_l1_mean_fwd */
-
-/* Measurement aid (bench.py): when enabled, every conv / BN launch is bracketed by HIP events on its stream.
- * ms_timing_report writes "label\tcount\ttotal_ms\tflops_per_launch\tbytes_per_launch\n" lines and returns the
- * bytes needed.  Not for use during graph capture. */
-int ms_timing_enable(int on);
-size_t ms_timing_report(char* buf, size_t cap);
-
-/* Test aid: the patch-staged conv kernel is used when a launch has at least this many workgroups (default 32);
- * tests set 0 to exercise it at small sizes.  Returns the previous value. */
-int ms_debug_set_patch_min_workgroups(int n);
-/* Tuning aid for the patch-staged conv kernel: intra_split < 0 switches the intra-workgroup K split of small 1-D k3
- * layers off (0 = planner's choice), and a forced split-K factor over workgroups (0 = planner's choice). */
-int ms_debug_set_patch_tuning(int intra_split, int force_splitk);
-
-/* Tuning aid for the 16-bit conv kernel: force the workgroup tile to 64*wm output channels x 64*wn pixels (0, 0: planner). */
-int ms_debug_set_conv16_tile(int wm, int wn);
-
-/* Self-test kernel: C(32x32) = A(32xK) * B(Kx32) through the fp32 MFMA path (checks fragment maps). */
-int ms_selftest_mfma(const float* A, const float* B, float* C, int K, void* stream);
 
 #ifdef __cplusplus
 }

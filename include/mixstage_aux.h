@@ -1,0 +1,57 @@
+/* mixstage_aux.h -- measurement, test and tuning aids of libmixstage_hip.so.
+ *
+ * NOT part of the drop-in boundary (include/mixstage.h): nothing a binding of the reference's modules needs.  These entry
+ * points exist for bench.py (per-launch HIP-event timing), the test-suite (dispatch knobs that force a kernel at small
+ * sizes, the MFMA fragment self-test) and for two scheduling experiments that were measured slower and are off
+ * (in-launch split reductions, weight gradients on a side stream).  The debug setters change
+ * process-global dispatch state: do not call them from product code.
+ */
+#ifndef MIXSTAGE_AUX_H_
+#define MIXSTAGE_AUX_H_
+
+#include "mixstage.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Optional: a persistent, ZERO-INITIALISED int32 buffer (n >= 4096 words recommended: 65536) for in-launch split-K
+ * reductions: with it, the workgroup that arrives last on a tile sums the K slices inside the conv launch (fixed order,
+ * bitwise reproducible) instead of a separate reduce kernel.  The buffer belongs to the caller, must stay zero between
+ * launches (the kernels restore it) and serves one device.  NULL disables the in-launch form. */
+int ms_set_counter_buffer(int32_t* zeroed_counters, int n);
+
+/* Same, with the weight gradient (dw) enqueued on `side_stream` (forked from `stream` once dy_raw exists; NOT joined
+ * here: the caller makes `stream` wait for `side_stream` before it reads dw, e.g. before the optimizer step).  The side
+ * stream gets its own scratch of ms_conv_block_bwd_workspace(d) bytes.  side_stream == NULL: identical to
+ * ms_conv_block_bwd.  x, x2, dy and dyr must stay valid until the streams are joined. */
+int ms_conv_block_bwd_overlap(const ms_conv_desc* d, const float* x, const float* x2, const float* w,
+                              const float* gamma, const float* running_mean, const float* running_var,
+                              const float* y_raw, const float* y, const float* save, const float* dy, float* dyr,
+                              float* dx, float* dx2, float* dw, float* dbias, float* dgamma, float* dbeta,
+                              void* workspace, size_t workspace_bytes, void* stream, void* side_stream,
+                              void* side_workspace, size_t side_workspace_bytes);
+
+/* Measurement aid (bench.py): when enabled, every conv / BN launch is bracketed by HIP events on its stream.
+ * ms_timing_report writes "label\tcount\ttotal_ms\tflops_per_launch\tbytes_per_launch\n" lines and returns the
+ * bytes needed.  Not for use during graph capture. */
+int ms_timing_enable(int on);
+size_t ms_timing_report(char* buf, size_t cap);
+
+/* Test aid: the patch-staged conv kernel is used when a launch has at least this many workgroups (default 32);
+ * tests set 0 to exercise it at small sizes.  Returns the previous value. */
+int ms_debug_set_patch_min_workgroups(int n);
+/* Tuning aid for the patch-staged conv kernel: intra_split < 0 switches the intra-workgroup K split of small 1-D k3
+ * layers off (0 = planner's choice), and a forced split-K factor over workgroups (0 = planner's choice). */
+int ms_debug_set_patch_tuning(int intra_split, int force_splitk);
+
+/* Tuning aid for the 16-bit conv kernel: force the workgroup tile to 64*wm output channels x 64*wn pixels (0, 0: planner). */
+int ms_debug_set_conv16_tile(int wm, int wn);
+
+/* Self-test kernel: C(32x32) = A(32xK) * B(Kx32) through the fp32 MFMA path (checks fragment maps). */
+int ms_selftest_mfma(const float* A, const float* B, float* C, int K, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIXSTAGE_AUX_H_ */

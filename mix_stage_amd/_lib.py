@@ -89,6 +89,8 @@ SIGNATURES = {
     'ms_transpose_bct': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     'ms_l1_mean_fwd': (c_int, [_P, _P, c_float, _P, _P, c_size_t, _P]),
     'ms_l1_mean_bwd': (c_int, [_P, _P, c_float, _P, _P, c_size_t, _P]),
+    'ms_l2_mean_fwd': (c_int, [_P, _P, c_float, _P, _P, c_size_t, _P]),
+    'ms_l2_mean_bwd': (c_int, [_P, _P, c_float, _P, _P, c_size_t, _P]),
     'ms_sqnorm': (c_int, [_P, c_size_t, _P, _P, _P]),
     'ms_adam_step': (c_int, [_P, _P, _P, _P, c_size_t, _P, c_float, c_float, c_float, c_float, c_float, _P, _P]),
     'ms_adam_step_segmented': (c_int, [_P, _P, _P, _P, c_size_t, _P, c_float, c_float, c_float, c_float, c_float, _P, _P, _P, _P,

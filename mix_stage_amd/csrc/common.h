@@ -5,6 +5,7 @@
 #include <stdio.h>
 
 #include "mixstage.h"
+#include "mixstage_aux.h"
 
 namespace ms {
 

@@ -634,12 +634,15 @@ __global__ __launch_bounds__(256) void velocity_bwd_kernel(const float* __restri
 // ----------------------------------------------------------------------------------------------
 // deterministic two-stage reductions
 #define RED_MAX_BLOCKS 1024
+template <int SQ>     // SQ = 0: |d| (L1Loss); 1: d*d (MSELoss)
 __global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, float target,
                                                          float* __restrict__ partials, size_t n) {
   __shared__ float red[4];
   float s = 0.f;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-    s += fabsf(a[i] - (b ? b[i] : target));
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float d = a[i] - (b ? b[i] : target);
+    s += SQ ? d * d : fabsf(d);
+  }
   s = block_sum_256(s, red);
   if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
@@ -667,12 +670,13 @@ __global__ __launch_bounds__(256) void reduce_final_kernel(const float* __restri
   }
 }
 
+template <int SQ>
 __global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, float target,
                                                      const float* __restrict__ gscale, float* __restrict__ da, size_t n) {
   const float g = gscale[0] / (float)n;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float d = a[i] - (b ? b[i] : target);
-    da[i] = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+    da[i] = SQ ? 2.f * g * d : (d > 0.f ? g : (d < 0.f ? -g : 0.f));
   }
 }
 
@@ -970,18 +974,34 @@ int ms_transpose_bct(const float* x, float* y, int B, int C, int T, void* stream
 
 size_t ms_reduce_partials_count(size_t n) { return (size_t)red_blocks(n); }
 
-int ms_l1_mean_fwd(const float* a, const float* b, float target, float* loss, float* partials, size_t n, void* stream) {
+static int lp_mean_fwd(int sq, const float* a, const float* b, float target, float* loss, float* partials, size_t n, void* stream) {
+  if (!a || !loss || !partials || n == 0) return set_error("ms_l%d_mean_fwd: bad argument", sq ? 2 : 1);
   const int nb = red_blocks(n);
-  hipLaunchKernelGGL(l1_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, b, target, partials, n);
+  if (sq) hipLaunchKernelGGL(l1_partial_kernel<1>, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, b, target, partials, n);
+  else hipLaunchKernelGGL(l1_partial_kernel<0>, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, b, target, partials, n);
   int rc = check_launch("l1_partial_kernel");
   if (rc) return rc;
   hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nb, loss, 1.0f / (float)n, 0);
   return check_launch("reduce_final_kernel");
 }
-
-int ms_l1_mean_bwd(const float* a, const float* b, float target, const float* gscale, float* da, size_t n, void* stream) {
-  hipLaunchKernelGGL(l1_bwd_kernel, dim3(red_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, target, gscale, da, n);
+static int lp_mean_bwd(int sq, const float* a, const float* b, float target, const float* gscale, float* da, size_t n, void* stream) {
+  if (!a || !gscale || !da || n == 0) return set_error("ms_l%d_mean_bwd: bad argument", sq ? 2 : 1);
+  if (sq) hipLaunchKernelGGL(l1_bwd_kernel<1>, dim3(red_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, target, gscale, da, n);
+  else hipLaunchKernelGGL(l1_bwd_kernel<0>, dim3(red_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, target, gscale, da, n);
   return check_launch("l1_bwd_kernel");
+}
+
+int ms_l1_mean_fwd(const float* a, const float* b, float target, float* loss, float* partials, size_t n, void* stream) {
+  return lp_mean_fwd(0, a, b, target, loss, partials, n, stream);
+}
+int ms_l1_mean_bwd(const float* a, const float* b, float target, const float* gscale, float* da, size_t n, void* stream) {
+  return lp_mean_bwd(0, a, b, target, gscale, da, n, stream);
+}
+int ms_l2_mean_fwd(const float* a, const float* b, float target, float* loss, float* partials, size_t n, void* stream) {
+  return lp_mean_fwd(1, a, b, target, loss, partials, n, stream);
+}
+int ms_l2_mean_bwd(const float* a, const float* b, float target, const float* gscale, float* da, size_t n, void* stream) {
+  return lp_mean_bwd(1, a, b, target, gscale, da, n, stream);
 }
 
 int ms_sqnorm(const float* g, size_t n, float* norm_out, float* partials, void* stream) {

@@ -20,7 +20,7 @@ class ConstantLambdaScheduler:
     return list(self.lmbdas)
 
 
-_SUPPORTED = {'L1Loss'}
+_SUPPORTED = {'L1Loss': 'l1_mean', 'MSELoss': 'l2_mean'}      # criterion -> fused mean-reduced kernel (gan.py:40,64-75)
 
 
 class GAN(nn.Module):
@@ -39,8 +39,9 @@ class GAN(nn.Module):
     self.lr = lr
     if criterion not in _SUPPORTED:
       raise NotImplementedError('criterion %s: the HIP path implements L1Loss (what src/jobs/mix-stage.py trains '
-                                'with)' % criterion)
+                                'with) and MSELoss (the constructor default)' % criterion)
     self.criterion_name = criterion
+    self._loss = getattr(ops, _SUPPORTED[criterion])
     self.joint = joint
     if joint:
       raise NotImplementedError('joint=True (D sees pose||audio) is not on the Mix-StAGE path')
@@ -63,10 +64,10 @@ class GAN(nn.Module):
     return torch.zeros_like(x)
 
   def get_gan_loss(self, y_cap, y, W=None):
-    return ops.l1_mean(y_cap, y)
+    return self._loss(y_cap, y)
 
   def get_loss(self, y_cap, y, W=None):
-    return ops.l1_mean(y_cap, y)
+    return self._loss(y_cap, y)
 
   def estimate_weights(self, x_audio, y_pose, **kwargs):
     # allocated on the device directly (a host->device copy would not be capturable in a HIP graph)
@@ -118,9 +119,9 @@ class GAN(nn.Module):
         self.G.train(self.training)
         self.fake_flag = True
         fake_pose_score = self._score(fake_pose.detach())
-        fake_D_loss = ops.l1_mean(fake_pose_score, target=0.0, scale=self.lambda_D)
+        fake_D_loss = self._loss(fake_pose_score, target=0.0, scale=self.lambda_D)
         real_pose_score = self._score(y_pose)
-        real_D_loss = ops.l1_mean(real_pose_score, target=1.0)
+        real_D_loss = self._loss(real_pose_score, target=1.0)
         internal_losses.append(real_D_loss)
         internal_losses.append(fake_D_loss)
         internal_losses += partial_i_loss
@@ -137,8 +138,8 @@ class GAN(nn.Module):
             fake_pose_score = self._score(fake_pose)
         else:
           fake_pose_score = self._score(fake_pose)
-        G_gan_loss = ops.l1_mean(fake_pose_score, target=1.0, scale=self.lambda_gan)
-        pose_loss = ops.l1_mean(fake_pose, y_pose)
+        G_gan_loss = self._loss(fake_pose_score, target=1.0, scale=self.lambda_gan)
+        pose_loss = self._loss(fake_pose, y_pose)
         internal_losses.append(pose_loss)
         internal_losses.append(G_gan_loss)
         internal_losses += partial_i_loss
@@ -146,7 +147,7 @@ class GAN(nn.Module):
     else:
       fake_pose, partial_i_loss, *args = self.G(x_audio, y_pose, **kwargs)
       args = args[0] if len(args) > 0 else {}
-      pose_loss = ops.l1_mean(fake_pose, y_pose)
+      pose_loss = self._loss(fake_pose, y_pose)
       internal_losses.append(pose_loss)
       internal_losses.append(torch.tensor(0))
       internal_losses += partial_i_loss

@@ -415,9 +415,39 @@ class _ConvBlockFn(torch.autograd.Function):
             None if direct_be else dbeta, None, None, None, None)
 
 
+def _f32(t):
+  return t.float() if isinstance(t, torch.Tensor) and t.dtype == torch.float64 else t
+
+
+def _bridge64(fn):
+  """float64 boundary (the reference trainer casts the model with .double(), trainer.py:138, and feeds float64 batches,
+  dataUtils.py:547): the kernels compute in fp32, so float64 tensors are cast on the way in (a differentiable cast: gradients
+  arrive back in float64) and fp32 results on the way out.  The state_dict keeps its float64 tensors."""
+  def wrapped(*args, **kw):
+    vals = list(args) + list(kw.values())
+    if not any(isinstance(a, torch.Tensor) and a.dtype == torch.float64 for a in vals):
+      return fn(*args, **kw)
+    out = fn(*[_f32(a) for a in args], **{k: _f32(v) for k, v in kw.items()})
+    back = lambda o: o.double() if isinstance(o, torch.Tensor) and o.dtype == torch.float32 else o
+    return tuple(back(o) for o in out) if isinstance(out, tuple) else back(out)
+  wrapped.__doc__, wrapped.__name__ = fn.__doc__, fn.__name__
+  return wrapped
+
+
 def conv_block(x, w, bias, geom, mode, gamma=None, beta=None, running_mean=None, running_var=None, x2=None,
                in_mode=MS_IN_PLAIN):
   """One conv block of the path on the HIP kernels (see include/mixstage.h: ms_conv_block_fwd/bwd)."""
+  if w.dtype == torch.float64 or x.dtype == torch.float64:
+    # .double() model: fp32 shadows of the parameters (differentiable casts) and of the running statistics, which the
+    # kernels update in place and which are written back to the float64 buffers
+    rm32, rv32 = _f32(running_mean), _f32(running_var)
+    stats = (rm32, rv32) if rm32 is not None else None
+    y = _ConvBlockFn.apply(_f32(x), _f32(x2), _f32(w), _f32(bias), _f32(gamma), _f32(beta), geom, mode, in_mode, stats)
+    if mode == MS_BN_TRAIN and running_mean is not None and running_mean.dtype == torch.float64:
+      with torch.no_grad():
+        running_mean.copy_(rm32)
+        running_var.copy_(rv32)
+    return y.double()
   stats = (running_mean, running_var) if running_mean is not None else None
   return _ConvBlockFn.apply(x, x2, w, bias, gamma, beta, geom, mode, in_mode, stats)
 
@@ -443,6 +473,7 @@ class _LerpTimeFn(torch.autograd.Function):
     return dx, None
 
 
+@_bridge64
 def lerp_time(x, t_out):
   """F.interpolate(x, size=(t_out, 1), mode='bilinear').squeeze(-1) (layers.py:197-198)."""
   return _LerpTimeFn.apply(x, int(t_out))
@@ -476,6 +507,7 @@ class _SoftmaxMixFn(torch.autograd.Function):
     return dz, dscore, None
 
 
+@_bridge64
 def softmax_mix(z, score, P):
   """(out (B,T,P), softmax (B,T,M)) of JL:186-187,194 from channel-major z (B,M*P,T), score (B,M,T).
   The returned softmax is a detached monitor (the reference's labels_cap_soft is only read by the
@@ -516,6 +548,7 @@ class _ConcatStyleFn(torch.autograd.Function):
     return dx, None if direct else demb, None
 
 
+@_bridge64
 def concat_style(x, emb_weight, ids):
   """(B, C+D, T) = [x ; emb_weight[ids]^T]: EmbLin 'emb' lookup + cat of JL:175-180, channel-major."""
   return _ConcatStyleFn.apply(x, emb_weight, ids)
@@ -553,6 +586,7 @@ class _CrossEntropyFn(torch.autograd.Function):
     return dscore, None, None, None
 
 
+@_bridge64
 def cross_entropy(score, target, layout='nc', scale=1.0):
   """scale * F.cross_entropy(...) with mean reduction; layout 'bct' = class axis 1 of (B,C,T)."""
   return _CrossEntropyFn.apply(score, target, layout, float(scale))
@@ -578,6 +612,7 @@ class _VelocityFn(torch.autograd.Function):
     return dx
 
 
+@_bridge64
 def velocity_cm(x):
   """GAN.get_velocity (gan.py:47-52) of x (B,T,P), returned channel-major (B,P,T) for D's first conv."""
   return _VelocityFn.apply(x)
@@ -600,11 +635,13 @@ class _TransposeFn(torch.autograd.Function):
     return _TransposeFn.apply(dy, not ctx.to_cm), None
 
 
+@_bridge64
 def to_channel_major(x):
   """(B,T,C) -> contiguous (B,C,T)."""
   return _TransposeFn.apply(x, True)
 
 
+@_bridge64
 def to_time_major(x):
   """(B,C,T) -> contiguous (B,T,C)."""
   return _TransposeFn.apply(x, False)
@@ -612,16 +649,17 @@ def to_time_major(x):
 
 class _L1MeanFn(torch.autograd.Function):
   @staticmethod
-  def forward(ctx, a, b, target, scale):
+  def forward(ctx, a, b, target, scale, squared=False):
     _need_hip(a, b)
     a = a.contiguous()
     b = b.contiguous() if b is not None else None
     n = a.numel()
     loss = torch.empty((), dtype=torch.float32, device=a.device)
     part = torch.empty(lib().ms_reduce_partials_count(n), dtype=torch.float32, device=a.device)
-    check(lib().ms_l1_mean_fwd(_ptr(a), _ptr(b), target, _ptr(loss), _ptr(part), n, _stream()), 'ms_l1_mean_fwd')
+    fwd = lib().ms_l2_mean_fwd if squared else lib().ms_l1_mean_fwd
+    check(fwd(_ptr(a), _ptr(b), target, _ptr(loss), _ptr(part), n, _stream()), 'ms_l2_mean_fwd' if squared else 'ms_l1_mean_fwd')
     ctx.save_for_backward(a, b)
-    ctx.target, ctx.scale = target, scale
+    ctx.target, ctx.scale, ctx.squared = target, scale, squared
     return loss * scale if scale != 1.0 else loss
 
   @staticmethod
@@ -629,14 +667,21 @@ class _L1MeanFn(torch.autograd.Function):
     a, b = ctx.saved_tensors
     g = (g * ctx.scale if ctx.scale != 1.0 else g).contiguous()
     da = torch.empty_like(a)
-    check(lib().ms_l1_mean_bwd(_ptr(a), _ptr(b), ctx.target, _ptr(g), _ptr(da), a.numel(), _stream()),
-          'ms_l1_mean_bwd')
-    return da, None, None, None
+    bwd = lib().ms_l2_mean_bwd if ctx.squared else lib().ms_l1_mean_bwd
+    check(bwd(_ptr(a), _ptr(b), ctx.target, _ptr(g), _ptr(da), a.numel(), _stream()), 'ms_l2_mean_bwd' if ctx.squared else 'ms_l1_mean_bwd')
+    return da, None, None, None, None
 
 
+@_bridge64
 def l1_mean(a, b=None, target=0.0, scale=1.0):
   """scale * mean|a - b| (b a tensor without grad, or the constant `target`): gan.py:64-75 with L1Loss."""
-  return _L1MeanFn.apply(a, b, float(target), float(scale))
+  return _L1MeanFn.apply(a, b, float(target), float(scale), False)
+
+
+@_bridge64
+def l2_mean(a, b=None, target=0.0, scale=1.0):
+  """scale * mean (a - b)^2: gan.py:64-75 with MSELoss, the GAN constructor's default criterion."""
+  return _L1MeanFn.apply(a, b, float(target), float(scale), True)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -342,9 +342,54 @@ def test_repeatability_bitwise():
   assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
-def test_double_model_fails_loudly():
-  hip = build_hip_gan(2, 2).double()
-  audio, pose, labels, style = [t.to(DEV) for t in O.synthetic_batch(2, M=2, S=2, dtype=torch.float64)]
-  hip.eval()
-  with pytest.raises(TypeError):
-    hip([audio, labels], pose, **O.model_kwargs(style))
+def test_double_model_runs_like_the_reference_trainer_casts_it():
+  """trainer.py:138 casts the model with .to(device).double() and dataUtils.py:547 feeds float64 batches.  The mirrored
+  modules accept exactly that: parameters, buffers and gradients stay float64 tensors (state_dict compatibility), the
+  kernels compute on fp32 shadows -- results within the fp32 bar of the float64 oracle."""
+  M = S = 2
+  batch64 = O.synthetic_batch(3, M=M, S=S, dtype=torch.float64)
+  ref = O.build_gan(M=M, S=S, dtype=torch.float64)
+  hip = build_hip_gan(M, S).to(DEV).double()
+  assert all(p.dtype == torch.float64 for p in hip.parameters())
+  for kind in ('G', 'D'):
+    f_ref, l_ref = _step(ref, batch64, kind, 'cpu')
+    f_hip, l_hip = _step(hip, batch64, kind, DEV)
+    assert f_hip.dtype == torch.float64
+    assert (f_hip.detach().cpu() - f_ref.detach()).abs().mean().item() <= 1e-4
+    for a, b in zip(l_hip, l_ref):
+      assert abs(float(a) - float(b)) <= 1e-4
+    mod_h, mod_r = (hip.G, ref.G) if kind == 'G' else (hip.D, ref.D)
+    for (n, p), (_, q) in zip(mod_h.named_parameters(), mod_r.named_parameters()):
+      if q.grad is None or n.endswith('conv.bias'):
+        continue
+      assert p.grad is not None and p.grad.dtype == torch.float64, n
+      assert ((p.grad.cpu() - q.grad).norm() / (q.grad.norm() + 1e-30)).item() <= 3e-2, n
+  for (k, a), (_, b) in zip(hip.state_dict().items(), ref.state_dict().items()):
+    if 'running_' in k:
+      assert a.dtype == torch.float64 and (a.cpu() - b).abs().max().item() <= 1e-4 * (1 + b.abs().max().item()), k
+
+
+@pytest.mark.parametrize('kind', ['G', 'D'])
+def test_mse_criterion_the_constructor_default(kind):
+  """GAN(criterion='MSELoss') -- gan.py:21,40: the constructor default -- on the fused squared-error kernels."""
+  import mix_stage_amd as A
+  M = S = 2
+  batch = O.synthetic_batch(3, M=M, S=S)
+  ref = O.build_gan(M=M, S=S, dtype=torch.float64)
+  ref.criterion = torch.nn.MSELoss(reduction='none')
+  G = A.JointLateClusterSoftStyle4_G(time_steps=64, out_feats=104, num_clusters=M, style_dict={i: i for i in range(S)},
+                                     style_dim=10, lambda_id=0.1, argmax=1, some_grad_flag=1, train_only=1, shape={})
+  hip = A.GAN(G, A.Speech2Gesture_D(in_channels=104), input_modalities=['audio/log_mel_400'], update_D_prob_flag=0, no_grad=0)
+  assert hip.criterion_name == 'MSELoss'
+  hip.load_state_dict(O.deterministic_state(hip.state_dict()))
+  hip.G.thresh.value, hip.G.thresh.iters = 1, 10 ** 9
+  hip = hip.to(DEV)
+  batch64 = [t.double() if t.is_floating_point() else t for t in batch]
+  f_ref, l_ref = _step(ref, batch64, kind, 'cpu')
+  f_hip, l_hip = _step(hip, batch, kind, DEV)
+  assert (f_hip.detach().cpu().double() - f_ref.detach()).abs().mean().item() <= 1e-4
+  for a, b in zip(l_hip, l_ref):
+    assert abs(float(a) - float(b)) <= 1e-4
+  probe = (lambda m: m.G.logits.weight) if kind == 'G' else (lambda m: m.D.conv3.conv.weight)
+  g_ref, g_hip = probe(ref).grad, probe(hip).grad.cpu().double()
+  assert ((g_hip - g_ref).norm() / g_ref.norm()).item() <= 2e-2
