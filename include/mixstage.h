@@ -128,7 +128,7 @@ int ms_conv_block_bwd(const ms_conv_desc* d, const float* x, const float* x2, co
 
 /* Full form of the backward.  All fields optional (zero = the behaviour of ms_conv_block_bwd). */
 typedef struct ms_bwd_options {
-  void* side_stream;            /* weight gradient on this stream, as ms_conv_block_bwd_overlap */
+  void* side_stream;            /* experimental (mixstage_aux.h): weight gradient on this stream; NULL */
   void* side_workspace;
   size_t side_workspace_bytes;
   const float* wt_prepared;     /* this block's buffer from ms_dgrad_weights_prepare (built for the same descriptor and
