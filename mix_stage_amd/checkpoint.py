@@ -6,6 +6,8 @@ pickled or torch.save'd mapping name -> tensor / numpy array, optionally under a
 DataParallel 'module.' prefix, in fp32 or fp64 (`.double()` models, trainer.py).  The module tree of this package mirrors the
 reference's state_dict schema (tests/test_boundary_cpu.py), so such a file loads with strict=True.
 """
+import io
+import os
 import pickle
 
 import torch
@@ -20,14 +22,39 @@ def _as_mapping(obj):
   return obj
 
 
-def read_weights(source):
-  """source: a path (pickle or torch.save file) or an already loaded mapping.  Returns an ordered name -> fp-tensor dict."""
-  if isinstance(source, (str, bytes)) and not isinstance(source, dict):
+class _TensorsOnlyUnpickler(pickle.Unpickler):
+  """A plain pickle of a state_dict needs only containers, torch tensors (rebuilt through torch._utils) and numpy arrays;
+  anything else in the stream is refused instead of executed."""
+  _ALLOWED = {
+      ('collections', 'OrderedDict'), ('builtins', 'dict'), ('builtins', 'list'), ('builtins', 'tuple'), ('builtins', 'set'),
+      ('torch._utils', '_rebuild_tensor_v2'), ('torch._utils', '_rebuild_parameter'), ('torch._utils', '_rebuild_tensor'),
+      ('torch', 'Size'), ('torch.storage', '_load_from_bytes'), ('torch', 'device'),
+      ('numpy.core.multiarray', '_reconstruct'), ('numpy._core.multiarray', '_reconstruct'), ('numpy', 'ndarray'),
+      ('numpy', 'dtype'), ('numpy.core.multiarray', 'scalar'), ('numpy._core.multiarray', 'scalar'),
+  }
+
+  def find_class(self, module, name):
+    if (module, name) in self._ALLOWED or (module == 'torch' and name.endswith(('Storage', 'Tensor'))) or \
+        (module == 'torch' and name in ('float32', 'float64', 'float16', 'bfloat16', 'int64', 'int32', 'uint8', 'bool')):
+      return super().find_class(module, name)
+    raise pickle.UnpicklingError('refusing to load %s.%s from a weights file (pass trusted=True for files you produced yourself)'
+                                 % (module, name))
+
+
+def read_weights(source, trusted=False):
+  """source: a path (str / os.PathLike; pickle or torch.save file) or an already loaded mapping.  Returns an ordered
+  name -> tensor dict.  Files are read with torch.load(weights_only=True) first, then as a plain pickle through an
+  unpickler restricted to containers, tensors and numpy arrays; trusted=True allows an unrestricted pickle.load (arbitrary
+  code execution: only for files you produced yourself)."""
+  if isinstance(source, (str, bytes, os.PathLike)) and not isinstance(source, dict):
+    path = os.fspath(source)
+    if not os.path.isfile(path):
+      raise FileNotFoundError(path)
     try:
-      obj = torch.load(source, map_location='cpu', weights_only=False)
-    except Exception:
-      with open(source, 'rb') as f:
-        obj = pickle.load(f)
+      obj = torch.load(path, map_location='cpu', weights_only=True)
+    except (pickle.UnpicklingError, RuntimeError, ValueError, EOFError, KeyError, AttributeError):
+      with open(path, 'rb') as f:
+        obj = pickle.load(f) if trusted else _TensorsOnlyUnpickler(io.BytesIO(f.read())).load()
   else:
     obj = source
   out = {}
@@ -38,11 +65,11 @@ def read_weights(source):
   return out
 
 
-def load_weights(model, source, strict=True):
+def load_weights(model, source, strict=True, trusted=False):
   """Load reference-format weights into a mix_stage_amd GAN (or any sub-module).  Floating-point tensors are cast to the
   module's dtype (fp64 checkpoints -> fp32); parameters owned by a MixStageTrainStep keep living in its flat buffers (the copy
   is in place) and the trainer notices the edit through the parameters' version counters."""
-  weights = read_weights(source)
+  weights = read_weights(source, trusted=trusted)
   own = model.state_dict()
   cast = {}
   for name, v in weights.items():

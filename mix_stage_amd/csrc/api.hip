@@ -22,7 +22,9 @@ static int validate(const ms_conv_desc* d, const char* who) {
   if (dt_of(d) == DT_F32 && (d->dtype & ~0xff)) return set_error("%s: MS_DT_OUT_F32 is a flag of the 16-bit modes", who);
   const double out_elems = (double)d->B * d->groups * d->Cout * d->OH * d->OW;
   const double in_elems = (double)d->B * d->groups * d->Cin * d->H * d->W;
-  if (out_elems >= 2147483648.0 || in_elems >= 2147483648.0) return set_error("%s: tensor exceeds 2^31 elements", who);
+  // the staging loads address a tensor with 32-bit BYTE offsets against one buffer descriptor: 2 GiB per tensor
+  const double lim = dt_of(d) == DT_F32 ? 536870912.0 : 1073741824.0;      // 2^29 fp32 / 2^30 16-bit elements
+  if (out_elems >= lim || in_elems >= lim) return set_error("%s: tensor of 2 GiB or more (%.0f elements)", who, std::max(out_elems, in_elems));
   return 0;
 }
 

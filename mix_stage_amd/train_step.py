@@ -320,6 +320,11 @@ class MixStageTrainStep:
 
   def _capture(self, key, k, st, opt):
     m = self.model
+    from .gan import ConstantLambdaScheduler
+    if not isinstance(m.lambda_scheduler, ConstantLambdaScheduler):
+      # the loss weights are baked into the captured kernels' constants and the scheduler is not stepped on replay
+      raise NotImplementedError('use_graphs=True needs the constant lambda scheduler (gan.py:30-33 stand-in); construct '
+                                'MixStageTrainStep(..., use_graphs=False) with a custom lambda_scheduler')
     rng = torch.get_rng_state()
     thresh = (m.G.thresh.value, m.G.thresh.iters)
     bn_state = {n: b.clone() for n, b in m.named_buffers()}

@@ -34,3 +34,28 @@ def test_pickled_double_checkpoint_loads_strictly(tmp_path):
   torch.save(ref.state_dict(), buf)
   assert list(read_weights(str(buf))) == list(ref.state_dict())
   assert not load_weights(_hip_gan_cpu(4, 4), ref.state_dict()).missing_keys
+
+
+def test_weight_files_cannot_execute_code(tmp_path):
+  """A weights file is data: a pickle that references anything but containers / tensors / numpy arrays is refused."""
+  import os
+  import pathlib
+  import pytest
+  from mix_stage_amd.checkpoint import read_weights
+
+  class Evil:
+    def __reduce__(self):
+      return (os.system, ('echo pwned > %s' % (tmp_path / 'pwned'),))
+  bad = tmp_path / 'evil_weights.p'
+  with open(bad, 'wb') as f:
+    pickle.dump({'model': {'w': Evil()}}, f)
+  with pytest.raises(Exception):
+    read_weights(bad)
+  assert not (tmp_path / 'pwned').exists()
+  good = tmp_path / 'np_weights.p'
+  with open(good, 'wb') as f:
+    pickle.dump({'G.eye': torch.eye(2).numpy(), 'n': torch.ones(3)}, f)
+  got = read_weights(pathlib.Path(good))                        # os.PathLike is accepted
+  assert torch.equal(got['G.eye'], torch.eye(2)) and torch.equal(got['n'], torch.ones(3))
+  with pytest.raises(FileNotFoundError):
+    read_weights(str(tmp_path / 'missing.p'))
