@@ -196,6 +196,24 @@ size_t ms_wgrad_partials_elems(const ms_conv_desc* d, int* splits);
 int ms_wgrad_reduce_multi(int n, const float* const* partials, float* const* dw, const int* elems, const int* splits,
                           void* stream);
 
+/* Cross-rank ("global") BatchNorm for data-parallel training: the reference normalises over the whole batch on one device
+ * (layers.py:65-70); with the batch sharded over ranks, a block = conv (MS_BARE block) + the pieces below around two small
+ * exchanges the host performs (all-gather of the statistics, all-reduce of the backward sums):
+ *   ms_bn_stats        stats[C][2] = per channel (sum, M2 about the local mean) of y_raw (B, C, HW)
+ *   ms_bn_train_apply  stats_all[world][C][2] (all-gathered, n_local = B*HW values each) -> save = mean|invstd|scale|shift of
+ *                      the GLOBAL batch, running statistics update (global count), y = lrelu(y_raw*scale + shift)
+ *   ms_bn_bwd_sums     sums[C][2] = this rank's (sum dz, sum dz*xhat), dz = dy*lrelu'(z): also its dbeta / dgamma
+ *   ms_bn_bwd_apply    dyr = gamma*invstd*(dz - S1/N - xhat*S2/N) with the all-reduced sums S and the global count N */
+int ms_bn_stats(const float* y_raw, float* stats, int B, int C, int HW, void* stream);
+int ms_bn_train_apply(const float* stats_all, int world, int n_local, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, const float* y_raw, float* y, float* save, int B, int C, int HW, float eps,
+                      float momentum, float slope, void* stream);
+size_t ms_bn_bwd_workspace(int B, int C);
+int ms_bn_bwd_sums(const float* dy, const float* y_raw, const float* save, float* sums, int B, int C, int HW, float slope,
+                   void* workspace, size_t workspace_bytes, void* stream);
+int ms_bn_bwd_apply(const float* dy, const float* y_raw, const float* save, const float* gamma, const float* sums_global,
+                    double n_global, float* dyr, int B, int C, int HW, float slope, void* stream);
+
 /* AudioEncoder resize (layers.py:197): bilinear to (T,1), align_corners=False, == 1-D lerp in time
  * of frequency column F/2.   x (B,C,Tin,F) -> y (B,C,Tout). */
 int ms_lerp_time_fwd(const float* x, float* y, int B, int C, int Tin, int F, int Tout, void* stream);

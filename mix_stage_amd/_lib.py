@@ -72,6 +72,11 @@ SIGNATURES = {
     'ms_cb8_to_plain': (c_int, [c_int, _P, _P, c_int, c_int, c_int, _P]),
     'ms_cb8_from_btc': (c_int, [c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),
     'ms_cb8_to_btc': (c_int, [c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    'ms_bn_stats': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    'ms_bn_train_apply': (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, _P]),
+    'ms_bn_bwd_workspace': (c_size_t, [c_int, c_int]),
+    'ms_bn_bwd_sums': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, c_size_t, _P]),
+    'ms_bn_bwd_apply': (c_int, [_P, _P, _P, _P, _P, ctypes.c_double, _P, c_int, c_int, c_int, c_float, _P]),
     'ms_lerp_time_fwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'ms_lerp_time_bwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'ms_softmax_mix_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -79,6 +79,61 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 }
 
 // ----------------------------------------------------------------------------------------------
+// Cross-rank ("global") BatchNorm, data parallel: the statistics of a block are exchanged between the ranks so that every
+// rank normalises with the statistics of the GLOBAL batch, like the single device the reference trains on (layers.py:65-70).
+// bn_stats: per channel (sum, M2 about the local mean) of y_raw -- the per-tile format bn_finalize_kernel combines, so the
+// all-gathered [world][C][2] array is finalized as `world` tiles of B*HW values each.
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ y_raw, float* __restrict__ out, int B, int C, int HW) {
+  __shared__ float red[4];
+  const int c = blockIdx.x, t = threadIdx.x, n = B * HW;
+  float s = 0.f;
+  for (int e = t; e < n; e += 256) {
+    const int b = e / HW, pix = e - b * HW;
+    s += y_raw[((size_t)b * C + c) * HW + pix];
+  }
+  s = block_sum_256(s, red);
+  const float mean = s / (float)n;
+  float q = 0.f;
+  for (int e = t; e < n; e += 256) {
+    const int b = e / HW, pix = e - b * HW;
+    const float d = y_raw[((size_t)b * C + c) * HW + pix] - mean;
+    q += d * d;
+  }
+  q = block_sum_256(q, red);
+  if (t == 0) { out[2 * c] = s; out[2 * c + 1] = q; }
+}
+
+// sums the per-chunk partials of bn_bwd_reduce_kernel: sums[c] = (sum dz, sum dz*xhat) of this rank
+__global__ void bn_bwd_sum_chunks_kernel(const float* __restrict__ partial, float* __restrict__ sums, int C, int nchunk) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = 0; k < nchunk; ++k) {
+    s1 += partial[((size_t)c * nchunk + k) * 2];
+    s2 += partial[((size_t)c * nchunk + k) * 2 + 1];
+  }
+  sums[2 * c] = s1; sums[2 * c + 1] = s2;
+}
+
+// dyr = gamma*invstd*(dz - S1/N - xhat*S2/N) with the GLOBAL sums S and the global count N
+__global__ __launch_bounds__(256) void bn_bwd_apply_sums_kernel(const float* __restrict__ dy, const float* __restrict__ y_raw,
+                                                                const float* __restrict__ save, const float* __restrict__ gamma,
+                                                                const float* __restrict__ sums, float inv_n_global,
+                                                                float* __restrict__ dyr, int B, int C, int HW, float slope) {
+  const int c = blockIdx.x, t = threadIdx.x, n = B * HW;
+  const float mean = save[c], invstd = save[C + c], sc = save[2 * C + c], sh = save[3 * C + c];
+  const float gi = gamma[c] * invstd, m1 = sums[2 * c] * inv_n_global, m2 = sums[2 * c + 1] * inv_n_global;
+  for (int e = t + blockIdx.y * 256; e < n; e += 256 * gridDim.y) {
+    const int b = e / HW, pix = e - b * HW;
+    const size_t off = ((size_t)b * C + c) * HW + pix;
+    const float yr = y_raw[off];
+    const float z = fmaf(yr, sc, sh);
+    const float dz = dy[off] * (z > 0.f ? 1.f : slope);
+    dyr[off] = gi * (dz - m1 - (yr - mean) * invstd * m2);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
 // BatchNorm + LeakyReLU backward.  grid (C, nchunk); chunk = contiguous range of batch items.
 //   dz = dy * lrelu'(z), z = y_raw*scale+shift (bit-identical to forward);  xh = (y_raw-mean)*invstd
 //   partial[c][chunk] = (sum dz, sum dz*xh)
@@ -881,6 +936,49 @@ int ms_softmax_mix_bwd(const float* z, const float* soft, const float* dout, flo
   if (rc) return rc;
   hipLaunchKernelGGL(softmax_mix_bwd_finish_kernel, dim3(cdiv(B * T, 256)), dim3(256), 0, (hipStream_t)stream, soft, dscore, B, M, T);
   return check_launch("softmax_mix_bwd_finish_kernel");
+}
+
+int ms_bn_stats(const float* y_raw, float* stats, int B, int C, int HW, void* stream) {
+  if (!y_raw || !stats || B < 1 || C < 1 || HW < 1) return set_error("ms_bn_stats: bad argument");
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, y_raw, stats, B, C, HW);
+  return check_launch("bn_stats_kernel");
+}
+
+int ms_bn_train_apply(const float* stats_all, int world, int n_local, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, const float* y_raw, float* y, float* save, int B, int C, int HW, float eps,
+                      float momentum, float slope, void* stream) {
+  if (!stats_all || world < 1 || n_local != B * HW || !gamma || !beta || !running_mean || !running_var || !y_raw || !y || !save)
+    return set_error("ms_bn_train_apply: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = launch_bn_finalize(stats_all, nullptr, world, n_local, world * n_local, C, gamma, beta, running_mean, running_var, save, eps,
+                              momentum, s);
+  if (rc) return rc;
+  return launch_bn_apply(y_raw, y, save, C, HW, (size_t)B * C * HW, slope, s);
+}
+
+size_t ms_bn_bwd_workspace(int B, int C) {
+  int bpc;
+  return (size_t)bwd_chunks(B, C, &bpc) * C * 2 * sizeof(float) + 256;
+}
+
+int ms_bn_bwd_sums(const float* dy, const float* y_raw, const float* save, float* sums, int B, int C, int HW, float slope,
+                   void* workspace, size_t workspace_bytes, void* stream) {
+  if (!dy || !y_raw || !save || !sums || !workspace || workspace_bytes < ms_bn_bwd_workspace(B, C)) return set_error("ms_bn_bwd_sums: bad argument");
+  int bpc;
+  const int nchunk = bwd_chunks(B, C, &bpc);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, nchunk), dim3(256), 0, s, dy, y_raw, save, (float*)workspace, B, C, HW, bpc, slope);
+  hipLaunchKernelGGL(bn_bwd_sum_chunks_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, (const float*)workspace, sums, C, nchunk);
+  return check_launch("bn_bwd_sums kernels");
+}
+
+int ms_bn_bwd_apply(const float* dy, const float* y_raw, const float* save, const float* gamma, const float* sums_global,
+                    double n_global, float* dyr, int B, int C, int HW, float slope, void* stream) {
+  if (!dy || !y_raw || !save || !gamma || !sums_global || !dyr || n_global < 1) return set_error("ms_bn_bwd_apply: bad argument");
+  const int gy = std::max(1, std::min(64, (B * HW + 2047) / 2048));
+  hipLaunchKernelGGL(bn_bwd_apply_sums_kernel, dim3(C, gy), dim3(256), 0, (hipStream_t)stream, dy, y_raw, save, gamma, sums_global,
+                     (float)(1.0 / n_global), dyr, B, C, HW, slope);
+  return check_launch("bn_bwd_apply_sums_kernel");
 }
 
 int ms_kmeans_labels(const float* pose, const int32_t* keep, const double* centers, int64_t* labels, int B, int T, int P,

@@ -171,6 +171,11 @@ class ConvNormRelu(nn.Module):
                              n.running_var, x2=x2, in_mode=in_mode, out_f32=out_f32,
                              bn_folded=getattr(self, '_bn_folded', False))
       return ops16.from_cb8(y, self.conv.weight.shape[0]) if (was_plain and not out_f32) else y
+    if mode == MS_BN_TRAIN and ops.bn_sync_active():
+      # data parallel with bn_sync='global': bare conv, then BatchNorm over the batch of ALL ranks (two small collectives)
+      g = self._geometry()
+      y_raw = ops.conv_block(x, self.conv.weight, self.conv.bias, g, MS_BARE, x2=x2, in_mode=in_mode)
+      return ops.sync_bn_act(y_raw, n.weight, n.bias, n.running_mean, n.running_var, g.slope, g.eps, g.momentum)
     return ops.conv_block(x, self.conv.weight, self.conv.bias, self._geometry(), mode, n.weight, n.bias,
                           n.running_mean, n.running_var, x2=x2, in_mode=in_mode)
 

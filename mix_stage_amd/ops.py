@@ -453,6 +453,82 @@ def conv_block(x, w, bias, geom, mode, gamma=None, beta=None, running_mean=None,
 
 
 # ------------------------------------------------------------------------------------------------
+# cross-rank ("global") BatchNorm for data-parallel training (include/mixstage.h: ms_bn_stats ...)
+_bn_sync = {'group': None, 'on': False}
+
+
+def set_bn_sync(on, process_group=None):
+  """bn_sync='global': every BatchNorm(train) block normalises with the statistics of the GLOBAL batch (all ranks), as the
+  single device of the reference does (layers.py:65-70).  Two small collectives per block and direction; not capturable in
+  a HIP graph (the exchanges run between the kernels)."""
+  _bn_sync['on'], _bn_sync['group'] = bool(on), process_group
+
+
+def bn_sync_active():
+  import torch.distributed as dist
+  return _bn_sync['on'] and dist.is_available() and dist.is_initialized() and dist.get_world_size(_bn_sync['group']) > 1
+
+
+class _SyncBNActFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, y_raw, gamma, beta, rm, rv, slope, eps, momentum):
+    import torch.distributed as dist
+    _need_hip(y_raw, gamma, beta, rm, rv)
+    y_raw = y_raw.contiguous()
+    B, C = y_raw.shape[0], y_raw.shape[1]
+    HW = y_raw.numel() // (B * C)
+    group = _bn_sync['group']
+    world = dist.get_world_size(group)
+    stats = torch.empty((C, 2), dtype=torch.float32, device=y_raw.device)
+    check(lib().ms_bn_stats(_ptr(y_raw), _ptr(stats), B, C, HW, _stream()), 'ms_bn_stats')
+    allstats = torch.empty((world, C, 2), dtype=torch.float32, device=y_raw.device)
+    dist.all_gather_into_tensor(allstats, stats, group=group) if dist.get_backend(group) == 'nccl' else \
+        allstats.copy_(torch.stack(_all_gather_list(stats, world, group)))
+    y = torch.empty_like(y_raw)
+    save = torch.empty(4 * C, dtype=torch.float32, device=y_raw.device)
+    check(lib().ms_bn_train_apply(_ptr(allstats), world, B * HW, _ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv), _ptr(y_raw),
+                                  _ptr(y), _ptr(save), B, C, HW, eps, momentum, slope, _stream()), 'ms_bn_train_apply')
+    ctx.save_for_backward(y_raw, gamma, save)
+    ctx.meta = (B, C, HW, slope, world, group)
+    ctx.params = (gamma, beta)
+    return y
+
+  @staticmethod
+  def backward(ctx, dy):
+    import torch.distributed as dist
+    y_raw, gamma, save = ctx.saved_tensors
+    B, C, HW, slope, world, group = ctx.meta
+    dy = dy.contiguous()
+    sums = torch.empty((C, 2), dtype=torch.float32, device=dy.device)
+    ws = workspace(lib().ms_bn_bwd_workspace(B, C), dy.device)
+    check(lib().ms_bn_bwd_sums(_ptr(dy), _ptr(y_raw), _ptr(save), _ptr(sums), B, C, HW, slope, _ptr(ws), ws.numel(), _stream()),
+          'ms_bn_bwd_sums')
+    # this rank's share of dgamma / dbeta (the gradient all-reduce averages the shares); the normalisation needs the global sums
+    pgamma, pbeta = ctx.params
+    dgamma, direct_g = _grad_slot(pgamma, gamma)
+    dbeta, direct_b = _grad_slot(pbeta, gamma)
+    dgamma.copy_(sums[:, 1]); dbeta.copy_(sums[:, 0])
+    gsum = sums.clone()
+    dist.all_reduce(gsum, op=dist.ReduceOp.SUM, group=group)
+    dyr = torch.empty_like(dy)
+    check(lib().ms_bn_bwd_apply(_ptr(dy), _ptr(y_raw), _ptr(save), _ptr(gamma), _ptr(gsum), float(world) * B * HW, _ptr(dyr), B, C,
+                                HW, slope, _stream()), 'ms_bn_bwd_apply')
+    return dyr, None if direct_g else dgamma, None if direct_b else dbeta, None, None, None, None, None
+
+
+def _all_gather_list(t, world, group):
+  import torch.distributed as dist
+  out = [torch.empty_like(t) for _ in range(world)]
+  dist.all_gather(out, t, group=group)
+  return out
+
+
+def sync_bn_act(y_raw, gamma, beta, running_mean, running_var, slope, eps, momentum):
+  """BatchNorm(train, statistics of the global batch over all ranks) + LeakyReLU of a bare conv output."""
+  return _SyncBNActFn.apply(y_raw, gamma, beta, running_mean, running_var, float(slope), float(eps), float(momentum))
+
+
+# ------------------------------------------------------------------------------------------------
 class _LerpTimeFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, x, t_out):

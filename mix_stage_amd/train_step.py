@@ -201,6 +201,11 @@ class MixStageTrainStep:
     if bn_sync not in ('local', 'global'):
       raise ValueError("bn_sync must be 'local' or 'global'")
     self.bn_sync = bn_sync
+    if bn_sync == 'global':
+      if getattr(model, '_ms_dt', 0):
+        raise NotImplementedError("bn_sync='global' is implemented for the fp32 path")
+      use_graphs = False        # the statistics exchanges run between the kernels of a block: not capturable
+    ops.set_bn_sync(bn_sync == 'global', process_group)
     # overlap_wgrad: weight gradients on a side HIP stream (ms_conv_block_bwd_overlap).  Measured on MI355X / ROCm 7.2
     # inside the captured step it is SLOWER (5.01 vs 4.67 ms/step: cross-stream edges in the HIP graph cost more than the
     # concurrency buys), so it is off by default.

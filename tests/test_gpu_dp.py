@@ -25,3 +25,35 @@ def test_two_ranks_stay_bit_identical():
   assert (a['g_step'], a['d_step']) == (b['g_step'], b['d_step']) == (a['kinds'].count('G'), a['kinds'].count('D'))
   assert a['losses'] != b['losses']                                # the ranks really saw different shards
   assert all(abs(v) < 1e3 for step in a['losses'] for v in step)
+
+
+def test_global_bn_dp_equals_single_device():
+  """bn_sync='global': two ranks with 2 clips each reproduce what ONE device computes on the 4 clips (the reference trains on
+  one device, layers.py:65-70): poses and losses of a G-step and a D-step against the oracle at B=4, within the fp32 bar."""
+  import numpy as np
+  import torch
+  from oracle import mixstage_oracle as O
+  env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+         '--master-port', '29543', os.path.join(ROOT, 'tests', 'helpers', 'dp_global_bn_worker.py')]
+  out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+  res = [json.loads(l.split('DPRESULT ', 1)[1]) for l in out.stdout.splitlines() if 'DPRESULT ' in l]
+  assert out.returncode == 0 and len(res) == 2, (out.stdout[-2000:], out.stderr[-4000:])
+  a, b = sorted(res, key=lambda r: r['rank'])
+  M = S = 2
+  ref = O.build_gan(M=M, S=S)
+  og = torch.optim.Adam(ref.G.parameters(), lr=1e-4)
+  od = torch.optim.Adam(ref.D.parameters(), lr=1e-4)
+  audio, pose, labels, style = O.synthetic_batch(4, M=M, S=S, seed=321)
+  for kind in ('G', 'D'):
+    torch.manual_seed(77)
+    fake, losses, _ = O.oracle_train_step(ref, og, od, audio, pose, labels, style, kind)
+    got = np.concatenate([np.array(a['out'][kind]['pose']), np.array(b['out'][kind]['pose'])])
+    assert np.abs(got - fake.numpy().reshape(-1)).mean() <= 1e-4, kind
+    # each rank's loss terms are means over its own clips: their average over the ranks is the single-device loss
+    mean_losses = (np.array(a['out'][kind]['losses']) + np.array(b['out'][kind]['losses'])) / 2
+    np.testing.assert_allclose(mean_losses, losses, atol=2e-4)
+  sd = ref.state_dict()
+  for k, v in a['probe'].items():
+    assert b['probe'][k] == v                                            # replicas identical
+    assert abs(v - float(sd[k].double().sum())) <= 2e-4 * max(1.0, sd[k].numel() ** 0.5), k
