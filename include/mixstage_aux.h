@@ -47,6 +47,8 @@ int ms_debug_set_patch_tuning(int intra_split, int force_splitk);
 
 /* Tuning aid for the 16-bit conv kernel: force the workgroup tile to 64*wm output channels x 64*wn pixels (0, 0: planner). */
 int ms_debug_set_conv16_tile(int wm, int wn);
+/* ... and its LDS-DMA ring depth (2..4, 0 = planner) / the 8-wave form of the 128 x 128 tile (measured: no gain). */
+int ms_debug_set_conv16_ring(int nstg, int wide8);
 
 /* Self-test kernel: C(32x32) = A(32xK) * B(Kx32) through the fp32 MFMA path (checks fragment maps). */
 int ms_selftest_mfma(const float* A, const float* B, float* C, int K, void* stream);

@@ -106,6 +106,7 @@ SIGNATURES = {
     'ms_debug_set_patch_min_workgroups': (c_int, [c_int]),
     'ms_debug_set_patch_tuning': (c_int, [c_int, c_int]),
     'ms_debug_set_conv16_tile': (c_int, [c_int, c_int]),
+    'ms_debug_set_conv16_ring': (c_int, [c_int, c_int]),
     'ms_selftest_mfma': (c_int, [_P, _P, _P, c_int, _P]),
 }
 

@@ -41,7 +41,8 @@ struct Conv16Args {
   int of_img, of_chan, of_row;         // out_f32 strides (elements)
   int PH, PW;
   int ltw, TH, PC, nchunks, tiles_x, tiles_y, gx, gy, gz;
-  int nstg;                            // LDS-DMA path: buffers in the ring (3 or 4)
+  int nstg;                            // LDS-DMA path: buffers in the ring (2..4)
+  int dbg;                             // tuning experiments only (ms_debug_set_conv16_ring): bit 0 no stores, 1 no statistics reduce, 2 no K loop
   int ncls, cls_PH[4], cls_PW[4], cls_OUTH[4], cls_OUTW[4], cls_ry[4], cls_rx[4];
   unsigned a_mt_stride, a_group_stride, a_cls_stride;   // vectors
   float slope, eps;
@@ -49,7 +50,7 @@ struct Conv16Args {
 };
 
 struct Conv16Plan {
-  int ok, wm, wn, tw, th, tiles_y, tiles_x, n_tiles, ck8, nchunks, pc, lds_bytes, dma, nstg;
+  int ok, wm, wn, nwn, tw, th, tiles_y, tiles_x, n_tiles, ck8, nchunks, pc, lds_bytes, dma, nstg;
 };
 Conv16Plan plan_conv16(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH, int SW, int B, int OH, int OW, int zmul,
                        bool up2);

@@ -20,6 +20,9 @@ static int ilog2(int v) {
 
 int g_conv16_force_wm = 0, g_conv16_force_wn = 0;     // tuning knob (ms_debug_set_conv16_tile)
 int g_conv16_dma = 1;                                 // tuning knob: 0 = register-staged path everywhere
+int g_conv16_wide8 = 0;                               // tuning knob: 8-wave form of the 128 x 128 tile (measured: no gain)
+int g_conv16_dbg = 0;
+int g_conv16_ring = 0;                                // tuning knob: force the LDS-DMA ring depth (0 = planner)                               // tuning knob: 8-wave form of the 128 x 128 tile
 
 Conv16Plan plan_conv16(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH, int SW, int B, int OH, int OW, int zmul,
                        bool up2) {
@@ -33,28 +36,32 @@ Conv16Plan plan_conv16(int nd, int Mg, int groups, int Kc, int KH, int KW, int S
   // candidate tiles, largest first: the first one that fills the chip (>= 192 workgroups), else the smallest
   const int cand[3][2] = {{2, 2}, {1, 2}, {1, 1}};
   for (int c = 0; c < 3; ++c) {
-    const int wm = cand[c][0], wn = cand[c][1];
+    int wm = cand[c][0], wn = cand[c][1], nwn = 2;
     const int bm = 64 * wm, bn = 64 * wn;
-    if (g_conv16_force_wm && (wm != g_conv16_force_wm || wn != g_conv16_force_wn)) continue;
+    // the 128 x 128 tile runs as 8 waves (2 x 4, 64 x 32 each) on the LDS-DMA path: same tile, half the per-wave overhead
+    if (c == 0 && g_conv16_wide8 && g_conv16_dma && !up2) { wn = 1; nwn = 4; }
+    const int nt = 128 * nwn;
+    if (g_conv16_force_wm && (cand[c][0] != g_conv16_force_wm || cand[c][1] != g_conv16_force_wn)) continue;
     if (c == 0 && Mg < 128) continue;          // 128-row tiles only for layers with >= 128 rows per group
     const int tw = std::min(pow2_at_least(OW), bn), th = bn / tw;
     const int pc = (tw - 1) * S + KW;
     const int tiles_y = cdiv(rows, th), tiles_x = cdiv(OW, tw);
     const long nwg = (long)imgs * tiles_y * tiles_x * cdiv(Mg, bm) * groups * zmul;
-    const bool fits = ck8 * th * pc <= CONV16_NP * 256;
+    const bool fits = ck8 * th * pc <= CONV16_NP * nt;
     if (!fits) continue;
     if (nwg >= 192 || c == 2 || g_conv16_force_wm) {
-      pl.ok = 1; pl.wm = wm; pl.wn = wn; pl.tw = tw; pl.th = th; pl.tiles_y = tiles_y; pl.tiles_x = tiles_x;
+      pl.ok = 1; pl.wm = wm; pl.wn = wn; pl.nwn = nwn; pl.tw = tw; pl.th = th; pl.tiles_y = tiles_y; pl.tiles_x = tiles_x;
       pl.n_tiles = imgs * tiles_y * tiles_x;
       pl.ck8 = ck8; pl.nchunks = cdiv(c8_of(Kc), ck8); pl.pc = pc;
       pl.lds_bytes = 2 * (KW * ck8 * bm + ck8 * th * pc + 1) * 16;
       if (g_conv16_dma && !up2) {
         // LDS-DMA ring: up to 4 buffers; when the grid holds more workgroups than CUs the ring is kept below half of the
         // CU's LDS so that two workgroups share a CU (one computes while the other waits for its stage)
-        const int stage = (KW * ck8 * bm + cdiv(ck8 * th * pc, 256) * 256) * 16;
+        const int stage = (KW * ck8 * bm + cdiv(ck8 * th * pc, nt) * nt) * 16;
         const int budget = nwg > 256 ? 80 * 1024 : 160 * 1024;
         int nstg = std::min(4, budget / stage);
         if (nstg < 2) nstg = std::min(4, 160 * 1024 / stage);
+        if (g_conv16_ring >= 2 && g_conv16_ring * stage <= 160 * 1024) nstg = g_conv16_ring;
         if (nstg >= 2) { pl.dma = 1; pl.nstg = nstg; pl.lds_bytes = nstg * stage; }
       }
       (void)SV;
@@ -162,16 +169,16 @@ int launch_prep16_multi(Prep16Batch& pb, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------------
 // dispatch
-template <typename DT, int KW, int WM, int WN, bool UP2, bool DMA>
+template <typename DT, int KW, int WM, int WN, bool UP2, bool DMA, int NWN = 2>
 static int launch_one(const Conv16Args& a, int lds_bytes, int nwg, hipStream_t s) {
   static bool attr_done = false;          // kernels that stage more than 64 KiB need the limit raised once
-  auto fn = conv16_kernel<DT, KW, WM, WN, UP2, DMA>;
+  auto fn = conv16_kernel<DT, KW, WM, WN, UP2, DMA, NWN>;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return set_error("conv16: cannot raise the dynamic LDS limit");
     attr_done = true;
   }
-  hipLaunchKernelGGL(fn, dim3(nwg), dim3(256), lds_bytes, s, a);
+  hipLaunchKernelGGL(fn, dim3(nwg), dim3(128 * NWN), lds_bytes, s, a);
   return 0;
 }
 
@@ -179,6 +186,7 @@ template <typename DT, int KW, bool UP2>
 static int launch_tile(const Conv16Args& a, const Conv16Plan& pl, int nwg, hipStream_t s) {
   if constexpr (!UP2) {
     if (pl.dma) {
+      if (pl.wm == 2 && pl.wn == 1 && pl.nwn == 4) return launch_one<DT, KW, 2, 1, false, true, 4>(a, pl.lds_bytes, nwg, s);
       if (pl.wm == 2 && pl.wn == 2) return launch_one<DT, KW, 2, 2, false, true>(a, pl.lds_bytes, nwg, s);
       if (pl.wm == 1 && pl.wn == 2) return launch_one<DT, KW, 1, 2, false, true>(a, pl.lds_bytes, nwg, s);
       return launch_one<DT, KW, 1, 1, false, true>(a, pl.lds_bytes, nwg, s);
@@ -210,7 +218,7 @@ int launch_conv16(int dt, const Conv16Args& a, const Conv16Plan& pl, int KW, boo
   Conv16Args b = a;
   b.ltw = ilog2(pl.tw); b.TH = pl.th; b.PC = pl.pc; b.nchunks = pl.nchunks; b.tiles_x = pl.tiles_x; b.tiles_y = pl.tiles_y;
   b.gx = pl.n_tiles; b.gy = cdiv(a.Mg, bm); b.gz = a.groups * std::max(1, a.ncls);
-  b.nstg = pl.nstg;
+  b.nstg = pl.nstg; b.dbg = g_conv16_dbg;
   const unsigned nav = (unsigned)(KW * pl.ck8 * bm);
   b.a_mt_stride = (unsigned)(pl.nchunks * a.KH) * nav;
   b.a_group_stride = (unsigned)b.gy * b.a_mt_stride;
@@ -219,9 +227,9 @@ int launch_conv16(int dt, const Conv16Args& a, const Conv16Plan& pl, int KW, boo
   if ((double)b.a_cls_stride * std::max(1, a.ncls) * 16.0 >= 4.0e9) return set_error("conv16: prepared weights of 4 GB or more");
   if (a.groups > 1 && (a.Mg & 7)) return set_error("conv16: grouped blocks need a multiple of 8 output channels per group");
   const int nwg = b.gx * b.gy * b.gz;
-  TimingScope ts(s, flops, bytes, "conv16_kernel<%s,%d,%d,%d,%d,%d>|conv_%s_cb8 k%dx%d s%d Mg%d Kg%d g%d tiles%d tile%dx%d tw%d%s%s",
-                 dt == DT_BF16 ? "bf16" : "f16", KW, pl.wm, pl.wn, up2 ? 1 : 0, pl.dma, a.is_dgrad ? "dgrad" : "fwd", a.KH, KW, a.S, a.Mg,
-                 a.Kc8g * 8 * a.KH * KW, a.groups, pl.n_tiles, bm, 64 * pl.wn, pl.tw, pl.dma ? (pl.nstg == 4 ? " dma4" : pl.nstg == 3 ? " dma3" : " dma2") : "",
+  TimingScope ts(s, flops, bytes, "conv16_kernel<%s,%d,%d,%d,%d,%d,%d>|conv_%s_cb8 k%dx%d s%d Mg%d Kg%d g%d tiles%d tile%dx%d tw%d%s%s",
+                 dt == DT_BF16 ? "bf16" : "f16", KW, pl.wm, pl.wn, up2 ? 1 : 0, pl.dma, pl.nwn, a.is_dgrad ? "dgrad" : "fwd", a.KH, KW, a.S, a.Mg,
+                 a.Kc8g * 8 * a.KH * KW, a.groups, pl.n_tiles, bm, 32 * pl.wn * pl.nwn, pl.tw, pl.dma ? (pl.nstg == 4 ? " dma4" : pl.nstg == 3 ? " dma3" : " dma2") : "",
                  a.ep == EP_RAW_STATS ? " +bnstats" : "");
   const int rc = dt == DT_BF16 ? launch_kw<BF16>(b, pl, KW, up2, nwg, s) : launch_kw<F16>(b, pl, KW, up2, nwg, s);
   if (rc) return rc;

@@ -128,12 +128,12 @@ __device__ inline void reduce16_over_half(float (&v)[16], int r) {
   v[0] += dpp_mov<0xB1>(v[0]);                             // quad_perm:[1,0,3,2]
 }
 
-template <typename DT, int WM, int WN, int EP, bool OUTF32>
+template <typename DT, int WM, int WN, int NWN, int EP, bool OUTF32>
 __device__ __forceinline__ void conv16_epilogue(const Conv16Args& p, const f32x16 (&acc)[WM][WN], const Tile16& tl, u32x4* smem) {
   constexpr int BM = 64 * WM;
   const int TW = 1 << p.ltw;
   const int ctot = p.groups * p.Mg;
-  float* red = reinterpret_cast<float*>(smem);     // EP_RAW_STATS: [2 pixel waves][BM][2]
+  float* red = reinterpret_cast<float*>(smem);     // EP_RAW_STATS: [NWN pixel waves][BM][2]
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
     const int mrow0 = tl.m0 + (tl.wm * WM + i) * 32 + 4 * tl.h;
@@ -212,7 +212,7 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16Args& p, const f32x1
                 reinterpret_cast<u32x4*>(p.out)[hb + (size_t)cb * (p.o_cblk >> 1)] = pack8<DT>(pair);
               }
             }
-          } else if (cval && cb < cb_end) {
+          } else if (cval && cb < cb_end && !(p.dbg & 1)) {
             reinterpret_cast<u32x4*>(p.out)[obase + (size_t)cb * p.o_cblk] = pack8<DT>(vec[pr]);
           }
         }
@@ -220,8 +220,10 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16Args& p, const f32x1
     }
     if (EP == EP_RAW_STATS) {
       // per-channel (sum, sum of squares) over the 32 pixels of a lane half; the two pixel waves meet in LDS below
-      reduce16_over_half(s1, tl.r);
-      reduce16_over_half(s2, tl.r);
+      if (!(p.dbg & 2)) {
+        reduce16_over_half(s1, tl.r);
+        reduce16_over_half(s2, tl.r);
+      }
       if (!(tl.r & 1)) {
         const int q = (tl.r >> 1) & 15;
         const int ml = (tl.wm * WM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * tl.h;
@@ -231,11 +233,13 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16Args& p, const f32x1
     }
   }
   if (EP == EP_RAW_STATS) {
-    // fixed order over the two pixel waves; stored as (sum, M2 about the tile mean) like the fp32 kernels
+    // fixed order over the pixel waves; stored as (sum, M2 about the tile mean) like the fp32 kernels
     __syncthreads();
     const int th_v = min(p.TH, tl.OUTH - tl.oy0), tw_v = min(TW, tl.OUTW - tl.ox0);
     if (tl.t < BM && tl.m0 + tl.t < p.Mg) {
-      const float sa = red[tl.t * 2] + red[(BM + tl.t) * 2], sb = red[tl.t * 2 + 1] + red[(BM + tl.t) * 2 + 1];
+      float sa = 0.f, sb = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWN; ++w) { sa += red[(w * BM + tl.t) * 2]; sb += red[(w * BM + tl.t) * 2 + 1]; }
       float* stp = p.stats + ((size_t)tl.bx * ctot + tl.g * p.Mg + tl.m0 + tl.t) * 2;
       stp[0] = sa;
       stp[1] = fmaxf(sb - sa * sa / (float)(th_v * tw_v), 0.f);
@@ -247,22 +251,26 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16Args& p, const f32x1
 // DMA = true: the stages are filled by LDS-DMA loads into a ring of p.nstg buffers -- no staging registers, no ds_write, and
 // the loads of the next nstg-2 stages stay in flight behind the current stage's MFMAs (counted vmcnt, one raw barrier per
 // stage).  DMA = false: global -> registers -> LDS, two buffers (needed where the input is formed on the way: UP2).
-template <typename DT, int KW, int WM, int WN, bool UP2, bool DMA>
-__global__ __launch_bounds__(256) void conv16_kernel(const Conv16Args p) {
+// NWN: waves along the pixels (2 waves along the channels): 2 = 4 waves, 4 = 8 waves (two per SIMD: one wave's staging and
+// epilogue arithmetic runs beside the other's MFMAs).  Tile = 64*WM channels x 32*WN*NWN pixels.
+template <typename DT, int KW, int WM, int WN, bool UP2, bool DMA, int NWN = 2>
+__global__ __launch_bounds__(128 * NWN) void conv16_kernel(const Conv16Args p) {
   constexpr int CK8 = conv16_ck8(KW), KS = CK8 / 2;
   constexpr int BM = 64 * WM;
-  constexpr int NAV = KW * CK8 * BM, NA = (NAV + 255) / 256;
+  constexpr int NT = 128 * NWN;
+  constexpr int NAV = KW * CK8 * BM, NA = (NAV + NT - 1) / NT;
+  static_assert(NAV % NT == 0, "the weight stage is copied in whole slabs");
   constexpr int NP = CONV16_NP;
   static_assert(!(UP2 && DMA), "the upsample-add input is formed in registers");
   extern __shared__ u32x4 smem[];
 
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
-  const int wm = wid >> 1, wn = wid & 1, r = lane & 31, h = lane >> 5;
+  const int wm = wid / NWN, wn = wid % NWN, r = lane & 31, h = lane >> 5;
   const int TW = 1 << p.ltw, TH = p.TH, PC = p.PC, S = p.S, SV = p.SV, KH = p.KH;
   const int thpc = TH * PC, pv = CK8 * thpc;
-  const int npd = (pv + 255) >> 8;               // DMA: 256-vector slabs of input rows per stage
+  const int npd = (pv + NT - 1) / NT;            // DMA: NT-vector slabs of input rows per stage
   // register path: + one dummy vector (out-of-range staging stores land there); DMA path: whole slabs
-  const int stage_vecs = DMA ? NAV + npd * 256 : NAV + pv + 1;
+  const int stage_vecs = DMA ? NAV + npd * NT : NAV + pv + 1;
 
   // logical block id: channel tile fastest, then pixel tile, then (class, group); one contiguous range per XCD
   const int vid = xcd_remap(blockIdx.x, p.gx * p.gy * p.gz);
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(const Conv16Args p) {
   bool pcol[NP];
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
-    const int e = t + i * 256;
+    const int e = t + i * NT;
     const int cb = e / thpc, rem = e - cb * thpc, ty = rem / PC, c = rem - ty * PC;
     const int iy = iy0 + ty * SV, ix = ix0 + c;
     pcol[i] = (e < pv) & ((unsigned)ix < (unsigned)p.SRCW);
@@ -304,8 +312,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(const Conv16Args p) {
     const unsigned sa = __builtin_amdgcn_readfirstlane(16u * (a_wg + (unsigned)st * NAV));
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int idx = t + i * 256;
-      ra[i] = buf_load_v(rsA, (NAV % 256 == 0 || idx < NAV) ? 16u * (unsigned)idx : BUF_OOB, sa);
+      ra[i] = buf_load_v(rsA, 16u * (unsigned)(t + i * NT), sa);
     }
     const int cb0 = ch * CK8;
     const int sbase = __builtin_amdgcn_readfirstlane(img * p.s_img + (cbase8 + cb0) * p.s_cblk);
@@ -327,8 +334,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(const Conv16Args p) {
     u32x4* st = smem + buf * stage_vecs;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int idx = t + i * 256;
-      if (NAV % 256 == 0 || idx < NAV) st[idx] = ra[i];
+      st[t + i * NT] = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -388,7 +394,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(const Conv16Args p) {
       u32x4* dst = smem + (st % p.nstg) * stage_vecs + wave * 64;
       const unsigned sa = __builtin_amdgcn_readfirstlane(16u * (a_wg + (unsigned)st * NAV));
 #pragma unroll
-      for (int i = 0; i < NA; ++i) dma16(rsA, dst + i * 256, 16u * (unsigned)(t + i * 256), sa);
+      for (int i = 0; i < NA; ++i) dma16(rsA, dst + i * NT, 16u * (unsigned)(t + i * NT), sa);
       const int cb0 = ch * CK8;
       const int sbase = __builtin_amdgcn_readfirstlane(img * p.s_img + (cbase8 + cb0) * p.s_cblk);
       const int khrow = kh * p.s_row;
@@ -396,19 +402,20 @@ __global__ __launch_bounds__(256) void conv16_kernel(const Conv16Args p) {
       for (int i = 0; i < NP; ++i) {
         if (i < npd) {
           const bool ok = pcol[i] & ((unsigned)(prow[i] + kh) < (unsigned)p.SRCH) & (cb0 + pcb[i] < p.Kc8g);
-          dma16(rsS, dst + NAV + i * 256, ok ? 16u * (unsigned)(poff[i] + khrow) : BUF_OOB, 16u * (unsigned)sbase);
+          dma16(rsS, dst + NAV + i * NT, ok ? 16u * (unsigned)(poff[i] + khrow) : BUF_OOB, 16u * (unsigned)sbase);
         }
       }
     };
     const int per_stage = NA + npd;                    // LDS-DMA instructions a wave issues per stage
     const int ahead = p.nstg - 2;                      // stages that stay in flight behind the one being computed
-    for (int st = 0; st < p.nstg - 1 && st < nstages; ++st) issue_stage(st);
-    for (int st = 0; st < nstages; ++st) {
+    const int nst_run = (p.dbg & 4) ? 0 : nstages;
+    for (int st = 0; st < p.nstg - 1 && st < nst_run; ++st) issue_stage(st);
+    for (int st = 0; st < nst_run; ++st) {
       // stage st has landed once at most `ahead` younger stages are outstanding (in the tail fewer are: drain)
-      wait_vmcnt(st + ahead < nstages ? ahead * per_stage : 0);
+      wait_vmcnt(st + ahead < nst_run ? ahead * per_stage : 0);
       __builtin_amdgcn_s_barrier();                    // everyone's part of stage st is in LDS, everyone is done with stage st-1
       asm volatile("" ::: "memory");
-      if (st + p.nstg - 1 < nstages) issue_stage(st + p.nstg - 1);    // refills the buffer of stage st-1
+      if (st + p.nstg - 1 < nst_run) issue_stage(st + p.nstg - 1);    // refills the buffer of stage st-1
       compute_stage(st % p.nstg);
     }
   } else {
@@ -430,17 +437,17 @@ __global__ __launch_bounds__(256) void conv16_kernel(const Conv16Args p) {
   // one specialised instance per epilogue kind (wave-uniform switch): no per-element branching on the kind
   if (p.out_f32) {
     switch (p.ep) {
-      case EP_BARE: conv16_epilogue<DT, WM, WN, EP_BARE, true>(p, acc, tl, smem); break;
-      case EP_LRELU: conv16_epilogue<DT, WM, WN, EP_LRELU, true>(p, acc, tl, smem); break;
-      default: conv16_epilogue<DT, WM, WN, EP_BN_EVAL, true>(p, acc, tl, smem); break;
+      case EP_BARE: conv16_epilogue<DT, WM, WN, NWN, EP_BARE, true>(p, acc, tl, smem); break;
+      case EP_LRELU: conv16_epilogue<DT, WM, WN, NWN, EP_LRELU, true>(p, acc, tl, smem); break;
+      default: conv16_epilogue<DT, WM, WN, NWN, EP_BN_EVAL, true>(p, acc, tl, smem); break;
     }
   } else {
     switch (p.ep) {
-      case EP_BARE: conv16_epilogue<DT, WM, WN, EP_BARE, false>(p, acc, tl, smem); break;
-      case EP_LRELU: conv16_epilogue<DT, WM, WN, EP_LRELU, false>(p, acc, tl, smem); break;
-      case EP_BN_EVAL: conv16_epilogue<DT, WM, WN, EP_BN_EVAL, false>(p, acc, tl, smem); break;
-      case EP_RAW_STATS: conv16_epilogue<DT, WM, WN, EP_RAW_STATS, false>(p, acc, tl, smem); break;
-      default: conv16_epilogue<DT, WM, WN, EP_DGRAD_UP2, false>(p, acc, tl, smem); break;
+      case EP_BARE: conv16_epilogue<DT, WM, WN, NWN, EP_BARE, false>(p, acc, tl, smem); break;
+      case EP_LRELU: conv16_epilogue<DT, WM, WN, NWN, EP_LRELU, false>(p, acc, tl, smem); break;
+      case EP_BN_EVAL: conv16_epilogue<DT, WM, WN, NWN, EP_BN_EVAL, false>(p, acc, tl, smem); break;
+      case EP_RAW_STATS: conv16_epilogue<DT, WM, WN, NWN, EP_RAW_STATS, false>(p, acc, tl, smem); break;
+      default: conv16_epilogue<DT, WM, WN, NWN, EP_DGRAD_UP2, false>(p, acc, tl, smem); break;
     }
   }
 }

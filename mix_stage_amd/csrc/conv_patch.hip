@@ -525,7 +525,12 @@ extern "C" int ms_debug_set_patch_tuning(int intra_split, int force_splitk) {
   return 0;
 }
 
-namespace ms { extern int g_conv16_force_wm, g_conv16_force_wn, g_conv16_dma; }
+namespace ms { extern int g_conv16_force_wm, g_conv16_force_wn, g_conv16_dma, g_conv16_wide8, g_conv16_ring, g_conv16_dbg; }
+extern "C" int ms_debug_set_conv16_ring(int nstg, int wide8) {
+  ++g_tuning_epoch;
+  ms::g_conv16_ring = nstg; ms::g_conv16_wide8 = wide8 & 1; ms::g_conv16_dbg = wide8 >> 4;
+  return 0;
+}
 extern "C" int ms_debug_set_conv16_tile(int wm, int wn) {
   ++g_tuning_epoch;
   ms::g_conv16_dma = wm >= 0 ? 1 : 0;          // negative wm: register-staged path (A/B against the LDS-DMA ring)

@@ -228,6 +228,9 @@ class MixStageTrainStep:
     weakref.finalize(self, ops.drop_trainer_caches, [self.optim_G.flat_p.untyped_storage().data_ptr(),
                                                      self.optim_D.flat_p.untyped_storage().data_ptr()])
     self.losses = None       # list of 0-dim device tensors of the last step (reference order)
+    # d(sum of losses)/d(loss) = 1: one constant on the default stream, made before any capture or side-stream pass
+    self._seed = torch.ones((), dtype=torch.float32, device=self.optim_G.flat_p.device)
+    self._last_src = {}
     self.fake_pose = None
 
   # ---- the eager pieces ------------------------------------------------------------------------------------
@@ -235,16 +238,21 @@ class MixStageTrainStep:
     return dict(input_modalities=self.model.input_modalities, desc='train', sample_flag=0, description='train',
                 style=style, time_steps=self.time_steps)
 
-  def _forward_backward(self, audio, labels, pose, style):
+  def _forward_backward(self, audio, labels, pose, style, kind=None):
     m = self.model
-    self.optim_G.zero_grad()
-    self.optim_D.zero_grad()
+    # the reference zeroes every gradient (trainer.py:604); only the network that steps receives gradients in a step (the
+    # other one is frozen or runs under no_grad), and its buffer was zeroed before its own last step: one memset, not two
+    if kind is None:
+      self.optim_G.zero_grad()
+      self.optim_D.zero_grad()
+    else:
+      (self.optim_G if kind == 'G' else self.optim_D).zero_grad()
     fake, losses, _ = m([audio, labels], pose, **self._kwargs(style))
     dev_losses = [l for l in losses if l.is_cuda and l.requires_grad]
     ops.reset_deferred_wgrad()
     ops.set_backward_overlap(self.side_stream)      # weight gradients on a side stream, joined below
     try:
-      torch.autograd.backward(dev_losses, [torch.ones_like(l) for l in dev_losses])   # == sum(losses).backward()
+      torch.autograd.backward(dev_losses, [self._seed] * len(dev_losses))   # == sum(losses).backward()
     finally:
       ops.join_backward_overlap()
       ops.set_backward_overlap(None)
@@ -282,7 +290,7 @@ class MixStageTrainStep:
       self.optim_G.resync_if_modified()
       self.optim_D.resync_if_modified()
       if not self.use_graphs:
-        self.fake_pose, self.losses = self._forward_backward(audio, labels, pose, style)
+        self.fake_pose, self.losses = self._forward_backward(audio, labels, pose, style, k)
         opt = self.optim_G if m.G_flag else self.optim_D
         active = opt.active_params()
         opt.mark_active(active)
@@ -303,8 +311,14 @@ class MixStageTrainStep:
       self._graphs = {}
     st = self._static
     for name, src in (('audio', audio), ('labels', labels), ('pose', pose), ('style', style)):
-      if src.data_ptr() != st[name].data_ptr():
+      if src.data_ptr() == st[name].data_ptr():
+        continue
+      # the very same tensor object as last step (kept alive here, so its address cannot have been recycled), unmodified
+      # as far as torch can tell: the static copy is still current
+      last = self._last_src.get(name)
+      if last is None or last[0] is not src or last[1] != src._version:
         st[name].copy_(src, non_blocking=True)
+        self._last_src[name] = (src, src._version)
     entry = self._graphs.get(key)
     opt = self.optim_G if k == 'G' else self.optim_D
     if entry is None:
@@ -340,7 +354,7 @@ class MixStageTrainStep:
     layers.set_train_tape(warm_tape)
     try:
       with torch.cuda.stream(side):
-        self._forward_backward(st['audio'], st['labels'], st['pose'], st['style'])
+        self._forward_backward(st['audio'], st['labels'], st['pose'], st['style'], k)
     finally:
       layers.set_train_tape(None)
     torch.cuda.current_stream().wait_stream(side)
@@ -360,7 +374,7 @@ class MixStageTrainStep:
     g1 = torch.cuda.CUDAGraph()
     try:
       with torch.cuda.graph(g1, capture_error_mode=mode):
-        fake, losses = self._forward_backward(st['audio'], st['labels'], st['pose'], st['style'])
+        fake, losses = self._forward_backward(st['audio'], st['labels'], st['pose'], st['style'], k)
         if self.world == 1:
           opt.clip_and_step(count=False)
     finally:

@@ -303,7 +303,10 @@ def test_cpu_tensor_fails_loudly():
   with pytest.raises(_lib.MixStageLibError):
     ops.velocity_cm(torch.zeros(1, 4, 3))
   with pytest.raises(TypeError):
-    ops.velocity_cm(torch.zeros(1, 4, 3, dtype=torch.float64, device=DEV))
+    ops.velocity_cm(torch.zeros(1, 4, 3, dtype=torch.float16, device=DEV))       # no silent cast of half tensors
+  # float64 (the reference trainer's dtype) is bridged: fp32 arithmetic, float64 in and out
+  v = ops.velocity_cm(torch.ones(1, 4, 3, dtype=torch.float64, device=DEV))
+  assert v.dtype == torch.float64 and float(v.abs().max()) == 0.0
 
 
 def test_bf16x6_mode_matches_fp32_accuracy():

@@ -8,6 +8,9 @@ from mix_stage_amd._lib import MS_BF16
 DEV = 'cuda:0'
 if len(sys.argv) > 2:
   _lib.lib().ms_debug_set_conv16_tile(int(sys.argv[1]), int(sys.argv[2]))
+if len(sys.argv) > 3:
+  _lib.lib().ms_debug_set_conv16_ring(int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 0)
+ONLY = os.environ.get('PROBE_ONLY')
 SHAPES = [
     # name, nd, B, cin, cout, groups, k, s, p, H, W
     ('dec g8 256->256 k3 T64', 1, 32, 256, 256, 8, 3, 1, 1, 1, 64),
@@ -19,6 +22,8 @@ SHAPES = [
     ('ae7 256->256 3x8 (8,16)', 2, 32, 256, 256, 1, (3, 8), 1, (1, 3), 8, 16),
 ]
 for name, nd, B, cin, cout, groups, k, s, p, H, W in SHAPES:
+  if ONLY and ONLY not in name:
+    continue
   sp = (H, W) if nd == 2 else (W,)
   kt = (k if isinstance(k, tuple) else (k, k)) if nd == 2 else (k,)
   x = torch.randn((B, cin * groups) + sp, device=DEV).requires_grad_()
