@@ -45,6 +45,7 @@ def parse():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-kernel-timing', action='store_true')
   ap.add_argument('--no-per-kind', action='store_true', help='skip the separate G-step / D-step timing')
+  ap.add_argument('--no-bf16-extra', action='store_true', help='skip the extra bf16-mode measurement attached to the fp32 line')
   ap.add_argument('--seed', type=int, default=4321)
   ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16x6', 'bf16'],
                   help='fp32: exact fp32 matrix products (default, the parity headline); bf16x6: both operands split exactly '
@@ -208,6 +209,33 @@ def kernel_roofline(ts, batch, kinds, precision):
   return roof, rows
 
 
+def bf16_extra(dev, batch, args):
+  """The same workload in the native bf16 arithmetic mode (BASELINE configs[1]/[3] dtype: bf16 operands and activations, fp32
+  accumulate / statistics / master weights), measured after the fp32 headline in the same process: G-step and D-step times,
+  their blend, and the north-star kernel's roofline entry.  Reported next to the headline, never as `value` (the 1e-4 pose
+  bar belongs to the fp32 path; bf16 pose L1 vs the fp64 oracle is measured in tests/test_gpu_model16.py)."""
+  import torch
+  from mix_stage_amd.train_step import MixStageTrainStep
+  model = build_model(dev, 'bf16')
+  ts = MixStageTrainStep(model, use_graphs=not args.no_graphs, time_steps=T)
+  torch.manual_seed(args.seed)
+  res = {}
+  n_k = max(5, min(20, args.steps))
+  for kind in ('G', 'D'):
+    for _ in range(3):
+      ts.step(*batch, kind=kind)
+    res[kind] = time_steps(ts, batch, n_k, kind, 1, None, dev)[0] / n_k
+  g_ms, d_ms = 1e3 * res['G'], 1e3 * res['D']
+  out = dict(dtype='bf16 (fp32 accumulate, fp32 BN statistics, fp32 master weights)', g_step_ms=round(g_ms, 4), d_step_ms=round(d_ms, 4),
+             value_blend_50_50=round(B_PER_GPU / (0.5e-3 * (g_ms + d_ms)), 2), unit='clips/s',
+             losses_finite=all(float(l.detach()) == float(l.detach()) for l in ts.losses))
+  if not args.no_kernel_timing:
+    out['roofline'], _ = kernel_roofline(ts, batch, ['G', 'D', 'G', 'D'], 'bf16')
+  del ts, model
+  torch.cuda.empty_cache()
+  return out
+
+
 def time_steps(ts, batch, n, kind, world, dist, dev):
   import torch
   torch.cuda.synchronize()
@@ -314,6 +342,8 @@ def main():
                                 total_ms=round(r['total_ms'], 3),
                                 tflops=round(r['flops'] / (r['total_ms'] / r['count'] * 1e-3) / 1e12, 2))
                            for r in rows[:12]]
+    if args.precision == 'fp32' and not args.no_bf16_extra and not args.no_per_kind:
+      out['bf16'] = bf16_extra(dev, batch, args)
     out['cpu_baseline'] = None if args.no_cpu_baseline else cpu_baseline(args.seed)
   if world > 1:
     dist.barrier()

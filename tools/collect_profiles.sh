@@ -1,24 +1,24 @@
 #!/bin/bash
 # GPU box: the round's measurement artifacts -> gpurun_out/final_<tag>/ (copy the summaries into profiles/ afterwards)
 set -eu
-TAG=${1:-e}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/final_$TAG
-mkdir -p $OUT
-cd $R && python bench.py > $OUT/bench_full.log 2>&1
-grep -o '{"metric.*' $OUT/bench_full.log > $OUT/bench.json
+mkdir -p "$OUT"
+cd "$R" && python bench.py > "$OUT/bench_full.log" 2>&1
+grep -o '{"metric.*' "$OUT/bench_full.log" > "$OUT/bench.json"
+python bench.py --precision bf16 --no-cpu-baseline > "$OUT/bench_bf16_full.log" 2>&1
+grep -o '{"metric.*' "$OUT/bench_bf16_full.log" > "$OUT/bench_bf16.json"
+python bench.py --precision bf16x6 --no-cpu-baseline --no-bf16-extra > "$OUT/bench_bf16x6_full.log" 2>&1
+grep -o '{"metric.*' "$OUT/bench_bf16x6_full.log" > "$OUT/bench_bf16x6.json"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --no-cpu-baseline > $OUT/stats_bench.log 2>&1
-rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 4 --warmup 2 --no-graphs --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1
-rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -- python3 $R/bench.py --steps 4 --warmup 2 --no-graphs --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1
-cd $R && python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json
-cp $OUT/stats/*/*kernel_stats.csv $OUT/kernel_stats.csv
-# keep the merge small: drop the raw traces
-rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write
-cut -c1-400 $OUT/bench.json
-# the opt-in bf16x6 arithmetic mode: bench line + kernel stats
-cd $R && python bench.py --precision bf16x6 --no-cpu-baseline > $OUT/bench_bf16x6_full.log 2>&1
-grep -o '{"metric.*' $OUT/bench_bf16x6_full.log > $OUT/bench_bf16x6.json
-cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats6 -- python3 $R/bench.py --precision bf16x6 --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1
-cp $OUT/stats6/*/*kernel_stats.csv $OUT/kernel_stats_bf16x6.csv; rm -rf $OUT/stats6
-cut -c1-200 $OUT/bench_bf16x6.json
+# rocprofv3 per-kernel durations of the same commands (graph replay); the program comes directly after `--`
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$R/bench.py" --no-cpu-baseline --no-bf16-extra > "$OUT/stats_bench.log" 2>&1
+cp "$OUT"/stats/*/*kernel_stats.csv "$OUT/kernel_stats.csv"; rm -rf "$OUT/stats"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats16" -- python3 "$R/bench.py" --precision bf16 --no-cpu-baseline > "$OUT/stats16_bench.log" 2>&1
+cp "$OUT"/stats16/*/*kernel_stats.csv "$OUT/kernel_stats_bf16.csv"; rm -rf "$OUT/stats16"
+# HBM traffic (FETCH_SIZE / WRITE_SIZE in separate passes) and SQ counters of the north-star launch, every arithmetic mode
+cd "$R" && bash tools/pmc_decoder.sh fp32 bf16x6 bf16 > "$OUT/pmc_decoder.log" 2>&1
+cp gpurun_out/pmc_decoder.json "$OUT/pmc_decoder.json"; cp gpurun_out/sq_counters.json "$OUT/sq_counters.json"
+rm -rf gpurun_out/pmcdec
+cut -c1-300 "$OUT/bench.json"; cut -c1-300 "$OUT/bench_bf16.json"

@@ -62,12 +62,20 @@ for prec in ('fp32', 'bf16x6', 'bf16'):
   if counters:
     w = counters
     der = {}
-    if 'SQ_VALU_MFMA_BUSY_CYCLES' in w and 'SQ_BUSY_CYCLES' in w and w['SQ_BUSY_CYCLES']:
-      der['mfma_busy_frac_of_sq_busy'] = round(w['SQ_VALU_MFMA_BUSY_CYCLES'] / w['SQ_BUSY_CYCLES'], 4)
-    if 'SQ_LDS_BANK_CONFLICT' in w and w.get('SQ_LDS_IDX_ACTIVE'):
-      der['lds_conflict_frac'] = round(w['SQ_LDS_BANK_CONFLICT'] / w['SQ_LDS_IDX_ACTIVE'], 4)
     if 'GRBM_GUI_ACTIVE' in w and w.get('avg_us_under_pmc'):
       der['clock_ghz_est'] = round(w['GRBM_GUI_ACTIVE'] / 8 / (w['avg_us_under_pmc'] * 1e3), 3)
+    if 'SQ_VALU_MFMA_BUSY_CYCLES' in w and w.get('avg_us_under_pmc'):
+      # busy cycles summed over the chip's 1024 SIMDs / (SIMDs x kernel cycles at the nominal 2.4 GHz)
+      der['mfma_busy_frac'] = round(w['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * w['avg_us_under_pmc'] * 2400.0), 4)
+    if 'SQ_WAVE_CYCLES' in w and w['SQ_WAVE_CYCLES']:
+      for k, name in (('SQ_WAIT_ANY', 'wait_frac_of_wave_cycles'), ('SQ_ACTIVE_INST_ANY', 'issue_frac_of_wave_cycles'),
+                      ('SQ_WAIT_INST_ANY', 'stall_frac_of_wave_cycles')):
+        if k in w:
+          der[name] = round(w[k] / w['SQ_WAVE_CYCLES'], 4)
+    if 'SQ_INSTS_VALU' in w and w.get('SQ_WAVES'):
+      der['valu_insts_per_wave'] = round(w['SQ_INSTS_VALU'] / w['SQ_WAVES'], 1)
+    if 'SQ_LDS_BANK_CONFLICT' in w and w.get('SQ_LDS_IDX_ACTIVE'):
+      der['lds_conflict_frac'] = round(w['SQ_LDS_BANK_CONFLICT'] / w['SQ_LDS_IDX_ACTIVE'], 4)
     w['derived'] = der
     w['src_hash'] = bench.source_hash()
     sq[prec] = w
