@@ -136,6 +136,10 @@ typedef struct ms_bwd_options {
   float* wgrad_partials;        /* ms_wgrad_partials_elems(d) floats: the pixel-split partial weight gradients are left
                                  * here and dw is NOT written; the caller adds them into dw later, for many blocks in one
                                  * launch, with ms_wgrad_reduce_multi.  Ignored by blocks whose dw needs no split. */
+  int defer_wgrad_launch;       /* 16-bit modes: the block's weight-gradient kernel is not launched but queued; ms_wgrad_flush
+                                 * launches every queued block in a few multi-block launches (the small layers' weight
+                                 * gradients are latency-bound one-wave kernels: side by side they cost one such latency).
+                                 * x, x2, dyr and dw / wgrad_partials must stay valid until the flush.  Ignored in fp32. */
 } ms_bwd_options;
 int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2, const float* w,
                          const float* gamma, const float* running_mean, const float* running_var,
@@ -193,6 +197,10 @@ int ms_dgrad_weights_prepare(int n, const ms_conv_desc* descs, const float* cons
  * kernel), so dw must hold zeros or the step's other contributions.
  *   ms_wgrad_partials_elems   floats of slab space for block d (0: dw is written directly), *splits = slab count */
 size_t ms_wgrad_partials_elems(const ms_conv_desc* d, int* splits);
+/* Launches the weight gradients queued by ms_bwd_options.defer_wgrad_launch on `stream`; call it
+ * before ms_wgrad_reduce_multi.  ms_wgrad_discard drops the queue (after a failed backward pass).  Returns 0 or an error. */
+int ms_wgrad_flush(void* stream);
+int ms_wgrad_discard(void);
 int ms_wgrad_reduce_multi(int n, const float* const* partials, float* const* dw, const int* elems, const int* splits,
                           void* stream);
 

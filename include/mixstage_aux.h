@@ -49,6 +49,9 @@ int ms_debug_set_patch_tuning(int intra_split, int force_splitk);
 int ms_debug_set_conv16_tile(int wm, int wn);
 /* ... and its LDS-DMA ring depth (2..4, 0 = planner) / the 8-wave form of the 128 x 128 tile (measured: no gain). */
 int ms_debug_set_conv16_ring(int nstg, int wide8);
+/* Timing ablations only: launches whose timing label contains one of the ';'-separated substrings are dropped (results are
+ * then meaningless); NULL or "" restores normal operation.  Returns the number of patterns. */
+int ms_debug_set_skip(const char* patterns);
 
 /* Self-test kernel: C(32x32) = A(32xK) * B(Kx32) through the fp32 MFMA path (checks fragment maps). */
 int ms_selftest_mfma(const float* A, const float* B, float* C, int K, void* stream);

@@ -16,7 +16,7 @@ c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_flo
 class BwdOptions(ctypes.Structure):
   """struct ms_bwd_options"""
   _fields_ = [('side_stream', ctypes.c_void_p), ('side_workspace', ctypes.c_void_p), ('side_workspace_bytes', ctypes.c_size_t),
-              ('wt_prepared', ctypes.c_void_p), ('wgrad_partials', ctypes.c_void_p)]
+              ('wt_prepared', ctypes.c_void_p), ('wgrad_partials', ctypes.c_void_p), ('defer_wgrad_launch', ctypes.c_int)]
 
 
 class FwdOptions(ctypes.Structure):
@@ -66,6 +66,8 @@ SIGNATURES = {
     'ms_get_precision': (c_int, []),
     'ms_wgrad_partials_elems': (c_size_t, [_DESC, _P]),
     'ms_wgrad_reduce_multi': (c_int, [c_int, _P, _P, _P, _P, _P]),
+    'ms_wgrad_flush': (c_int, [_P]),
+    'ms_wgrad_discard': (c_int, []),
     'ms_weights16_bytes': (c_size_t, [_DESC, c_int]),
     'ms_weights16_prepare': (c_int, [c_int, _P, _P]),
     'ms_cb8_from_plain': (c_int, [c_int, _P, _P, c_int, c_int, c_int, _P]),
@@ -107,6 +109,7 @@ SIGNATURES = {
     'ms_debug_set_patch_tuning': (c_int, [c_int, c_int]),
     'ms_debug_set_conv16_tile': (c_int, [c_int, c_int]),
     'ms_debug_set_conv16_ring': (c_int, [c_int, c_int]),
+    'ms_debug_set_skip': (c_int, [ctypes.c_char_p]),
     'ms_selftest_mfma': (c_int, [_P, _P, _P, c_int, _P]),
 }
 

@@ -430,7 +430,7 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
     if (side_stream) return set_error("ms_conv_block_bwd: no side-stream form in the 16-bit modes");
     if (d->mode == MS_BARE && out_f32_of(d) && !dyr) return set_error("ms_conv_block_bwd: fp32 dy needs the dyr scratch");
     return block_bwd16(d, x, x2, w, gamma, y_raw, y, save, dy, dyr, dx, dx2, dw, dbias, dgamma, dbeta, workspace, workspace_bytes,
-                       (hipStream_t)stream, wt_prepared, opt->wgrad_partials);
+                       (hipStream_t)stream, wt_prepared, opt->wgrad_partials, opt->defer_wgrad_launch);
   }
   if (workspace_bytes < ms_conv_block_bwd_workspace(d)) return set_error("ms_conv_block_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;

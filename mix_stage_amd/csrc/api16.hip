@@ -188,7 +188,7 @@ int block_fwd16(const ms_conv_desc* d, const void* x, const void* x2, const floa
 int block_bwd16(const ms_conv_desc* d, const void* x, const void* x2, const float* w, const float* gamma, const void* y_raw,
                 const void* y, const float* save, const void* dy, void* dyr, void* dx, void* dx2, float* dw, float* dbias,
                 float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, hipStream_t s, const void* wt_prepared,
-                float* wgrad_partials) {
+                float* wgrad_partials, int defer_wgrad_launch) {
   const Geo16 g = geo_of(d);
   if (g.dt != DT_BF16 && g.dt != DT_F16) return set_error("ms_conv_block_bwd: dtype %d", d->dtype);
   if (workspace_bytes < block_bwd16_workspace(d)) return set_error("ms_conv_block_bwd: workspace too small");
@@ -289,6 +289,8 @@ int block_bwd16(const ms_conv_desc* d, const void* x, const void* x2, const floa
     }
     const double flops = 2.0 * d->Cout * d->Cin * d->KH * d->KW * (double)g.npix * d->groups;
     const double bytes = 2.0 * ((double)g.npix * g.C + (double)d->B * g.cin_tot * d->H * d->W) + 4.0 * (double)wsize;
+    // queued form: only when nothing of this call reads the result (dw written in place, or slabs left for the caller)
+    if (defer_wgrad_launch && (wp.splits == 1 || defer)) return queue_wgrad16(g.dt, a, wp, g.up2 != 0, flops, bytes);
     rc = launch_wgrad16(g.dt, a, wp, g.up2 != 0, flops, bytes, s);
     if (rc) return rc;
     if (wp.splits > 1 && !defer) rc = launch_reduce_splits(wg_part, dw, (int)wsize, wp.splits, s);
@@ -301,6 +303,9 @@ int block_bwd16(const ms_conv_desc* d, const void* x, const void* x2, const floa
 using namespace ms;
 
 extern "C" {
+
+int ms_wgrad_flush(void* stream) { return wgrad16_flush((hipStream_t)stream); }
+int ms_wgrad_discard(void) { wgrad16_discard(); return 0; }
 
 size_t ms_weights16_bytes(const ms_conv_desc* d, int which) {
   if (!d || (dt_of(d) != DT_BF16 && dt_of(d) != DT_F16) || (which != 0 && which != 1)) return 0;

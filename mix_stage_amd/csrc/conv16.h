@@ -41,7 +41,7 @@ struct Conv16Args {
   int of_img, of_chan, of_row;         // out_f32 strides (elements)
   int PH, PW;
   int ltw, TH, PC, nchunks, tiles_x, tiles_y, gx, gy, gz;
-  int nstg;                            // LDS-DMA path: buffers in the ring (2..4)
+  int nstg;                            // LDS-DMA path: buffers in the ring (2..CONV16_MAX_RING)
   int dbg;                             // tuning experiments only (ms_debug_set_conv16_ring): bit 0 no stores, 1 no statistics reduce, 2 no K loop
   int ncls, cls_PH[4], cls_PW[4], cls_OUTH[4], cls_OUTW[4], cls_ry[4], cls_rx[4];
   unsigned a_mt_stride, a_group_stride, a_cls_stride;   // vectors
@@ -86,11 +86,22 @@ struct Wgrad16Args {
   int ltw, TH, PCX, tiles_x, tiles_y, n_tiles, tiles_per_split, splits;
   int ktg;              // tap groups per kernel row
   int gx, gy, gz;
+  int accumulate;       // splits == 1 only: out += result instead of out = result (queued launches)
   size_t out_split_stride;
 };
 struct Wgrad16Plan { int tp, tw, th, tiles_y, tiles_x, n_tiles, splits, tiles_per_split, ktg, pcx, lds_bytes; };
 Wgrad16Plan plan_wgrad16(int nd, int Cog, int Cig, int groups, int KH, int KW, int SH, int SW, int B, int OH, int OW);
 int launch_wgrad16(int dt, const Wgrad16Args& a, const Wgrad16Plan& pl, bool up2, double flops, double bytes, hipStream_t s);
+// the same launch queued (process-wide queue) for wgrad16_flush: many blocks' kernels side by side in one multi-block launch
+constexpr int WG16_MAX_JOBS = 20;    // 20 x sizeof(Wgrad16Args) + the table of block ranges stays below the 4 KB of kernel arguments
+struct Wgrad16Batch {
+  int n;
+  int block_end[WG16_MAX_JOBS];      // exclusive prefix sums of the jobs' workgroup counts
+  Wgrad16Args job[WG16_MAX_JOBS];
+};
+int queue_wgrad16(int dt, const Wgrad16Args& a, const Wgrad16Plan& pl, bool up2, double flops, double bytes);
+int wgrad16_flush(hipStream_t s);
+void wgrad16_discard();
 
 // ---- elementwise (elementwise16.hip)
 int launch_bn_apply16(int dt, const void* y_raw, void* y, float* y_f32, const float* save, int B, int C, int HW, float slope,
@@ -120,7 +131,7 @@ int block_fwd16(const ms_conv_desc* d, const void* x, const void* x2, const floa
 int block_bwd16(const ms_conv_desc* d, const void* x, const void* x2, const float* w, const float* gamma, const void* y_raw,
                 const void* y, const float* save, const void* dy, void* dyr, void* dx, void* dx2, float* dw, float* dbias,
                 float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, hipStream_t s, const void* wt_prepared,
-                float* wgrad_partials);
+                float* wgrad_partials, int defer_wgrad_launch);
 size_t weights16_bytes(const ms_conv_desc* d, int which);
 int wgrad16_splits(const ms_conv_desc* d);
 

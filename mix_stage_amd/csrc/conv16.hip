@@ -22,7 +22,7 @@ int g_conv16_force_wm = 0, g_conv16_force_wn = 0;     // tuning knob (ms_debug_s
 int g_conv16_dma = 1;                                 // tuning knob: 0 = register-staged path everywhere
 int g_conv16_wide8 = 0;                               // tuning knob: 8-wave form of the 128 x 128 tile (measured: no gain)
 int g_conv16_dbg = 0;
-int g_conv16_ring = 0;                                // tuning knob: force the LDS-DMA ring depth (0 = planner)                               // tuning knob: 8-wave form of the 128 x 128 tile
+int g_conv16_ring = 0;                                // tuning knob: force the LDS-DMA ring depth (0 = planner)
 
 Conv16Plan plan_conv16(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH, int SW, int B, int OH, int OW, int zmul,
                        bool up2) {
@@ -59,9 +59,12 @@ Conv16Plan plan_conv16(int nd, int Mg, int groups, int Kc, int KH, int KW, int S
         // CU's LDS so that two workgroups share a CU (one computes while the other waits for its stage)
         const int stage = (KW * ck8 * bm + cdiv(ck8 * th * pc, nt) * nt) * 16;
         const int budget = nwg > 256 ? 80 * 1024 : 160 * 1024;
-        int nstg = std::min(4, budget / stage);
+        // (depth up to 8: the small layers -- 64 x 64 tiles, a handful of workgroups -- are pure latency chains, and with the
+        // whole reduction in flight at once they pay one memory round trip instead of one per 3 stages)
+        const int nstages = cdiv(c8_of(Kc), ck8) * KH;
+        int nstg = std::min(std::min(CONV16_MAX_RING, nstages + 1), budget / stage);
         if (nstg < 2) nstg = std::min(4, 160 * 1024 / stage);
-        if (g_conv16_ring >= 2 && g_conv16_ring * stage <= 160 * 1024) nstg = g_conv16_ring;
+        if (g_conv16_ring >= 2) nstg = std::min(nstg, g_conv16_ring);   // knob: cap the depth
         if (nstg >= 2) { pl.dma = 1; pl.nstg = nstg; pl.lds_bytes = nstg * stage; }
       }
       (void)SV;
@@ -163,6 +166,7 @@ int launch_prep16_multi(Prep16Batch& pb, hipStream_t s) {
     jb.block_end = blocks;
   }
   TimingScope ts(s, 0, 48.0 * total, "prep16_multi_kernel|prep16_multi jobs%d", pb.n);
+  if (ts.skip()) return 0;
   hipLaunchKernelGGL(prep16_multi_kernel, dim3(blocks), dim3(256), 0, s, pb);
   return check_launch("prep16_multi_kernel");
 }
@@ -227,10 +231,13 @@ int launch_conv16(int dt, const Conv16Args& a, const Conv16Plan& pl, int KW, boo
   if ((double)b.a_cls_stride * std::max(1, a.ncls) * 16.0 >= 4.0e9) return set_error("conv16: prepared weights of 4 GB or more");
   if (a.groups > 1 && (a.Mg & 7)) return set_error("conv16: grouped blocks need a multiple of 8 output channels per group");
   const int nwg = b.gx * b.gy * b.gz;
+  char ring[16] = "";
+  if (pl.dma) snprintf(ring, sizeof(ring), " dma%d", pl.nstg);
   TimingScope ts(s, flops, bytes, "conv16_kernel<%s,%d,%d,%d,%d,%d,%d>|conv_%s_cb8 k%dx%d s%d Mg%d Kg%d g%d tiles%d tile%dx%d tw%d%s%s",
                  dt == DT_BF16 ? "bf16" : "f16", KW, pl.wm, pl.wn, up2 ? 1 : 0, pl.dma, pl.nwn, a.is_dgrad ? "dgrad" : "fwd", a.KH, KW, a.S, a.Mg,
-                 a.Kc8g * 8 * a.KH * KW, a.groups, pl.n_tiles, bm, 32 * pl.wn * pl.nwn, pl.tw, pl.dma ? (pl.nstg == 4 ? " dma4" : pl.nstg == 3 ? " dma3" : " dma2") : "",
+                 a.Kc8g * 8 * a.KH * KW, a.groups, pl.n_tiles, bm, 32 * pl.wn * pl.nwn, pl.tw, ring,
                  a.ep == EP_RAW_STATS ? " +bnstats" : "");
+  if (ts.skip()) return 0;
   const int rc = dt == DT_BF16 ? launch_kw<BF16>(b, pl, KW, up2, nwg, s) : launch_kw<F16>(b, pl, KW, up2, nwg, s);
   if (rc) return rc;
   return check_launch("conv16_kernel");

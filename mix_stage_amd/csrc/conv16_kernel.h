@@ -64,6 +64,7 @@ __device__ inline u32x4 buf_load_v(__amdgpu_buffer_rsrc_t r, unsigned voff, unsi
 
 constexpr int conv16_ck8(int KW) { return KW == 8 ? 2 : 4; }
 constexpr int CONV16_NP = 6;      // patch vectors a thread stages per stage at most (plan_conv16 keeps CK8*TH*PC <= 6*256)
+constexpr int CONV16_MAX_RING = 8; // LDS-DMA ring depth limit (buffers; one less is in flight)
 
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
 __device__ inline void wait_vmcnt(int n) {
@@ -72,7 +73,9 @@ __device__ inline void wait_vmcnt(int n) {
     MS_VM(0) MS_VM(1) MS_VM(2) MS_VM(3) MS_VM(4) MS_VM(5) MS_VM(6) MS_VM(7) MS_VM(8) MS_VM(9) MS_VM(10) MS_VM(11) MS_VM(12)
     MS_VM(13) MS_VM(14) MS_VM(15) MS_VM(16) MS_VM(17) MS_VM(18) MS_VM(19) MS_VM(20) MS_VM(21) MS_VM(22) MS_VM(23) MS_VM(24)
     MS_VM(25) MS_VM(26) MS_VM(27) MS_VM(28) MS_VM(29) MS_VM(30) MS_VM(31) MS_VM(32) MS_VM(33) MS_VM(34) MS_VM(35) MS_VM(36)
-    MS_VM(37) MS_VM(38) MS_VM(39) MS_VM(40) MS_VM(41) MS_VM(42)
+    MS_VM(37) MS_VM(38) MS_VM(39) MS_VM(40) MS_VM(41) MS_VM(42) MS_VM(43) MS_VM(44) MS_VM(45) MS_VM(46) MS_VM(47) MS_VM(48)
+    MS_VM(49) MS_VM(50) MS_VM(51) MS_VM(52) MS_VM(53) MS_VM(54) MS_VM(55) MS_VM(56) MS_VM(57) MS_VM(58) MS_VM(59) MS_VM(60)
+    MS_VM(61) MS_VM(62) MS_VM(63)
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 #undef MS_VM

@@ -86,6 +86,7 @@ int launch_conv_c1(const float* x, const float* w, const float* bias, float* out
   const double npix = (double)B * H * W;
   TimingScope ts(s, 2.0 * npix * 64 * 9, 4.0 * npix * 65, "conv_c1_3x3_kernel<64>|conv_fwd_c1 k3x3 Cout64 N%.0f%s", npix,
                  ep == EP_RAW_STATS ? " +bnstats" : "");
+  if (ts.skip()) return 0;
   hipLaunchKernelGGL(conv_c1_3x3_kernel<64>, dim3(cdiv(B * H * W, 256)), dim3(256), 0, s, x, w, bias, out, bn_g, bn_b, bn_m, bn_v,
                      stats, counts, B, H, W, ep, slope, eps);
   return check_launch("conv_c1_3x3_kernel");

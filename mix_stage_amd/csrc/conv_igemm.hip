@@ -578,6 +578,7 @@ int launch_gather(GatherArgs a, bool transposed, bool up2, const GatherPlan& pla
                  "igemm_gather_kernel<%d,%d,%d,%d,%d,%d>|%s k%dx%d s%d Mg%d Kg%d g%d N%.0f tile%d splitk%d%s", plan.tm, plan.tn,
                  a.KH, a.KW, transposed ? 1 : 0, (up2 && !transposed) ? 1 : 0, transposed ? "conv_dgrad" : "conv_fwd", a.KH, a.KW,
                  a.SW, a.Mg, a.Kg, a.groups, opix, bm, plan.splitk, a.ep == EP_RAW_STATS ? " +bnstats" : "");
+  if (ts.skip()) return 0;
   if (transposed) up2 = false;  // the UP2 split store of the data gradient is a runtime epilogue (EP_DGRAD_UP2)
   if (plan.tm == 2) {
     if (transposed) launch_gather_khw<2, 2, true, false>(a, grid, s);
@@ -589,6 +590,19 @@ int launch_gather(GatherArgs a, bool transposed, bool up2, const GatherPlan& pla
     else launch_gather_khw<1, 1, false, false>(a, grid, s);
   }
   return check_launch("igemm_gather_kernel");
+}
+
+// acc + p[0] + p[stride] + ... (slices in order); 4 loads in flight instead of a load -> wait -> add chain per slice
+__device__ inline float sum_slices(const float* __restrict__ p, int n, size_t stride, float acc) {
+  for (int k0 = 0; k0 < n; k0 += 4) {
+    float tmp[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) tmp[kk] = p[(size_t)min(k0 + kk, n - 1) * stride];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      if (k0 + kk < n) acc += tmp[kk];
+  }
+  return acc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -613,16 +627,31 @@ __global__ __launch_bounds__(256) void splitk_fwd_epilogue_kernel(const float* _
   float s1 = 0.f;
 #pragma unroll
   for (int i = 0; i < NE; ++i) {
-    const int e = t + i * 256;
+    const int e = min(t + i * 256, N - 1);
     const int b = e / HW, pix = e - b * HW;
     off[i] = ((size_t)b * C + c) * HW + pix;
-    float acc = 0.f;
-    if (e < N) {
-      acc = bsv;
-      for (int k = 0; k < splitk; ++k) acc += part[(size_t)k * part_stride + off[i]];
+    v[i] = bsv;
+  }
+  // slices summed in order k = 0, 1, ... per element; the loads of 4 slices x NE elements are in flight together
+  for (int k0 = 0; k0 < splitk; k0 += 4) {
+    float tmp[4][NE];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const float* pk = part + (size_t)min(k0 + kk, splitk - 1) * part_stride;
+#pragma unroll
+      for (int i = 0; i < NE; ++i) tmp[kk][i] = pk[off[i]];
     }
-    v[i] = acc;
-    s1 += acc;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      if (k0 + kk < splitk) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) v[i] += tmp[kk][i];
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    if (t + i * 256 >= N) v[i] = 0.f;
+    s1 += v[i];
   }
   if (ep != EP_RAW_STATS) {
     float sc = 1.f, sh = 0.f;
@@ -691,15 +720,15 @@ __global__ __launch_bounds__(256) void splitk_fwd_epilogue_big_kernel(const floa
   for (int e = t; e < N; e += 256) {
     const int b = e / HW, pix = e - b * HW;
     const size_t off = ((size_t)b * C + c) * HW + pix;
-    float v = bsv;
-    for (int k = 0; k < splitk; ++k) v += part[(size_t)k * part_stride + off];
+    const float v = sum_slices(part + off, splitk, part_stride, bsv);
     if (ep == EP_RAW_STATS) {
       y_raw[off] = v;
       s1 += v;
     } else {
-      if (ep == EP_BN_EVAL) v = lrelu(fmaf(v, sc, sh), slope);
-      if (ep == EP_LRELU) v = lrelu(v, slope);
-      y[off] = v;
+      float o = v;
+      if (ep == EP_BN_EVAL) o = lrelu(fmaf(o, sc, sh), slope);
+      if (ep == EP_LRELU) o = lrelu(o, slope);
+      y[off] = o;
     }
   }
   if (ep != EP_RAW_STATS) return;
@@ -737,17 +766,19 @@ __global__ __launch_bounds__(256) void splitk_dgrad_epilogue_kernel(const float*
                                                                     float* __restrict__ dx2, size_t n, int up2) {
   if (!up2) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-      float v = 0.f;
-      for (int k = 0; k < splitk; ++k) v += part[(size_t)k * part_stride + i];
-      dx[i] = v;
+      dx[i] = sum_slices(part + i, splitk, part_stride, 0.f);
     }
   } else {
     const size_t half = n >> 1;   // W is even: pairs never straddle rows
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < half; i += (size_t)gridDim.x * 256) {
       float v0 = 0.f, v1 = 0.f;
-      for (int k = 0; k < splitk; ++k) {
-        v0 += part[(size_t)k * part_stride + 2 * i];
-        v1 += part[(size_t)k * part_stride + 2 * i + 1];
+      for (int k0 = 0; k0 < splitk; k0 += 4) {
+        float2 tmp[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) tmp[kk] = *(const float2*)(part + (size_t)min(k0 + kk, splitk - 1) * part_stride + 2 * i);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          if (k0 + kk < splitk) { v0 += tmp[kk].x; v1 += tmp[kk].y; }
       }
       dx2[2 * i] = v0;
       dx2[2 * i + 1] = v1;
@@ -760,6 +791,7 @@ int launch_splitk_fwd_epilogue(const float* part, int splitk, size_t part_stride
                                const float* beta, float* rm, float* rv, float* y_raw, float* y, float* save, int B, int C,
                                int HW, int ep, float slope, float eps, float momentum, hipStream_t s) {
   TimingScope ts(s, 0, 4.0 * B * C * HW * (splitk + 3), "splitk_fwd_epilogue C%d N%d splitk%d ep%d", C, B * HW, splitk, ep);
+  if (ts.skip()) return 0;
 #define MS_SKE(K) hipLaunchKernelGGL(K, dim3(C), dim3(256), 0, s, part, splitk, part_stride, bias, gamma, beta, rm, rv, \
                                      y_raw, y, save, B, C, HW, ep, slope, eps, momentum)
   const long n = (long)B * HW;
@@ -777,6 +809,7 @@ int launch_splitk_dgrad_epilogue(const float* part, int splitk, size_t part_stri
                                  int up2, hipStream_t s) {
   (void)W;
   TimingScope ts(s, 0, 4.0 * n * (splitk + 1), "splitk_dgrad_epilogue n%zu splitk%d", n, splitk);
+  if (ts.skip()) return 0;
   const size_t work = up2 ? n / 2 : n;
   int blocks = (int)std::min<size_t>((work + 255) / 256, 2048);
   if (blocks < 1) blocks = 1;
@@ -816,6 +849,7 @@ static void launch_wgrad_khw(const WgradArgs& a, dim3 grid, hipStream_t s) {
 
 int launch_reduce_splits(const float* part, float* out, int n, int splits, hipStream_t s) {
   TimingScope ts(s, 0, 4.0 * n * (splits + 1), "wgrad_reduce_splits n%d splits%d", n, splits);
+  if (ts.skip()) return 0;
   if (splits >= 32 && n <= 65536)
     hipLaunchKernelGGL(reduce_splits_wave_kernel, dim3(cdiv(n, 4)), dim3(256), 0, s, part, out, n, splits);
   else
@@ -834,6 +868,7 @@ int launch_reduce_splits_multi(ReduceBatch& rb, hipStream_t s) {
     bytes += 4.0 * jb.n * (jb.splits + 2);
   }
   TimingScope ts(s, 0, bytes, "wgrad_reduce_multi jobs%d", rb.n);
+  if (ts.skip()) return 0;
   hipLaunchKernelGGL(reduce_splits_multi_kernel, dim3(blocks), dim3(256), 0, s, rb);
   return check_launch("reduce_splits_multi_kernel");
 }
@@ -853,6 +888,7 @@ int launch_wgrad(WgradArgs a, bool up2, float* dw, float* partial_ws, bool defer
                    "wgrad_kernel<1,1,%d,%d,%d>|conv_wgrad k%dx%d s%d Cog%d Kg%d g%d N%d splits%d", a.KH, a.KW, up2 ? 1 : 0, a.KH,
                    a.KW, a.SW, a.Cog, a.Kg, a.groups, a.Npix,
                    a.splits);
+    if (ts.skip()) return 0;
     if (up2) launch_wgrad_khw<true>(a, grid, s); else launch_wgrad_khw<false>(a, grid, s);
     rc = check_launch("wgrad_kernel");
   }
@@ -874,6 +910,7 @@ int launch_transpose_weight(const float* w, float* wt, int groups, int Cog, int 
   TransposeJob jb = {w, wt, groups, Cog, Cig, KH, KW, SH, SW, PH, PW, flip, 0};
   const int total = transpose_total(jb);
   TimingScope ts(s, 0, 8.0 * total, "transpose_weight n%d", total);
+  if (ts.skip()) return 0;
   hipLaunchKernelGGL(transpose_weight_kernel, dim3(min(cdiv(total, 256), 4096)), dim3(256), 0, s, jb);
   return check_launch("transpose_weight_kernel");
 }
@@ -888,6 +925,7 @@ int launch_transpose_weight_multi(TransposeBatch& tb, hipStream_t s) {
     total += n;
   }
   TimingScope ts(s, 0, 8.0 * total, "transpose_weight_multi jobs%d n%.0f", tb.n, total);
+  if (ts.skip()) return 0;
   hipLaunchKernelGGL(transpose_weight_multi_kernel, dim3(blocks), dim3(256), 0, s, tb);
   return check_launch("transpose_weight_multi_kernel");
 }

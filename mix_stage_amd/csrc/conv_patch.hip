@@ -494,6 +494,7 @@ int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S,
                  KH, KW, S, pl.tw, up2 ? 1 : 0, am, pl.wm, pl.ksi, a.is_dgrad ? "dgrad" : "fwd", KH, KW, S, a.Mg, a.Kg,
                  a.groups, pl.n_tiles, bm, pl.tw, a.splitk, pl.ksi > 1 ? " intra4" : "",
                  (a.ep == EP_RAW_STATS && !a.part) ? " +bnstats" : "");
+  if (ts.skip()) return 0;
   if (pl.ksi > 1) {
     if (pl.wm != 1 || pl.ksi != 4 || KH != 1 || KW != 3 || S != 1 || pl.tw < 32) return set_error("patch conv: no such intra-split kernel");
     if (am == 2) launch_patch_intra<2>(b, pl.tw, up2, grid, s);

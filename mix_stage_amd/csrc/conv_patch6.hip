@@ -110,6 +110,7 @@ int launch_split_weights_multi(SplitBatch& sb, hipStream_t s) {
     total += (double)n;
   }
   TimingScope ts(s, 0, 10.0 * total, "split_weights_multi jobs%d n%.0f", sb.n, total);
+  if (ts.skip()) return 0;
   hipLaunchKernelGGL(split_weights_multi_kernel, dim3(blocks), dim3(256), 0, s, sb);
   return check_launch("split_weights_multi_kernel");
 }
@@ -118,6 +119,7 @@ int launch_split_weights(const float* w, unsigned short* planes, int rows, int K
   const int khw = KH * KW, re = patch6_row_elems(Kc, KH, KW);
   const size_t total = (size_t)rows * re;
   TimingScope ts(s, 0, 4.0 * rows * Kc * khw + 6.0 * total, "split_weights rows%d Kc%d khw%d", rows, Kc, khw);
+  if (ts.skip()) return 0;
   hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, s, w, planes,
                      rows, Kc, khw, p6_ck(khw), re);
   return check_launch("split_weights_kernel");
@@ -430,6 +432,7 @@ int launch_patch6(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S
   TimingScope ts(s, flops, bytes, "conv_patch6_kernel<%d,%d,%d,%d,%d>|conv_%s_patch6 k%dx%d s%d Mg%d Kg%d g%d tiles%d tw%d splitk%d%s",
                  KH, KW, S, pl.tw, up2 ? 1 : 0, a.is_dgrad ? "dgrad" : "fwd", KH, KW, S, a.Mg, a.Kg, a.groups, pl.n_tiles, pl.tw,
                  a.splitk, (a.ep == EP_RAW_STATS && !a.part) ? " +bnstats" : "");
+  if (ts.skip()) return 0;
   if (KH == 1 && KW == 3 && S == 1) {
     if (up2) launch_p6_tw<1, 3, 1, true>(b, pl.tw, grid, s);
     else launch_p6_tw<1, 3, 1, false>(b, pl.tw, grid, s);
@@ -645,6 +648,7 @@ int launch_wgrad_patch6(const WgradPatchArgs& a, const WgradPatchPlan& pl, int K
   dim3 grid(b.gx * b.gy * b.gz);
   TimingScope ts(s, flops, bytes, "wgrad_patch6_kernel<%d,%d,%d,%d,%d>|conv_wgrad_patch6 k%dx%d s%d Cog%d Kg%d g%d tiles%d tw%d splits%d",
                  KH, KW, S, pl.tw, up2 ? 1 : 0, KH, KW, S, a.Cog, a.Kg, a.groups, pl.n_tiles, pl.tw, a.splits);
+  if (ts.skip()) return 0;
   if (!wgrad6_supported(KH, KW, S)) return set_error("wgrad6: unsupported geometry");
   if (KH == 1 && KW == 3 && S == 1) {
     if (up2) launch_wg6_tw<1, 3, 1, true>(b, pl.tw, grid, s);

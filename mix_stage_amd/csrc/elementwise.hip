@@ -210,36 +210,40 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const float* __restri
   __shared__ float red[4];
   const int c = blockIdx.x, t = threadIdx.x;
   const int n = B * HW;
-  const float mean = save[c], invstd = save[C + c], sc = save[2 * C + c], sh = save[3 * C + c];
+  // every load is issued before the first one is consumed (clamped indices instead of branches): the kernel pays one
+  // memory round trip, not NE of them -- with one wave per SIMD nothing else hides that latency
+  float ry[NE], rg[NE];
+  size_t ofs[NE];
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = min(t + i * 256, n - 1);
+    const int b = e / HW, pix = e - b * HW;
+    ofs[i] = ((size_t)b * C + c) * HW + pix;
+    ry[i] = y_raw[ofs[i]];
+    rg[i] = dy[ofs[i]];
+  }
+  const float mean = save[c], invstd = save[C + c], sc = save[2 * C + c], sh = save[3 * C + c], gm = gamma[c];
   float dz[NE], xh[NE];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < NE; ++i) {
-    const int e = t + i * 256;
-    dz[i] = 0.f; xh[i] = 0.f;
-    if (e < n) {
-      const int b = e / HW, pix = e - b * HW;
-      const size_t off = ((size_t)b * C + c) * HW + pix;
-      const float yr = y_raw[off];
-      const float z = fmaf(yr, sc, sh);
-      dz[i] = dy[off] * (z > 0.f ? 1.f : slope);
-      xh[i] = (yr - mean) * invstd;
-      s1 += dz[i];
-      s2 += dz[i] * xh[i];
-    }
+    const bool ok = t + i * 256 < n;
+    const float z = fmaf(ry[i], sc, sh);
+    dz[i] = ok ? rg[i] * (z > 0.f ? 1.f : slope) : 0.f;
+    xh[i] = ok ? (ry[i] - mean) * invstd : 0.f;
+    s1 += dz[i];
+    s2 += dz[i] * xh[i];
   }
   s1 = block_sum_256(s1, red);
   s2 = block_sum_256(s2, red);
   const float invN = 1.0f / (float)n;
-  const float gi = gamma[c] * invstd, m1 = s1 * invN, m2 = s2 * invN;
+  const float gi = gm * invstd, m1 = s1 * invN, m2 = s2 * invN;
   float cs = 0.f;
 #pragma unroll
   for (int i = 0; i < NE; ++i) {
-    const int e = t + i * 256;
-    if (e < n) {
-      const int b = e / HW, pix = e - b * HW;
+    if (t + i * 256 < n) {
       const float v = gi * (dz[i] - m1 - xh[i] * m2);
-      dyr[((size_t)b * C + c) * HW + pix] = v;
+      dyr[ofs[i]] = v;
       cs += v;
     }
   }
@@ -827,6 +831,7 @@ static inline int red_blocks(size_t n) {
 int launch_bn_finalize(const float* stats, const float* counts, int n_tiles, int tile_n, int N, int C, const float* gamma,
                        const float* beta, float* rm, float* rv, float* save, float eps, float momentum, hipStream_t s) {
   TimingScope ts(s, 0, 8.0 * n_tiles * C, "bn_finalize C%d tiles%d", C, n_tiles);
+  if (ts.skip()) return 0;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, s, stats, counts, n_tiles, tile_n, N, C, gamma, beta, rm, rv, save,
                      eps, momentum);
   return check_launch("bn_finalize_kernel");
@@ -837,6 +842,7 @@ int launch_bn_apply(const float* y_raw, float* y, const float* save, int C, int 
   int blocks = (int)std::min<size_t>((work + 255) / 256, 4096);
   if (blocks < 1) blocks = 1;
   TimingScope ts(s, 0, 8.0 * total, "bn_apply C%d HW%d n%zu", C, HW, total);
+  if (ts.skip()) return 0;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, s, y_raw, y, save, C, HW, total, slope);
   return check_launch("bn_apply_kernel");
 }
@@ -858,6 +864,7 @@ int launch_bn_bwd(const float* dy, const float* y_raw, const float* save, const 
   const long n = (long)B * HW;
   if (n <= 256 * 16) {
     TimingScope ts(s, 0, 12.0 * B * C * HW, "bn_bwd_fused C%d HW%d B%d", C, HW, B);
+    if (ts.skip()) return 0;
     if (n <= 256 * 4)
       hipLaunchKernelGGL(bn_bwd_fused_kernel<4>, dim3(C), dim3(256), 0, s, dy, y_raw, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope);
     else if (n <= 256 * 8)
@@ -870,6 +877,7 @@ int launch_bn_bwd(const float* dy, const float* y_raw, const float* save, const 
   int bpc;
   const int nchunk = bwd_chunks(B, C, &bpc);
   TimingScope ts(s, 0, 20.0 * B * C * HW, "bn_bwd(reduce+apply) C%d HW%d B%d", C, HW, B);
+  if (ts.skip()) return 0;
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, nchunk), dim3(256), 0, s, dy, y_raw, save, partial, B, C, HW, bpc, slope);
   int rc = check_launch("bn_bwd_reduce_kernel");
   if (rc) return rc;
@@ -883,6 +891,7 @@ int launch_act_bwd(const float* dy, const float* y, float* dyr, float* colpart, 
   int bpc;
   const int nchunk = bwd_chunks(B, C, &bpc);
   TimingScope ts(s, 0, (mode == 1 ? 12.0 : 4.0) * B * C * HW, "act_bwd C%d HW%d B%d mode%d", C, HW, B, mode);
+  if (ts.skip()) return 0;
   hipLaunchKernelGGL(act_bwd_kernel, dim3(C, nchunk), dim3(256), 0, s, dy, y, dyr, colpart, B, C, HW, bpc, mode, slope);
   return check_launch("act_bwd_kernel");
 }
@@ -901,18 +910,24 @@ using namespace ms;
 extern "C" {
 
 int ms_lerp_time_fwd(const float* x, float* y, int B, int C, int Tin, int F, int Tout, void* stream) {
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_lerp_time_fwd");
+  if (ts.skip()) return 0;
   const int n = B * C * Tout;
   hipLaunchKernelGGL(lerp_time_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, B * C, Tin, F, Tout);
   return check_launch("lerp_time_fwd_kernel");
 }
 
 int ms_lerp_time_bwd(const float* dy, float* dx, int B, int C, int Tin, int F, int Tout, void* stream) {
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_lerp_time_bwd");
+  if (ts.skip()) return 0;
   const int n = B * C * Tin * F;
   hipLaunchKernelGGL(lerp_time_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, B * C, Tin, F, Tout);
   return check_launch("lerp_time_bwd_kernel");
 }
 
 int ms_softmax_mix_fwd(const float* z, const float* score, float* soft, float* out, int B, int M, int P, int T, void* stream) {
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_softmax_mix_fwd");
+  if (ts.skip()) return 0;
   // feature chunks: enough workgroups for the chip (B=32, T=64 alone gives 32)
   const int tiles = cdiv(T, MIX_TT) * B;
   int nch = std::max(1, std::min(P, 512 / std::max(1, tiles)));
@@ -927,6 +942,8 @@ int ms_softmax_mix_fwd(const float* z, const float* score, float* soft, float* o
 
 int ms_softmax_mix_bwd(const float* z, const float* soft, const float* dout, float* dz, float* dscore, int B, int M, int P,
                        int T, void* stream) {
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_softmax_mix_bwd");
+  if (ts.skip()) return 0;
   const size_t lds = ((size_t)4 * MIX_TT + (size_t)MIX_TT * (P + 1)) * sizeof(float);
   if (lds > 160 * 1024) return set_error("ms_softmax_mix_bwd: M=%d P=%d needs %zu B of LDS", M, P, lds);
   if (M > 65535) return set_error("ms_softmax_mix_bwd: M=%d", M);
@@ -939,6 +956,8 @@ int ms_softmax_mix_bwd(const float* z, const float* soft, const float* dout, flo
 }
 
 int ms_bn_stats(const float* y_raw, float* stats, int B, int C, int HW, void* stream) {
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_bn_stats");
+  if (ts.skip()) return 0;
   if (!y_raw || !stats || B < 1 || C < 1 || HW < 1) return set_error("ms_bn_stats: bad argument");
   hipLaunchKernelGGL(bn_stats_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, y_raw, stats, B, C, HW);
   return check_launch("bn_stats_kernel");
@@ -947,6 +966,8 @@ int ms_bn_stats(const float* y_raw, float* stats, int B, int C, int HW, void* st
 int ms_bn_train_apply(const float* stats_all, int world, int n_local, const float* gamma, const float* beta, float* running_mean,
                       float* running_var, const float* y_raw, float* y, float* save, int B, int C, int HW, float eps,
                       float momentum, float slope, void* stream) {
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_bn_train_apply");
+  if (ts.skip()) return 0;
   if (!stats_all || world < 1 || n_local != B * HW || !gamma || !beta || !running_mean || !running_var || !y_raw || !y || !save)
     return set_error("ms_bn_train_apply: bad argument");
   hipStream_t s = (hipStream_t)stream;
@@ -963,6 +984,8 @@ size_t ms_bn_bwd_workspace(int B, int C) {
 
 int ms_bn_bwd_sums(const float* dy, const float* y_raw, const float* save, float* sums, int B, int C, int HW, float slope,
                    void* workspace, size_t workspace_bytes, void* stream) {
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_bn_bwd_sums");
+  if (ts.skip()) return 0;
   if (!dy || !y_raw || !save || !sums || !workspace || workspace_bytes < ms_bn_bwd_workspace(B, C)) return set_error("ms_bn_bwd_sums: bad argument");
   int bpc;
   const int nchunk = bwd_chunks(B, C, &bpc);
@@ -974,6 +997,8 @@ int ms_bn_bwd_sums(const float* dy, const float* y_raw, const float* save, float
 
 int ms_bn_bwd_apply(const float* dy, const float* y_raw, const float* save, const float* gamma, const float* sums_global,
                     double n_global, float* dyr, int B, int C, int HW, float slope, void* stream) {
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_bn_bwd_apply");
+  if (ts.skip()) return 0;
   if (!dy || !y_raw || !save || !gamma || !sums_global || !dyr || n_global < 1) return set_error("ms_bn_bwd_apply: bad argument");
   const int gy = std::max(1, std::min(64, (B * HW + 2047) / 2048));
   hipLaunchKernelGGL(bn_bwd_apply_sums_kernel, dim3(C, gy), dim3(256), 0, (hipStream_t)stream, dy, y_raw, save, gamma, sums_global,
@@ -983,6 +1008,8 @@ int ms_bn_bwd_apply(const float* dy, const float* y_raw, const float* save, cons
 
 int ms_kmeans_labels(const float* pose, const int32_t* keep, const double* centers, int64_t* labels, int B, int T, int P,
                      int PK, int M, int feats, void* stream) {
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_kmeans_labels");
+  if (ts.skip()) return 0;
   if (!pose || !keep || !centers || !labels || B < 1 || T < 1 || PK < 1 || M < 1) return set_error("ms_kmeans_labels: bad argument");
   if (!(feats & 7) || (feats & ~7) || ((feats & 4) && (PK & 1))) return set_error("ms_kmeans_labels: feats must be a subset of pose|velocity|speed (1|2|4)");
   const int BT = B * T;
@@ -993,6 +1020,8 @@ int ms_kmeans_labels(const float* pose, const int32_t* keep, const double* cente
 
 int ms_znorm_select(const float* x, const int32_t* keep, const double* mean, const double* inv_std, float* y, size_t rows, int P,
                     int PK, void* stream) {
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_znorm_select");
+  if (ts.skip()) return 0;
   int blocks = (int)std::min<size_t>((rows * PK + 255) / 256, 2048);
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(znorm_select_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, keep, mean, inv_std, y, rows, P, PK);
@@ -1001,6 +1030,8 @@ int ms_znorm_select(const float* x, const int32_t* keep, const double* mean, con
 
 int ms_step_metrics(const float* ycap, const float* gt, const int32_t* keep, const int32_t* slot_of, const double* mean,
                     const double* stdv, const float* alphas, int n_alpha, double* out, int B, int T, int P, int PK, void* stream) {
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_step_metrics");
+  if (ts.skip()) return 0;
   if (P / 2 > 64) return set_error("ms_step_metrics: more than 64 joints");
   const size_t lds = (size_t)(2 + n_alpha * (P / 2) + 8) * sizeof(double);
   hipLaunchKernelGGL(step_metrics_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, ycap, gt, keep, slot_of, mean, stdv, alphas,
@@ -1010,6 +1041,8 @@ int ms_step_metrics(const float* ycap, const float* gt, const int32_t* keep, con
 
 int ms_concat_style_fwd(const float* x, const float* emb, const int64_t* ids, int ids_stride_b, int ids_stride_t, float* out,
                         int B, int C, int D, int T, void* stream) {
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_concat_style_fwd");
+  if (ts.skip()) return 0;
   const size_t total = (size_t)B * (C + D) * T;
   int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
   hipLaunchKernelGGL(concat_style_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, emb, ids, ids_stride_b,
@@ -1019,6 +1052,8 @@ int ms_concat_style_fwd(const float* x, const float* emb, const int64_t* ids, in
 
 int ms_concat_style_bwd(const float* dout, const int64_t* ids, int ids_stride_b, int ids_stride_t, float* dx, float* demb,
                         int B, int C, int D, int T, int S, void* stream) {
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_concat_style_bwd");
+  if (ts.skip()) return 0;
   if (dx) {
     const size_t total = (size_t)B * C * T;
     int blocks = (int)std::min<size_t>((total + 255) / 256, 2048);
@@ -1036,6 +1071,8 @@ int ms_concat_style_bwd(const float* dout, const int64_t* ids, int ids_stride_b,
 
 int ms_cross_entropy_fwd(const float* score, const int64_t* target, float* loss, float* row_scratch, int n_outer, int n_inner,
                          int C, int stride_outer, int stride_c, int stride_inner, void* stream) {
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_cross_entropy_fwd");
+  if (ts.skip()) return 0;
   (void)row_scratch;
   hipLaunchKernelGGL(cross_entropy_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, score, target, loss, n_outer, n_inner,
                      C, stride_outer, stride_c, stride_inner);
@@ -1044,6 +1081,8 @@ int ms_cross_entropy_fwd(const float* score, const int64_t* target, float* loss,
 
 int ms_cross_entropy_bwd(const float* score, const int64_t* target, const float* gscale, float* dscore, int n_outer, int n_inner,
                          int C, int stride_outer, int stride_c, int stride_inner, int accumulate, void* stream) {
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_cross_entropy_bwd");
+  if (ts.skip()) return 0;
   const int rows = n_outer * n_inner;
   hipLaunchKernelGGL(cross_entropy_bwd_kernel, dim3(cdiv(rows, 64)), dim3(64), 0, (hipStream_t)stream, score, target, gscale,
                      dscore, n_outer, n_inner, C, stride_outer, stride_c, stride_inner, accumulate);
@@ -1051,21 +1090,29 @@ int ms_cross_entropy_bwd(const float* score, const int64_t* target, const float*
 }
 
 int ms_velocity_fwd(const float* x, float* v, int B, int T, int P, void* stream) {
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_velocity_fwd");
+  if (ts.skip()) return 0;
   hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(P, 32), cdiv(T, 32), B), dim3(256), 0, (hipStream_t)stream, x, v, T, P, 1);
   return check_launch("transpose_kernel(velocity)");
 }
 
 int ms_velocity_bwd(const float* dv, float* dx, int B, int T, int P, void* stream) {
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_velocity_bwd");
+  if (ts.skip()) return 0;
   hipLaunchKernelGGL(velocity_bwd_kernel, dim3(cdiv(T, 32), cdiv(P, 32), B), dim3(256), 0, (hipStream_t)stream, dv, dx, T, P);
   return check_launch("velocity_bwd_kernel");
 }
 
 int ms_transpose_btc(const float* x, float* y, int B, int T, int C, void* stream) {
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_transpose_btc");
+  if (ts.skip()) return 0;
   hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(C, 32), cdiv(T, 32), B), dim3(256), 0, (hipStream_t)stream, x, y, T, C, 0);
   return check_launch("transpose_kernel");
 }
 
 int ms_transpose_bct(const float* x, float* y, int B, int C, int T, void* stream) {
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_transpose_bct");
+  if (ts.skip()) return 0;
   hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(T, 32), cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream, x, y, C, T, 0);
   return check_launch("transpose_kernel");
 }
@@ -1090,19 +1137,29 @@ static int lp_mean_bwd(int sq, const float* a, const float* b, float target, con
 }
 
 int ms_l1_mean_fwd(const float* a, const float* b, float target, float* loss, float* partials, size_t n, void* stream) {
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_l1_mean_fwd");
+  if (ts.skip()) return 0;
   return lp_mean_fwd(0, a, b, target, loss, partials, n, stream);
 }
 int ms_l1_mean_bwd(const float* a, const float* b, float target, const float* gscale, float* da, size_t n, void* stream) {
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_l1_mean_bwd");
+  if (ts.skip()) return 0;
   return lp_mean_bwd(0, a, b, target, gscale, da, n, stream);
 }
 int ms_l2_mean_fwd(const float* a, const float* b, float target, float* loss, float* partials, size_t n, void* stream) {
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_l2_mean_fwd");
+  if (ts.skip()) return 0;
   return lp_mean_fwd(1, a, b, target, loss, partials, n, stream);
 }
 int ms_l2_mean_bwd(const float* a, const float* b, float target, const float* gscale, float* da, size_t n, void* stream) {
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_l2_mean_bwd");
+  if (ts.skip()) return 0;
   return lp_mean_bwd(1, a, b, target, gscale, da, n, stream);
 }
 
 int ms_sqnorm(const float* g, size_t n, float* norm_out, float* partials, void* stream) {
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_sqnorm");
+  if (ts.skip()) return 0;
   const int nb = red_blocks(n);
   hipLaunchKernelGGL(sq_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, partials, n);
   int rc = check_launch("sq_partial_kernel");
@@ -1113,6 +1170,8 @@ int ms_sqnorm(const float* g, size_t n, float* norm_out, float* partials, void* 
 
 int ms_adam_step(float* p, const float* g, float* m, float* v, size_t n, const float* norm, float max_norm, float lr,
                  float beta1, float beta2, float eps, int32_t* step_state, void* stream) {
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_adam_step");
+  if (ts.skip()) return 0;
   hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_state, norm, max_norm, lr, beta1, beta2);
   int rc = check_launch("adam_prep_kernel");
   if (rc) return rc;
@@ -1125,6 +1184,8 @@ int ms_adam_step(float* p, const float* g, float* m, float* v, size_t n, const f
 int ms_adam_step_segmented(float* p, const float* g, float* m, float* v, size_t n, const float* norm, float max_norm, float lr,
                            float beta1, float beta2, float eps, int32_t* step_state, const int32_t* seg_of_chunk,
                            const int32_t* seg_first_step, float* seg_scratch, int n_seg, void* stream) {
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_adam_step_segmented");
+  if (ts.skip()) return 0;
   hipLaunchKernelGGL(adam_prep_seg_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, step_state, norm, max_norm, lr, beta1,
                      beta2, seg_first_step, seg_scratch, n_seg);
   int rc = check_launch("adam_prep_seg_kernel");

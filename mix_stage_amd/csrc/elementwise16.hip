@@ -42,6 +42,7 @@ int launch_bn_apply16(int dt, const void* y_raw, void* y, float* y_f32, const fl
   const size_t total = (size_t)B * C8 * HW;
   const int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
   TimingScope ts(s, 0, (y_f32 ? 2.0 + 4.0 : 4.0) * 8.0 * total, "bn_apply16_kernel|bn_apply16 C%d N%d", C, B * HW);
+  if (ts.skip()) return 0;
   if (dt == DT_BF16)
     hipLaunchKernelGGL(bn_apply16_kernel<BF16>, dim3(blocks), dim3(256), 0, s, (const u32x4*)y_raw, (u32x4*)y, y_f32, save, C, C8, HW,
                        total, slope);
@@ -54,6 +55,16 @@ int launch_bn_apply16(int dt, const void* y_raw, void* y, float* y_f32, const fl
 // BatchNorm finalize + apply in ONE launch for layers with few statistics tiles (every 1-D layer): each workgroup combines
 // the per-tile partials of its 8 channels itself (same order everywhere: identical results), chunk 0 also records them
 // (save = mean | invstd | scale | shift, running statistics), then normalises its share of the channel block.
+// Per-channel parameters of a channel block: unconditional loads with a clamped index (no branch between them, so the
+// scalar loads go out back to back and are waited for once).
+__device__ inline void load_chan8(const float* __restrict__ p, int c0, int C, float (&o)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = p[min(c0 + j, C - 1)];
+}
+
+// Every global load of the kernel -- tile statistics, BN parameters, the first FIN_PRE data vectors of each thread -- is
+// issued before anything is consumed: the kernel costs ONE memory round trip plus the reduction, not four.
+constexpr int FIN_PRE = 4;
 template <typename DT>
 __global__ __launch_bounds__(256) void bn_finalize_apply16_kernel(const float* __restrict__ stats, const float* __restrict__ counts,
                                                                   int n_tiles, int N, const float* __restrict__ gamma,
@@ -67,25 +78,39 @@ __global__ __launch_bounds__(256) void bn_finalize_apply16_kernel(const float* _
   const int cb = blockIdx.x, ch = blockIdx.y, t = threadIdx.x;
   const int j = t >> 5, i = t & 31, c = cb * 8 + j;
   const bool cv = c < C;
-  double s = 0.0;
-  if (cv)
-    for (int k = i; k < n_tiles; k += 32) s += (double)stats[((size_t)k * C + c) * 2];
-  part[j][i] = s;
+  const int cc = min(c, C - 1);
+  const int b0 = ch * b_per_chunk, nb = min(b_per_chunk, B - b0);
+  const int n = nb * HW;
+  // statistics of tiles i and i + 32 (n_tiles <= 64) and the channel's parameters
+  const int k0 = min(i, n_tiles - 1), k1 = min(i + 32, n_tiles - 1);
+  const float2 st0 = *(const float2*)(stats + ((size_t)k0 * C + cc) * 2), st1 = *(const float2*)(stats + ((size_t)k1 * C + cc) * 2);
+  const float cnt0 = counts[k0], cnt1 = counts[k1];
+  const float g = gamma[cc], bt = beta[cc], rm = running_mean[cc], rv = running_var[cc];
+  // data prefetch, issued AFTER the statistics: loads return in order, and the statistics (L2 hits, just written by the conv)
+  // must not queue behind HBM reads
+  __builtin_amdgcn_sched_barrier(0);
+  u32x4 raw[FIN_PRE];
+  size_t vofs[FIN_PRE];
+#pragma unroll
+  for (int q = 0; q < FIN_PRE; ++q) {
+    const int e = min(t + q * 256, n - 1);
+    const int bl = e / HW, pix = e - bl * HW;
+    vofs[q] = ((size_t)(b0 + bl) * C8 + cb) * HW + pix;
+    raw[q] = y_raw[vofs[q]];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const bool u0 = cv && i < n_tiles, u1 = cv && i + 32 < n_tiles;
+  part[j][i] = (u0 ? (double)st0.x : 0.0) + (u1 ? (double)st1.x : 0.0);
   __syncthreads();
   double tot = 0.0;
 #pragma unroll 8
   for (int k = 0; k < 32; ++k) tot += part[j][k];
   const double mean = tot / (double)N;
   __syncthreads();
-  double q = 0.0;
-  if (cv)
-    for (int k = i; k < n_tiles; k += 32) {
-      const float* st = stats + ((size_t)k * C + c) * 2;
-      const double cnt = (double)counts[k];
-      const double dlt = (double)st[0] / cnt - mean;
-      q += (double)st[1] + cnt * dlt * dlt;
-    }
-  part[j][i] = q;
+  double q2 = 0.0;
+  if (u0) { const double cn = (double)cnt0, dlt = (double)st0.x / cn - mean; q2 += (double)st0.y + cn * dlt * dlt; }
+  if (u1) { const double cn = (double)cnt1, dlt = (double)st1.x / cn - mean; q2 += (double)st1.y + cn * dlt * dlt; }
+  part[j][i] = q2;
   __syncthreads();
   if (i == 0) {
     double m2 = 0.0;
@@ -95,16 +120,16 @@ __global__ __launch_bounds__(256) void bn_finalize_apply16_kernel(const float* _
       const float var = (float)(m2 / (double)N);
       const float invstd = 1.0f / sqrtf(var + eps);
       const float fmean = (float)mean;
-      sc = gamma[c] * invstd;
-      shf = beta[c] - fmean * sc;
+      sc = g * invstd;
+      shf = bt - fmean * sc;
       if (ch == 0) {
         save[c] = fmean;
         save[C + c] = invstd;
         save[2 * C + c] = sc;
         save[3 * C + c] = shf;
         const float unbiased = N > 1 ? (float)(m2 / (double)(N - 1)) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * fmean;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+        running_mean[c] = (1.f - momentum) * rm + momentum * fmean;
+        running_var[c] = (1.f - momentum) * rv + momentum * unbiased;
       }
     }
     scsh[j] = sc; scsh[8 + j] = shf;
@@ -113,22 +138,34 @@ __global__ __launch_bounds__(256) void bn_finalize_apply16_kernel(const float* _
   float sc[8], shf[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) { sc[k] = scsh[k]; shf[k] = scsh[8 + k]; }
-  const int b0 = ch * b_per_chunk, nb = min(b_per_chunk, B - b0);
-  const int n = nb * HW;
-  for (int e = t; e < n; e += 256) {
-    const int bl = e / HW, pix = e - bl * HW;
-    const size_t b = b0 + bl, v = (b * C8 + cb) * HW + pix;
+  auto emit = [&](const u32x4& rawv, size_t v, int e) {
     float f[8];
-    unpack8<DT>(y_raw[v], f);
+    unpack8<DT>(rawv, f);
 #pragma unroll
     for (int k = 0; k < 8; ++k) f[k] = cb * 8 + k < C ? lrelu(fmaf(f[k], sc[k], shf[k]), slope) : 0.f;
     if (y_f32) {
+      const int bl = e / HW, pix = e - bl * HW;
 #pragma unroll
       for (int k = 0; k < 8; ++k)
-        if (cb * 8 + k < C) y_f32[(b * C + cb * 8 + k) * HW + pix] = f[k];
+        if (cb * 8 + k < C) y_f32[((size_t)(b0 + bl) * C + cb * 8 + k) * HW + pix] = f[k];
     } else {
       y[v] = pack8<DT>(f);
     }
+  };
+#pragma unroll
+  for (int q = 0; q < FIN_PRE; ++q)
+    if (t + q * 256 < n) emit(raw[q], vofs[q], t + q * 256);
+  for (int e0 = t + FIN_PRE * 256; e0 < n; e0 += FIN_PRE * 256) {
+#pragma unroll
+    for (int q = 0; q < FIN_PRE; ++q) {
+      const int e = min(e0 + q * 256, n - 1);
+      const int bl = e / HW, pix = e - bl * HW;
+      vofs[q] = ((size_t)(b0 + bl) * C8 + cb) * HW + pix;
+      raw[q] = y_raw[vofs[q]];
+    }
+#pragma unroll
+    for (int q = 0; q < FIN_PRE; ++q)
+      if (e0 + q * 256 < n) emit(raw[q], vofs[q], e0 + q * 256);
   }
 }
 
@@ -141,6 +178,7 @@ int launch_bn_finalize_apply16(int dt, const float* stats, const float* counts, 
   const dim3 grid(C8, nchunk);
   TimingScope ts(s, 0, (y_f32 ? 6.0 : 4.0) * 8.0 * (double)B * C8 * HW, "bn_finalize_apply16_kernel|bn_finalize_apply16 C%d N%d tiles%d", C,
                  B * HW, n_tiles);
+  if (ts.skip()) return 0;
   if (dt == DT_BF16)
     hipLaunchKernelGGL(bn_finalize_apply16_kernel<BF16>, grid, dim3(256), 0, s, stats, counts, n_tiles, N, gamma, beta, rm, rv, save, eps,
                        momentum, (const u32x4*)y_raw, (u32x4*)y, y_f32, B, C, C8, HW, bpc, slope);
@@ -168,6 +206,29 @@ __device__ inline void block_sum8(float (&v)[8], float* red) {
 #pragma unroll
     for (int w = 0; w < NW; ++w) a += red[w * 8 + j];
     v[j] = a;
+  }
+}
+
+// block-wide sums of NV values per thread, result in EVERY thread.  red: NW*NV floats of LDS (rows read back as float4).
+template <int NV, int NW>
+__device__ inline void block_sum_n(float (&v)[NV], float* red) {
+#pragma unroll
+  for (int j = 0; j < NV; ++j) v[j] = wave_sum(v[j]);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) red[(threadIdx.x >> 6) * NV + j] = v[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NV; j += 4) {
+    float4 a = *(const float4*)(red + j);
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+      const float4 b = *(const float4*)(red + w * NV + j);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    v[j] = a.x; v[j + 1] = a.y; v[j + 2] = a.z; v[j + 3] = a.w;
   }
 }
 
@@ -200,18 +261,42 @@ __global__ __launch_bounds__(256) void bn_bwd16_reduce_kernel(const u32x4* __res
   }
   float s1[8] = {}, s2[8] = {};
   const int n = nb * HW;
-  for (int e = t; e < n; e += 256) {
-    const int bl = e / HW, pix = e - bl * HW;
-    const size_t b = b0 + bl, v = (b * C8 + cb) * HW + pix;
-    float g[8], yr[8];
-    load_dy8<DT, DYF32>(dy, dy_f32, v, b, cb, pix, C, HW, g);
-    unpack8<DT>(y_raw[v], yr);
+  // 4 vectors per thread and step, all loads issued before the first use
+  for (int e0 = t; e0 < n; e0 += 1024) {
+    u32x4 ry[4], rg[4];
+    float gf[DYF32 ? 4 : 1][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float z = fmaf(yr[j], sc[j], sh[j]);
-      const float dz = g[j] * (z > 0.f ? 1.f : slope);
-      s1[j] += dz;
-      s2[j] = fmaf(dz, (yr[j] - mean[j]) * invstd[j], s2[j]);
+    for (int q = 0; q < 4; ++q) {
+      const int e = min(e0 + q * 256, n - 1);
+      const int bl = e / HW, pix = e - bl * HW;
+      const size_t b = b0 + bl, v = (b * C8 + cb) * HW + pix;
+      ry[q] = y_raw[v];
+      if (DYF32) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gf[q][j] = dy_f32[(b * C + min(cb * 8 + j, C - 1)) * HW + pix];
+      } else {
+        rg[q] = dy[v];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (e0 + q * 256 < n) {
+        float g[8], yr[8];
+        if (DYF32) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) g[j] = cb * 8 + j < C ? gf[q][j] : 0.f;
+        } else {
+          unpack8<DT>(rg[q], g);
+        }
+        unpack8<DT>(ry[q], yr);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float z = fmaf(yr[j], sc[j], sh[j]);
+          const float dz = g[j] * (z > 0.f ? 1.f : slope);
+          s1[j] += dz;
+          s2[j] = fmaf(dz, (yr[j] - mean[j]) * invstd[j], s2[j]);
+        }
+      }
     }
   }
   block_sum8(s1, red);
@@ -239,39 +324,74 @@ __global__ __launch_bounds__(256) void bn_bwd16_apply_kernel(const u32x4* __rest
   __shared__ float red[32];
   const int cb = blockIdx.x, ch = blockIdx.y, t = threadIdx.x, nchunk = gridDim.y;
   const float invN = 1.0f / (float)((size_t)B * HW);
+  // prologue in one memory round trip: a 32-lane group sums one channel's chunk partials, the 40 per-channel parameters
+  // arrive through LDS
+  __shared__ float prm[56];
+  {
+    const int jj = t >> 5, ii = t & 31, cj = min(cb * 8 + jj, C - 1);
+    float a = 0.f, b2 = 0.f;
+    for (int k = ii; k < nchunk; k += 32) {
+      const float2 pp = *(const float2*)(partial + ((size_t)cj * nchunk + k) * 2);
+      a += pp.x; b2 += pp.y;
+    }
+    const int tp = min(t, 39);
+    const float pv = (tp < 32 ? save + (size_t)(tp >> 3) * C : gamma)[min(cb * 8 + (tp & 7), C - 1)];
+    a = half_wave_sum(a); b2 = half_wave_sum(b2);
+    if (ii == 0) { prm[40 + jj] = a; prm[48 + jj] = b2; }
+    if (t < 40) prm[t] = pv;
+  }
+  __syncthreads();
   float mean[8], invstd[8], sc[8], sh[8], gi[8], m1[8], m2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const int c = min(cb * 8 + j, C - 1);
-    const bool cv = cb * 8 + j < C;
-    float a = 0.f, b2 = 0.f;
-    for (int k = 0; k < nchunk; ++k) {
-      a += partial[((size_t)c * nchunk + k) * 2];
-      b2 += partial[((size_t)c * nchunk + k) * 2 + 1];
-    }
-    mean[j] = save[c]; invstd[j] = save[C + c]; sc[j] = save[2 * C + c]; sh[j] = save[3 * C + c];
-    gi[j] = cv ? gamma[c] * invstd[j] : 0.f;
-    m1[j] = a * invN; m2[j] = b2 * invN;
-    if (t == 0 && ch == 0 && cv && dgamma) { dgamma[c] = b2; dbeta[c] = a; }
+    mean[j] = prm[j]; invstd[j] = prm[8 + j]; sc[j] = prm[16 + j]; sh[j] = prm[24 + j];
+    gi[j] = cb * 8 + j < C ? prm[32 + j] * invstd[j] : 0.f;
+    m1[j] = prm[40 + j] * invN; m2[j] = prm[48 + j] * invN;
   }
+  if (t < 8 && ch == 0 && cb * 8 + t < C && dgamma) { dgamma[cb * 8 + t] = prm[48 + t]; dbeta[cb * 8 + t] = prm[40 + t]; }
   const int b0 = ch * b_per_chunk, nb = min(b_per_chunk, B - b0);
   const int n = nb * HW;
   float cs[8] = {};
-  for (int e = t; e < n; e += 256) {
-    const int bl = e / HW, pix = e - bl * HW;
-    const size_t b = b0 + bl, v = (b * C8 + cb) * HW + pix;
-    float g[8], yr[8], o[8];
-    load_dy8<DT, DYF32>(dy, dy_f32, v, b, cb, pix, C, HW, g);
-    unpack8<DT>(y_raw[v], yr);
+  for (int e0 = t; e0 < n; e0 += 1024) {
+    u32x4 ry[4], rg[4];
+    float gf[DYF32 ? 4 : 1][8];
+    size_t vofs[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float z = fmaf(yr[j], sc[j], sh[j]);
-      const float dz = g[j] * (z > 0.f ? 1.f : slope);
-      const float xh = (yr[j] - mean[j]) * invstd[j];
-      o[j] = gi[j] * (dz - m1[j] - xh * m2[j]);
-      cs[j] += o[j];
+    for (int q = 0; q < 4; ++q) {
+      const int e = min(e0 + q * 256, n - 1);
+      const int bl = e / HW, pix = e - bl * HW;
+      const size_t b = b0 + bl;
+      vofs[q] = (b * C8 + cb) * HW + pix;
+      ry[q] = y_raw[vofs[q]];
+      if (DYF32) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gf[q][j] = dy_f32[(b * C + min(cb * 8 + j, C - 1)) * HW + pix];
+      } else {
+        rg[q] = dy[vofs[q]];
+      }
     }
-    dyr[v] = pack8<DT>(o);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (e0 + q * 256 < n) {
+        float g[8], yr[8], o[8];
+        if (DYF32) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) g[j] = cb * 8 + j < C ? gf[q][j] : 0.f;
+        } else {
+          unpack8<DT>(rg[q], g);
+        }
+        unpack8<DT>(ry[q], yr);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float z = fmaf(yr[j], sc[j], sh[j]);
+          const float dz = g[j] * (z > 0.f ? 1.f : slope);
+          const float xh = (yr[j] - mean[j]) * invstd[j];
+          o[j] = gi[j] * (dz - m1[j] - xh * m2[j]);
+          cs[j] += o[j];
+        }
+        dyr[vofs[q]] = pack8<DT>(o);
+      }
+    }
   }
   block_sum8(cs, red);
   if (t == 0) {
@@ -289,66 +409,84 @@ __global__ __launch_bounds__(NT) void bn_bwd16_fused_kernel(const u32x4* __restr
                                                              const u32x4* __restrict__ y_raw, const float* __restrict__ save,
                                                              const float* __restrict__ gamma, u32x4* __restrict__ dyr, float* dbias,
                                                              float* dgamma, float* dbeta, int B, int C, int C8, int HW, float slope) {
-  __shared__ float red[(NT / 64) * 8];
+  __shared__ float red[(NT / 64) * 16];
   const int cb = blockIdx.x, t = threadIdx.x;
   const int n = B * HW;
+  // all loads first (clamped indices, no branches): one memory round trip for the whole kernel
+  // (the 40 per-channel parameters travel through LDS: as scalar loads the compiler sinks them behind the data and waits
+  // for them in four more round trips)
+  __shared__ float prm[40];
+  const int tp = min(t, 39);
+  const float pv = (tp < 32 ? save + (size_t)(tp >> 3) * C : gamma)[min(cb * 8 + (tp & 7), C - 1)];
+  u32x4 ry[NE], rg[NE];
+  float gf[DYF32 ? NE : 1][8];
+  size_t vofs[NE];
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = min(t + i * NT, n - 1);
+    const int bl = e / HW, pix = e - bl * HW;
+    vofs[i] = ((size_t)bl * C8 + cb) * HW + pix;
+    ry[i] = y_raw[vofs[i]];
+    if (DYF32) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gf[i][j] = dy_f32[((size_t)bl * C + min(cb * 8 + j, C - 1)) * HW + pix];
+    } else {
+      rg[i] = dy[vofs[i]];
+    }
+  }
+  if (t < 40) prm[t] = pv;
+  __syncthreads();
   float mean[8], invstd[8], sc[8], sh[8], gi[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const int c = min(cb * 8 + j, C - 1);
-    mean[j] = save[c]; invstd[j] = save[C + c]; sc[j] = save[2 * C + c]; sh[j] = save[3 * C + c];
-    gi[j] = cb * 8 + j < C ? gamma[c] * invstd[j] : 0.f;
+    mean[j] = prm[j]; invstd[j] = prm[8 + j]; sc[j] = prm[16 + j]; sh[j] = prm[24 + j];
+    gi[j] = cb * 8 + j < C ? prm[32 + j] * invstd[j] : 0.f;
   }
   float dz[NE][8], xh[NE][8];
-  float s1[8] = {}, s2[8] = {};
+  float s12[16] = {};
 #pragma unroll
   for (int i = 0; i < NE; ++i) {
-    const int e = t + i * NT;
+    const bool ok = t + i * NT < n;
+    float g[8], yr[8];
+    if (DYF32) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { dz[i][j] = 0.f; xh[i][j] = 0.f; }
-    if (e < n) {
-      const int bl = e / HW, pix = e - bl * HW;
-      const size_t v = ((size_t)bl * C8 + cb) * HW + pix;
-      float g[8], yr[8];
-      load_dy8<DT, DYF32>(dy, dy_f32, v, bl, cb, pix, C, HW, g);
-      unpack8<DT>(y_raw[v], yr);
+      for (int j = 0; j < 8; ++j) g[j] = cb * 8 + j < C ? gf[i][j] : 0.f;
+    } else {
+      unpack8<DT>(rg[i], g);
+    }
+    unpack8<DT>(ry[i], yr);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float z = fmaf(yr[j], sc[j], sh[j]);
-        dz[i][j] = g[j] * (z > 0.f ? 1.f : slope);
-        xh[i][j] = (yr[j] - mean[j]) * invstd[j];
-        s1[j] += dz[i][j];
-        s2[j] = fmaf(dz[i][j], xh[i][j], s2[j]);
-      }
+    for (int j = 0; j < 8; ++j) {
+      const float z = fmaf(yr[j], sc[j], sh[j]);
+      dz[i][j] = ok ? g[j] * (z > 0.f ? 1.f : slope) : 0.f;
+      xh[i][j] = ok ? (yr[j] - mean[j]) * invstd[j] : 0.f;
+      s12[j] += dz[i][j];
+      s12[8 + j] = fmaf(dz[i][j], xh[i][j], s12[8 + j]);
     }
   }
-  block_sum8<NT / 64>(s1, red);
-  block_sum8<NT / 64>(s2, red);
+  block_sum_n<16, NT / 64>(s12, red);
   const float invN = 1.0f / (float)n;
   float cs[8] = {};
 #pragma unroll
   for (int i = 0; i < NE; ++i) {
-    const int e = t + i * NT;
-    if (e < n) {
-      const int bl = e / HW, pix = e - bl * HW;
-      float o[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        o[j] = gi[j] * (dz[i][j] - s1[j] * invN - xh[i][j] * (s2[j] * invN));
-        cs[j] += o[j];
-      }
-      dyr[((size_t)bl * C8 + cb) * HW + pix] = pack8<DT>(o);
-    }
-  }
-  block_sum8<NT / 64>(cs, red);
-  if (t == 0) {
+    float o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int c = cb * 8 + j;
-      if (c < C) {
-        if (dbias) dbias[c] = cs[j];
-        if (dgamma) { dgamma[c] = s2[j]; dbeta[c] = s1[j]; }
-      }
+      o[j] = gi[j] * (dz[i][j] - s12[j] * invN - xh[i][j] * (s12[8 + j] * invN));
+      cs[j] += t + i * NT < n ? o[j] : 0.f;
+    }
+    if (t + i * NT < n) dyr[vofs[i]] = pack8<DT>(o);
+  }
+  block_sum_n<8, NT / 64>(cs, red);
+  if (t < 8) {
+    const int c = cb * 8 + t;
+    if (c < C) {
+      float csj = 0.f, s1j = 0.f, s2j = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (t == j) { csj = cs[j]; s1j = s12[j]; s2j = s12[8 + j]; }
+      if (dbias) dbias[c] = csj;
+      if (dgamma) { dgamma[c] = s2j; dbeta[c] = s1j; }
     }
   }
 }
@@ -374,6 +512,7 @@ int launch_bn_bwd16(int dt, const void* dy, const float* dy_f32, const void* y_r
     const int nt = 256;       // (1024-thread workgroups measured 2x slower here: 29 vs 15 us at C = 256, B*T = 2048)
     const int ne = (n + nt - 1) / nt;
     TimingScope ts(s, 0, 16.0 * (dy_f32 ? 4.0 + 1.0 + 1.0 : 3.0) * (double)B * C8 * HW, "bn_bwd16_fused_kernel|bn_bwd16 C%d N%d fused", C, B * HW);
+    if (ts.skip()) return 0;
 #define MS_BNF(DT, F, NE, NT)                                                                                                      \
     hipLaunchKernelGGL((bn_bwd16_fused_kernel<DT, F, NE, NT>), dim3(C8), dim3(NT), 0, s, (const u32x4*)dy, dy_f32, (const u32x4*)y_raw, \
                        save, gamma, (u32x4*)dyr, dbias, dgamma, dbeta, B, C, C8, HW, slope)
@@ -390,6 +529,7 @@ int launch_bn_bwd16(int dt, const void* dy, const float* dy_f32, const void* y_r
   const dim3 grid(C8, nchunk);
   const double vec = (double)B * C8 * HW;
   TimingScope ts(s, 0, 16.0 * (dy_f32 ? 4.0 + 2.0 + 1.0 : 5.0) * vec, "bn_bwd16_kernels|bn_bwd16 C%d N%d", C, B * HW);
+  if (ts.skip()) return 0;
 #define MS_BNB(DT, F)                                                                                                              \
   do {                                                                                                                             \
     hipLaunchKernelGGL((bn_bwd16_reduce_kernel<DT, F>), grid, dim3(256), 0, s, (const u32x4*)dy, dy_f32, (const u32x4*)y_raw, save,   \
@@ -445,6 +585,7 @@ int launch_act_bwd16(int dt, const void* dy, const float* dy_f32, const void* y,
   const int nchunk = bwd16_chunks(B, C8, HW, &bpc);
   const dim3 grid(C8, nchunk);
   TimingScope ts(s, 0, 16.0 * 3.0 * (double)B * C8 * HW, "act_bwd16_kernel|act_bwd16 C%d N%d mode%d", C, B * HW, mode);
+  if (ts.skip()) return 0;
 #define MS_ACT(DT, F)                                                                                                          \
   hipLaunchKernelGGL((act_bwd16_kernel<DT, F>), grid, dim3(256), 0, s, (const u32x4*)dy, dy_f32, (const u32x4*)y, (u32x4*)dyr,   \
                      colpart, B, C, C8, HW, bpc, mode, slope)
@@ -576,6 +717,7 @@ int ms_cb8_from_plain(int dtype, const float* x, void* y, int B, int C, int HW, 
   const size_t total = (size_t)B * C8 * HW;
   hipStream_t s = (hipStream_t)stream;
   TimingScope ts(s, 0, 6.0 * 8.0 * total, "cb8_from_plain_kernel|cb8_from_plain C%d N%d", C, B * HW);
+  if (ts.skip()) return 0;
   if (dtype == MS_BF16) hipLaunchKernelGGL(cb8_from_plain_kernel<BF16>, dim3(conv_blocks(total)), dim3(256), 0, s, x, (u32x4*)y, C, C8, HW, total);
   else hipLaunchKernelGGL(cb8_from_plain_kernel<F16>, dim3(conv_blocks(total)), dim3(256), 0, s, x, (u32x4*)y, C, C8, HW, total);
   return check_launch("cb8_from_plain_kernel");
@@ -588,12 +730,15 @@ int ms_cb8_to_plain(int dtype, const void* x, float* y, int B, int C, int HW, vo
   const size_t total = (size_t)B * C8 * HW;
   hipStream_t s = (hipStream_t)stream;
   TimingScope ts(s, 0, 6.0 * 8.0 * total, "cb8_to_plain_kernel|cb8_to_plain C%d N%d", C, B * HW);
+  if (ts.skip()) return 0;
   if (dtype == MS_BF16) hipLaunchKernelGGL(cb8_to_plain_kernel<BF16>, dim3(conv_blocks(total)), dim3(256), 0, s, (const u32x4*)x, y, C, C8, HW, total);
   else hipLaunchKernelGGL(cb8_to_plain_kernel<F16>, dim3(conv_blocks(total)), dim3(256), 0, s, (const u32x4*)x, y, C, C8, HW, total);
   return check_launch("cb8_to_plain_kernel");
 }
 
 int ms_cb8_from_btc(int dtype, const float* x, void* y, int B, int T, int C, int velocity, void* stream) {
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_cb8_from_btc");
+  if (ts.skip()) return 0;
   if (dtype != MS_BF16 && dtype != MS_F16) return set_error("ms_cb8_from_btc: dtype %d", dtype);
   if (!x || !y || B < 1 || C < 1 || T < 1) return set_error("ms_cb8_from_btc: bad argument");
   const int C8 = c8_of(C);
@@ -605,6 +750,8 @@ int ms_cb8_from_btc(int dtype, const float* x, void* y, int B, int T, int C, int
 }
 
 int ms_cb8_to_btc(int dtype, const void* x, float* y, int B, int T, int C, int velocity_bwd, void* stream) {
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_cb8_to_btc");
+  if (ts.skip()) return 0;
   if (dtype != MS_BF16 && dtype != MS_F16) return set_error("ms_cb8_to_btc: dtype %d", dtype);
   if (!x || !y || B < 1 || C < 1 || T < 1) return set_error("ms_cb8_to_btc: bad argument");
   const int C8 = c8_of(C);

@@ -42,8 +42,10 @@ struct WgradArgs {
 struct TimingScope {
   TimingScope(hipStream_t s, double flops, double bytes, const char* fmt, ...);
   ~TimingScope();
+  bool skip() const { return skip_; }   // ms_debug_set_skip matched this launch's label: the launcher returns without launching
   int idx_;
   hipStream_t s_;
+  bool skip_;
 };
 
 // ---- patch-staged forward conv (conv_patch.hip)

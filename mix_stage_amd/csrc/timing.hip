@@ -12,19 +12,23 @@
 namespace ms {
 
 static bool g_timing = false;
+static std::vector<std::string> g_skip;   // ms_debug_set_skip: label substrings whose launches are dropped (timing ablations)
 struct TimingRec { std::string label; hipEvent_t a, b; double flops, bytes; };
 static std::vector<TimingRec> g_recs;
 static std::mutex g_mu;
 
 bool timing_enabled() { return g_timing; }
 
-TimingScope::TimingScope(hipStream_t s, double flops, double bytes, const char* fmt, ...) : idx_(-1), s_(s) {
-  if (!g_timing) return;
+TimingScope::TimingScope(hipStream_t s, double flops, double bytes, const char* fmt, ...) : idx_(-1), s_(s), skip_(false) {
+  if (!g_timing && g_skip.empty()) return;
   char buf[256];
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
+  for (auto& pat : g_skip)
+    if (strstr(buf, pat.c_str())) { skip_ = true; return; }
+  if (!g_timing) return;
   TimingRec r;
   r.label = buf; r.flops = flops; r.bytes = bytes;
   if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
@@ -41,6 +45,21 @@ TimingScope::~TimingScope() {
 }
 
 }  // namespace ms
+
+extern "C" int ms_debug_set_skip(const char* patterns) {
+  std::lock_guard<std::mutex> lk(ms::g_mu);
+  ms::g_skip.clear();
+  if (!patterns) return 0;
+  std::string p(patterns);
+  size_t i = 0;
+  while (i <= p.size()) {
+    size_t j = p.find(';', i);
+    if (j == std::string::npos) j = p.size();
+    if (j > i) ms::g_skip.push_back(p.substr(i, j - i));
+    i = j + 1;
+  }
+  return (int)ms::g_skip.size();
+}
 
 extern "C" int ms_timing_enable(int on) {
   std::lock_guard<std::mutex> lk(ms::g_mu);

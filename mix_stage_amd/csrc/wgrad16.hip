@@ -13,6 +13,8 @@
 // [8 blocks][TH][(TW-1)*S + TP] as 16-byte vectors.  Pixel splits leave fp32 partial slabs that are summed in a fixed order
 // by the caller (ms_wgrad_reduce_multi), like the fp32 kernels'.
 #include <algorithm>
+#include <mutex>
+#include <vector>
 
 #include "conv16_kernel.h"
 
@@ -38,15 +40,14 @@ __device__ inline u32x4 tr_read2(const u32x4* base, int vec0, int vec1, int sub8
 constexpr int WG16_NPX = 8;   // input-row vectors a thread stages per tile at most (plan_wgrad16 keeps 8*TH*PCX <= 8*256)
 
 template <typename DT, int TP, bool UP2>
-__global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args p) {
-  extern __shared__ u32x4 smem[];
+__device__ __forceinline__ void wgrad16_body(const Wgrad16Args& p, const int bid, u32x4* smem) {
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wm = wid >> 1, wn = wid & 1, h = lane >> 5;
   const int TW = 1 << p.ltw, TH = p.TH, PCX = p.PCX, S = p.S, SV = p.SV;
   const int xv = 8 * TH * PCX;                 // input-row vectors per tile
   const int stage_vecs = 512 + xv + 1;
 
-  const int vid = xcd_remap(blockIdx.x, p.gx * p.gy * p.gz);
+  const int vid = xcd_remap(bid, p.gx * p.gy * p.gz);
   const int bx_ = vid % p.gx, by_ = (vid / p.gx) % p.gy, bz_ = vid / (p.gx * p.gy);
   // z = ((group * KH + kh) * ktg + tap group) * splits + split
   const int split = bz_ % p.splits;
@@ -187,16 +188,33 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args p) {
       float* dst = out + (((size_t)(g * p.Cog + co) * p.Cig + ci) * p.KH + kh) * p.KW + kw0;
       if (kw0 + TP <= p.KW) {
         Taps tv;
+        if (p.accumulate) tv = *reinterpret_cast<const Taps*>(dst);
 #pragma unroll
-        for (int q = 0; q < TP; ++q) tv.v[q] = acc[q][e];
+        for (int q = 0; q < TP; ++q) tv.v[q] = p.accumulate ? tv.v[q] + acc[q][e] : acc[q][e];
         *reinterpret_cast<Taps*>(dst) = tv;
       } else {
 #pragma unroll
         for (int q = 0; q < TP; ++q)
-          if (kw0 + q < p.KW) dst[q] = acc[q][e];
+          if (kw0 + q < p.KW) dst[q] = p.accumulate ? dst[q] + acc[q][e] : acc[q][e];
       }
     }
   }
+}
+
+template <typename DT, int TP, bool UP2>
+__global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args p) {
+  extern __shared__ u32x4 smem[];
+  wgrad16_body<DT, TP, UP2>(p, (int)blockIdx.x, smem);
+}
+
+// many blocks' weight gradients in one launch: a workgroup finds its job in the table of block ranges
+template <typename DT, int TP, bool UP2>
+__global__ __launch_bounds__(256) void wgrad16_multi_kernel(const Wgrad16Batch b) {
+  extern __shared__ u32x4 smem[];
+  int j = 0;
+  while (j + 1 < b.n && (int)blockIdx.x >= b.block_end[j]) ++j;
+  const int b0 = j ? b.block_end[j - 1] : 0;
+  wgrad16_body<DT, TP, UP2>(b.job[j], (int)blockIdx.x - b0, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -247,6 +265,31 @@ static int launch_w(const Wgrad16Args& a, int lds, int nwg, hipStream_t s) {
   return 0;
 }
 
+template <typename DT, int TP, bool UP2>
+static int launch_wm(const Wgrad16Batch& b, int lds, hipStream_t s) {
+  static bool attr_done = false;
+  auto fn = wgrad16_multi_kernel<DT, TP, UP2>;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return set_error("wgrad16: cannot raise the dynamic LDS limit");
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(fn, dim3(b.block_end[b.n - 1]), dim3(256), lds, s, b);
+  return 0;
+}
+
+template <typename DT>
+static int launch_tp_multi(const Wgrad16Batch& b, int tp, bool up2, int lds, hipStream_t s) {
+  if (up2) return launch_wm<DT, 3, true>(b, lds, s);
+  switch (tp) {
+    case 1: return launch_wm<DT, 1, false>(b, lds, s);
+    case 2: return launch_wm<DT, 2, false>(b, lds, s);
+    case 3: return launch_wm<DT, 3, false>(b, lds, s);
+    case 4: return launch_wm<DT, 4, false>(b, lds, s);
+  }
+  return set_error("wgrad16: no kernel for %d taps", tp);
+}
+
 template <typename DT>
 static int launch_tp(const Wgrad16Args& a, const Wgrad16Plan& pl, bool up2, int nwg, hipStream_t s) {
   if (up2) return launch_w<DT, 3, true>(a, pl.lds_bytes, nwg, s);
@@ -259,19 +302,104 @@ static int launch_tp(const Wgrad16Args& a, const Wgrad16Plan& pl, bool up2, int 
   return set_error("wgrad16: no kernel for %d taps", pl.tp);
 }
 
-int launch_wgrad16(int dt, const Wgrad16Args& a, const Wgrad16Plan& pl, bool up2, double flops, double bytes, hipStream_t s) {
-  if (!pl.tp) return set_error("wgrad16: geometry not supported");
-  if (up2 && pl.tp != 3) return set_error("wgrad16: the upsample-add input needs a k3 block");
-  if ((a.groups > 1) && ((a.Cog & 7) || (!a.bcast && (a.Cig & 7)))) return set_error("wgrad16: grouped blocks need channels per group % 8 == 0");
+// plan fields and grid of a launch; returns the workgroup count (0: error set)
+static double finish_wgrad16_args(const Wgrad16Args& a, const Wgrad16Plan& pl, bool up2, Wgrad16Args* out) {
+  if (!pl.tp) { set_error("wgrad16: geometry not supported"); return 0; }
+  if (up2 && pl.tp != 3) { set_error("wgrad16: the upsample-add input needs a k3 block"); return 0; }
+  if ((a.groups > 1) && ((a.Cog & 7) || (!a.bcast && (a.Cig & 7)))) {
+    set_error("wgrad16: grouped blocks need channels per group % 8 == 0");
+    return 0;
+  }
   Wgrad16Args b = a;
   b.ltw = ilog2(pl.tw); b.TH = pl.th; b.PCX = pl.pcx; b.tiles_x = pl.tiles_x; b.tiles_y = pl.tiles_y; b.n_tiles = pl.n_tiles;
   b.tiles_per_split = pl.tiles_per_split; b.splits = pl.splits; b.ktg = pl.ktg;
   b.gx = cdiv(a.Cig, 64); b.gy = cdiv(a.Cog, 64); b.gz = a.groups * a.KH * pl.ktg * pl.splits;
   const double nwg = (double)b.gx * b.gy * b.gz;
-  if (nwg > 2.0e9) return set_error("wgrad16: grid too large");
+  if (nwg > 2.0e9) { set_error("wgrad16: grid too large"); return 0; }
+  *out = b;
+  return nwg;
+}
+
+// ---- queued launches (ms_bwd_options.defer_wgrad_launch / ms_wgrad_flush)
+struct PendingWgrad16 { int dt, tp, up2, lds, nwg; double flops, bytes; Wgrad16Args a; };
+// process-wide: autograd runs the blocks' backward on its device thread and the end-of-backward callback on the caller's
+static std::vector<PendingWgrad16> t_pending;
+static std::mutex t_pending_mu;
+
+int queue_wgrad16(int dt, const Wgrad16Args& a, const Wgrad16Plan& pl, bool up2, double flops, double bytes) {
+  PendingWgrad16 pw;
+  const double nwg = finish_wgrad16_args(a, pl, up2, &pw.a);
+  if (nwg <= 0) return -1;
+  // a queued kernel that writes dw itself (no pixel split) ADDS to it: by the time it runs, autograd may already have
+  // accumulated the parameter's other uses of this step into the same slot (the slot starts the step zeroed)
+  if (pl.splits == 1) pw.a.accumulate = 1;
+  pw.dt = dt; pw.tp = up2 ? 3 : pl.tp; pw.up2 = up2 ? 1 : 0; pw.lds = pl.lds_bytes; pw.nwg = (int)nwg; pw.flops = flops; pw.bytes = bytes;
+  std::lock_guard<std::mutex> lk(t_pending_mu);
+  t_pending.push_back(pw);
+  return 0;
+}
+
+void wgrad16_discard() {
+  std::lock_guard<std::mutex> lk(t_pending_mu);
+  t_pending.clear();
+}
+
+int wgrad16_flush(hipStream_t s) {
+  // one launch per kernel instance (element type, taps per row, input form) and per WG16_MAX_JOBS blocks, in queue order
+  std::vector<PendingWgrad16> q;
+  {
+    std::lock_guard<std::mutex> lk(t_pending_mu);
+    q.swap(t_pending);
+  }
+  std::vector<char> done(q.size(), 0);
+  for (size_t i = 0; i < q.size(); ++i) {
+    if (done[i]) continue;
+    Wgrad16Batch b;
+    b.n = 0;
+    int lds = 0;
+    long blocks = 0;
+    double flops = 0, bytes = 0;
+    auto launch = [&]() -> int {
+      if (!b.n) return 0;
+      TimingScope ts(s, flops, bytes, "wgrad16_multi_kernel<%s,%d,%d>|conv_wgrad_cb8 multi taps%d up%d jobs%d wgs%ld",
+                     q[i].dt == DT_BF16 ? "bf16" : "f16", q[i].tp, q[i].up2, q[i].tp, q[i].up2, b.n, blocks);
+      int rc = 0;
+      if (!ts.skip()) {
+        rc = q[i].dt == DT_BF16 ? launch_tp_multi<BF16>(b, q[i].tp, q[i].up2 != 0, lds, s)
+                                : launch_tp_multi<F16>(b, q[i].tp, q[i].up2 != 0, lds, s);
+        if (!rc) rc = check_launch("wgrad16_multi_kernel");
+      }
+      b.n = 0; lds = 0; blocks = 0; flops = bytes = 0;
+      return rc;
+    };
+    for (size_t k = i; k < q.size(); ++k) {
+      if (done[k] || q[k].dt != q[i].dt || q[k].tp != q[i].tp || q[k].up2 != q[i].up2) continue;
+      if (b.n == WG16_MAX_JOBS || blocks + q[k].nwg > 0x3fffffff) {
+        const int rc = launch();
+        if (rc) return rc;
+      }
+      blocks += q[k].nwg;
+      b.block_end[b.n] = (int)blocks;
+      b.job[b.n] = q[k].a;
+      ++b.n;
+      lds = std::max(lds, q[k].lds);
+      flops += q[k].flops; bytes += q[k].bytes;
+      done[k] = 1;
+    }
+    const int rc = launch();
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int launch_wgrad16(int dt, const Wgrad16Args& a, const Wgrad16Plan& pl, bool up2, double flops, double bytes, hipStream_t s) {
+  Wgrad16Args b;
+  const double nwg = finish_wgrad16_args(a, pl, up2, &b);
+  if (nwg <= 0) return -1;
   TimingScope ts(s, flops, bytes, "wgrad16_kernel<%s,%d,%d>|conv_wgrad_cb8 k%dx%d s%d Cog%d Kg%d g%d tiles%d tw%d splits%d",
                  dt == DT_BF16 ? "bf16" : "f16", pl.tp, up2 ? 1 : 0, a.KH, a.KW, a.S, a.Cog, a.Cig * a.KH * a.KW, a.groups, pl.n_tiles,
                  pl.tw, pl.splits);
+  if (ts.skip()) return 0;
   const int rc = dt == DT_BF16 ? launch_tp<BF16>(b, pl, up2, (int)nwg, s) : launch_tp<F16>(b, pl, up2, (int)nwg, s);
   if (rc) return rc;
   return check_launch("wgrad16_kernel");

@@ -224,6 +224,7 @@ int launch_wgrad_patch(const WgradPatchArgs& a, const WgradPatchPlan& pl, int KH
   dim3 grid(b.gx * b.gy * b.gz);
   TimingScope ts(s, flops, bytes, "wgrad_patch_kernel<%d,%d,%d,%d,%d>|conv_wgrad_patch k%dx%d s%d Cog%d Kg%d g%d tiles%d tw%d splits%d",
                  KH, KW, S, pl.tw, up2 ? 1 : 0, KH, KW, S, a.Cog, a.Kg, a.groups, pl.n_tiles, pl.tw, a.splits);
+  if (ts.skip()) return 0;
   if (KH == 1 && KW == 3 && S == 1) {
     if (up2) launch_wgp_tw<1, 3, 1, true>(b, pl.tw, grid, s);
     else launch_wgp_tw<1, 3, 1, false>(b, pl.tw, grid, s);

@@ -5,6 +5,7 @@ Every function below enqueues hand-written gfx950 kernels through the C-ABI with
 pointers; there is no eager/CPU fallback -- a CPU tensor or a missing library raises.
 """
 import ctypes
+import os
 
 import torch
 
@@ -197,13 +198,16 @@ def prepared_count(flat_params):
 # deferred weight-gradient reductions (ms_wgrad_reduce_multi): blocks that split dw's pixel reduction leave their partial
 # slabs in per-block buffers; ONE launch at the end of the backward pass adds them all into the gradient slots.  Only for
 # gradients written straight into the flat buffer (nobody downstream in autograd reads them).  Opt-in, like the above.
-_deferred = {'on': False, 'jobs': [], 'queued': False, 'bufs': {}}
+# In the 16-bit modes the weight-gradient KERNELS are deferred as well (ms_bwd_options.defer_wgrad_launch / ms_wgrad_flush):
+# nothing in the backward chain reads them, and launched side by side in a few multi-block launches the small layers'
+# one-wave kernels cost one launch latency instead of one each.  'keep' holds the tensors those kernels read until the flush.
+_deferred = {'on': False, 'jobs': [], 'queued': False, 'bufs': {}, 'keep': [], 'launches': 0}
+DEFER_WGRAD_LAUNCH = os.environ.get('MS_DEFER_WGRAD_LAUNCH', '1') != '0'   # experiments: MS_DEFER_WGRAD_LAUNCH=0 launches per block
 
 
 def enable_deferred_wgrad(on):
   _deferred['on'] = bool(on)
-  _deferred['jobs'].clear()
-  _deferred['queued'] = False
+  reset_deferred_wgrad()
   if not on:
     _deferred['bufs'].clear()
 
@@ -211,7 +215,17 @@ def enable_deferred_wgrad(on):
 def reset_deferred_wgrad():
   """Drop jobs a failed backward pass may have left behind."""
   _deferred['jobs'].clear()
+  _deferred['keep'].clear()
   _deferred['queued'] = False
+  if _deferred['launches']:
+    _deferred['launches'] = 0
+    lib().ms_wgrad_discard()
+
+
+def _queue_deferred_flush():
+  if not _deferred['queued']:
+    _deferred['queued'] = True
+    torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred_wgrad)
 
 
 def _wgrad_partials_for(w, d):
@@ -235,6 +249,12 @@ def _wgrad_partials_for(w, d):
 def _flush_deferred_wgrad():
   jobs = _deferred['jobs']
   _deferred['queued'] = False
+  if _deferred['launches']:
+    _deferred['launches'] = 0
+    try:
+      check(lib().ms_wgrad_flush(_stream()), 'ms_wgrad_flush')
+    finally:
+      _deferred['keep'].clear()
   if not jobs:
     return
   n = len(jobs)
@@ -403,9 +423,7 @@ class _ConvBlockFn(torch.autograd.Function):
                                          ctypes.byref(opt)), 'ms_conv_block_bwd_ex')
         if part is not None:
           _deferred['jobs'].append((part, dw, nsplit))
-          if not _deferred['queued']:
-            _deferred['queued'] = True
-            torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred_wgrad)
+          _queue_deferred_flush()
       else:
         check(lib().ms_conv_block_bwd(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(gamma), None, None, _ptr(y_raw),
                                       _ptr(y), _ptr(save), _ptr(dy), _ptr(dyr), _ptr(dx), _ptr(dx2), _ptr(dw),

@@ -253,16 +253,21 @@ class _ConvBlock16Fn(torch.autograd.Function):
     D = ops._deferred
     if D['on'] and direct_w:
       part, nsplit = ops._wgrad_partials_for(w, d)
-    opt = BwdOptions(None, None, 0, wt.data_ptr() if wt is not None else None, part.data_ptr() if part is not None else None)
+    # the weight-gradient kernel itself is queued too when nothing downstream reads dw (it lands in the flat buffer)
+    defer_launch = bool(D['on'] and direct_w and dw is not None and ops.DEFER_WGRAD_LAUNCH)
+    opt = BwdOptions(None, None, 0, wt.data_ptr() if wt is not None else None, part.data_ptr() if part is not None else None,
+                     1 if defer_launch else 0)
     check(lib().ms_conv_block_bwd_ex(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(gamma), None, None, _ptr(y_raw),
                                      _ptr(y), _ptr(save), _ptr(dy), _ptr(dyr), _ptr(dx), _ptr(dx2), _ptr(dw),
                                      _ptr(dbias), _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), _stream(),
                                      ctypes.byref(opt)), 'ms_conv_block_bwd_ex')
+    if defer_launch:
+      D['launches'] += 1
+      D['keep'].append((x, x2, dy, dyr, dw, part))
+      ops._queue_deferred_flush()
     if part is not None:
       D['jobs'].append((part, dw, nsplit))
-      if not D['queued']:
-        D['queued'] = True
-        torch.autograd.Variable._execution_engine.queue_callback(ops._flush_deferred_wgrad)
+      ops._queue_deferred_flush()
     return (dx, dx2, None if direct_w else dw, None if direct_b else dbias, None if direct_g else dgamma,
             None if direct_be else dbeta, None, None, None, None, None)
 

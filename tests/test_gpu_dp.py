@@ -23,12 +23,24 @@ def _run_ranks(cmd, env, timeout=240):
       cmd = [c if not c.isdigit() or int(c) < 29000 else str(int(c) + 7) for c in cmd]
 
 
+def _results(stdout):
+  """Every 'DPRESULT {json}' record of the ranks' merged stdout (two ranks may land on one line)."""
+  dec, res, i = json.JSONDecoder(), [], 0
+  while True:
+    i = stdout.find('DPRESULT ', i)
+    if i < 0:
+      return res
+    obj, end = dec.raw_decode(stdout, i + len('DPRESULT '))
+    res.append(obj)
+    i = end
+
+
 def test_two_ranks_stay_bit_identical():
   env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
          '--master-port', '29541', os.path.join(ROOT, 'tests', 'helpers', 'dp_worker.py')]
   out = _run_ranks(cmd, env)
-  res = [json.loads(l.split('DPRESULT ', 1)[1]) for l in out.stdout.splitlines() if 'DPRESULT ' in l]
+  res = _results(out.stdout)
   assert out.returncode == 0 and len(res) == 2, (out.stdout[-2000:], out.stderr[-4000:])
   a, b = sorted(res, key=lambda r: r['rank'])
   assert a['kinds'] == b['kinds'] and set(a['kinds']) <= {'G', 'D'}
@@ -48,7 +60,7 @@ def test_global_bn_dp_equals_single_device():
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
          '--master-port', '29543', os.path.join(ROOT, 'tests', 'helpers', 'dp_global_bn_worker.py')]
   out = _run_ranks(cmd, env)
-  res = [json.loads(l.split('DPRESULT ', 1)[1]) for l in out.stdout.splitlines() if 'DPRESULT ' in l]
+  res = _results(out.stdout)
   assert out.returncode == 0 and len(res) == 2, (out.stdout[-2000:], out.stderr[-4000:])
   a, b = sorted(res, key=lambda r: r['rank'])
   M = S = 2

@@ -7,7 +7,8 @@ from mix_stage_amd.train_step import MixStageTrainStep
 from oracle import mixstage_oracle as O
 from torch.profiler import profile, ProfilerActivity
 dev = torch.device('cuda:0')
-model = bench.build_model(dev)
+precision = sys.argv[1] if len(sys.argv) > 1 else "fp32"
+model = bench.build_model(dev, precision)
 ts = MixStageTrainStep(model, use_graphs=False)
 audio, pose, labels, style = O.synthetic_batch(32, M=8, S=8)
 batch = [t.to(dev) for t in (audio, labels, pose, style)]
