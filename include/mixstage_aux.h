@@ -49,6 +49,9 @@ int ms_debug_set_patch_tuning(int intra_split, int force_splitk);
 int ms_debug_set_conv16_tile(int wm, int wn);
 /* ... and its LDS-DMA ring depth (2..4, 0 = planner) / the 8-wave form of the 128 x 128 tile (measured: no gain). */
 int ms_debug_set_conv16_ring(int nstg, int wide8);
+/* ... and the number of workgroups a 16-bit weight-gradient launch aims for when it splits the pixel reduction (default 128);
+ * returns the previous value.  Scratch and slab sizes follow: set it before any step is captured. */
+int ms_debug_set_wgrad16_target(int workgroups);
 /* Timing ablations only: launches whose timing label contains one of the ';'-separated substrings are dropped (results are
  * then meaningless); NULL or "" restores normal operation.  Returns the number of patterns. */
 int ms_debug_set_skip(const char* patterns);

@@ -87,67 +87,127 @@ size_t conv16_weight_bytes(const Conv16Plan& pl, int Mg, int groups, int Kc, int
 // data gradient: row = input channel, reduction channel = output channel (bcast: of ANY group, all groups sum into the
 //                shared input), class (ry, rx) of a strided conv keeps taps kh0 + SH*jh, kw0 + SW*jw, reversed -- the
 //                same slabs transpose_weight_kernel(flip=1) builds for the fp32 kernels.
-template <typename DT>
-__device__ inline void prep16_vec(const Prep16Job& jb, size_t v) {
-  const int KS = jb.CK8 / 2, BM = jb.BM;
-  const bool dg = jb.dgrad != 0;
-  const int KHs = dg ? cdiv_dev(jb.KH, jb.SH) : jb.KH, KWs = dg ? cdiv_dev(jb.KW, jb.SW) : jb.KW;
-  const int tg = (dg && jb.bcast) ? 1 : jb.groups;
-  size_t x = v;
-  const int row = (int)(x % BM); x /= BM;
-  const int h = (int)(x % 2); x /= 2;
-  const int ks = (int)(x % KS); x /= KS;
-  const int kw = (int)(x % KWs); x /= KWs;
-  const int kh = (int)(x % KHs); x /= KHs;
-  const int ch = (int)(x % jb.nchunks); x /= jb.nchunks;
-  const int mt = (int)(x % jb.n_mt); x /= jb.n_mt;
-  const int g = (int)(x % tg); x /= tg;
-  const int cls = (int)x;
-  const int m = mt * BM + row;
-  const int k0 = ch * jb.CK8 * 8 + (2 * ks + h) * 8;
-  float f[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int k = k0 + j;
-    float val = 0.f;
-    if (!dg) {
-      if (m < jb.Cog && k < jb.Cig) {
-        const int co = g * jb.Cog + m;
-        val = jb.w[(((size_t)co * jb.Cig + k) * jb.KH + kh) * jb.KW + kw];
-        if (jb.scale) val *= jb.scale[co];
-      }
-    } else {
-      const int tcog = jb.bcast ? jb.groups * jb.Cog : jb.Cog;
-      if (m < jb.Cig && k < tcog) {
-        const int gg = jb.bcast ? k / jb.Cog : g, co = jb.bcast ? k - gg * jb.Cog : k;
-        const int ry = cls / jb.SW, rx = cls - ry * jb.SW;
-        const int jh = KHs - 1 - kh, jw = KWs - 1 - kw;                 // taps reversed: the data gradient is a forward conv
-        const int okh = (ry + jb.PH) % jb.SH + jb.SH * jh, okw = (rx + jb.PW) % jb.SW + jb.SW * jw;
-        if (okh < jb.KH && okw < jb.KW)
-          val = jb.w[((((size_t)(gg * jb.Cog + co)) * jb.Cig + m) * jb.KH + okh) * jb.KW + okw];
-      }
-    }
-    f[j] = val;
-  }
-  reinterpret_cast<u32x4*>(jb.out)[v] = pack8<DT>(f);
+// A workgroup converts one unit = (group, row tile, reduction chunk, block of R rows) for ALL taps (and, for the data
+// gradient, all stride classes): phase 1 reads the unit's fp32 source -- per row (forward) or per reduction channel (data
+// gradient) one CONTIGUOUS run of the weight tensor -- coalesced into LDS; phase 2 gathers each output vector's 8 reduction
+// channels from LDS and writes the vectors in output order (consecutive lanes = consecutive rows).  Every weight is read
+// from HBM once, in full cache lines.
+constexpr int PREP16_LDS = 8192;     // floats
+__host__ __device__ inline int prep16_rows(int BM, int khw) {
+  int r = 1;
+  while (r * 2 <= BM && (r * 2) * (32 * khw + 1) <= PREP16_LDS && 32 * ((r * 2) * khw + 1) <= PREP16_LDS) r *= 2;
+  return r;
+}
+__host__ __device__ inline int prep16_units(const Prep16Job& jb) {
+  const int tg = (jb.dgrad && jb.bcast) ? 1 : jb.groups;
+  return tg * jb.n_mt * jb.nchunks * (jb.BM / prep16_rows(jb.BM, jb.KH * jb.KW));
 }
 
-__device__ inline size_t prep16_total(const Prep16Job& jb) {
+template <typename DT>
+__device__ inline void prep16_unit(const Prep16Job& jb, int unit, float* lds) {
+  const int t = threadIdx.x;
+  const int KS = jb.CK8 / 2, BM = jb.BM, KH = jb.KH, KW = jb.KW, KHW = KH * KW;
   const bool dg = jb.dgrad != 0;
-  const int KHs = dg ? cdiv_dev(jb.KH, jb.SH) : jb.KH, KWs = dg ? cdiv_dev(jb.KW, jb.SW) : jb.KW;
+  const int KHs = dg ? cdiv_dev(KH, jb.SH) : KH, KWs = dg ? cdiv_dev(KW, jb.SW) : KW;
   const int tg = (dg && jb.bcast) ? 1 : jb.groups, ncls = dg ? jb.SH * jb.SW : 1;
-  return (size_t)ncls * tg * jb.n_mt * jb.nchunks * KHs * KWs * jb.CK8 * jb.BM;
+  const int R = prep16_rows(BM, KHW), nrb = BM / R;
+  int x = unit;
+  const int rb = x % nrb; x /= nrb;
+  const int ch = x % jb.nchunks; x /= jb.nchunks;
+  const int mt = x % jb.n_mt;
+  const int g = x / jb.n_mt;
+  const int m0 = mt * BM + rb * R, k0 = ch * jb.CK8 * 8;
+  const int nk = jb.CK8 * 8;                                   // reduction channels of a chunk (<= 32)
+  __syncthreads();                                             // the previous unit's gathers are done
+  if (!dg) {
+    // lds[row][kk*KHW + tap], row pitch nk*KHW + 1
+    const int run = nk * KHW, pitch = run + 1;
+    // 8 loads in flight per thread (clamped addresses, masked values): the unit is a latency chain otherwise
+    for (int e0 = t; e0 < R * run; e0 += 8 * 256) {
+      float val[8];
+      int dst[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = e0 + q * 256;
+        const int ec = min(e, R * run - 1);
+        const int row = ec / run, off = ec - row * run;
+        const int m = m0 + row, kk = off / KHW;
+        const bool ok = e < R * run && m < jb.Cog && k0 + kk < jb.Cig;
+        const int co = g * jb.Cog + min(m, jb.Cog - 1);
+        const size_t src = ((size_t)co * jb.Cig + k0) * KHW + off;
+        val[q] = jb.w[ok ? src : 0];
+        if (jb.scale) val[q] *= jb.scale[co];
+        if (!ok) val[q] = 0.f;
+        dst[q] = e < R * run ? row * pitch + off : -1;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (dst[q] >= 0) lds[dst[q]] = val[q];
+    }
+  } else {
+    // lds[kk][row*KHW + tap], pitch R*KHW + 1; reduction channel k = output channel (bcast: of any group)
+    const int run = R * KHW, pitch = run + 1;
+    const int tcog = jb.bcast ? jb.groups * jb.Cog : jb.Cog;
+    for (int e0 = t; e0 < nk * run; e0 += 8 * 256) {
+      float val[8];
+      int dst[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = e0 + q * 256;
+        const int ec = min(e, nk * run - 1);
+        const int kk = ec / run, off = ec - kk * run;
+        const int row = off / KHW, m = m0 + row, k = k0 + kk;
+        const bool ok = e < nk * run && m < jb.Cig && k < tcog;
+        const int co = jb.bcast ? k : g * jb.Cog + k;
+        val[q] = jb.w[ok ? ((size_t)co * jb.Cig + m0) * KHW + off : 0];
+        if (!ok) val[q] = 0.f;
+        dst[q] = e < nk * run ? kk * pitch + off : -1;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (dst[q] >= 0) lds[dst[q]] = val[q];
+    }
+  }
+  __syncthreads();
+  const int nvec = ncls * KHs * KWs * KS * 2 * R;
+  for (int ov = t; ov < nvec; ov += 256) {
+    int y = ov;
+    const int row = y % R; y /= R;
+    const int h = y & 1; y >>= 1;
+    const int ks = y % KS; y /= KS;
+    const int kw = y % KWs; y /= KWs;
+    const int kh = y % KHs;
+    const int cls = y / KHs;
+    float f[8];
+    if (!dg) {
+      const float* src = lds + row * (nk * KHW + 1) + ((2 * ks + h) * 8) * KHW + kh * KW + kw;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = src[j * KHW];
+    } else {
+      const int ry = cls / jb.SW, rx = cls - ry * jb.SW;
+      const int jh = KHs - 1 - kh, jw = KWs - 1 - kw;              // taps reversed: the data gradient is a forward conv
+      const int okh = (ry + jb.PH) % jb.SH + jb.SH * jh, okw = (rx + jb.PW) % jb.SW + jb.SW * jw;
+      const bool tap_ok = okh < KH && okw < KW;
+      const float* src = lds + ((2 * ks + h) * 8) * (R * KHW + 1) + row * KHW + okh * KW + okw;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = tap_ok ? src[j * (R * KHW + 1)] : 0.f;
+    }
+    const size_t v = ((((((((size_t)cls * tg + g) * jb.n_mt + mt) * jb.nchunks + ch) * KHs + kh) * KWs + kw) * KS + ks) * 2 + h) * BM +
+                     rb * R + row;
+    reinterpret_cast<u32x4*>(jb.out)[v] = pack8<DT>(f);
+  }
 }
 
 __global__ __launch_bounds__(256) void prep16_multi_kernel(const Prep16Batch pb) {
+  __shared__ float lds[PREP16_LDS + 64];
   int j = 0;
   while (j + 1 < pb.n && (int)blockIdx.x >= pb.job[j].block_end) ++j;
   const Prep16Job& jb = pb.job[j];
   const int b0 = j ? pb.job[j - 1].block_end : 0, nb = jb.block_end - b0;
-  const size_t total = prep16_total(jb);
-  for (size_t v = (size_t)((int)blockIdx.x - b0) * 256 + threadIdx.x; v < total; v += (size_t)nb * 256) {
-    if (jb.dt == DT_BF16) prep16_vec<BF16>(jb, v);
-    else prep16_vec<F16>(jb, v);
+  const int units = prep16_units(jb);
+  for (int u = (int)blockIdx.x - b0; u < units; u += nb) {
+    if (jb.dt == DT_BF16) prep16_unit<BF16>(jb, u, lds);
+    else prep16_unit<F16>(jb, u, lds);
   }
 }
 
@@ -162,7 +222,7 @@ int launch_prep16_multi(Prep16Batch& pb, hipStream_t s) {
     const int tg = (dg && jb.bcast) ? 1 : jb.groups, ncls = dg ? jb.SH * jb.SW : 1;
     const double n = (double)ncls * tg * jb.n_mt * jb.nchunks * KHs * KWs * jb.CK8 * jb.BM;
     total += n;
-    blocks += (int)std::min<double>(2048.0, std::max(1.0, n / 1024.0));
+    blocks += std::min(4096, std::max(1, prep16_units(jb)));
     jb.block_end = blocks;
   }
   TimingScope ts(s, 0, 48.0 * total, "prep16_multi_kernel|prep16_multi jobs%d", pb.n);

@@ -37,6 +37,11 @@ __device__ inline u32x4 tr_read2(const u32x4* base, int vec0, int vec1, int sub8
   return v;
 }
 
+// workgroups a layer's launch aims for through pixel splits (ms_debug_set_wgrad16_target).  The trainer launches the layers'
+// kernels side by side (ms_wgrad_flush), so a layer need not fill the chip alone; measured on the train step: 512 -> 3.17 ms,
+// 256 -> 3.12, 128 -> 3.06, 64 -> 3.15 per G-step (fewer, longer workgroups leave fewer partial slabs to store and reduce)
+int g_wgrad16_target_wgs = 128;
+
 constexpr int WG16_NPX = 8;   // input-row vectors a thread stages per tile at most (plan_wgrad16 keeps 8*TH*PCX <= 8*256)
 
 template <typename DT, int TP, bool UP2>
@@ -243,7 +248,7 @@ Wgrad16Plan plan_wgrad16(int nd, int Cog, int Cig, int groups, int KH, int KW, i
   pl.n_tiles = imgs * pl.tiles_y * pl.tiles_x;
   // pixel splits: fill ~2 workgroups per CU, at least 2 tiles per workgroup
   const long base = (long)cdiv(Cog, 64) * cdiv(Cig, 64) * groups * KH * pl.ktg;
-  int splits = (int)std::max<long>(1, std::min<long>((512 + base - 1) / base, pl.n_tiles / 2));
+  int splits = (int)std::max<long>(1, std::min<long>((g_wgrad16_target_wgs + base - 1) / base, pl.n_tiles / 2));
   splits = std::min(splits, 64);
   pl.tiles_per_split = cdiv(pl.n_tiles, std::max(1, splits));
   pl.splits = cdiv(pl.n_tiles, pl.tiles_per_split);

@@ -24,15 +24,15 @@ batch = [t.to(dev) for t in (audio, labels, pose, style)]
 
 FAMILIES = {
     'fp32': [('conv fwd', 'conv_fwd'), ('conv dgrad', 'conv_dgrad'), ('conv wgrad', 'conv_wgrad'),
-             ('split-K epilogues', 'splitk_'), ('wgrad slab reduce', 'reduce_splits'), ('bn fwd', 'bn_finalize;bn_apply'),
+             ('split-K epilogues', 'splitk_'), ('wgrad slab reduce', 'reduce_splits;wgrad_reduce'), ('bn fwd', 'bn_finalize;bn_apply'),
              ('bn bwd', 'bn_bwd;act_bwd'), ('weight prep', 'transpose_weight;split_weights'),
              ('losses, mixing, Adam, converters', 'ew_'),
-             ('everything labelled', 'conv_;reduce_splits;bn_;act_bwd;transpose_weight;split_weights;splitk_;ew_')],
+             ('everything labelled', 'conv_;reduce_splits;wgrad_reduce;bn_;act_bwd;transpose_weight;split_weights;splitk_;ew_')],
     'bf16': [('conv fwd', 'conv_fwd'), ('conv dgrad', 'conv_dgrad'), ('conv wgrad', 'conv_wgrad'),
-             ('wgrad slab reduce', 'reduce_splits'), ('bn fwd', 'bn_finalize;bn_apply'), ('bn bwd', 'bn_bwd;act_bwd'),
+             ('wgrad slab reduce', 'reduce_splits;wgrad_reduce'), ('bn fwd', 'bn_finalize;bn_apply'), ('bn bwd', 'bn_bwd;act_bwd'),
              ('weight prep', 'prep16'), ('layout converters', 'cb8_'),
              ('losses, mixing, Adam', 'ew_'),
-             ('everything labelled', 'conv_;reduce_splits;bn_;act_bwd;prep16;cb8_;splitk_;ew_')],
+             ('everything labelled', 'conv_;reduce_splits;wgrad_reduce;bn_;act_bwd;prep16;cb8_;splitk_;ew_')],
 }
 FAMILIES['bf16x6'] = FAMILIES['fp32']
 
@@ -58,6 +58,8 @@ def measure(skip):
 
 if os.environ.get('MS_RING'):          # cap the conv16 LDS-DMA ring depth (experiments)
   _lib.lib().ms_debug_set_conv16_ring(int(os.environ['MS_RING']), 0)
+if os.environ.get('MS_WG16_TARGET'):   # workgroups a 16-bit weight-gradient launch aims for (pixel splits)
+  _lib.lib().ms_debug_set_wgrad16_target(int(os.environ['MS_WG16_TARGET']))
 base = measure('')
 print('%-24s G %.3f ms   D %.3f ms' % ('complete step', base['G'], base['D']))
 for name, pat in ([] if os.environ.get('ABL_BASE_ONLY') else FAMILIES[precision]):
