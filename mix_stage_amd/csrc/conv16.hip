@@ -49,7 +49,9 @@ Conv16Plan plan_conv16(int nd, int Mg, int groups, int Kc, int KH, int KW, int S
     const long nwg = (long)imgs * tiles_y * tiles_x * cdiv(Mg, bm) * groups * zmul;
     const bool fits = ck8 * th * pc <= CONV16_NP * nt;
     if (!fits) continue;
-    if (nwg >= 192 || c == 2 || g_conv16_force_wm) {
+    // the 128 x 128 tile only when it leaves >= 384 workgroups: with 256 (the grouped decoder) every CU would hold ONE
+    // workgroup whose LDS reads and MFMAs alternate; 64 x 128 tiles put two on a CU and they overlap (20.2 -> 18.7 us)
+    if (nwg >= (c == 0 ? 384 : 192) || c == 2 || g_conv16_force_wm) {
       pl.ok = 1; pl.wm = wm; pl.wn = wn; pl.nwn = nwn; pl.tw = tw; pl.th = th; pl.tiles_y = tiles_y; pl.tiles_x = tiles_x;
       pl.n_tiles = imgs * tiles_y * tiles_x;
       pl.ck8 = ck8; pl.nchunks = cdiv(c8_of(Kc), ck8); pl.pc = pc;

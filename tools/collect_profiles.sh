@@ -21,4 +21,7 @@ cp "$OUT"/stats16/*/*kernel_stats.csv "$OUT/kernel_stats_bf16.csv"; rm -rf "$OUT
 cd "$R" && bash tools/pmc_decoder.sh fp32 bf16x6 bf16 > "$OUT/pmc_decoder.log" 2>&1
 cp gpurun_out/pmc_decoder.json "$OUT/pmc_decoder.json"; cp gpurun_out/sq_counters.json "$OUT/sq_counters.json"
 rm -rf gpurun_out/pmcdec
+# what each kernel family costs inside the captured step (launches of a family dropped, step re-captured and re-timed)
+python tools/ablate_step.py fp32 2>&1 | grep -v amdgpu.ids > "$OUT/ablation_fp32.txt"
+python tools/ablate_step.py bf16 2>&1 | grep -v amdgpu.ids > "$OUT/ablation_bf16.txt"
 cut -c1-300 "$OUT/bench.json"; cut -c1-300 "$OUT/bench_bf16.json"
