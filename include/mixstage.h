@@ -136,10 +136,12 @@ typedef struct ms_bwd_options {
   float* wgrad_partials;        /* ms_wgrad_partials_elems(d) floats: the pixel-split partial weight gradients are left
                                  * here and dw is NOT written; the caller adds them into dw later, for many blocks in one
                                  * launch, with ms_wgrad_reduce_multi.  Ignored by blocks whose dw needs no split. */
-  int defer_wgrad_launch;       /* 16-bit modes: the block's weight-gradient kernel is not launched but queued; ms_wgrad_flush
-                                 * launches every queued block in a few multi-block launches (the small layers' weight
-                                 * gradients are latency-bound one-wave kernels: side by side they cost one such latency).
-                                 * x, x2, dyr and dw / wgrad_partials must stay valid until the flush.  Ignored in fp32. */
+  int defer_wgrad_launch;       /* the block's weight-gradient kernel is not launched but queued; ms_wgrad_flush launches
+                                 * every queued block in a few multi-block launches (the small layers' weight gradients
+                                 * are latency-bound one-wave kernels: side by side they cost one such latency).  x, x2,
+                                 * dy / dyr and dw / wgrad_partials must stay valid until the flush; a queued kernel that
+                                 * writes dw itself ADDS to it (dw holds zeros or the step's other contributions).  Blocks
+                                 * whose kernel cannot be queued (bf16x6, im2col-gather path) launch at once as before. */
 } ms_bwd_options;
 int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2, const float* w,
                          const float* gamma, const float* running_mean, const float* running_var,

@@ -52,6 +52,7 @@ int ms_debug_set_conv16_ring(int nstg, int wide8);
 /* ... and the number of workgroups a 16-bit weight-gradient launch aims for when it splits the pixel reduction (default 128);
  * returns the previous value.  Scratch and slab sizes follow: set it before any step is captured. */
 int ms_debug_set_wgrad16_target(int workgroups);
+int ms_debug_set_wgrad_target(int workgroups);      /* the same for the fp32 patch-staged weight gradient (default 768) */
 /* Timing ablations only: launches whose timing label contains one of the ';'-separated substrings are dropped (results are
  * then meaningless); NULL or "" restores normal operation.  Returns the number of patterns. */
 int ms_debug_set_skip(const char* patterns);

@@ -111,6 +111,7 @@ SIGNATURES = {
     'ms_debug_set_conv16_ring': (c_int, [c_int, c_int]),
     'ms_debug_set_skip': (c_int, [ctypes.c_char_p]),
     'ms_debug_set_wgrad16_target': (c_int, [c_int]),
+    'ms_debug_set_wgrad_target': (c_int, [c_int]),
     'ms_selftest_mfma': (c_int, [_P, _P, _P, c_int, _P]),
 }
 

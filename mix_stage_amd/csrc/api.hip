@@ -618,6 +618,10 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
         q.counters = counter_region(CNT_WGRAD, cdiv(q.Kg, 64) * cdiv(d->Cout, 64) * d->groups);
         q.final_out = dw;
       }
+      // queued form (ms_wgrad_flush): only when nothing of this call reads the result -- dw written in place, or slabs left
+      // for the caller's ms_wgrad_reduce_multi
+      if (opt->defer_wgrad_launch && !wp.p6 && ws_stream == s && (wp.splits == 1 || defer_wgrad))
+        return queue_wgrad_patch(q, wp, d->KH, d->KW, d->SW, up2, flops, bytes);
       rc = wp.p6 ? launch_wgrad_patch6(q, wp, d->KH, d->KW, d->SW, up2, flops, bytes, ws_stream)
                  : launch_wgrad_patch(q, wp, d->KH, d->KW, d->SW, up2, flops, bytes, ws_stream);
       if (rc) return rc;

@@ -304,8 +304,12 @@ using namespace ms;
 
 extern "C" {
 
-int ms_wgrad_flush(void* stream) { return wgrad16_flush((hipStream_t)stream); }
-int ms_wgrad_discard(void) { wgrad16_discard(); return 0; }
+int ms_wgrad_flush(void* stream) {
+  const int rc = wgrad_patch_flush((hipStream_t)stream);
+  const int rc16 = wgrad16_flush((hipStream_t)stream);
+  return rc ? rc : rc16;
+}
+int ms_wgrad_discard(void) { wgrad_patch_discard(); wgrad16_discard(); return 0; }
 
 size_t ms_weights16_bytes(const ms_conv_desc* d, int which) {
   if (!d || (dt_of(d) != DT_BF16 && dt_of(d) != DT_F16) || (which != 0 && which != 1)) return 0;

@@ -540,7 +540,13 @@ extern "C" int ms_debug_set_conv16_tile(int wm, int wn) {
   return 0;
 }
 
-namespace ms { extern int g_wgrad16_target_wgs; }
+namespace ms { extern int g_wgrad16_target_wgs, g_wgrad_patch_target_wgs; }
+extern "C" int ms_debug_set_wgrad_target(int workgroups) {
+  const int old = ms::g_wgrad_patch_target_wgs;
+  ++g_tuning_epoch;
+  ms::g_wgrad_patch_target_wgs = workgroups > 0 ? workgroups : 768;
+  return old;
+}
 extern "C" int ms_debug_set_wgrad16_target(int workgroups) {
   const int old = ms::g_wgrad16_target_wgs;
   ++g_tuning_epoch;

@@ -124,10 +124,21 @@ struct WgradPatchArgs {
   int OUTH, OUTW, o_img, o_chan, o_row;
   int tiles_x, tiles_y, n_tiles, tiles_per_split, splits;
   int gx, gy, gz;      // logical grid (column tiles, channel tiles, groups*splits); launched 1-D, XCD-remapped
+  int accumulate;      // splits == 1 only: out += result instead of out = result (queued launches, ms_wgrad_flush)
   int* counters;       // per (group, channel tile, column tile) arrival counters: the last split sums the slabs in-launch
   float* final_out;    // dw, written by the last arriver
 };
 struct WgradPatchPlan { int ok, tw, tiles_y, tiles_x, n_tiles, splits, tiles_per_split, p6; };
+// queued launches: many blocks' weight gradients side by side in one multi-block launch per kernel instance
+constexpr int WGP_MAX_JOBS = 24;
+struct WgradPatchBatch {
+  int n;
+  int block_end[WGP_MAX_JOBS];
+  WgradPatchArgs job[WGP_MAX_JOBS];
+};
+int queue_wgrad_patch(const WgradPatchArgs& a, const WgradPatchPlan& pl, int KH, int KW, int S, bool up2, double flops, double bytes);
+int wgrad_patch_flush(hipStream_t s);
+void wgrad_patch_discard();
 bool wgrad6_supported(int KH, int KW, int S);
 int launch_wgrad_patch6(const WgradPatchArgs& a, const WgradPatchPlan& pl, int KH, int KW, int S, bool up2, double flops,
                         double bytes, hipStream_t s);

@@ -7,10 +7,14 @@
 // pixel offset, so the inner loop is ds_read_b32 with immediate offsets + v_mfma_f32_32x32x2_f32.  Patch pitches are
 // chosen so that consecutive columns n fall in consecutive LDS banks (row pitch = KW, channel pitch = KH*KW mod 32).
 #include <algorithm>
+#include <mutex>
+#include <vector>
 
 #include "kernels.h"
 
 namespace ms {
+
+int g_wgrad_patch_target_wgs = 768;   // workgroups a layer's launch aims for through pixel splits (ms_debug_set_wgrad_target)
 
 constexpr int pitch_mod32(int at_least, int want_mod) {
   int v = at_least;
@@ -19,7 +23,7 @@ constexpr int pitch_mod32(int at_least, int want_mod) {
 }
 
 template <int KH, int KW, int S, int TW, bool UP2>
-__global__ __launch_bounds__(256) void wgrad_patch_kernel(const WgradPatchArgs p) {
+__device__ __forceinline__ void wgrad_patch_body(const WgradPatchArgs& p, const int bid) {
   constexpr int BM = 64, BN = 64, NPIX = 64, TH = NPIX / TW;
   constexpr int SV = (KH == 1) ? 1 : S;
   constexpr int KHW = KH * KW;
@@ -36,7 +40,7 @@ __global__ __launch_bounds__(256) void wgrad_patch_kernel(const WgradPatchArgs p
   const int wm = wid >> 1, wn = wid & 1, khalf = lane >> 5;
   // logical block id: column tile fastest, then channel tile, then (group, pixel split); one contiguous range per XCD:
   // all workgroups of a pixel split (which re-read the same dy / x tiles) sit behind the same L2
-  const int vid = xcd_remap(blockIdx.x, p.gx * p.gy * p.gz);
+  const int vid = xcd_remap(bid, p.gx * p.gy * p.gz);
   const int bx_ = vid % p.gx, by_ = (vid / p.gx) % p.gy, bz_ = vid / (p.gx * p.gy);
   const int g = bz_ / p.splits, sp = bz_ - g * p.splits;
   const int m0 = by_ * BM, n0 = bx_ * BN;
@@ -154,7 +158,10 @@ __global__ __launch_bounds__(256) void wgrad_patch_kernel(const WgradPatchArgs p
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-    if (m < p.Cog && nc < p.Kg) outp[(size_t)(g * p.Cog + m) * p.Kg + nc] = acc[r];
+    if (m < p.Cog && nc < p.Kg) {
+      float* dst = outp + (size_t)(g * p.Cog + m) * p.Kg + nc;
+      *dst = p.accumulate ? *dst + acc[r] : acc[r];
+    }
   }
   if (p.counters == nullptr || p.splits == 1) return;
   // in-launch reduction over the pixel splits: the last workgroup to arrive for this tile sums the slabs in split order
@@ -170,6 +177,20 @@ __global__ __launch_bounds__(256) void wgrad_patch_kernel(const WgradPatchArgs p
       p.final_out[off] = v;
     }
   }
+}
+
+template <int KH, int KW, int S, int TW, bool UP2>
+__global__ __launch_bounds__(256) void wgrad_patch_kernel(const WgradPatchArgs p) {
+  wgrad_patch_body<KH, KW, S, TW, UP2>(p, (int)blockIdx.x);
+}
+
+// many blocks' weight gradients in one launch: a workgroup finds its job in the table of block ranges
+template <int KH, int KW, int S, int TW, bool UP2>
+__global__ __launch_bounds__(256) void wgrad_patch_multi_kernel(const WgradPatchBatch b) {
+  int j = 0;
+  while (j + 1 < b.n && (int)blockIdx.x >= b.block_end[j]) ++j;
+  const int b0 = j ? b.block_end[j - 1] : 0;
+  wgrad_patch_body<KH, KW, S, TW, UP2>(b.job[j], (int)blockIdx.x - b0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -194,7 +215,7 @@ WgradPatchPlan plan_wgrad_patch(int nd, int Cog, int Kg, int groups, int KH, int
   int splits = 1;
   // 3 workgroups share a CU: fill one round of 768 (the decoder layer: 384 tiles x 2); layers with few tiles take as many
   // pixel splits as that allows -- measured: 512 -> 768 target
-  if (base < 768) splits = std::max(1, (int)(768 / base));
+  if (base < g_wgrad_patch_target_wgs) splits = std::max(1, (int)(g_wgrad_patch_target_wgs / base));
   splits = std::min(splits, std::max(1, pl.n_tiles / 1));      // at least 1 pixel tile per split
   pl.tiles_per_split = cdiv(pl.n_tiles, splits);
   pl.splits = cdiv(pl.n_tiles, pl.tiles_per_split);
@@ -214,6 +235,101 @@ static void launch_wgp_tw(const WgradPatchArgs& a, int tw, dim3 grid, hipStream_
     else MS_WP(16);
   }
 #undef MS_WP
+}
+
+// ---- queued launches (ms_bwd_options.defer_wgrad_launch / ms_wgrad_flush)
+template <int KH, int KW, int S, bool UP2>
+static void launch_wgpm_tw(const WgradPatchBatch& b, int tw, hipStream_t s) {
+  const dim3 grid(b.block_end[b.n - 1]);
+#define MS_WPM(TW) hipLaunchKernelGGL((wgrad_patch_multi_kernel<KH, KW, S, TW, UP2>), grid, dim3(256), 0, s, b)
+  if constexpr (KH == 1) {
+    if (tw == 64) MS_WPM(64);
+    else if (tw == 32) MS_WPM(32);
+    else MS_WPM(16);
+  } else {
+    if (tw == 32) MS_WPM(32);
+    else MS_WPM(16);
+  }
+#undef MS_WPM
+}
+
+struct PendingWgradPatch { int KH, KW, S, tw, up2, nwg; double flops, bytes; WgradPatchArgs a; };
+static std::vector<PendingWgradPatch> g_pending;     // process-wide (autograd's device thread queues, the caller's thread flushes)
+static std::mutex g_pending_mu;
+
+int queue_wgrad_patch(const WgradPatchArgs& a, const WgradPatchPlan& pl, int KH, int KW, int S, bool up2, double flops, double bytes) {
+  PendingWgradPatch pw;
+  pw.a = a;
+  pw.a.gx = cdiv(a.Kg, 64); pw.a.gy = cdiv(a.Cog, 64); pw.a.gz = a.groups * a.splits;
+  const double nwg = (double)pw.a.gx * pw.a.gy * pw.a.gz;
+  if (nwg > 1.0e9) return set_error("wgrad grid too large");
+  pw.a.counters = nullptr; pw.a.final_out = nullptr;
+  // a queued kernel that writes dw itself ADDS to it: autograd may already have accumulated the parameter's other uses of the
+  // step into the slot (which starts the step zeroed)
+  pw.a.accumulate = a.splits == 1 ? 1 : 0;
+  pw.KH = KH; pw.KW = KW; pw.S = S; pw.tw = pl.tw; pw.up2 = up2 ? 1 : 0; pw.nwg = (int)nwg; pw.flops = flops; pw.bytes = bytes;
+  std::lock_guard<std::mutex> lk(g_pending_mu);
+  g_pending.push_back(pw);
+  return 0;
+}
+
+void wgrad_patch_discard() {
+  std::lock_guard<std::mutex> lk(g_pending_mu);
+  g_pending.clear();
+}
+
+int wgrad_patch_flush(hipStream_t s) {
+  std::vector<PendingWgradPatch> q;
+  {
+    std::lock_guard<std::mutex> lk(g_pending_mu);
+    q.swap(g_pending);
+  }
+  std::vector<char> done(q.size(), 0);
+  for (size_t i = 0; i < q.size(); ++i) {
+    if (done[i]) continue;
+    WgradPatchBatch b;
+    b.n = 0;
+    long blocks = 0;
+    double flops = 0, bytes = 0;
+    const PendingWgradPatch& h = q[i];
+    auto launch = [&]() -> int {
+      if (!b.n) return 0;
+      TimingScope ts(s, flops, bytes, "wgrad_patch_multi_kernel<%d,%d,%d,%d,%d>|conv_wgrad_patch multi k%dx%d s%d tw%d up%d jobs%d wgs%ld",
+                     h.KH, h.KW, h.S, h.tw, h.up2, h.KH, h.KW, h.S, h.tw, h.up2, b.n, blocks);
+      int rc = 0;
+      if (!ts.skip()) {
+        const int KH = h.KH, KW = h.KW, S = h.S;
+        if (KH == 1 && KW == 3 && S == 1) {
+          if (h.up2) launch_wgpm_tw<1, 3, 1, true>(b, h.tw, s);
+          else launch_wgpm_tw<1, 3, 1, false>(b, h.tw, s);
+        } else if (KH == 1 && KW == 4 && S == 2) launch_wgpm_tw<1, 4, 2, false>(b, h.tw, s);
+        else if (KH == 1 && KW == 4 && S == 1) launch_wgpm_tw<1, 4, 1, false>(b, h.tw, s);
+        else if (KH == 1 && KW == 1 && S == 1) launch_wgpm_tw<1, 1, 1, false>(b, h.tw, s);
+        else if (KH == 3 && KW == 3 && S == 1) launch_wgpm_tw<3, 3, 1, false>(b, h.tw, s);
+        else if (KH == 4 && KW == 4 && S == 2) launch_wgpm_tw<4, 4, 2, false>(b, h.tw, s);
+        else launch_wgpm_tw<3, 8, 1, false>(b, h.tw, s);
+        rc = check_launch("wgrad_patch_multi_kernel");
+      }
+      b.n = 0; blocks = 0; flops = bytes = 0;
+      return rc;
+    };
+    for (size_t k = i; k < q.size(); ++k) {
+      if (done[k] || q[k].KH != h.KH || q[k].KW != h.KW || q[k].S != h.S || q[k].tw != h.tw || q[k].up2 != h.up2) continue;
+      if (b.n == WGP_MAX_JOBS || blocks + q[k].nwg > 0x3fffffff) {
+        const int rc = launch();
+        if (rc) return rc;
+      }
+      blocks += q[k].nwg;
+      b.block_end[b.n] = (int)blocks;
+      b.job[b.n] = q[k].a;
+      ++b.n;
+      flops += q[k].flops; bytes += q[k].bytes;
+      done[k] = 1;
+    }
+    const int rc = launch();
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 int launch_wgrad_patch(const WgradPatchArgs& a, const WgradPatchPlan& pl, int KH, int KW, int S, bool up2, double flops,

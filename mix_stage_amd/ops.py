@@ -414,13 +414,20 @@ class _ConvBlockFn(torch.autograd.Function):
       part, nsplit = (None, 1)
       if _deferred['on'] and direct_w:
         part, nsplit = _wgrad_partials_for(w, d)
-      if wt is not None or part is not None:
+      # the weight-gradient kernel itself is queued (ms_wgrad_flush at the end of the backward pass) when nothing downstream
+      # reads dw: it lands in the flat gradient buffer
+      defer_launch = bool(_deferred['on'] and direct_w and dw is not None and DEFER_WGRAD_LAUNCH)
+      if wt is not None or part is not None or defer_launch:
         opt = BwdOptions(None, None, 0, wt.data_ptr() if wt is not None else None,
-                         part.data_ptr() if part is not None else None)
+                         part.data_ptr() if part is not None else None, 1 if defer_launch else 0)
         check(lib().ms_conv_block_bwd_ex(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(gamma), None, None, _ptr(y_raw),
                                          _ptr(y), _ptr(save), _ptr(dy), _ptr(dyr), _ptr(dx), _ptr(dx2), _ptr(dw),
                                          _ptr(dbias), _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), _stream(),
                                          ctypes.byref(opt)), 'ms_conv_block_bwd_ex')
+        if defer_launch:
+          _deferred['launches'] += 1
+          _deferred['keep'].append((x, x2, dy, dyr, dw, part))
+          _queue_deferred_flush()
         if part is not None:
           _deferred['jobs'].append((part, dw, nsplit))
           _queue_deferred_flush()

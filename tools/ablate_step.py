@@ -58,6 +58,8 @@ def measure(skip):
 
 if os.environ.get('MS_RING'):          # cap the conv16 LDS-DMA ring depth (experiments)
   _lib.lib().ms_debug_set_conv16_ring(int(os.environ['MS_RING']), 0)
+if os.environ.get('MS_WG_TARGET'):     # the same for the fp32 patch-staged weight gradient
+  _lib.lib().ms_debug_set_wgrad_target(int(os.environ['MS_WG_TARGET']))
 if os.environ.get('MS_WG16_TARGET'):   # workgroups a 16-bit weight-gradient launch aims for (pixel splits)
   _lib.lib().ms_debug_set_wgrad16_target(int(os.environ['MS_WG16_TARGET']))
 base = measure('')
