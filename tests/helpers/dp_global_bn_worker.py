@@ -14,6 +14,17 @@ import torch.distributed as dist
 from oracle import mixstage_oracle as O
 
 
+def _emit(rec):
+  """One record per rank: a file when the test asks for it (two ranks' long lines interleave in a shared pipe), else stdout."""
+  d = os.environ.get('DP_RESULT_DIR')
+  if d:
+    with open(os.path.join(d, 'rank%d.json' % rec['rank']), 'w') as f:
+      json.dump(rec, f)
+  else:
+    print('DPRESULT ' + json.dumps(rec), flush=True)
+
+
+
 def main():
   rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
   dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -36,7 +47,7 @@ def main():
   sd = model.state_dict()
   probe = {k: float(sd[k].double().sum()) for k in ('G.decoder.1.conv.weight', 'G.audio_encoder.conv.3.norm.running_var',
                                                     'D.conv3.conv.weight', 'G.unet.conv1.2.norm.weight')}
-  print('DPRESULT ' + json.dumps(dict(rank=rank, out=out, probe=probe)), flush=True)
+  _emit(dict(rank=rank, out=out, probe=probe))
   dist.barrier()
   dist.destroy_process_group()
 

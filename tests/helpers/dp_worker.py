@@ -13,6 +13,17 @@ import torch.distributed as dist
 from oracle import mixstage_oracle as O
 
 
+def _emit(rec):
+  """One record per rank: a file when the test asks for it (two ranks' long lines interleave in a shared pipe), else stdout."""
+  d = os.environ.get('DP_RESULT_DIR')
+  if d:
+    with open(os.path.join(d, 'rank%d.json' % rec['rank']), 'w') as f:
+      json.dump(rec, f)
+  else:
+    print('DPRESULT ' + json.dumps(rec), flush=True)
+
+
+
 def main():
   rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
   dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -33,8 +44,8 @@ def main():
     kinds.append(ts.step(audio.cuda(), labels.cuda(), pose.cuda(), style.cuda()))
     losses.append([float(l.detach()) for l in ts.losses])
   torch.cuda.synchronize()
-  print('DPRESULT ' + json.dumps(dict(rank=rank, kinds=kinds, sums=ts.state_checksums(), losses=losses,
-                                      g_step=ts.optim_G.step_count, d_step=ts.optim_D.step_count)), flush=True)
+  _emit(dict(rank=rank, kinds=kinds, sums=ts.state_checksums(), losses=losses,
+                                      g_step=ts.optim_G.step_count, d_step=ts.optim_D.step_count))
   dist.barrier()
   dist.destroy_process_group()
 

@@ -13,34 +13,30 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run_ranks(cmd, env, timeout=240):
-  """Both ranks share one GPU through gloo here (the boxes have one): bounded, with one retry on another port."""
+  """Both ranks share one GPU through gloo here (the boxes have one): bounded, with one retry on another port.  Every rank
+  leaves its record in a file of its own (long lines of two ranks interleave in a shared stdout pipe)."""
+  import tempfile
   for attempt in range(2):
-    try:
-      return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
-    except subprocess.TimeoutExpired:
-      if attempt:
-        raise
-      cmd = [c if not c.isdigit() or int(c) < 29000 else str(int(c) + 7) for c in cmd]
-
-
-def _results(stdout):
-  """Every 'DPRESULT {json}' record of the ranks' merged stdout (two ranks may land on one line)."""
-  dec, res, i = json.JSONDecoder(), [], 0
-  while True:
-    i = stdout.find('DPRESULT ', i)
-    if i < 0:
-      return res
-    obj, end = dec.raw_decode(stdout, i + len('DPRESULT '))
-    res.append(obj)
-    i = end
+    with tempfile.TemporaryDirectory() as d:
+      try:
+        out = subprocess.run(cmd, env=dict(env, DP_RESULT_DIR=d), capture_output=True, text=True, timeout=timeout)
+      except subprocess.TimeoutExpired:
+        if attempt:
+          raise
+        cmd = [c if not c.isdigit() or int(c) < 29000 else str(int(c) + 7) for c in cmd]
+        continue
+      res = []
+      for name in sorted(os.listdir(d)):
+        with open(os.path.join(d, name)) as f:
+          res.append(json.load(f))
+      return out, res
 
 
 def test_two_ranks_stay_bit_identical():
   env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
          '--master-port', '29541', os.path.join(ROOT, 'tests', 'helpers', 'dp_worker.py')]
-  out = _run_ranks(cmd, env)
-  res = _results(out.stdout)
+  out, res = _run_ranks(cmd, env)
   assert out.returncode == 0 and len(res) == 2, (out.stdout[-2000:], out.stderr[-4000:])
   a, b = sorted(res, key=lambda r: r['rank'])
   assert a['kinds'] == b['kinds'] and set(a['kinds']) <= {'G', 'D'}
@@ -59,8 +55,7 @@ def test_global_bn_dp_equals_single_device():
   env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
          '--master-port', '29543', os.path.join(ROOT, 'tests', 'helpers', 'dp_global_bn_worker.py')]
-  out = _run_ranks(cmd, env)
-  res = _results(out.stdout)
+  out, res = _run_ranks(cmd, env)
   assert out.returncode == 0 and len(res) == 2, (out.stdout[-2000:], out.stderr[-4000:])
   a, b = sorted(res, key=lambda r: r['rank'])
   M = S = 2

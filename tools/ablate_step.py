@@ -26,12 +26,12 @@ FAMILIES = {
     'fp32': [('conv fwd', 'conv_fwd'), ('conv dgrad', 'conv_dgrad'), ('conv wgrad', 'conv_wgrad'),
              ('split-K epilogues', 'splitk_'), ('wgrad slab reduce', 'reduce_splits;wgrad_reduce'), ('bn fwd', 'bn_finalize;bn_apply'),
              ('bn bwd', 'bn_bwd;act_bwd'), ('weight prep', 'transpose_weight;split_weights'),
-             ('losses, mixing, Adam, converters', 'ew_'),
+             ('losses, mixing, Adam, converters', 'ew_'), ('softmax mixture alone (fwd + bwd)', 'ew_softmax_mix'),
              ('everything labelled', 'conv_;reduce_splits;wgrad_reduce;bn_;act_bwd;transpose_weight;split_weights;splitk_;ew_')],
     'bf16': [('conv fwd', 'conv_fwd'), ('conv dgrad', 'conv_dgrad'), ('conv wgrad', 'conv_wgrad'),
              ('wgrad slab reduce', 'reduce_splits;wgrad_reduce'), ('bn fwd', 'bn_finalize;bn_apply'), ('bn bwd', 'bn_bwd;act_bwd'),
              ('weight prep', 'prep16'), ('layout converters', 'cb8_'),
-             ('losses, mixing, Adam', 'ew_'),
+             ('losses, mixing, Adam', 'ew_'), ('softmax mixture alone (fwd + bwd)', 'ew_softmax_mix'),
              ('everything labelled', 'conv_;reduce_splits;wgrad_reduce;bn_;act_bwd;prep16;cb8_;splitk_;ew_')],
 }
 FAMILIES['bf16x6'] = FAMILIES['fp32']
