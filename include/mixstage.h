@@ -260,6 +260,16 @@ int ms_znorm_select(const float* x, const int32_t* keep, const double* mean, con
 int ms_step_metrics(const float* ycap, const float* gt, const int32_t* keep, const int32_t* slot_of, const double* mean,
                     const double* stdv, const float* alphas, int n_alpha, double* out, int B, int T, int P, int PK,
                     void* stream);
+/* N3, evaluation accumulators: FID sufficient statistics and the W1 histograms of one batch ADDED to running device buffers
+ * (reference: evaluation/metrics.py:374-394 FID.__call__, :476-520 W1.__call__, called after every step on CPU copies,
+ * model/trainer.py:887,896).  ycap (B,T,PK) normalised prediction in the kept (xy, joint) order, gt (B,T,P) normalised ground
+ * truth, keep[PK] columns of gt, mean / stdv [P] (W1 works on de-normalised poses).
+ *   fid_sums [2][PK], fid_gram [2][PK][PK] fp64: [0] prediction, [1] ground truth; rows = (b, t), summed in row order
+ *   w1_hist [2][2][nbins] u64: [prediction | ground truth][speed | acceleration], edges k * bin_width, k = 0..nbins
+ * Any of the two groups may be NULL. */
+int ms_eval_accumulate(const float* ycap, const float* gt, const int32_t* keep, const double* mean, const double* stdv,
+                       double* fid_sums, double* fid_gram, unsigned long long* w1_hist, int B, int T, int P, int PK,
+                       double bin_width, int nbins, void* stream);
 
 /* content || style-embedding concat in channel-major layout (replaces EmbLin 'emb' lookup + torch.cat + transposes,
  * JL:175-180, layers.py:659-663): out (B, C+D, T) = [x (B,C,T) ; E[ids[b,t]] (D)].  ids is addressed as

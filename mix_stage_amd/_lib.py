@@ -86,6 +86,7 @@ SIGNATURES = {
     'ms_kmeans_labels': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'ms_znorm_select': (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, c_int, _P]),
     'ms_step_metrics': (c_int, [_P] * 7 + [c_int, _P, c_int, c_int, c_int, c_int, _P]),
+    'ms_eval_accumulate': (c_int, [_P] * 8 + [c_int, c_int, c_int, c_int, ctypes.c_double, c_int, _P]),
     'ms_concat_style_fwd': (c_int, [_P, _P, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     'ms_concat_style_bwd': (c_int, [_P, _P, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'ms_cross_entropy_fwd': (c_int, [_P, _P, _P, _P] + [c_int] * 6 + [_P]),

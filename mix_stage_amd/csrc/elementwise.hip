@@ -553,6 +553,73 @@ __global__ __launch_bounds__(256) void step_metrics_kernel(const float* __restri
 }
 
 // ----------------------------------------------------------------------------------------------
+// Evaluation accumulators ("next" row N3): FID sufficient statistics and the W1 speed / acceleration histograms of one batch,
+// ADDED to running device buffers (no host round trip per step; the reference copies y_cap to the CPU after every step).
+//   metrics.py:374-394  FID.__call__: rows = (b,t), columns = kept (xy, joint) of the NORMALISED poses:
+//                        sum[c] += sum_rows v[r][c],  gram[c][d] += sum_rows v[r][c] * v[r][d]          (fp64, row order)
+// grid (PK), block PK threads: thread d of block c walks the rows in order -- fixed summation order, coalesced over d.
+__global__ void fid_accumulate_kernel(const float* __restrict__ ycap, const float* __restrict__ gt, const int32_t* __restrict__ keep,
+                                      double* __restrict__ sums, double* __restrict__ gram, int rows, int P, int PK) {
+  const int c = blockIdx.x, d = threadIdx.x, which = blockIdx.y;        // which: 0 = prediction, 1 = ground truth
+  if (d >= PK) return;
+  const int kc = keep[c], kd = keep[d];
+  double g = 0.0, sm = 0.0;
+  for (int r = 0; r < rows; ++r) {
+    const double vc = which ? (double)gt[(size_t)r * P + kc] : (double)ycap[(size_t)r * PK + c];
+    const double vd = which ? (double)gt[(size_t)r * P + kd] : (double)ycap[(size_t)r * PK + d];
+    g = fma(vc, vd, g);
+    sm += vd;
+  }
+  gram[((size_t)which * PK + c) * PK + d] += g;
+  if (c == 0) sums[(size_t)which * PK + d] += sm;
+}
+
+//   metrics.py:476-520  W1: de-normalised poses (removed joints never enter), per frame transition the speed of every kept
+//   joint sqrt(dx^2 + dy^2), averaged over the joints -> one value per (b, t); the same on second differences; histogram over
+//   the edges k * width, k = 0 .. nbins (numpy.histogram with explicit edges: [e_k, e_k+1), last bin closed).
+// One workgroup per clip; thread = frame transition; integer counts (atomicAdd: order-free).
+__device__ inline int w1_bin(double v, double width, int nbins) {
+  if (!(v >= 0.0) || v > (double)nbins * width) return -1;
+  int k = (int)(v / width);
+  if (k > nbins) k = nbins;
+  while (k > 0 && v < (double)k * width) --k;                 // the edges are k * width as numpy.arange computes them
+  while (k < nbins && v >= (double)(k + 1) * width) ++k;
+  if (k >= nbins) k = v == (double)nbins * width ? nbins - 1 : -1;
+  return k;
+}
+__global__ __launch_bounds__(256) void w1_accumulate_kernel(const float* __restrict__ ycap, const float* __restrict__ gt,
+                                                            const int32_t* __restrict__ keep, const double* __restrict__ mean,
+                                                            const double* __restrict__ stdv, unsigned long long* __restrict__ hist,
+                                                            int T, int P, int PK, double width, int nbins) {
+  const int b = blockIdx.x, which = blockIdx.y, JK = PK / 2;
+  const float* yc = ycap + (size_t)b * T * PK;
+  const float* g = gt + (size_t)b * T * P;
+  auto val = [&](int t, int d) -> double {                  // de-normalised coordinate, d in the kept (xy, joint) order
+    const int col = keep[d];
+    const double v = which ? (double)g[(size_t)t * P + col] : (double)yc[(size_t)t * PK + d];
+    return v * stdv[col] + mean[col];
+  };
+  for (int t = threadIdx.x; t + 1 < T; t += blockDim.x) {
+    double sv = 0.0, sa = 0.0;
+    for (int j = 0; j < JK; ++j) {
+      const double x0 = val(t, j), x1 = val(t + 1, j), y0 = val(t, JK + j), y1 = val(t + 1, JK + j);
+      const double vx = x1 - x0, vy = y1 - y0;
+      sv += sqrt(vx * vx + vy * vy);
+      if (t + 2 < T) {
+        const double ax = (val(t + 2, j) - x1) - vx, ay = (val(t + 2, JK + j) - y1) - vy;
+        sa += sqrt(ax * ax + ay * ay);
+      }
+    }
+    const int kv = w1_bin(sv / JK, width, nbins);
+    if (kv >= 0) atomicAdd(&hist[((size_t)which * 2 + 0) * nbins + kv], 1ull);
+    if (t + 2 < T) {
+      const int ka = w1_bin(sa / JK, width, nbins);
+      if (ka >= 0) atomicAdd(&hist[((size_t)which * 2 + 1) * nbins + ka], 1ull);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
 // content || style concat (JL:175-180) in channel-major layout: out[b,c,t] = c < C ? x[b,c,t] : E[ids[b,t]][c-C]
 __global__ __launch_bounds__(256) void concat_style_fwd_kernel(const float* __restrict__ x, const float* __restrict__ emb,
                                                                const int64_t* __restrict__ ids, int ids_sb, int ids_st,
@@ -1037,6 +1104,29 @@ int ms_step_metrics(const float* ycap, const float* gt, const int32_t* keep, con
   hipLaunchKernelGGL(step_metrics_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, ycap, gt, keep, slot_of, mean, stdv, alphas,
                      n_alpha, out, T, P, PK);
   return check_launch("step_metrics_kernel");
+}
+
+int ms_eval_accumulate(const float* ycap, const float* gt, const int32_t* keep, const double* mean, const double* stdv,
+                       double* fid_sums, double* fid_gram, unsigned long long* w1_hist, int B, int T, int P, int PK,
+                       double bin_width, int nbins, void* stream) {
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_eval_accumulate");
+  if (ts.skip()) return 0;
+  if (!ycap || !gt || !keep) return set_error("ms_eval_accumulate: null tensor");
+  if (PK < 2 || PK > 1024 || (PK & 1) || PK > P) return set_error("ms_eval_accumulate: %d kept columns", PK);
+  hipStream_t s = (hipStream_t)stream;
+  if (fid_sums && fid_gram) {
+    hipLaunchKernelGGL(fid_accumulate_kernel, dim3(PK, 2), dim3(((PK + 63) / 64) * 64), 0, s, ycap, gt, keep, fid_sums, fid_gram,
+                       B * T, P, PK);
+    const int rc = check_launch("fid_accumulate_kernel");
+    if (rc) return rc;
+  }
+  if (w1_hist) {
+    if (!mean || !stdv || nbins < 1 || !(bin_width > 0.0)) return set_error("ms_eval_accumulate: W1 needs mean / std / bins");
+    hipLaunchKernelGGL(w1_accumulate_kernel, dim3(B, 2), dim3(256), 0, s, ycap, gt, keep, mean, stdv, w1_hist, T, P, PK, bin_width,
+                       nbins);
+    return check_launch("w1_accumulate_kernel");
+  }
+  return 0;
 }
 
 int ms_concat_style_fwd(const float* x, const float* emb, const int64_t* ids, int ids_stride_b, int ids_stride_t, float* out,

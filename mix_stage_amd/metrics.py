@@ -3,7 +3,10 @@
 Reference: TrainerBase.calculate_metrics (src/model/trainer.py:865-915) copies y_cap to the CPU after EVERY step and runs
 evaluation.metrics.{L1, VelL1, PCK, ...} there (metrics.py:94-131,247-303).  Here one kernel produces the numerators per
 clip from the device-resident prediction; the running averages are kept on the host exactly like the reference's
-AverageMeter objects (weights n = B, resp. n = B*T*len(kept) for PCK).  FID / W1 / diversity / F1 stay out of scope.
+AverageMeter objects (weights n = B, resp. n = B*T*len(kept) for PCK).  DeviceEvalAccumulators keeps the FID sufficient
+statistics and the W1 speed / acceleration histograms (metrics.py:374-532) in device buffers across steps; only the final
+reduction (matrix square root, Wasserstein distance: scipy, as in the reference) runs on the host.  Diversity / expressiveness
+/ cluster F1 stay out of scope.
 """
 import ctypes
 
@@ -79,3 +82,82 @@ class DeviceStepMetrics:
     for a in self.alphas:
       out['%s_pck_%s' % (desc, a)] = self.pck_mask[a][0] / max(1, self.pck_mask[a][1])
     return out
+
+
+class DeviceEvalAccumulators:
+  """FID and W1 of evaluation/metrics.py (classes FID :374-473, W1 :476-532) with the per-step accumulation on the device:
+  `update` adds one batch to running fp64 sums / Gram matrices / integer histograms without any host synchronisation;
+  `averages` copies them once and finishes on the host exactly like FID.get_averages / W1.get_averages."""
+
+  def __init__(self, pose_mean, pose_var, mask=(0, 7, 8, 9), num_feats=104, bin_width=0.1, max_value=300.0, device='cuda:0'):
+    dev = torch.device(device)
+    J = num_feats // 2
+    kept = [j for j in range(J) if j not in set(mask)]
+    keep = [xy * J + j for xy in range(2) for j in kept]
+    self.P, self.PK = num_feats, len(keep)
+    self.keep = torch.tensor(keep, dtype=torch.int32, device=dev)
+    self.mean = torch.as_tensor(pose_mean, dtype=torch.float64).reshape(-1).to(dev)
+    self.std = (torch.as_tensor(pose_var, dtype=torch.float64).reshape(-1) ** 0.5).to(dev)
+    import numpy as np
+    self.edges = np.arange(0, max_value, bin_width)            # metrics.py:482
+    self.bin_width, self.nbins = float(bin_width), len(self.edges) - 1
+    self.dev = dev
+    self.reset()
+
+  def reset(self):
+    self.rows = 0
+    self.fid_sums = torch.zeros((2, self.PK), dtype=torch.float64, device=self.dev)
+    self.fid_gram = torch.zeros((2, self.PK, self.PK), dtype=torch.float64, device=self.dev)
+    self.w1_hist = torch.zeros((2, 2, self.nbins), dtype=torch.int64, device=self.dev)
+
+  def update(self, y_cap, gt_full_norm):
+    """y_cap (B,T,PK) fp32 normalised prediction (kept joints), gt_full_norm (B,T,P) fp32 normalised ground truth."""
+    if not (y_cap.is_cuda and gt_full_norm.is_cuda):
+      raise TypeError('DeviceEvalAccumulators runs on the MI355X')
+    y_cap, gt = y_cap.detach().contiguous(), gt_full_norm.contiguous()
+    B, T, PK = y_cap.shape
+    assert PK == self.PK and gt.shape == (B, T, self.P) and y_cap.dtype == torch.float32 and gt.dtype == torch.float32
+    check(lib().ms_eval_accumulate(_p(y_cap), _p(gt), _p(self.keep), _p(self.mean), _p(self.std), _p(self.fid_sums),
+                                   _p(self.fid_gram), _p(self.w1_hist), B, T, self.P, PK, self.bin_width, self.nbins,
+                                   _vp(torch.cuda.current_stream().cuda_stream)), 'ms_eval_accumulate')
+    self.rows += B * T
+
+  def statistics(self):
+    """(mu, sigma) of prediction and ground truth as FID.get_averages forms them (metrics.py:448-466), and the histograms."""
+    N = self.rows
+    sums, gram = self.fid_sums.cpu().numpy(), self.fid_gram.cpu().numpy()
+    out = {}
+    for i, name in enumerate(('y', 'gt')):
+      mu = sums[i] / N
+      sigma = (gram[i] - sums[i][:, None] * sums[i][None, :] / N) / (N - 1)
+      out[name] = (mu, sigma)
+    out['hist'] = self.w1_hist.cpu().numpy()
+    return out
+
+  def averages(self, desc='train'):
+    import numpy as np
+    import scipy.stats
+    from scipy import linalg
+    st = self.statistics()
+    (mu_y, sig_y), (mu_g, sig_g) = st['y'], st['gt']
+    try:                                                    # calculate_frechet_distance(gt, y), metrics.py:396-446
+      diff = mu_g - mu_y
+      covmean, _ = linalg.sqrtm(sig_g.dot(sig_y), disp=False)
+      if not np.isfinite(covmean).all():
+        off = np.eye(sig_g.shape[0]) * 1e-6
+        covmean = linalg.sqrtm((sig_g + off).dot(sig_y + off))
+      if np.iscomplexobj(covmean):
+        if not np.allclose(np.diagonal(covmean).imag, 0, atol=1e-3):
+          raise ValueError('imaginary component')
+        covmean = covmean.real
+      fid = float(diff.dot(diff) + np.trace(sig_g) + np.trace(sig_y) - 2 * np.trace(covmean))
+    except Exception:                                       # the reference reports 1000 on any failure (metrics.py:467-468)
+      fid = 1000
+    centers = self.edges[:-1]
+    h = st['hist']
+    try:
+      w1_vel = scipy.stats.wasserstein_distance(centers, centers, h[0, 0], h[1, 0])
+      w1_acc = scipy.stats.wasserstein_distance(centers, centers, h[0, 1], h[1, 1])
+    except Exception:
+      w1_vel = w1_acc = 1000
+    return {'%s_FID' % desc: fid, '%s_W1_vel' % desc: w1_vel, '%s_W1_acc' % desc: w1_acc}

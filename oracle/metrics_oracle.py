@@ -8,7 +8,10 @@ CPU after every step ("next" row N3 of SURVEY.md section 8f), restated from /roo
                                   poses, undo the normalisation, put the root joint at (0,0), PCK on (B*T, 2, J)
   data/transform.py:228-229       ZNorm.inv_znorm  x * var**0.5 + mean
 
-PINNED for L1, VelL1 and PCK: tests/test_oracle_vs_reference.py runs the reference's own metrics.py (behind the stubs of
+  evaluation/metrics.py:374-473   FID     running sums / Gram matrices of the kept columns, Frechet distance of the Gaussians
+  evaluation/metrics.py:476-532   W1      histograms of the per-frame mean joint speed / acceleration, Wasserstein-1
+
+PINNED for L1, VelL1, PCK, FID and W1: tests/test_oracle_vs_reference.py runs the reference's own metrics.py (behind the stubs of
 oracle/refload.load_transform_and_metrics) and tests/golden/n1n3.npz holds values it produced.  PARITY UNPINNED for the
 glue around them (reinsert_joints / step_metrics): RemoveJoints(inv=True) delegates to pycasper.torchUtils.add_slices;
 "masked joints take the ground truth's values" (parents=None) is inferred from transform.py:483-497.
@@ -67,3 +70,68 @@ def step_metrics(y_cap_kept, gt_full_norm, mean, var, mask, alphas=(0.1, 0.2)):
   gd[..., 0] = 0
   res['pck'] = pck(yd, gd, mask, alphas)
   return res
+
+
+class EvalAccumulators:
+  """FID (metrics.py:374-473) and W1 (:476-532) restated: the same running quantities the reference keeps in its AverageMeter
+  objects (sum += val * n), the same final formulas.  update() takes what calculate_metrics (trainer.py:865-896) hands them:
+  the normalised prediction with its removed joints re-inserted (FID) and the de-normalised poses (W1)."""
+
+  def __init__(self, mean, var, mask=(0, 7, 8, 9), bin_width=0.1, max_value=300.0):
+    self.mean, self.std = np.asarray(mean, np.float64), np.asarray(var, np.float64) ** 0.5
+    self.mask = list(mask)
+    self.ranges = np.arange(0, max_value, bin_width)
+    self.n = 0
+    self.sum = {k: 0 for k in ('y', 'gt')}
+    self.sq = {k: 0 for k in ('y', 'gt')}
+    self.hist = {k: 0 for k in ('y_vel', 'y_acc', 'gt_vel', 'gt_acc')}
+
+  @staticmethod
+  def _vel_acc(y):                                            # W1.get_vel_acc
+    diff = lambda x: x[:, 1:] - x[:, :-1]
+    absolute = lambda x: ((x ** 2).sum(2) ** 0.5).mean(-1).reshape(-1)
+    vel = diff(y)
+    acc = diff(vel)
+    return absolute(vel), absolute(acc)
+
+  def update(self, y_cap_kept, gt_full_norm):
+    y_cap_kept, gt = y_cap_kept.astype(np.float64), gt_full_norm.astype(np.float64)
+    y_full = reinsert_joints(y_cap_kept, gt, self.mask)
+    B, T, P = gt.shape
+    J = P // 2
+    kept = sorted(set(range(J)) - set(self.mask))
+    rows = {'y': y_full.reshape(B, T, 2, J)[..., kept].reshape(B * T, -1), 'gt': gt.reshape(B, T, 2, J)[..., kept].reshape(B * T, -1)}
+    n = B * T
+    self.n += n
+    for k, v in rows.items():                                 # FID.__call__
+      self.sum[k] = self.sum[k] + v.mean(0, keepdims=True) * n
+      self.sq[k] = self.sq[k] + (v.T @ v / n) * n
+    for k, v in (('y', y_full), ('gt', gt)):                  # W1.__call__ on the de-normalised poses
+      d = (v * self.std + self.mean).reshape(B, T, 2, J)[..., kept]
+      vel, acc = self._vel_acc(d)
+      self.hist[k + '_vel'] = self.hist[k + '_vel'] + np.histogram(vel, bins=self.ranges)[0]
+      self.hist[k + '_acc'] = self.hist[k + '_acc'] + np.histogram(acc, bins=self.ranges)[0]
+
+  def statistics(self):
+    out = {}
+    for k in ('y', 'gt'):
+      s, N = self.sum[k], self.n
+      out[k] = ((s / N).squeeze(), (self.sq[k] - s.T @ s / N) / (N - 1))
+    return out
+
+  def averages(self):
+    import scipy.stats
+    from scipy import linalg
+    st = self.statistics()
+    (mu1, s1), (mu2, s2) = st['gt'], st['y']                  # calculate_frechet_distance(gt_mu, gt_sigma, y_mu, y_sigma)
+    diff = mu1 - mu2
+    covmean, _ = linalg.sqrtm(s1.dot(s2), disp=False)
+    if not np.isfinite(covmean).all():
+      off = np.eye(s1.shape[0]) * 1e-6
+      covmean = linalg.sqrtm((s1 + off).dot(s2 + off))
+    if np.iscomplexobj(covmean):
+      covmean = covmean.real
+    fid = float(diff.dot(diff) + np.trace(s1) + np.trace(s2) - 2 * np.trace(covmean))
+    N = self.ranges[:-1]
+    return dict(FID=fid, W1_vel=scipy.stats.wasserstein_distance(N, N, self.hist['y_vel'], self.hist['gt_vel']),
+                W1_acc=scipy.stats.wasserstein_distance(N, N, self.hist['y_acc'], self.hist['gt_acc']))

@@ -150,11 +150,47 @@ def run_n1n3():
   print('n1n3 ok', {k: getattr(v, 'shape', v) for k, v in rec.items()})
 
 
+def run_evalacc():
+  """FID / W1 (N3) from the reference's own metrics.py over three batches fed as calculate_metrics feeds them (trainer.py:884-896):
+  inputs, the running histograms / Gram matrices and the final numbers."""
+  from oracle import metrics_oracle as MO
+  Mx = refload.load_transform_and_metrics().metrics
+  mask = [0, 7, 8, 9]
+  kept = [j for j in range(52) if j not in mask]
+  rng = np.random.default_rng(29)
+  mean, var = rng.standard_normal(104) * 20 + 150, rng.random(104) * 400 + 25
+  std = var ** 0.5
+  fid, w1 = Mx.FID(), Mx.W1()
+  ys, gts = [], []
+  B, Tn = 5, 24
+  for step in range(3):
+    gt = rng.standard_normal((B, 1, 104)) * 0.5 + np.cumsum(rng.standard_normal((B, Tn, 104)) * 0.08, axis=1)
+    y_kept = (gt.reshape(B, Tn, 2, 52)[..., kept] + 0.15 * rng.standard_normal((B, Tn, 2, 48))).reshape(B, Tn, 96)
+    y_kept, gt = y_kept.astype(np.float32), gt.astype(np.float32)
+    ys.append(y_kept); gts.append(gt)
+    y_full = MO.reinsert_joints(y_kept.astype(np.float64), gt.astype(np.float64), mask)
+    fid(torch.from_numpy(y_full), torch.from_numpy(gt.astype(np.float64)), mask_idx=mask)
+    w1(torch.from_numpy((y_full * std + mean).reshape(B, Tn, 2, 52)),
+       torch.from_numpy((gt.astype(np.float64) * std + mean).reshape(B, Tn, 2, 52)), mask_idx=mask)
+  fa, wa = fid.get_averages('t'), w1.get_averages('t')
+  rec = dict(y=np.stack(ys), gt=np.stack(gts), mean=mean, var=var, mask=np.array(mask),
+             FID=np.float64(fa['t_FID']), W1_vel=np.float64(wa['t_W1_vel']), W1_acc=np.float64(wa['t_W1_acc']),
+             hist=np.stack([w1.y_vel_meter.sum, w1.y_acc_meter.sum, w1.gt_vel_meter.sum, w1.gt_acc_meter.sum]).astype(np.int64),
+             y_sum=fid.y_sum_meter.sum.numpy(), gt_sum=fid.gt_sum_meter.sum.numpy(),
+             y_square=fid.y_square_meter.sum.numpy(), gt_square=fid.gt_square_meter.sum.numpy())
+  np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'evalacc.npz'), **rec)
+  print('evalacc ok', {k: getattr(v, 'shape', v) for k, v in rec.items()})
+
+
 if __name__ == '__main__':
   assert refload.available(), 'needs /root/reference'
   if len(sys.argv) > 1 and sys.argv[1] == 'n1n3':
     run_n1n3()
     sys.exit(0)
+  if len(sys.argv) > 1 and sys.argv[1] == 'evalacc':
+    run_evalacc()
+    sys.exit(0)
   for name, cfg in CONFIGS.items():
     run(name, *cfg)
   run_n1n3()
+  run_evalacc()

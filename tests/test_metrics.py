@@ -53,3 +53,44 @@ def test_oracle_matches_reference_vectors():
   res = MO.pck(z['m_y'].reshape(-1, 2, 52), z['m_gt'].reshape(-1, 2, 52), mask, alphas=(0.1, 0.2))
   for i, a in enumerate((0.1, 0.2)):
     assert np.abs(res[a][0] - z['pck'][i]).max() <= 1e-6 and abs(res[a][1] - z['pck_mean'][i]) <= 1e-6
+
+
+def _evalacc_golden(golden_dir):
+  import os
+  return np.load(os.path.join(golden_dir, 'evalacc.npz'))
+
+
+def test_fid_w1_oracle_matches_reference_fixture(golden_dir):
+  """FID / W1: the oracle against numbers, histograms and Gram matrices the reference's own metrics.py produced over three
+  batches (tests/golden/make_golden.py evalacc)."""
+  z = _evalacc_golden(golden_dir)
+  acc = MO.EvalAccumulators(z['mean'], z['var'], list(z['mask']))
+  for y, gt in zip(z['y'], z['gt']):
+    acc.update(y, gt)
+  got = acc.averages()
+  assert abs(got['FID'] - float(z['FID'])) <= 1e-9 * max(1.0, abs(float(z['FID'])))
+  assert abs(got['W1_vel'] - float(z['W1_vel'])) <= 1e-12 and abs(got['W1_acc'] - float(z['W1_acc'])) <= 1e-12
+  hist = np.stack([acc.hist['y_vel'], acc.hist['y_acc'], acc.hist['gt_vel'], acc.hist['gt_acc']])
+  assert np.array_equal(hist, z['hist'])
+  np.testing.assert_allclose(acc.sq['gt'], z['gt_square'], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_hip_fid_w1_accumulators_match_reference_fixture(golden_dir):
+  """The device accumulators over the same three batches: histograms bit-exact, sums / Gram matrices to fp64 rounding, final
+  FID / W1 equal to the reference's numbers."""
+  from mix_stage_amd.metrics import DeviceEvalAccumulators
+  z = _evalacc_golden(golden_dir)
+  dev = DeviceEvalAccumulators(z['mean'], z['var'], mask=tuple(int(v) for v in z['mask']))
+  for y, gt in zip(z['y'], z['gt']):
+    dev.update(torch.from_numpy(y).cuda(), torch.from_numpy(gt).cuda())
+  h = dev.w1_hist.cpu().numpy()                     # [prediction | gt][speed | acceleration]
+  assert np.array_equal(np.stack([h[0, 0], h[0, 1], h[1, 0], h[1, 1]]), z['hist'])
+  np.testing.assert_allclose(dev.fid_sums.cpu().numpy()[0], z['y_sum'][0], rtol=1e-12, atol=1e-12)
+  np.testing.assert_allclose(dev.fid_gram.cpu().numpy()[0], z['y_square'], rtol=1e-12, atol=1e-11)
+  np.testing.assert_allclose(dev.fid_gram.cpu().numpy()[1], z['gt_square'], rtol=1e-12, atol=1e-11)
+  got = dev.averages('t')
+  assert abs(got['t_FID'] - float(z['FID'])) <= 1e-8 * max(1.0, abs(float(z['FID'])))
+  assert abs(got['t_W1_vel'] - float(z['W1_vel'])) <= 1e-12 and abs(got['t_W1_acc'] - float(z['W1_acc'])) <= 1e-12
+  dev.reset()
+  assert int(dev.w1_hist.sum()) == 0 and dev.rows == 0

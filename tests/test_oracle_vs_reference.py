@@ -136,3 +136,36 @@ def test_metrics_oracle_vs_reference_metrics():
     for j in range(52):
       assert abs(per_joint[j] - ref['t_pck_%s_%d' % (a, j)]) <= 1e-6, (a, j)
     assert abs(kept_mean - ref['t_pck_%s' % a]) <= 1e-6
+
+
+def test_fid_w1_oracle_vs_reference_metrics():
+  """N3: FID and W1 of the reference's own metrics.py, fed as calculate_metrics feeds them (trainer.py:884-896) over three
+  batches: running statistics, histograms and the final numbers."""
+  import numpy as np
+  from oracle import metrics_oracle as MO
+  Mx = refload.load_transform_and_metrics().metrics
+  mask = [0, 7, 8, 9]
+  rng = np.random.default_rng(29)
+  mean, var = rng.standard_normal(104) * 20 + 150, rng.random(104) * 400 + 25
+  std = var ** 0.5
+  fid, w1 = Mx.FID(), Mx.W1()
+  acc = MO.EvalAccumulators(mean, var, mask)
+  kept = [j for j in range(52) if j not in mask]
+  for step in range(3):
+    B, T = 5, 24
+    gt = rng.standard_normal((B, 1, 104)) * 0.5 + np.cumsum(rng.standard_normal((B, T, 104)) * 0.08, axis=1)
+    y_kept = (gt.reshape(B, T, 2, 52)[..., kept] + 0.15 * rng.standard_normal((B, T, 2, 48))).reshape(B, T, 96)
+    y_kept, gt = y_kept.astype(np.float32), gt.astype(np.float32)          # the device path holds fp32 tensors
+    acc.update(y_kept, gt)
+    y_full = MO.reinsert_joints(y_kept.astype(np.float64), gt.astype(np.float64), mask)
+    fid(torch.from_numpy(y_full), torch.from_numpy(gt.astype(np.float64)), mask_idx=mask)
+    yd = torch.from_numpy((y_full * std + mean).reshape(B, T, 2, 52))
+    gd = torch.from_numpy((gt.astype(np.float64) * std + mean).reshape(B, T, 2, 52))
+    w1(yd, gd, mask_idx=mask)
+  ref = dict(fid.get_averages('t'), **w1.get_averages('t'))
+  mine = acc.averages()
+  assert ref['t_FID'] != 1000 and ref['t_W1_vel'] != 1000
+  assert abs(mine['FID'] - ref['t_FID']) <= 1e-9 * max(1.0, abs(ref['t_FID']))
+  assert abs(mine['W1_vel'] - ref['t_W1_vel']) <= 1e-12 and abs(mine['W1_acc'] - ref['t_W1_acc']) <= 1e-12
+  assert np.array_equal(acc.hist['y_vel'], w1.y_vel_meter.sum) and np.array_equal(acc.hist['gt_acc'], w1.gt_acc_meter.sum)
+  assert np.abs(acc.sq['y'] - fid.y_square_meter.sum.numpy()).max() <= 1e-9 * np.abs(acc.sq['y']).max()
