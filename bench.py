@@ -273,7 +273,9 @@ def main():
     local_rank = 0
   torch.cuda.set_device(local_rank)
   dev = torch.device('cuda', local_rank)
-  if world > 1:
+  # MS_DP_SINGLE_RANK=1 under a launcher: ONE rank takes the data-parallel form of the step (split graphs, eager RCCL
+  # all-reduce) -- what that machinery costs without any inter-GPU transfer, measurable on a one-GPU box
+  if world > 1 or (os.environ.get('MS_DP_SINGLE_RANK') == '1' and 'RANK' in os.environ):
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if args.dist_backend == 'nccl':
       dist.init_process_group('nccl', device_id=dev)
@@ -345,7 +347,7 @@ def main():
     if args.precision == 'fp32' and not args.no_bf16_extra and not args.no_per_kind:
       out['bf16'] = bf16_extra(dev, batch, args)
     out['cpu_baseline'] = None if args.no_cpu_baseline else cpu_baseline(args.seed)
-  if world > 1:
+  if dist.is_initialized():
     dist.barrier()
     dist.destroy_process_group()
   if rank == 0:

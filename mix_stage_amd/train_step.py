@@ -15,6 +15,7 @@ MI355X-first structure:
     (bn_sync='local'); host-side random decisions come from identically seeded CPU generators so all
     ranks take the same D-vs-G branch (gan.py:105) and curriculum branch (JL:127).
 """
+import os
 import weakref
 
 import torch
@@ -25,6 +26,20 @@ from . import layers, ops
 _ALIGN = 64  # elements: every parameter starts 256-B aligned inside the flat buffer
 
 
+def _single_rank_dp():
+  """Test aid: MS_DP_SINGLE_RANK=1 makes a ONE-rank process group take the data-parallel path (split graphs, eager RCCL
+  all-reduce, broadcast), so that the RCCL calls of that path can be executed on a box with a single GPU."""
+  return os.environ.get('MS_DP_SINGLE_RANK', '0') == '1'
+
+
+def _dp_world(process_group=None):
+  """Ranks of the data-parallel job; 1 = no exchange step."""
+  if not (dist.is_available() and dist.is_initialized()):
+    return 1
+  world = dist.get_world_size(process_group)
+  return 2 if (world == 1 and _single_rank_dp()) else world
+
+
 def average_flat_gradients(flat_g, process_group=None):
   """The data-parallel exchange step: one all-reduce (RCCL over xGMI on the GPUs; gloo in the CPU tests) of the flat
   gradient buffer, leaving the mean over ranks -- what a single device would have computed on the global batch of
@@ -32,7 +47,7 @@ def average_flat_gradients(flat_g, process_group=None):
   if not (dist.is_available() and dist.is_initialized()):
     return flat_g
   world = dist.get_world_size(process_group)
-  if world == 1:
+  if world == 1 and not _single_rank_dp():
     return flat_g
   if dist.get_backend(process_group) == 'nccl':
     dist.all_reduce(flat_g, op=dist.ReduceOp.AVG, group=process_group)
@@ -45,7 +60,7 @@ def average_flat_gradients(flat_g, process_group=None):
 def broadcast_from_rank0(tensors, process_group=None):
   """Start every rank from rank 0's values (parameters, BatchNorm buffers): with identical weights and identical
   averaged gradients the replicas stay bit-identical without any further parameter traffic."""
-  if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+  if _dp_world(process_group) == 1:
     return
   for t in tensors:
     dist.broadcast(t, src=0, group=process_group)
@@ -220,7 +235,7 @@ class MixStageTrainStep:
     self.use_graphs = use_graphs
     self.time_steps = time_steps
     self.pg = process_group
-    self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+    self.world = _dp_world(process_group)          # > 1: the data-parallel form of the step (see _single_rank_dp)
     if self.world > 1:
       broadcast_from_rank0([self.optim_G.flat_p, self.optim_D.flat_p] + [b for b in model.buffers()], process_group)
     self._graphs = {}

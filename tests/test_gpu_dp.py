@@ -75,3 +75,18 @@ def test_global_bn_dp_equals_single_device():
   for k, v in a['probe'].items():
     assert b['probe'][k] == v                                            # replicas identical
     assert abs(v - float(sd[k].double().sum())) <= 2e-4 * max(1.0, sd[k].numel() ** 0.5), k
+
+
+def test_rccl_path_single_rank():
+  """The RCCL calls of the data-parallel step, executed on the one GPU the box has: a single `nccl` rank forced onto the
+  data-parallel form of the step (split graphs around the eager all-reduce, broadcast) reproduces the plain step bit for bit,
+  in the fp32 and the bf16 mode."""
+  env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+         '--master-port', '29545', os.path.join(ROOT, 'tests', 'helpers', 'dp_rccl1_worker.py')]
+  out, res = _run_ranks(cmd, env)
+  assert out.returncode == 0 and len(res) == 1, (out.stdout[-2000:], out.stderr[-4000:])
+  assert res[0]['backend'] == 'nccl'
+  for precision, r in res[0]['out'].items():
+    assert r['plain']['sums'] == r['dp']['sums'], precision
+    assert r['plain']['losses'] == r['dp']['losses'], precision
