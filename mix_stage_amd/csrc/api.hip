@@ -155,9 +155,8 @@ int ms_conv_block_fwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
                         d->eps, s);
     if (rc) return rc;
     if (d->mode == MS_BN_TRAIN) {
-      rc = launch_bn_finalize(stats, counts, nt, 0, npix, C, gamma, beta, running_mean, running_var, save, d->eps, d->momentum, s);
-      if (rc) return rc;
-      rc = launch_bn_apply(y_raw, y, save, C, hw, (size_t)npix * C, d->slope, s);
+      rc = launch_bn_finalize_apply(stats, counts, nt, 0, npix, C, gamma, beta, running_mean, running_var, save, d->eps, d->momentum,
+                                    y_raw, y, d->B, hw, d->slope, s);
     }
     return rc;
   }
@@ -212,10 +211,8 @@ int ms_conv_block_fwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
       return launch_splitk_fwd_epilogue(q.part, pp.splitk, q.part_stride, bias, gamma, beta, running_mean, running_var, y_raw,
                                         y, save, d->B, C, hw, a.ep, d->slope, d->eps, d->momentum, s);
     if (d->mode == MS_BN_TRAIN) {
-      rc = launch_bn_finalize(q.stats, q.counts, pp.n_tiles, 0, npix, C, gamma, beta, running_mean, running_var, save, d->eps,
-                              d->momentum, s);
-      if (rc) return rc;
-      rc = launch_bn_apply(y_raw, y, save, C, hw, (size_t)npix * C, d->slope, s);
+      rc = launch_bn_finalize_apply(q.stats, q.counts, pp.n_tiles, 0, npix, C, gamma, beta, running_mean, running_var, save, d->eps,
+                                    d->momentum, y_raw, y, d->B, hw, d->slope, s);
     }
     return rc;
   }
@@ -232,10 +229,8 @@ int ms_conv_block_fwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
                                       save, d->B, C, hw, a.ep, d->slope, d->eps, d->momentum, s);
   }
   if (d->mode == MS_BN_TRAIN) {
-    rc = launch_bn_finalize(a.stats, nullptr, pl.n_tiles, 64 * pl.tn, npix, C, gamma, beta, running_mean, running_var, save, d->eps,
-                            d->momentum, s);
-    if (rc) return rc;
-    rc = launch_bn_apply(y_raw, y, save, C, hw, (size_t)npix * C, d->slope, s);
+    rc = launch_bn_finalize_apply(a.stats, nullptr, pl.n_tiles, 64 * pl.tn, npix, C, gamma, beta, running_mean, running_var, save,
+                                  d->eps, d->momentum, y_raw, y, d->B, hw, d->slope, s);
   }
   return rc;
 }

@@ -52,6 +52,85 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   }
 }
 
+// bn_finalize_kernel + bn_apply_kernel in ONE launch for layers with at most 64 statistics tiles (every 1-D layer): each
+// workgroup combines the per-tile partials of its channel itself -- the same operations in the same order as
+// bn_finalize_kernel, so the statistics are bit-identical -- chunk 0 records them, and every workgroup normalises its share of
+// the channel (grid (C, chunks of batch items)).  All loads (partials, parameters, FA_PRE data values per thread) are issued
+// before the first use.
+constexpr int FA_PRE = 8;
+__global__ __launch_bounds__(256) void bn_finalize_apply_kernel(const float* __restrict__ stats, const float* __restrict__ counts,
+                                                                int n_tiles, int tile_n, int N, int C,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float* running_mean, float* running_var, float* __restrict__ save,
+                                                                float eps, float momentum, const float* __restrict__ y_raw,
+                                                                float* __restrict__ y, int B, int HW, int b_per_chunk, float slope) {
+  __shared__ double red[4];
+  const int c = blockIdx.x, ch = blockIdx.y, t = threadIdx.x;
+  const int b0 = ch * b_per_chunk, nb = min(b_per_chunk, B - b0);
+  const int n = nb * HW;
+  const int tc = min(t, n_tiles - 1);
+  const float2 st = *(const float2*)(stats + ((size_t)tc * C + c) * 2);
+  const float cntf = counts ? counts[tc] : 0.f;
+  const float g = gamma[c], bt = beta[c], rm = running_mean[c], rv = running_var[c];
+  __builtin_amdgcn_sched_barrier(0);
+  float v[FA_PRE];
+  size_t ofs[FA_PRE];
+#pragma unroll
+  for (int q = 0; q < FA_PRE; ++q) {
+    const int e = min(t + q * 256, n - 1);
+    const int bl = e / HW, pix = e - bl * HW;
+    ofs[q] = ((size_t)(b0 + bl) * C + c) * HW + pix;
+    v[q] = y_raw[ofs[q]];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const bool has = t < n_tiles;
+  double s = has ? (double)st.x : 0.0;
+  s = wave_sum_d(s);
+  if ((t & 63) == 0) red[t >> 6] = s;
+  __syncthreads();
+  const double mean = (red[0] + red[1] + red[2] + red[3]) / (double)N;
+  __syncthreads();
+  double q2 = 0.0;
+  if (has) {
+    const int cnt = counts ? (int)cntf : min(tile_n, N - t * tile_n);
+    const double d = (double)st.x / (double)cnt - mean;
+    q2 = (double)st.y + (double)cnt * d * d;
+  }
+  q2 = wave_sum_d(q2);
+  if ((t & 63) == 0) red[t >> 6] = q2;
+  __syncthreads();
+  const double m2 = red[0] + red[1] + red[2] + red[3];
+  const float var = (float)(m2 / (double)N);
+  const float invstd = 1.0f / sqrtf(var + eps);
+  const float fmean = (float)mean;
+  const float sc = g * invstd;
+  const float sh = bt - fmean * sc;
+  if (t == 0 && ch == 0) {
+    save[c] = fmean;
+    save[C + c] = invstd;
+    save[2 * C + c] = sc;
+    save[3 * C + c] = sh;
+    const float unbiased = N > 1 ? (float)(m2 / (double)(N - 1)) : var;
+    running_mean[c] = (1.f - momentum) * rm + momentum * fmean;
+    running_var[c] = (1.f - momentum) * rv + momentum * unbiased;
+  }
+#pragma unroll
+  for (int q = 0; q < FA_PRE; ++q)
+    if (t + q * 256 < n) y[ofs[q]] = lrelu(fmaf(v[q], sc, sh), slope);
+  for (int e0 = t + FA_PRE * 256; e0 < n; e0 += FA_PRE * 256) {
+#pragma unroll
+    for (int q = 0; q < FA_PRE; ++q) {
+      const int e = min(e0 + q * 256, n - 1);
+      const int bl = e / HW, pix = e - bl * HW;
+      ofs[q] = ((size_t)(b0 + bl) * C + c) * HW + pix;
+      v[q] = y_raw[ofs[q]];
+    }
+#pragma unroll
+    for (int q = 0; q < FA_PRE; ++q)
+      if (e0 + q * 256 < n) y[ofs[q]] = lrelu(fmaf(v[q], sc, sh), slope);
+  }
+}
+
 // y = lrelu(y_raw * scale[c] + shift[c]);  layout (B, C, HW)
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ y_raw, float* __restrict__ y,
                                                        const float* __restrict__ save, int C, int HW, size_t total,
@@ -902,6 +981,24 @@ int launch_bn_finalize(const float* stats, const float* counts, int n_tiles, int
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, s, stats, counts, n_tiles, tile_n, N, C, gamma, beta, rm, rv, save,
                      eps, momentum);
   return check_launch("bn_finalize_kernel");
+}
+
+// finalize + apply: one launch when the layer has at most 64 statistics tiles, else the two kernels
+int launch_bn_finalize_apply(const float* stats, const float* counts, int n_tiles, int tile_n, int N, int C, const float* gamma,
+                             const float* beta, float* rm, float* rv, float* save, float eps, float momentum, const float* y_raw,
+                             float* y, int B, int HW, float slope, hipStream_t s) {
+  if (n_tiles > 64 || n_tiles < 1) {
+    const int rc = launch_bn_finalize(stats, counts, n_tiles, tile_n, N, C, gamma, beta, rm, rv, save, eps, momentum, s);
+    if (rc) return rc;
+    return launch_bn_apply(y_raw, y, save, C, HW, (size_t)N * C, slope, s);
+  }
+  int bpc;
+  const int nchunk = bwd_chunks(B, C, &bpc);
+  TimingScope ts(s, 0, 8.0 * (double)N * C, "bn_finalize_apply C%d N%d tiles%d", C, N, n_tiles);
+  if (ts.skip()) return 0;
+  hipLaunchKernelGGL(bn_finalize_apply_kernel, dim3(C, nchunk), dim3(256), 0, s, stats, counts, n_tiles, tile_n, N, C, gamma, beta, rm,
+                     rv, save, eps, momentum, y_raw, y, B, HW, bpc, slope);
+  return check_launch("bn_finalize_apply_kernel");
 }
 
 int launch_bn_apply(const float* y_raw, float* y, const float* save, int C, int HW, size_t total, float slope, hipStream_t s) {

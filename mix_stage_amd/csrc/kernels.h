@@ -182,6 +182,9 @@ size_t dgrad_weight_elems(int groups, int Cog, int Cig, int KH, int KW, int SH, 
 int launch_bn_finalize(const float* stats, const float* counts, int n_tiles, int tile_n, int N, int C, const float* gamma,
                        const float* beta, float* rm, float* rv, float* save, float eps, float momentum, hipStream_t s);
 int launch_bn_apply(const float* y_raw, float* y, const float* save, int C, int HW, size_t total, float slope, hipStream_t s);
+int launch_bn_finalize_apply(const float* stats, const float* counts, int n_tiles, int tile_n, int N, int C, const float* gamma,
+                             const float* beta, float* rm, float* rv, float* save, float eps, float momentum, const float* y_raw,
+                             float* y, int B, int HW, float slope, hipStream_t s);
 int bwd_chunks(int B, int C, int* b_per_chunk);
 int launch_bn_bwd(const float* dy, const float* y_raw, const float* save, const float* gamma, float* partial, float* dyr,
                   float* colpart, float* dbias, float* dgamma, float* dbeta, int B, int C, int HW, float slope, int* fused,
