@@ -338,15 +338,25 @@ def main():
   if rank == 0 and world == 1:
     roof, rows = (None, [])
     if not args.no_kernel_timing:
-      roof, rows = kernel_roofline(ts, batch, ['G', 'D', 'G', 'D'], args.precision)
+      try:
+        roof, rows = kernel_roofline(ts, batch, ['G', 'D', 'G', 'D'], args.precision)
+      except Exception as e:  # noqa: BLE001
+        roof = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
     out['roofline'] = roof
     out['kernel_table'] = [dict(label=r['label'].split('|')[-1], count=r['count'], avg_us=round(1e3 * r['total_ms'] / r['count'], 2),
                                 total_ms=round(r['total_ms'], 3),
                                 tflops=round(r['flops'] / (r['total_ms'] / r['count'] * 1e-3) / 1e12, 2))
                            for r in rows[:12]]
+    # auxiliary measurements must never cost the headline line: a failure is reported in place
     if args.precision == 'fp32' and not args.no_bf16_extra and not args.no_per_kind:
-      out['bf16'] = bf16_extra(dev, batch, args)
-    out['cpu_baseline'] = None if args.no_cpu_baseline else cpu_baseline(args.seed)
+      try:
+        out['bf16'] = bf16_extra(dev, batch, args)
+      except Exception as e:  # noqa: BLE001
+        out['bf16'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+    try:
+      out['cpu_baseline'] = None if args.no_cpu_baseline else cpu_baseline(args.seed)
+    except Exception as e:  # noqa: BLE001
+      out['cpu_baseline'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
   if dist.is_initialized():
     dist.barrier()
     dist.destroy_process_group()
