@@ -79,6 +79,37 @@ __device__ inline float block_sum_256(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// e / d for a wave-uniform divisor by multiply-high with floor(2^32 / d) + 1 (exact while e * d < 2^32, which `max_e` vouches
+// for; otherwise, and for d == 1, the plain division): the generic 32-bit division is ~25 instructions, and the small kernels'
+// address arithmetic sits in front of their first load.
+struct FastDiv {
+  unsigned m, d;
+  bool ok;
+  __device__ __forceinline__ FastDiv(int d_, int max_e)
+      : m(d_ > 1 ? 0xFFFFFFFFu / (unsigned)d_ + 1u : 0u), d((unsigned)d_), ok(d_ > 1 && (unsigned long long)max_e * (unsigned)d_ < (1ull << 32)) {}
+  __device__ __forceinline__ int div(int e) const { return ok ? (int)__umulhi((unsigned)e, m) : e / (int)d; }
+};
+
+// Kernel arguments are a few hundred bytes of struct; the compiler fetches the fields lazily, next to their first use, so a
+// kernel start walks through 4-5 scalar-cache misses ONE AFTER THE OTHER (each a trip to L2).  This touches every 64-byte
+// line of the first `BYTES` bytes of the argument block at once and waits for them once: the later s_loads hit the scalar cache.
+template <int BYTES>
+__device__ __forceinline__ void prefetch_kernargs(int byte_offset = 0) {
+  const auto ka = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + (byte_offset & ~63);
+  unsigned d0, d1, d2, d3, d4, d5;
+  if constexpr (BYTES > 320)
+    asm volatile("s_load_dword %0, %6, 0x0\n\ts_load_dword %1, %6, 0x40\n\ts_load_dword %2, %6, 0x80\n\ts_load_dword %3, %6, 0xc0\n\t"
+                 "s_load_dword %4, %6, 0x100\n\ts_load_dword %5, %6, 0x140\n\ts_waitcnt lgkmcnt(0)"
+                 : "=s"(d0), "=s"(d1), "=s"(d2), "=s"(d3), "=s"(d4), "=s"(d5) : "s"(ka) : "memory");
+  else if constexpr (BYTES > 192)
+    asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=s"(d0), "=s"(d1), "=s"(d2), "=s"(d3) : "s"(ka) : "memory");
+  else
+    asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                 : "=s"(d0), "=s"(d1) : "s"(ka) : "memory");
+}
+
 // XCD-aware workgroup id: MI355X deals consecutive workgroup ids round-robin over its 8 XCDs (each with a private
 // L2).  This bijective remap gives every XCD one CONTIGUOUS range of logical ids, so workgroups that share operand
 // tiles (neighbouring logical ids) hit the same L2.  Speed only, never correctness.

@@ -258,6 +258,7 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16Args& p, const f32x1
 // epilogue arithmetic runs beside the other's MFMAs).  Tile = 64*WM channels x 32*WN*NWN pixels.
 template <typename DT, int KW, int WM, int WN, bool UP2, bool DMA, int NWN = 2>
 __global__ __launch_bounds__(128 * NWN) void conv16_kernel(const Conv16Args p) {
+  prefetch_kernargs<sizeof(Conv16Args)>();
   constexpr int CK8 = conv16_ck8(KW), KS = CK8 / 2;
   constexpr int BM = 64 * WM;
   constexpr int NT = 128 * NWN;
@@ -290,13 +291,31 @@ __global__ __launch_bounds__(128 * NWN) void conv16_kernel(const Conv16Args p) {
   const int iy0 = oy0 * SV - PHc, ix0 = ox0 * S - PWc;
   const int cbase8 = p.bcast ? 0 : g * p.Kc8g;
 
-  // ---- stage-invariant staging offsets of the input rows
+  const __amdgpu_buffer_rsrc_t rsA = buf_rsrc(p.A), rsS = buf_rsrc(p.src), rsS2 = buf_rsrc(UP2 ? p.src2 : p.src);
+  const unsigned a_wg = (unsigned)cls * p.a_cls_stride + (unsigned)g * p.a_group_stride + (unsigned)by_ * p.a_mt_stride;
+  const int nstages = p.nchunks * KH;
+  const int nst_run = (p.dbg & 4) ? 0 : nstages;
+  // the weight slab of stage 0 needs nothing but the tile indices: its LDS-DMA goes out BEFORE the ~300 vector instructions of
+  // per-thread offset arithmetic below (the kernel start is a latency chain; this puts the first memory round trip under it)
+  if constexpr (DMA) {
+    if (nst_run > 0) {
+      u32x4* dst0 = smem + __builtin_amdgcn_readfirstlane(wid) * 64;
+      const unsigned sa0 = __builtin_amdgcn_readfirstlane(16u * a_wg);
+#pragma unroll
+      for (int i = 0; i < NA; ++i) dma16(rsA, dst0 + i * NT, 16u * (unsigned)(t + i * NT), sa0);
+    }
+  }
+
+  // ---- stage-invariant staging offsets of the input rows (e / thpc and rem / PC by multiply-high with a reciprocal formed
+  // once: e < 2^16 and the divisors are small, for which floor(2^32 / d) + 1 is exact)
   int poff[NP], prow[NP], plds[NP], pcb[NP], pix[UP2 ? NP : 1];
   bool pcol[NP];
+  const unsigned mg_thpc = 0xFFFFFFFFu / (unsigned)thpc + 1u, mg_pc = 0xFFFFFFFFu / (unsigned)PC + 1u;
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const int e = t + i * NT;
-    const int cb = e / thpc, rem = e - cb * thpc, ty = rem / PC, c = rem - ty * PC;
+    const int cb = thpc == 1 ? e : (int)__umulhi((unsigned)e, mg_thpc), rem = e - cb * thpc;
+    const int ty = PC == 1 ? rem : (int)__umulhi((unsigned)rem, mg_pc), c = rem - ty * PC;
     const int iy = iy0 + ty * SV, ix = ix0 + c;
     pcol[i] = (e < pv) & ((unsigned)ix < (unsigned)p.SRCW);
     prow[i] = iy;
@@ -305,10 +324,6 @@ __global__ __launch_bounds__(128 * NWN) void conv16_kernel(const Conv16Args p) {
     if (UP2) pix[i] = ix;
     plds[i] = e < pv ? NAV + e : NAV + pv;
   }
-  const __amdgpu_buffer_rsrc_t rsA = buf_rsrc(p.A), rsS = buf_rsrc(p.src), rsS2 = buf_rsrc(UP2 ? p.src2 : p.src);
-  const unsigned a_wg = (unsigned)cls * p.a_cls_stride + (unsigned)g * p.a_group_stride + (unsigned)by_ * p.a_mt_stride;
-  const int nstages = p.nchunks * KH;
-
   u32x4 ra[NA], rb[NP], rb2[UP2 ? NP : 1];
   auto load_stage = [&](int st) {
     const int ch = st / KH, kh = st - ch * KH;
@@ -405,8 +420,10 @@ __global__ __launch_bounds__(128 * NWN) void conv16_kernel(const Conv16Args p) {
       const int ch = st / KH, kh = st - ch * KH;
       u32x4* dst = smem + (st % p.nstg) * stage_vecs + wave * 64;
       const unsigned sa = __builtin_amdgcn_readfirstlane(16u * (a_wg + (unsigned)st * NAV));
+      if (st > 0) {                                    // (stage 0's weight slab left at the top of the kernel)
 #pragma unroll
-      for (int i = 0; i < NA; ++i) dma16(rsA, dst + i * NT, 16u * (unsigned)(t + i * NT), sa);
+        for (int i = 0; i < NA; ++i) dma16(rsA, dst + i * NT, 16u * (unsigned)(t + i * NT), sa);
+      }
       const int cb0 = ch * CK8;
       const int sbase = __builtin_amdgcn_readfirstlane(img * p.s_img + (cbase8 + cb0) * p.s_cblk);
       const int khrow = kh * p.s_row;
@@ -420,7 +437,6 @@ __global__ __launch_bounds__(128 * NWN) void conv16_kernel(const Conv16Args p) {
     };
     const int per_stage = NA + npd;                    // LDS-DMA instructions a wave issues per stage
     const int ahead = p.nstg - 2;                      // stages that stay in flight behind the one being computed
-    const int nst_run = (p.dbg & 4) ? 0 : nstages;
     for (int st = 0; st < p.nstg - 1 && st < nst_run; ++st) issue_stage(st);
     for (int st = 0; st < nst_run; ++st) {
       // stage st has landed once at most `ahead` younger stages are outstanding (in the tail fewer are: drain)

@@ -17,6 +17,7 @@ namespace ms {
 
 template <int TM, int TN, int KH_, int KW_, bool TRANSPOSED, bool UP2>
 __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherArgs p) {
+  prefetch_kernargs<sizeof(GatherArgs)>();
   constexpr int BM = 64 * TM, BN = 64 * TN, BK = (TM == 1 ? 64 : 32);
   constexpr int LDA = BM + 2, LDB = BN;
   constexpr int STAGE = BK * LDA + BK * LDB;
@@ -617,6 +618,8 @@ __global__ __launch_bounds__(256) void splitk_fwd_epilogue_kernel(const float* _
                                                                   float* __restrict__ y_raw, float* __restrict__ y,
                                                                   float* __restrict__ save, int B, int C, int HW, int ep,
                                                                   float slope, float eps, float momentum) {
+  prefetch_kernargs<192>();
+  const FastDiv fdHW(HW, B * HW);
   // the channel's B*HW <= 256*NE values stay in registers between the passes
   __shared__ float red[4];
   const int c = blockIdx.x, t = threadIdx.x;
@@ -628,7 +631,7 @@ __global__ __launch_bounds__(256) void splitk_fwd_epilogue_kernel(const float* _
 #pragma unroll
   for (int i = 0; i < NE; ++i) {
     const int e = min(t + i * 256, N - 1);
-    const int b = e / HW, pix = e - b * HW;
+    const int b = fdHW.div(e), pix = e - b * HW;
     off[i] = ((size_t)b * C + c) * HW + pix;
     v[i] = bsv;
   }
@@ -706,6 +709,7 @@ __global__ __launch_bounds__(256) void splitk_fwd_epilogue_big_kernel(const floa
                                                                       float* __restrict__ y_raw, float* __restrict__ y,
                                                                       float* __restrict__ save, int B, int C, int HW, int ep,
                                                                       float slope, float eps, float momentum) {
+  prefetch_kernargs<192>();
   __shared__ float red[4];
   const int c = blockIdx.x, t = threadIdx.x;
   const int N = B * HW;
@@ -764,6 +768,7 @@ __global__ __launch_bounds__(256) void splitk_fwd_epilogue_big_kernel(const floa
 __global__ __launch_bounds__(256) void splitk_dgrad_epilogue_kernel(const float* __restrict__ part, int splitk,
                                                                     size_t part_stride, float* __restrict__ dx,
                                                                     float* __restrict__ dx2, size_t n, int up2) {
+  prefetch_kernargs<192>();
   if (!up2) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
       dx[i] = sum_slices(part + i, splitk, part_stride, 0.f);

@@ -42,6 +42,7 @@ constexpr int patch_row_pitch(int pc, int sv, int tw) {
 template <int KH, int KW, int S, int TW, bool UP2, int AM, int WM = 2, int KS = 1>
 __global__ __launch_bounds__(128 * WM * KS, (KS == 1 && WM == 2 && KH * KW <= 3 && TW >= 32 ? 4 : 1))
 void conv_patch_kernel(const PatchArgs p) {
+  prefetch_kernargs<sizeof(PatchArgs)>();
   using Cfg = PatchCfg<KH, KW>;
   constexpr int NT = 128 * WM * KS;                     // threads
   constexpr int BM = 32 * WM, BN = 64, TH = BN / TW;

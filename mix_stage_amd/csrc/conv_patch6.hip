@@ -146,6 +146,7 @@ __device__ inline void split3(const float (&x)[8], bf16x8& hi, bf16x8& mid, bf16
 
 template <int KH, int KW, int S, int TW, bool UP2>
 __global__ __launch_bounds__(256, 2) void conv_patch6_kernel(const PatchArgs p) {
+  prefetch_kernargs<sizeof(PatchArgs)>();
   constexpr int KHW = KH * KW, CK = p6_ck(KHW), CG = CK / 8, NHB = p6_nhb(KHW), NKB = p6_nkb(KHW);
   constexpr int BM = 64, BN = 128, TH = BN / TW;
   constexpr int SV = (KH == 1) ? 1 : S;

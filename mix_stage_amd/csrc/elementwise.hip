@@ -17,6 +17,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           const float* __restrict__ beta, float* running_mean,
                                                           float* running_var, float* __restrict__ save, float eps,
                                                           float momentum) {
+  prefetch_kernargs<128>();
   __shared__ double red[4];
   const int c = blockIdx.x, t = threadIdx.x;
   double s = 0.0;
@@ -64,6 +65,8 @@ __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(const float* __r
                                                                 float* running_mean, float* running_var, float* __restrict__ save,
                                                                 float eps, float momentum, const float* __restrict__ y_raw,
                                                                 float* __restrict__ y, int B, int HW, int b_per_chunk, float slope) {
+  prefetch_kernargs<128>();
+  const FastDiv fdHW(HW, B * HW);
   __shared__ double red[4];
   const int c = blockIdx.x, ch = blockIdx.y, t = threadIdx.x;
   const int b0 = ch * b_per_chunk, nb = min(b_per_chunk, B - b0);
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(const float* __r
 #pragma unroll
   for (int q = 0; q < FA_PRE; ++q) {
     const int e = min(t + q * 256, n - 1);
-    const int bl = e / HW, pix = e - bl * HW;
+    const int bl = fdHW.div(e), pix = e - bl * HW;
     ofs[q] = ((size_t)(b0 + bl) * C + c) * HW + pix;
     v[q] = y_raw[ofs[q]];
   }
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(const float* __r
 #pragma unroll
     for (int q = 0; q < FA_PRE; ++q) {
       const int e = min(e0 + q * 256, n - 1);
-      const int bl = e / HW, pix = e - bl * HW;
+      const int bl = fdHW.div(e), pix = e - bl * HW;
       ofs[q] = ((size_t)(b0 + bl) * C + c) * HW + pix;
       v[q] = y_raw[ofs[q]];
     }
@@ -135,6 +138,7 @@ __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(const float* __r
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ y_raw, float* __restrict__ y,
                                                        const float* __restrict__ save, int C, int HW, size_t total,
                                                        float slope) {
+  prefetch_kernargs<128>();
   const float* scale = save + 2 * (size_t)C;
   const float* shift = save + 3 * (size_t)C;
   if ((HW & 3) == 0) {
@@ -219,6 +223,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_sums_kernel(const float* __r
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y_raw,
                                                             const float* __restrict__ save, float* __restrict__ partial,
                                                             int B, int C, int HW, int b_per_chunk, float slope) {
+  prefetch_kernargs<128>();
   __shared__ float red[4];
   const int c = blockIdx.x, ch = blockIdx.y, t = threadIdx.x;
   const int b0 = ch * b_per_chunk, nb = min(b_per_chunk, B - b0);
@@ -248,6 +253,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ partial, float* __restrict__ dyr,
                                                            float* __restrict__ colpart, float* dgamma, float* dbeta,
                                                            int B, int C, int HW, int b_per_chunk, float slope) {
+  prefetch_kernargs<128>();
   __shared__ float red[4];
   const int c = blockIdx.x, ch = blockIdx.y, t = threadIdx.x, nchunk = gridDim.y;
   float s1 = 0.f, s2 = 0.f;
@@ -286,6 +292,8 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const float* __restri
                                                            const float* __restrict__ save, const float* __restrict__ gamma,
                                                            float* __restrict__ dyr, float* dbias, float* dgamma, float* dbeta,
                                                            int B, int C, int HW, float slope) {
+  prefetch_kernargs<128>();
+  const FastDiv fdHW(HW, B * HW);
   __shared__ float red[4];
   const int c = blockIdx.x, t = threadIdx.x;
   const int n = B * HW;
@@ -296,7 +304,7 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const float* __restri
 #pragma unroll
   for (int i = 0; i < NE; ++i) {
     const int e = min(t + i * 256, n - 1);
-    const int b = e / HW, pix = e - b * HW;
+    const int b = fdHW.div(e), pix = e - b * HW;
     ofs[i] = ((size_t)b * C + c) * HW + pix;
     ry[i] = y_raw[ofs[i]];
     rg[i] = dy[ofs[i]];
@@ -338,6 +346,7 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const float* __restri
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                       float* __restrict__ dyr, float* __restrict__ colpart, int B, int C,
                                                       int HW, int b_per_chunk, int mode, float slope) {
+  prefetch_kernargs<128>();
   __shared__ float red[4];
   const int c = blockIdx.x, ch = blockIdx.y, t = threadIdx.x, nchunk = gridDim.y;
   const int b0 = ch * b_per_chunk, nb = min(b_per_chunk, B - b0);

@@ -13,6 +13,7 @@ template <typename DT>
 __global__ __launch_bounds__(256) void bn_apply16_kernel(const u32x4* __restrict__ y_raw, u32x4* __restrict__ y,
                                                          float* __restrict__ y_f32, const float* __restrict__ save, int C,
                                                          int C8, int HW, size_t total, float slope) {
+  prefetch_kernargs<192>();
   const float* scale = save + 2 * (size_t)C;
   const float* shift = save + 3 * (size_t)C;
   for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (size_t)gridDim.x * 256) {
@@ -73,6 +74,8 @@ __global__ __launch_bounds__(256) void bn_finalize_apply16_kernel(const float* _
                                                                   float momentum, const u32x4* __restrict__ y_raw,
                                                                   u32x4* __restrict__ y, float* __restrict__ y_f32, int B, int C,
                                                                   int C8, int HW, int b_per_chunk, float slope) {
+  prefetch_kernargs<192>();
+  const FastDiv fdHW(HW, B * HW);
   __shared__ double part[8][33];
   __shared__ float scsh[16];
   const int cb = blockIdx.x, ch = blockIdx.y, t = threadIdx.x;
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(256) void bn_finalize_apply16_kernel(const float* _
 #pragma unroll
   for (int q = 0; q < FIN_PRE; ++q) {
     const int e = min(t + q * 256, n - 1);
-    const int bl = e / HW, pix = e - bl * HW;
+    const int bl = fdHW.div(e), pix = e - bl * HW;
     vofs[q] = ((size_t)(b0 + bl) * C8 + cb) * HW + pix;
     raw[q] = y_raw[vofs[q]];
   }
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256) void bn_finalize_apply16_kernel(const float* _
 #pragma unroll
     for (int k = 0; k < 8; ++k) f[k] = cb * 8 + k < C ? lrelu(fmaf(f[k], sc[k], shf[k]), slope) : 0.f;
     if (y_f32) {
-      const int bl = e / HW, pix = e - bl * HW;
+      const int bl = fdHW.div(e), pix = e - bl * HW;
 #pragma unroll
       for (int k = 0; k < 8; ++k)
         if (cb * 8 + k < C) y_f32[((size_t)(b0 + bl) * C + cb * 8 + k) * HW + pix] = f[k];
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(256) void bn_finalize_apply16_kernel(const float* _
 #pragma unroll
     for (int q = 0; q < FIN_PRE; ++q) {
       const int e = min(e0 + q * 256, n - 1);
-      const int bl = e / HW, pix = e - bl * HW;
+      const int bl = fdHW.div(e), pix = e - bl * HW;
       vofs[q] = ((size_t)(b0 + bl) * C8 + cb) * HW + pix;
       raw[q] = y_raw[vofs[q]];
     }
@@ -250,6 +253,8 @@ __global__ __launch_bounds__(256) void bn_bwd16_reduce_kernel(const u32x4* __res
                                                               const u32x4* __restrict__ y_raw, const float* __restrict__ save,
                                                               float* __restrict__ partial, int B, int C, int C8, int HW,
                                                               int b_per_chunk, float slope) {
+  prefetch_kernargs<192>();
+  const FastDiv fdHW(HW, B * HW);
   __shared__ float red[32];
   const int cb = blockIdx.x, ch = blockIdx.y, t = threadIdx.x, nchunk = gridDim.y;
   const int b0 = ch * b_per_chunk, nb = min(b_per_chunk, B - b0);
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(256) void bn_bwd16_reduce_kernel(const u32x4* __res
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int e = min(e0 + q * 256, n - 1);
-      const int bl = e / HW, pix = e - bl * HW;
+      const int bl = fdHW.div(e), pix = e - bl * HW;
       const size_t b = b0 + bl, v = (b * C8 + cb) * HW + pix;
       ry[q] = y_raw[v];
       if (DYF32) {
@@ -321,6 +326,8 @@ __global__ __launch_bounds__(256) void bn_bwd16_apply_kernel(const u32x4* __rest
                                                              u32x4* __restrict__ dyr, float* __restrict__ colpart, float* dgamma,
                                                              float* dbeta, int B, int C, int C8, int HW, int b_per_chunk,
                                                              float slope) {
+  prefetch_kernargs<192>();
+  const FastDiv fdHW(HW, B * HW);
   __shared__ float red[32];
   const int cb = blockIdx.x, ch = blockIdx.y, t = threadIdx.x, nchunk = gridDim.y;
   const float invN = 1.0f / (float)((size_t)B * HW);
@@ -359,7 +366,7 @@ __global__ __launch_bounds__(256) void bn_bwd16_apply_kernel(const u32x4* __rest
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int e = min(e0 + q * 256, n - 1);
-      const int bl = e / HW, pix = e - bl * HW;
+      const int bl = fdHW.div(e), pix = e - bl * HW;
       const size_t b = b0 + bl;
       vofs[q] = (b * C8 + cb) * HW + pix;
       ry[q] = y_raw[vofs[q]];
@@ -409,6 +416,8 @@ __global__ __launch_bounds__(NT) void bn_bwd16_fused_kernel(const u32x4* __restr
                                                              const u32x4* __restrict__ y_raw, const float* __restrict__ save,
                                                              const float* __restrict__ gamma, u32x4* __restrict__ dyr, float* dbias,
                                                              float* dgamma, float* dbeta, int B, int C, int C8, int HW, float slope) {
+  prefetch_kernargs<192>();
+  const FastDiv fdHW(HW, B * HW);
   __shared__ float red[(NT / 64) * 16];
   const int cb = blockIdx.x, t = threadIdx.x;
   const int n = B * HW;
@@ -424,7 +433,7 @@ __global__ __launch_bounds__(NT) void bn_bwd16_fused_kernel(const u32x4* __restr
 #pragma unroll
   for (int i = 0; i < NE; ++i) {
     const int e = min(t + i * NT, n - 1);
-    const int bl = e / HW, pix = e - bl * HW;
+    const int bl = fdHW.div(e), pix = e - bl * HW;
     vofs[i] = ((size_t)bl * C8 + cb) * HW + pix;
     ry[i] = y_raw[vofs[i]];
     if (DYF32) {
@@ -550,13 +559,15 @@ __global__ __launch_bounds__(256) void act_bwd16_kernel(const u32x4* __restrict_
                                                         const u32x4* __restrict__ y, u32x4* __restrict__ dyr,
                                                         float* __restrict__ colpart, int B, int C, int C8, int HW, int b_per_chunk,
                                                         int mode, float slope) {
+  prefetch_kernargs<192>();
+  const FastDiv fdHW(HW, B * HW);
   __shared__ float red[32];
   const int cb = blockIdx.x, ch = blockIdx.y, t = threadIdx.x, nchunk = gridDim.y;
   const int b0 = ch * b_per_chunk, nb = min(b_per_chunk, B - b0);
   const int n = nb * HW;
   float cs[8] = {};
   for (int e = t; e < n; e += 256) {
-    const int bl = e / HW, pix = e - bl * HW;
+    const int bl = fdHW.div(e), pix = e - bl * HW;
     const size_t b = b0 + bl, v = (b * C8 + cb) * HW + pix;
     float g[8];
     load_dy8<DT, DYF32>(dy, dy_f32, v, b, cb, pix, C, HW, g);

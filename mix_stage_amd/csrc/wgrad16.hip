@@ -208,6 +208,7 @@ __device__ __forceinline__ void wgrad16_body(const Wgrad16Args& p, const int bid
 
 template <typename DT, int TP, bool UP2>
 __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args p) {
+  prefetch_kernargs<sizeof(Wgrad16Args)>();
   extern __shared__ u32x4 smem[];
   wgrad16_body<DT, TP, UP2>(p, (int)blockIdx.x, smem);
 }
@@ -216,9 +217,11 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args p) {
 template <typename DT, int TP, bool UP2>
 __global__ __launch_bounds__(256) void wgrad16_multi_kernel(const Wgrad16Batch b) {
   extern __shared__ u32x4 smem[];
+  prefetch_kernargs<128>();                                   // n and the table of block ranges
   int j = 0;
   while (j + 1 < b.n && (int)blockIdx.x >= b.block_end[j]) ++j;
   const int b0 = j ? b.block_end[j - 1] : 0;
+  prefetch_kernargs<sizeof(Wgrad16Args)>((int)offsetof(Wgrad16Batch, job) + j * (int)sizeof(Wgrad16Args));
   wgrad16_body<DT, TP, UP2>(b.job[j], (int)blockIdx.x - b0, smem);
 }
 

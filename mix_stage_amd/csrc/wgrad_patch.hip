@@ -181,15 +181,18 @@ __device__ __forceinline__ void wgrad_patch_body(const WgradPatchArgs& p, const 
 
 template <int KH, int KW, int S, int TW, bool UP2>
 __global__ __launch_bounds__(256) void wgrad_patch_kernel(const WgradPatchArgs p) {
+  prefetch_kernargs<sizeof(WgradPatchArgs)>();
   wgrad_patch_body<KH, KW, S, TW, UP2>(p, (int)blockIdx.x);
 }
 
 // many blocks' weight gradients in one launch: a workgroup finds its job in the table of block ranges
 template <int KH, int KW, int S, int TW, bool UP2>
 __global__ __launch_bounds__(256) void wgrad_patch_multi_kernel(const WgradPatchBatch b) {
+  prefetch_kernargs<128>();                                   // n and the table of block ranges
   int j = 0;
   while (j + 1 < b.n && (int)blockIdx.x >= b.block_end[j]) ++j;
   const int b0 = j ? b.block_end[j - 1] : 0;
+  prefetch_kernargs<sizeof(WgradPatchArgs)>((int)offsetof(WgradPatchBatch, job) + j * (int)sizeof(WgradPatchArgs));
   wgrad_patch_body<KH, KW, S, TW, UP2>(b.job[j], (int)blockIdx.x - b0);
 }
 
