@@ -132,7 +132,8 @@ __device__ inline void reduce16_over_half(float (&v)[16], int r) {
 }
 
 template <typename DT, int WM, int WN, int NWN, int EP, bool OUTF32>
-__device__ __forceinline__ void conv16_epilogue(const Conv16Args& p, const f32x16 (&acc)[WM][WN], const Tile16& tl, u32x4* smem) {
+__device__ __forceinline__ void conv16_epilogue(const Conv16Args& p, const f32x16 (&acc)[WM][WN], const Tile16& tl, u32x4* smem,
+                                                const float (&bias_pre)[WM][16]) {
   constexpr int BM = 64 * WM;
   const int TW = 1 << p.ltw;
   const int ctot = p.groups * p.Mg;
@@ -145,7 +146,7 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16Args& p, const f32x1
     for (int q = 0; q < 16; ++q) {
       const int m = mrow0 + (q & 3) + 8 * (q >> 2);
       const int chn = tl.g * p.Mg + min(m, p.Mg - 1);
-      bsv[q] = (p.bias && m < p.Mg) ? p.bias[chn] : 0.f;
+      bsv[q] = m < p.Mg ? bias_pre[i][q] : 0.f;       // fetched before the K loop (conv16_kernel)
       if (EP == EP_BN_EVAL) {
         const float sc = p.bn_g[chn] * (1.0f / sqrtf(p.bn_v[chn] + p.eps));
         scv[q] = sc; shv[q] = p.bn_b[chn] - p.bn_m[chn] * sc;
@@ -306,6 +307,24 @@ __global__ __launch_bounds__(128 * NWN) void conv16_kernel(const Conv16Args p) {
     }
   }
 
+  // the epilogue's bias values, requested now (clamped addresses, no branches): after the K loop they were 16 dependent
+  // load -> wait rounds.  They are older than every staging load below, so the counted waits of the ring cover them.
+  float bias_pre[WM][16];
+  if (p.bias) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int m = m0 + (wm * WM + i) * 32 + 4 * h + (q & 3) + 8 * (q >> 2);
+        bias_pre[i][q] = p.bias[g * p.Mg + min(m, p.Mg - 1)];
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) bias_pre[i][q] = 0.f;
+  }
+
   // ---- stage-invariant staging offsets of the input rows (e / thpc and rem / PC by multiply-high with a reciprocal formed
   // once: e < 2^16 and the divisors are small, for which floor(2^32 / d) + 1 is exact)
   int poff[NP], prow[NP], plds[NP], pcb[NP], pix[UP2 ? NP : 1];
@@ -313,6 +332,7 @@ __global__ __launch_bounds__(128 * NWN) void conv16_kernel(const Conv16Args p) {
   const unsigned mg_thpc = 0xFFFFFFFFu / (unsigned)thpc + 1u, mg_pc = 0xFFFFFFFFu / (unsigned)PC + 1u;
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
+    if (DMA && i >= npd) continue;                 // the LDS-DMA path stages whole slabs: only npd of the NP slots exist
     const int e = t + i * NT;
     const int cb = thpc == 1 ? e : (int)__umulhi((unsigned)e, mg_thpc), rem = e - cb * thpc;
     const int ty = PC == 1 ? rem : (int)__umulhi((unsigned)rem, mg_pc), c = rem - ty * PC;
@@ -465,17 +485,17 @@ __global__ __launch_bounds__(128 * NWN) void conv16_kernel(const Conv16Args p) {
   // one specialised instance per epilogue kind (wave-uniform switch): no per-element branching on the kind
   if (p.out_f32) {
     switch (p.ep) {
-      case EP_BARE: conv16_epilogue<DT, WM, WN, NWN, EP_BARE, true>(p, acc, tl, smem); break;
-      case EP_LRELU: conv16_epilogue<DT, WM, WN, NWN, EP_LRELU, true>(p, acc, tl, smem); break;
-      default: conv16_epilogue<DT, WM, WN, NWN, EP_BN_EVAL, true>(p, acc, tl, smem); break;
+      case EP_BARE: conv16_epilogue<DT, WM, WN, NWN, EP_BARE, true>(p, acc, tl, smem, bias_pre); break;
+      case EP_LRELU: conv16_epilogue<DT, WM, WN, NWN, EP_LRELU, true>(p, acc, tl, smem, bias_pre); break;
+      default: conv16_epilogue<DT, WM, WN, NWN, EP_BN_EVAL, true>(p, acc, tl, smem, bias_pre); break;
     }
   } else {
     switch (p.ep) {
-      case EP_BARE: conv16_epilogue<DT, WM, WN, NWN, EP_BARE, false>(p, acc, tl, smem); break;
-      case EP_LRELU: conv16_epilogue<DT, WM, WN, NWN, EP_LRELU, false>(p, acc, tl, smem); break;
-      case EP_BN_EVAL: conv16_epilogue<DT, WM, WN, NWN, EP_BN_EVAL, false>(p, acc, tl, smem); break;
-      case EP_RAW_STATS: conv16_epilogue<DT, WM, WN, NWN, EP_RAW_STATS, false>(p, acc, tl, smem); break;
-      default: conv16_epilogue<DT, WM, WN, NWN, EP_DGRAD_UP2, false>(p, acc, tl, smem); break;
+      case EP_BARE: conv16_epilogue<DT, WM, WN, NWN, EP_BARE, false>(p, acc, tl, smem, bias_pre); break;
+      case EP_LRELU: conv16_epilogue<DT, WM, WN, NWN, EP_LRELU, false>(p, acc, tl, smem, bias_pre); break;
+      case EP_BN_EVAL: conv16_epilogue<DT, WM, WN, NWN, EP_BN_EVAL, false>(p, acc, tl, smem, bias_pre); break;
+      case EP_RAW_STATS: conv16_epilogue<DT, WM, WN, NWN, EP_RAW_STATS, false>(p, acc, tl, smem, bias_pre); break;
+      default: conv16_epilogue<DT, WM, WN, NWN, EP_DGRAD_UP2, false>(p, acc, tl, smem, bias_pre); break;
     }
   }
 }
