@@ -149,11 +149,24 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  const int a_off = wm * TM * 32 + (lane & 31), b_off = wn * TN * 32 + (lane & 31), khalf = lane >> 5;
+  // the epilogue's bias values are requested now (clamped addresses, no branches): fetched after the K loop they were 16*TM
+  // dependent load -> wait rounds at the very end of the kernel
+  float bias_pre[TM][16];
+  {
+    const bool want = p.bias != nullptr && p.splitk <= 1 && p.ep != EP_DGRAD && p.ep != EP_DGRAD_UP2;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        bias_pre[i][r] = want ? p.bias[g * p.Mg + (m < p.Mg ? m : 0)] : 0.f;
+      }
+  }
   const int nk = (kend - kbeg + BK - 1) / BK;
   load_tiles(kbeg);
   store_tiles(0);
   __syncthreads();
-  const int a_off = wm * TM * 32 + (lane & 31), b_off = wn * TN * 32 + (lane & 31), khalf = lane >> 5;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * BK);
@@ -237,7 +250,7 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherArgs p) {
           }
         }
       } else {
-        const float bsv = p.bias ? p.bias[ch] : 0.f;
+        const float bsv = bias_pre[i][r];
         float sc = 1.f, sh = 0.f;
         if (ep == EP_BN_EVAL) {
           const float inv = 1.0f / sqrtf(p.bn_v[ch] + p.eps);

@@ -186,6 +186,15 @@ __device__ __forceinline__ void wgrad16_body(const Wgrad16Args& p, const int bid
   float* out = p.out + (size_t)split * p.out_split_stride;
   const int ci = ci0 + wn * 32 + r;
   struct __attribute__((packed, aligned(4))) Taps { float v[TP]; };
+  // accumulating form (queued launches that write dw themselves): all 16 read-modify-writes read first, then write
+  Taps prev[16];
+  if (p.accumulate && kw0 + TP <= p.KW) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int co = min(co0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, p.Cog - 1);
+      prev[e] = *reinterpret_cast<const Taps*>(out + (((size_t)(g * p.Cog + co) * p.Cig + min(ci, p.Cig - 1)) * p.KH + kh) * p.KW + kw0);
+    }
+  }
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int co = co0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -193,9 +202,8 @@ __device__ __forceinline__ void wgrad16_body(const Wgrad16Args& p, const int bid
       float* dst = out + (((size_t)(g * p.Cog + co) * p.Cig + ci) * p.KH + kh) * p.KW + kw0;
       if (kw0 + TP <= p.KW) {
         Taps tv;
-        if (p.accumulate) tv = *reinterpret_cast<const Taps*>(dst);
 #pragma unroll
-        for (int q = 0; q < TP; ++q) tv.v[q] = p.accumulate ? tv.v[q] + acc[q][e] : acc[q][e];
+        for (int q = 0; q < TP; ++q) tv.v[q] = p.accumulate ? prev[e].v[q] + acc[q][e] : acc[q][e];
         *reinterpret_cast<Taps*>(dst) = tv;
       } else {
 #pragma unroll

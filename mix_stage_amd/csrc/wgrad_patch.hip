@@ -155,13 +155,18 @@ __device__ __forceinline__ void wgrad_patch_body(const WgradPatchArgs& p, const 
 
   float* outp = p.out + (size_t)sp * ctot * p.Kg;
   const int nc = n0 + wn * 32 + (lane & 31);
+  float prev[16];
+  if (p.accumulate) {          // queued launches that write dw themselves: all 16 reads first, then the writes
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = min(m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf, p.Cog - 1);
+      prev[r] = outp[(size_t)(g * p.Cog + m) * p.Kg + min(nc, p.Kg - 1)];
+    }
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-    if (m < p.Cog && nc < p.Kg) {
-      float* dst = outp + (size_t)(g * p.Cog + m) * p.Kg + nc;
-      *dst = p.accumulate ? *dst + acc[r] : acc[r];
-    }
+    if (m < p.Cog && nc < p.Kg) outp[(size_t)(g * p.Cog + m) * p.Kg + nc] = p.accumulate ? prev[r] + acc[r] : acc[r];
   }
   if (p.counters == nullptr || p.splits == 1) return;
   // in-launch reduction over the pixel splits: the last workgroup to arrive for this tile sums the slabs in split order
