@@ -675,16 +675,21 @@ __global__ __launch_bounds__(256) void cb8_from_btc_kernel(const float* __restri
     const size_t bc = v / T;
     const int cb = (int)(bc % C8), t = (int)(v - bc * T);
     const size_t b = bc / C8;
-    const float* row = x + (b * T + t) * C + cb * 8;
-    float f[8];
+    const float* row = x + (b * T + t) * C;
+    const float* prow = x + (b * T + (t > 0 ? t - 1 : 0)) * C;
+    // all 16 loads unconditional (clamped channel), then masked: one round trip instead of a load -> wait chain per channel
+    float cur[8], prv[8], f[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float val = 0.f;
-      if (cb * 8 + j < C) {
-        val = row[j];
-        if (velocity) val = t > 0 ? val - row[j - C] : 0.f;
-      }
-      f[j] = val;
+      const int c = min(cb * 8 + j, C - 1);
+      cur[j] = row[c];
+      prv[j] = velocity ? prow[c] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float val = cur[j];
+      if (velocity) val = t > 0 ? val - prv[j] : 0.f;
+      f[j] = cb * 8 + j < C ? val : 0.f;
     }
     y[v] = pack8<DT>(f);
   }
