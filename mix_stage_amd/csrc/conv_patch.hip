@@ -290,12 +290,25 @@ void conv_patch_kernel(const PatchArgs p) {
     }
     return;
   }
+  // the 16 bias values of this lane's rows in ONE round trip (clamped addresses, no branches between the loads): fetched one by
+  // one next to their use they were 16 dependent load -> wait -> store rounds at the end of every forward launch
+  float bias_r[16];
+  if (p.bias) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      bias_r[r] = p.bias[g * p.Mg + (m < p.Mg ? m : 0)];
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias_r[r] = 0.f;
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
     const bool mval = m < p.Mg;
     const int chn = g * p.Mg + (mval ? m : 0);
-    const float bsv = p.bias ? p.bias[chn] : 0.f;
+    const float bsv = bias_r[r];
     float sc = 1.f, sh = 0.f;
     if (ep == EP_BN_EVAL) {
       const float inv = 1.0f / sqrtf(p.bn_v[chn] + p.eps);
