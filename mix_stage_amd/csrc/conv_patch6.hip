@@ -336,6 +336,14 @@ __global__ __launch_bounds__(256, 2) void conv_patch6_kernel(const PatchArgs p) 
       }
     return;
   }
+  float bias_r[2][16];                 // one round trip for all bias values (see conv_patch.hip)
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
+      bias_r[mi][r] = p.bias ? p.bias[g * p.Mg + (m < p.Mg ? m : 0)] : 0.f;
+    }
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -343,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void conv_patch6_kernel(const PatchArgs p) 
       const int m = m0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
       const bool mval = m < p.Mg;
       const int chn = g * p.Mg + (mval ? m : 0);
-      const float bsv = p.bias ? p.bias[chn] : 0.f;
+      const float bsv = bias_r[mi][r];
       float sc = 1.f, sh = 0.f;
       if (ep == EP_BN_EVAL) {
         const float inv = 1.0f / sqrtf(p.bn_v[chn] + p.eps);
