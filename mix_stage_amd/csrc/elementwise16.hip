@@ -82,8 +82,9 @@ __global__ __launch_bounds__(256) void bn_finalize_apply16_kernel(const float* _
   const int j = t >> 5, i = t & 31, c = cb * 8 + j;
   const bool cv = c < C;
   const int cc = min(c, C - 1);
-  const int b0 = ch * b_per_chunk, nb = min(b_per_chunk, B - b0);
-  const int n = nb * HW;
+  // chunk = b_per_chunk consecutive vectors of this channel block's flattened (batch item, pixel) space
+  const int e_base = ch * b_per_chunk, b0 = 0;
+  const int n = min(b_per_chunk, B * HW - e_base);
   // statistics of tiles i and i + 32 (n_tiles <= 64) and the channel's parameters
   const int k0 = min(i, n_tiles - 1), k1 = min(i + 32, n_tiles - 1);
   const float2 st0 = *(const float2*)(stats + ((size_t)k0 * C + cc) * 2), st1 = *(const float2*)(stats + ((size_t)k1 * C + cc) * 2);
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void bn_finalize_apply16_kernel(const float* _
 #pragma unroll
   for (int q = 0; q < FIN_PRE; ++q) {
     const int e = min(t + q * 256, n - 1);
-    const int bl = fdHW.div(e), pix = e - bl * HW;
+    const int bl = fdHW.div(e_base + e), pix = e_base + e - bl * HW;
     vofs[q] = ((size_t)(b0 + bl) * C8 + cb) * HW + pix;
     raw[q] = y_raw[vofs[q]];
   }
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256) void bn_finalize_apply16_kernel(const float* _
 #pragma unroll
     for (int k = 0; k < 8; ++k) f[k] = cb * 8 + k < C ? lrelu(fmaf(f[k], sc[k], shf[k]), slope) : 0.f;
     if (y_f32) {
-      const int bl = fdHW.div(e), pix = e - bl * HW;
+      const int bl = fdHW.div(e_base + e), pix = e_base + e - bl * HW;
 #pragma unroll
       for (int k = 0; k < 8; ++k)
         if (cb * 8 + k < C) y_f32[((size_t)(b0 + bl) * C + cb * 8 + k) * HW + pix] = f[k];
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void bn_finalize_apply16_kernel(const float* _
 #pragma unroll
     for (int q = 0; q < FIN_PRE; ++q) {
       const int e = min(e0 + q * 256, n - 1);
-      const int bl = fdHW.div(e), pix = e - bl * HW;
+      const int bl = fdHW.div(e_base + e), pix = e_base + e - bl * HW;
       vofs[q] = ((size_t)(b0 + bl) * C8 + cb) * HW + pix;
       raw[q] = y_raw[vofs[q]];
     }
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256) void bn_bwd16_reduce_kernel(const u32x4* __res
   const FastDiv fdHW(HW, B * HW);
   __shared__ float red[32];
   const int cb = blockIdx.x, ch = blockIdx.y, t = threadIdx.x, nchunk = gridDim.y;
-  const int b0 = ch * b_per_chunk, nb = min(b_per_chunk, B - b0);
+  const int e_base = ch * b_per_chunk, b0 = 0;                   // chunk of the flattened (batch item, pixel) space
   float mean[8], invstd[8], sc[8], sh[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(256) void bn_bwd16_reduce_kernel(const u32x4* __res
     mean[j] = save[c]; invstd[j] = save[C + c]; sc[j] = save[2 * C + c]; sh[j] = save[3 * C + c];
   }
   float s1[8] = {}, s2[8] = {};
-  const int n = nb * HW;
+  const int n = min(b_per_chunk, B * HW - e_base);
   // 4 vectors per thread and step, all loads issued before the first use
   for (int e0 = t; e0 < n; e0 += 1024) {
     u32x4 ry[4], rg[4];
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256) void bn_bwd16_reduce_kernel(const u32x4* __res
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int e = min(e0 + q * 256, n - 1);
-      const int bl = fdHW.div(e), pix = e - bl * HW;
+      const int bl = fdHW.div(e_base + e), pix = e_base + e - bl * HW;
       const size_t b = b0 + bl, v = (b * C8 + cb) * HW + pix;
       ry[q] = y_raw[v];
       if (DYF32) {
@@ -356,8 +357,9 @@ __global__ __launch_bounds__(256) void bn_bwd16_apply_kernel(const u32x4* __rest
     m1[j] = prm[40 + j] * invN; m2[j] = prm[48 + j] * invN;
   }
   if (t < 8 && ch == 0 && cb * 8 + t < C && dgamma) { dgamma[cb * 8 + t] = prm[48 + t]; dbeta[cb * 8 + t] = prm[40 + t]; }
-  const int b0 = ch * b_per_chunk, nb = min(b_per_chunk, B - b0);
-  const int n = nb * HW;
+  // chunk = b_per_chunk consecutive vectors of this channel block's flattened (batch item, pixel) space
+  const int e_base = ch * b_per_chunk, b0 = 0;
+  const int n = min(b_per_chunk, B * HW - e_base);
   float cs[8] = {};
   for (int e0 = t; e0 < n; e0 += 1024) {
     u32x4 ry[4], rg[4];
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(256) void bn_bwd16_apply_kernel(const u32x4* __rest
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int e = min(e0 + q * 256, n - 1);
-      const int bl = fdHW.div(e), pix = e - bl * HW;
+      const int bl = fdHW.div(e_base + e), pix = e_base + e - bl * HW;
       const size_t b = b0 + bl;
       vofs[q] = (b * C8 + cb) * HW + pix;
       ry[q] = y_raw[vofs[q]];
@@ -501,12 +503,14 @@ __global__ __launch_bounds__(NT) void bn_bwd16_fused_kernel(const u32x4* __restr
 }
 
 int bwd16_chunks(int B, int C8, int HW, int* b_per_chunk) {
-  (void)HW;
-  int nchunk = std::min(B, std::max(1, 768 / std::max(1, C8)));
-  const int bpc = cdiv(B, nchunk);
-  nchunk = cdiv(B, bpc);
-  if (b_per_chunk) *b_per_chunk = bpc;
-  return nchunk;
+  // chunk = *b_per_chunk consecutive vectors of a channel block's B*HW (batch item, pixel) vectors.  ~2048 workgroups in all
+  // (the 2-D layers stream tens of MB: 4 waves per CU do not hide the latency), at least one vector per thread
+  const long V = (long)B * HW;
+  long nchunk = std::max<long>(1, std::min<long>(cdiv(2048, std::max(1, C8)), (V + 255) / 256));
+  long vpc = ((V + nchunk - 1) / nchunk + 255) / 256 * 256;
+  nchunk = (V + vpc - 1) / vpc;
+  if (b_per_chunk) *b_per_chunk = (int)vpc;
+  return (int)nchunk;
 }
 
 int launch_bn_bwd16(int dt, const void* dy, const float* dy_f32, const void* y_raw, const float* save, const float* gamma,
@@ -563,11 +567,12 @@ __global__ __launch_bounds__(256) void act_bwd16_kernel(const u32x4* __restrict_
   const FastDiv fdHW(HW, B * HW);
   __shared__ float red[32];
   const int cb = blockIdx.x, ch = blockIdx.y, t = threadIdx.x, nchunk = gridDim.y;
-  const int b0 = ch * b_per_chunk, nb = min(b_per_chunk, B - b0);
-  const int n = nb * HW;
+  // chunk = b_per_chunk consecutive vectors of this channel block's flattened (batch item, pixel) space
+  const int e_base = ch * b_per_chunk, b0 = 0;
+  const int n = min(b_per_chunk, B * HW - e_base);
   float cs[8] = {};
   for (int e = t; e < n; e += 256) {
-    const int bl = fdHW.div(e), pix = e - bl * HW;
+    const int bl = fdHW.div(e_base + e), pix = e_base + e - bl * HW;
     const size_t b = b0 + bl, v = (b * C8 + cb) * HW + pix;
     float g[8];
     load_dy8<DT, DYF32>(dy, dy_f32, v, b, cb, pix, C, HW, g);
@@ -606,16 +611,18 @@ int launch_act_bwd16(int dt, const void* dy, const float* dy_f32, const void* y,
   return check_launch("act_bwd16_kernel");
 }
 
-__global__ void colsum16_kernel(const float* __restrict__ colpart, float* __restrict__ out, int C, int nchunk) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// bias gradient = sum of the chunks' column sums: one wave per channel, lanes stride over the chunks, fixed-order wave sum
+__global__ __launch_bounds__(256) void colsum16_kernel(const float* __restrict__ colpart, float* __restrict__ out, int C, int nchunk) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= C) return;
   float s = 0.f;
-  for (int k = 0; k < nchunk; ++k) s += colpart[(size_t)c * nchunk + k];
-  out[c] = s;
+  for (int k = lane; k < nchunk; k += 64) s += colpart[(size_t)c * nchunk + k];
+  s = wave_sum(s);
+  if (lane == 0) out[c] = s;
 }
 
 int launch_colsum16(const float* colpart, float* out, int C, int nchunk, hipStream_t s) {
-  hipLaunchKernelGGL(colsum16_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, colpart, out, C, nchunk);
+  hipLaunchKernelGGL(colsum16_kernel, dim3(cdiv(C, 4)), dim3(256), 0, s, colpart, out, C, nchunk);
   return check_launch("colsum16_kernel");
 }
 
