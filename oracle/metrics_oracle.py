@@ -87,12 +87,13 @@ class EvalAccumulators:
     self.hist = {k: 0 for k in ('y_vel', 'y_acc', 'gt_vel', 'gt_acc')}
 
   @staticmethod
-  def _vel_acc(y):                                            # W1.get_vel_acc
-    diff = lambda x: x[:, 1:] - x[:, :-1]
-    absolute = lambda x: ((x ** 2).sum(2) ** 0.5).mean(-1).reshape(-1)
-    vel = diff(y)
-    acc = diff(vel)
-    return absolute(vel), absolute(acc)
+  def _vel_acc(poses):
+    """(B,T,2,J) -> per frame transition the joint speeds' mean, flattened; the same for second differences (W1.get_vel_acc)."""
+    def mean_joint_norm(d):                                   # d: (B, T', 2, J) -> (B*T',)
+      return np.sqrt(np.square(d).sum(axis=2)).mean(axis=-1).ravel()
+    first = np.diff(poses, n=1, axis=1)
+    second = np.diff(first, n=1, axis=1)
+    return mean_joint_norm(first), mean_joint_norm(second)
 
   def update(self, y_cap_kept, gt_full_norm):
     y_cap_kept, gt = y_cap_kept.astype(np.float64), gt_full_norm.astype(np.float64)
