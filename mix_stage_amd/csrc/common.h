@@ -93,6 +93,7 @@ struct FastDiv {
 // Kernel arguments are a few hundred bytes of struct; the compiler fetches the fields lazily, next to their first use, so a
 // kernel start walks through 4-5 scalar-cache misses ONE AFTER THE OTHER (each a trip to L2).  This touches every 64-byte
 // line of the first `BYTES` bytes of the argument block at once and waits for them once: the later s_loads hit the scalar cache.
+// (Early-clobber outputs: a destination must not share a register with the base pointer the following loads still read.)
 template <int BYTES>
 __device__ __forceinline__ void prefetch_kernargs(int byte_offset = 0) {
   const auto ka = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + (byte_offset & ~63);
@@ -100,14 +101,14 @@ __device__ __forceinline__ void prefetch_kernargs(int byte_offset = 0) {
   if constexpr (BYTES > 320)
     asm volatile("s_load_dword %0, %6, 0x0\n\ts_load_dword %1, %6, 0x40\n\ts_load_dword %2, %6, 0x80\n\ts_load_dword %3, %6, 0xc0\n\t"
                  "s_load_dword %4, %6, 0x100\n\ts_load_dword %5, %6, 0x140\n\ts_waitcnt lgkmcnt(0)"
-                 : "=s"(d0), "=s"(d1), "=s"(d2), "=s"(d3), "=s"(d4), "=s"(d5) : "s"(ka) : "memory");
+                 : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5) : "s"(ka) : "memory");
   else if constexpr (BYTES > 192)
     asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0\n\t"
                  "s_waitcnt lgkmcnt(0)"
-                 : "=s"(d0), "=s"(d1), "=s"(d2), "=s"(d3) : "s"(ka) : "memory");
+                 : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3) : "s"(ka) : "memory");
   else
     asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
-                 : "=s"(d0), "=s"(d1) : "s"(ka) : "memory");
+                 : "=&s"(d0), "=&s"(d1) : "s"(ka) : "memory");
 }
 
 // XCD-aware workgroup id: MI355X deals consecutive workgroup ids round-robin over its 8 XCDs (each with a private
