@@ -142,7 +142,8 @@ class JointLateClusterSoftStyle4_G(nn.Module):
     if pose_style_encoder_flag:
       mode = 'lin'
       pose_style_score = self.pose_style_encoder(y)             # (B, S)
-      id_in_loss = ops.cross_entropy(pose_style_score, style[:, 0], scale=self.lambda_id)
+      style_id = style[:, 0].contiguous()                       # one copy of the strided column for both cross-entropy terms
+      id_in_loss = ops.cross_entropy(pose_style_score, style_id, scale=self.lambda_id)
       if self.softmax:
         pose_style = torch.softmax(pose_style_score, dim=-1)    # per clip; the reference expands over T first,
         if self.argmax:                                         # which repeats identical rows (JL:160-165)
@@ -192,7 +193,7 @@ class JointLateClusterSoftStyle4_G(nn.Module):
           pose_style_score_out = self.pose_style_encoder(x)
       else:
         pose_style_score_out = self.pose_style_encoder(x)
-      id_out_loss = ops.cross_entropy(pose_style_score_out, style[:, 0], scale=self.lambda_id)
+      id_out_loss = ops.cross_entropy(pose_style_score_out, style_id, scale=self.lambda_id)
     else:
       id_out_loss = torch.zeros(1)[0]
 
