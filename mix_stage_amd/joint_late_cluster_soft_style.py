@@ -98,17 +98,6 @@ class JointLateClusterSoftStyle4_G(nn.Module):
     self.thresh = Curriculum(0, 1, 1000)
     self.labels_cap_soft = None
 
-  def index_select_outputs(self, x, labels, groups):
-    '''
-    x: (B, num_clusters*out_feats, T)
-    labels: (B, T, num_clusters)
-    (API parity; the forward pass uses the fused ops.softmax_mix instead)
-    '''
-    x = x.transpose(2, 1)
-    x = x.view(x.shape[0], x.shape[1], groups, -1)
-    labels = labels.view(x.shape[0], x.shape[1], x.shape[2])
-    return (x * labels.unsqueeze(-1)).sum(dim=-2)
-
   def forward(self, x, y, time_steps=None, **kwargs):
     internal_losses = []
     labels = x[-1]          # cluster labels ride along with the inputs (JL:119)

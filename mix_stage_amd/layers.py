@@ -373,8 +373,7 @@ class ClusterClassify(nn.Module):
 
 
 class Group(nn.Module):
-  """layers.py:593-650.  Constructed by the generator (state_dict keys style_dec_gr.*) but never called
-  on the audio path; forward() is provided for API parity using this package's ops."""
+  """layers.py:593-650.  Constructed by the generator (state_dict keys style_dec_gr.*) but never called on the audio path."""
 
   def __init__(self, models, groups=1, dim=1):
     super().__init__()
@@ -384,25 +383,9 @@ class Group(nn.Module):
     self.groups = groups
     self.dim = dim
 
-  def index_select_outputs(self, x, labels):
-    x = x.transpose(2, 1)
-    x = x.view(x.shape[0], x.shape[1], self.groups, -1)
-    labels = labels.view(x.shape[0], x.shape[1], x.shape[2])
-    return (x * labels.unsqueeze(-1)).sum(dim=-2)
-
-  def forward(self, x, labels=None, transpose=True, **kwargs):
-    if self.dim == 0:
-      self.groups = len(x)
-    if isinstance(x, list):
-      x = torch.cat(x, dim=self.dim)
-    if transpose:
-      x = x.transpose(-1, -2)
-    for model in self.models:
-      x = model(x, **kwargs) if kwargs else model(x)
-    if labels is not None:
-      return self.index_select_outputs(x, labels).transpose(-1, -2)
-    channels = int(x.shape[self.dim] / self.groups)
-    return list(torch.split(x, channels, dim=self.dim % x.dim()))
+  def forward(self, *args, **kwargs):
+    raise NotImplementedError('Group.forward is not on the Mix-StAGE audio path (the generator only constructs it: '
+                              'state_dict keys style_dec_gr.*)')
 
 
 class EmbLin(nn.Module):
