@@ -23,6 +23,7 @@ int g_conv16_dma = 1;                                 // tuning knob: 0 = regist
 int g_conv16_wide8 = 0;                               // tuning knob: 8-wave form of the 128 x 128 tile (measured: no gain)
 int g_conv16_dbg = 0;
 int g_conv16_ring = 0;                                // tuning knob: force the LDS-DMA ring depth (0 = planner)
+int g_conv16_big_stages = 1;                          // tuning knob: 0 = short stages everywhere (ms_debug_set_conv16_ring, bit 8 of the flags)
 
 Conv16Plan plan_conv16(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH, int SW, int B, int OH, int OW, int zmul,
                        bool up2) {
@@ -56,6 +57,20 @@ Conv16Plan plan_conv16(int nd, int Mg, int groups, int Kc, int KH, int KW, int S
       pl.n_tiles = imgs * tiles_y * tiles_x;
       pl.ck8 = ck8; pl.nchunks = cdiv(c8_of(Kc), ck8); pl.pc = pc;
       pl.lds_bytes = 2 * (KW * ck8 * bm + ck8 * th * pc + 1) * 16;
+      // 64 x 64 tiles on at most 256 workgroups (one per CU, the small layers): stages of twice the channels.  Measured per
+      // launch: 256->256 k3 T=64 12.9 -> 9.9 us, k4 s2 13.9 -> 10.8, 3x3 (8,16) 23.0 -> 16.8, 3x8 38.0 -> 30.2; the tiles that share
+      // a CU (decoder, first audio-encoder layers) lose 10 % with it and keep the short stages
+      if (g_conv16_dma && !up2 && c == 2 && nwg <= 256 && g_conv16_big_stages && 2 * ck8 * th * pc <= CONV16_NP * nt &&
+          2 * (KW * 2 * ck8 * bm + cdiv(2 * ck8 * th * pc, nt) * nt) * 16 <= 160 * 1024) {
+        const int ck8b = 2 * ck8;
+        pl.ck8 = ck8b; pl.nchunks = cdiv(c8_of(Kc), ck8b);
+        const int stage = (KW * ck8b * bm + cdiv(ck8b * th * pc, nt) * nt) * 16;
+        const int nstages = pl.nchunks * KH;
+        int nstg = std::min(std::min(CONV16_MAX_RING, nstages + 1), 160 * 1024 / stage);
+        if (g_conv16_ring >= 2) nstg = std::min(nstg, g_conv16_ring);
+        pl.dma = 1; pl.nstg = std::max(2, nstg); pl.lds_bytes = pl.nstg * stage;
+        return pl;
+      }
       if (g_conv16_dma && !up2) {
         // LDS-DMA ring: up to 4 buffers; when the grid holds more workgroups than CUs the ring is kept below half of the
         // CU's LDS so that two workgroups share a CU (one computes while the other waits for its stage)
@@ -95,14 +110,14 @@ size_t conv16_weight_bytes(const Conv16Plan& pl, int Mg, int groups, int Kc, int
 // channels from LDS and writes the vectors in output order (consecutive lanes = consecutive rows).  Every weight is read
 // from HBM once, in full cache lines.
 constexpr int PREP16_LDS = 8192;     // floats
-__host__ __device__ inline int prep16_rows(int BM, int khw) {
+__host__ __device__ inline int prep16_rows(int BM, int khw, int nk) {      // nk = reduction channels of a chunk (CK8 * 8)
   int r = 1;
-  while (r * 2 <= BM && (r * 2) * (32 * khw + 1) <= PREP16_LDS && 32 * ((r * 2) * khw + 1) <= PREP16_LDS) r *= 2;
+  while (r * 2 <= BM && (r * 2) * (nk * khw + 1) <= PREP16_LDS && nk * ((r * 2) * khw + 1) <= PREP16_LDS) r *= 2;
   return r;
 }
 __host__ __device__ inline int prep16_units(const Prep16Job& jb) {
   const int tg = (jb.dgrad && jb.bcast) ? 1 : jb.groups;
-  return tg * jb.n_mt * jb.nchunks * (jb.BM / prep16_rows(jb.BM, jb.KH * jb.KW));
+  return tg * jb.n_mt * jb.nchunks * (jb.BM / prep16_rows(jb.BM, jb.KH * jb.KW, jb.CK8 * 8));
 }
 
 template <typename DT>
@@ -112,14 +127,14 @@ __device__ inline void prep16_unit(const Prep16Job& jb, int unit, float* lds) {
   const bool dg = jb.dgrad != 0;
   const int KHs = dg ? cdiv_dev(KH, jb.SH) : KH, KWs = dg ? cdiv_dev(KW, jb.SW) : KW;
   const int tg = (dg && jb.bcast) ? 1 : jb.groups, ncls = dg ? jb.SH * jb.SW : 1;
-  const int R = prep16_rows(BM, KHW), nrb = BM / R;
+  const int R = prep16_rows(BM, KHW, jb.CK8 * 8), nrb = BM / R;
   int x = unit;
   const int rb = x % nrb; x /= nrb;
   const int ch = x % jb.nchunks; x /= jb.nchunks;
   const int mt = x % jb.n_mt;
   const int g = x / jb.n_mt;
   const int m0 = mt * BM + rb * R, k0 = ch * jb.CK8 * 8;
-  const int nk = jb.CK8 * 8;                                   // reduction channels of a chunk (<= 32)
+  const int nk = jb.CK8 * 8;                                   // reduction channels of a chunk
   __syncthreads();                                             // the previous unit's gathers are done
   if (!dg) {
     // lds[row][kk*KHW + tap], row pitch nk*KHW + 1
@@ -235,10 +250,10 @@ int launch_prep16_multi(Prep16Batch& pb, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------------
 // dispatch
-template <typename DT, int KW, int WM, int WN, bool UP2, bool DMA, int NWN = 2>
+template <typename DT, int KW, int WM, int WN, bool UP2, bool DMA, int NWN = 2, int CKX = 1>
 static int launch_one(const Conv16Args& a, int lds_bytes, int nwg, hipStream_t s) {
   static bool attr_done = false;          // kernels that stage more than 64 KiB need the limit raised once
-  auto fn = conv16_kernel<DT, KW, WM, WN, UP2, DMA, NWN>;
+  auto fn = conv16_kernel<DT, KW, WM, WN, UP2, DMA, NWN, CKX>;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return set_error("conv16: cannot raise the dynamic LDS limit");
@@ -255,6 +270,7 @@ static int launch_tile(const Conv16Args& a, const Conv16Plan& pl, int nwg, hipSt
       if (pl.wm == 2 && pl.wn == 1 && pl.nwn == 4) return launch_one<DT, KW, 2, 1, false, true, 4>(a, pl.lds_bytes, nwg, s);
       if (pl.wm == 2 && pl.wn == 2) return launch_one<DT, KW, 2, 2, false, true>(a, pl.lds_bytes, nwg, s);
       if (pl.wm == 1 && pl.wn == 2) return launch_one<DT, KW, 1, 2, false, true>(a, pl.lds_bytes, nwg, s);
+      if (pl.ck8 == 2 * conv16_ck8(KW)) return launch_one<DT, KW, 1, 1, false, true, 2, 2>(a, pl.lds_bytes, nwg, s);
       return launch_one<DT, KW, 1, 1, false, true>(a, pl.lds_bytes, nwg, s);
     }
   }

@@ -142,11 +142,16 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16Args& p, const f32x1
   for (int i = 0; i < WM; ++i) {
     const int mrow0 = tl.m0 + (tl.wm * WM + i) * 32 + 4 * tl.h;
     float bsv[16], scv[EP == EP_BN_EVAL ? 16 : 1], shv[EP == EP_BN_EVAL ? 16 : 1];
+    if (WM == 2) {                                     // 128-row tiles: this row block's 16 values now, in one round trip
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        bsv[q] = p.bias ? p.bias[tl.g * p.Mg + min(mrow0 + (q & 3) + 8 * (q >> 2), p.Mg - 1)] : 0.f;
+    }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int m = mrow0 + (q & 3) + 8 * (q >> 2);
       const int chn = tl.g * p.Mg + min(m, p.Mg - 1);
-      bsv[q] = m < p.Mg ? bias_pre[i][q] : 0.f;       // fetched before the K loop (conv16_kernel)
+      bsv[q] = m < p.Mg ? (WM == 2 ? bsv[q] : bias_pre[i][q]) : 0.f;       // WM == 1: fetched before the K loop (conv16_kernel)
       if (EP == EP_BN_EVAL) {
         const float sc = p.bn_g[chn] * (1.0f / sqrtf(p.bn_v[chn] + p.eps));
         scv[q] = sc; shv[q] = p.bn_b[chn] - p.bn_m[chn] * sc;
@@ -257,10 +262,12 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16Args& p, const f32x1
 // stage).  DMA = false: global -> registers -> LDS, two buffers (needed where the input is formed on the way: UP2).
 // NWN: waves along the pixels (2 waves along the channels): 2 = 4 waves, 4 = 8 waves (two per SIMD: one wave's staging and
 // epilogue arithmetic runs beside the other's MFMAs).  Tile = 64*WM channels x 32*WN*NWN pixels.
-template <typename DT, int KW, int WM, int WN, bool UP2, bool DMA, int NWN = 2>
+template <typename DT, int KW, int WM, int WN, bool UP2, bool DMA, int NWN = 2, int CKX = 1>
 __global__ __launch_bounds__(128 * NWN) void conv16_kernel(const Conv16Args p) {
   prefetch_kernargs<sizeof(Conv16Args)>();
-  constexpr int CK8 = conv16_ck8(KW), KS = CK8 / 2;
+  // CKX = 2: stages of twice the channels (half as many barriers / waits / DMA issues per reduction) for the layers whose
+  // workgroups run alone on their CU -- their K loop is a latency chain, not a throughput problem (plan_conv16)
+  constexpr int CK8 = conv16_ck8(KW) * CKX, KS = CK8 / 2;
   constexpr int BM = 64 * WM;
   constexpr int NT = 128 * NWN;
   constexpr int NAV = KW * CK8 * BM, NA = (NAV + NT - 1) / NT;
@@ -309,8 +316,10 @@ __global__ __launch_bounds__(128 * NWN) void conv16_kernel(const Conv16Args p) {
 
   // the epilogue's bias values, requested now (clamped addresses, no branches): after the K loop they were 16 dependent
   // load -> wait rounds.  They are older than every staging load below, so the counted waits of the ring cover them.
+  // (128-row tiles fetch them at the start of the epilogue instead, in one round trip: 32 more registers across the K loop
+  // would put the kernel over 256 and cost it its second wave per SIMD)
   float bias_pre[WM][16];
-  if (p.bias) {
+  if (WM == 1 && p.bias) {
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
