@@ -23,7 +23,7 @@ int g_conv16_dma = 1;                                 // tuning knob: 0 = regist
 int g_conv16_wide8 = 0;                               // tuning knob: 8-wave form of the 128 x 128 tile (measured: no gain)
 int g_conv16_dbg = 0;
 int g_conv16_ring = 0;                                // tuning knob: force the LDS-DMA ring depth (0 = planner)
-int g_conv16_big_stages = 1;                          // tuning knob: 0 = short stages everywhere (ms_debug_set_conv16_ring, bit 8 of the flags)
+int g_conv16_big_stages = 2;                          // tuning knob: 0 = short stages everywhere (ms_debug_set_conv16_ring, bit 8 of the flags)
 
 Conv16Plan plan_conv16(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH, int SW, int B, int OH, int OW, int zmul,
                        bool up2) {
@@ -62,7 +62,12 @@ Conv16Plan plan_conv16(int nd, int Mg, int groups, int Kc, int KH, int KW, int S
       // a CU (decoder, first audio-encoder layers) lose 10 % with it and keep the short stages
       if (g_conv16_dma && !up2 && c == 2 && nwg <= 256 && g_conv16_big_stages && 2 * ck8 * th * pc <= CONV16_NP * nt &&
           2 * (KW * 2 * ck8 * bm + cdiv(2 * ck8 * th * pc, nt) * nt) * 16 <= 160 * 1024) {
-        const int ck8b = 2 * ck8;
+        int mult = 2;
+        // four times the channels where two such stages still fit (k <= 3 taps per row) and the reduction has more than 2 of them
+        if (g_conv16_big_stages >= 2 && KW <= 3 && 4 * ck8 * th * pc <= CONV16_NP * nt && c8_of(Kc) > 2 * ck8 &&
+            2 * (KW * 4 * ck8 * bm + cdiv(4 * ck8 * th * pc, nt) * nt) * 16 <= 160 * 1024)
+          mult = 4;
+        const int ck8b = mult * ck8;
         pl.ck8 = ck8b; pl.nchunks = cdiv(c8_of(Kc), ck8b);
         const int stage = (KW * ck8b * bm + cdiv(ck8b * th * pc, nt) * nt) * 16;
         const int nstages = pl.nchunks * KH;
@@ -270,6 +275,9 @@ static int launch_tile(const Conv16Args& a, const Conv16Plan& pl, int nwg, hipSt
       if (pl.wm == 2 && pl.wn == 1 && pl.nwn == 4) return launch_one<DT, KW, 2, 1, false, true, 4>(a, pl.lds_bytes, nwg, s);
       if (pl.wm == 2 && pl.wn == 2) return launch_one<DT, KW, 2, 2, false, true>(a, pl.lds_bytes, nwg, s);
       if (pl.wm == 1 && pl.wn == 2) return launch_one<DT, KW, 1, 2, false, true>(a, pl.lds_bytes, nwg, s);
+      if constexpr (KW <= 3) {
+        if (pl.ck8 == 4 * conv16_ck8(KW)) return launch_one<DT, KW, 1, 1, false, true, 2, 4>(a, pl.lds_bytes, nwg, s);
+      }
       if (pl.ck8 == 2 * conv16_ck8(KW)) return launch_one<DT, KW, 1, 1, false, true, 2, 2>(a, pl.lds_bytes, nwg, s);
       return launch_one<DT, KW, 1, 1, false, true>(a, pl.lds_bytes, nwg, s);
     }
