@@ -57,14 +57,14 @@ Conv16Plan plan_conv16(int nd, int Mg, int groups, int Kc, int KH, int KW, int S
       pl.n_tiles = imgs * tiles_y * tiles_x;
       pl.ck8 = ck8; pl.nchunks = cdiv(c8_of(Kc), ck8); pl.pc = pc;
       pl.lds_bytes = 2 * (KW * ck8 * bm + ck8 * th * pc + 1) * 16;
-      // 64 x 64 tiles on at most 256 workgroups (one per CU, the small layers): stages of twice the channels.  Measured per
+      // 64 x 64 (and 64 x 128) tiles on at most 256 workgroups (one per CU, the small layers): stages of twice the channels.  Measured per
       // launch: 256->256 k3 T=64 12.9 -> 9.9 us, k4 s2 13.9 -> 10.8, 3x3 (8,16) 23.0 -> 16.8, 3x8 38.0 -> 30.2; the tiles that share
       // a CU (decoder, first audio-encoder layers) lose 10 % with it and keep the short stages
-      if (g_conv16_dma && !up2 && c == 2 && nwg <= 256 && g_conv16_big_stages && 2 * ck8 * th * pc <= CONV16_NP * nt &&
+      if (g_conv16_dma && !up2 && (c == 2 || c == 1) && nwg <= 256 && g_conv16_big_stages && 2 * ck8 * th * pc <= CONV16_NP * nt &&
           2 * (KW * 2 * ck8 * bm + cdiv(2 * ck8 * th * pc, nt) * nt) * 16 <= 160 * 1024) {
         int mult = 2;
         // four times the channels where two such stages still fit (k <= 3 taps per row) and the reduction has more than 2 of them
-        if (g_conv16_big_stages >= 2 && KW <= 3 && 4 * ck8 * th * pc <= CONV16_NP * nt && c8_of(Kc) > 2 * ck8 &&
+        if (g_conv16_big_stages >= 2 && c == 2 && KW <= 3 && 4 * ck8 * th * pc <= CONV16_NP * nt && c8_of(Kc) > 2 * ck8 &&
             2 * (KW * 4 * ck8 * bm + cdiv(4 * ck8 * th * pc, nt) * nt) * 16 <= 160 * 1024)
           mult = 4;
         const int ck8b = mult * ck8;
@@ -274,7 +274,9 @@ static int launch_tile(const Conv16Args& a, const Conv16Plan& pl, int nwg, hipSt
     if (pl.dma) {
       if (pl.wm == 2 && pl.wn == 1 && pl.nwn == 4) return launch_one<DT, KW, 2, 1, false, true, 4>(a, pl.lds_bytes, nwg, s);
       if (pl.wm == 2 && pl.wn == 2) return launch_one<DT, KW, 2, 2, false, true>(a, pl.lds_bytes, nwg, s);
-      if (pl.wm == 1 && pl.wn == 2) return launch_one<DT, KW, 1, 2, false, true>(a, pl.lds_bytes, nwg, s);
+      if (pl.wm == 1 && pl.wn == 2)
+        return pl.ck8 == 2 * conv16_ck8(KW) ? launch_one<DT, KW, 1, 2, false, true, 2, 2>(a, pl.lds_bytes, nwg, s)
+                                            : launch_one<DT, KW, 1, 2, false, true>(a, pl.lds_bytes, nwg, s);
       if constexpr (KW <= 3) {
         if (pl.ck8 == 4 * conv16_ck8(KW)) return launch_one<DT, KW, 1, 1, false, true, 2, 4>(a, pl.lds_bytes, nwg, s);
       }
