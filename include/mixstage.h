@@ -167,6 +167,19 @@ typedef struct ms_prep16_item {
 size_t ms_weights16_bytes(const ms_conv_desc* d, int which);
 int ms_weights16_prepare(int n, const ms_prep16_item* items, void* stream);
 
+/* 16-bit modes, BN_TRAIN blocks: BatchNorm INSIDE the conv launch.  layers.py:77-78 is one expression, relu(norm(conv(x))); with
+ * this buffer registered, a block whose conv grid is resident on the device all at once computes it in ONE launch and one HBM
+ * pass: the workgroups that share a channel tile exchange their partial batch statistics through `zeroed_words` (arrival
+ * counters) and the block's scratch, and normalise + activate their accumulators from registers -- y_raw is written (the backward
+ * pass reads it) but never re-read, and there is no separate normalising launch.  Larger grids keep the two-launch form.
+ *   zeroed_words  persistent, ZERO-INITIALISED int32 device buffer of n words (65536 recommended; 32 per channel tile and
+ *                 group of the largest block + 32), owned by the caller, serving ONE device and ONE stream at a time (blocks
+ *                 launched concurrently on two streams must not share it); the kernels restore the zeros.  Word 0 is an error
+ *                 flag: non-zero after a workgroup gave up waiting for its peers (the caller copies word 0 back
+ *                 when it wants to check).
+ *   NULL / 0 unregisters: every BN_TRAIN block runs conv + statistics, then the normalising launch. */
+int ms_set_bn_sync_buffer(int32_t* zeroed_words, int n);
+
 /* cb8 <-> fp32 at the boundaries of the 16-bit path (dtype = MS_BF16 / MS_F16):
  *   plain: fp32 (B, C, HW) channel-major, the layout of the fp32 kernels;  btc: fp32 (B, T, C) time-major, the layout of the
  *   reference's pose tensors (layers.py:229,280).  velocity: v[t] = x[t] - x[t-1], v[0] = 0 (gan.py:47-52) fused into the

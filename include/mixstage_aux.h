@@ -53,6 +53,11 @@ int ms_debug_set_conv16_ring(int nstg, int wide8);
  * returns the previous value.  Scratch and slab sizes follow: set it before any step is captured. */
 int ms_debug_set_wgrad16_target(int workgroups);
 int ms_debug_set_wgrad_target(int workgroups);      /* the same for the fp32 patch-staged weight gradient (default 768) */
+/* Test / ablation aid: 0 = 16-bit BN_TRAIN blocks never take the in-launch BatchNorm form (ms_set_bn_sync_buffer), 1 = they do
+ * when eligible (default).  Returns the previous value. */
+int ms_debug_set_bn_fused(int on);
+/* ... and the smallest conv grid (workgroups) that takes it; returns the previous value. */
+int ms_debug_set_bn_fused_min_workgroups(int n);
 /* Timing ablations only: launches whose timing label contains one of the ';'-separated substrings are dropped (results are
  * then meaningless); NULL or "" restores normal operation.  Returns the number of patterns. */
 int ms_debug_set_skip(const char* patterns);

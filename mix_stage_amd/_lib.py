@@ -50,6 +50,9 @@ SIGNATURES = {
     'ms_last_error': (ctypes.c_char_p, []),
     'ms_abi_version': (c_int, []),
     'ms_set_counter_buffer': (c_int, [_P, c_int]),
+    'ms_set_bn_sync_buffer': (c_int, [_P, c_int]),
+    'ms_debug_set_bn_fused': (c_int, [c_int]),
+    'ms_debug_set_bn_fused_min_workgroups': (c_int, [c_int]),
     'ms_conv_block_fwd_workspace': (c_size_t, [_DESC]),
     'ms_conv_block_bwd_workspace': (c_size_t, [_DESC]),
     'ms_conv_block_fwd': (c_int, [_DESC] + [_P] * 11 + [_P, c_size_t, _P]),
@@ -138,6 +141,10 @@ def lib():
       if mode not in ('fp32', 'bf16x6'):
         raise MixStageLibError('MS_PRECISION=%s: expected fp32 or bf16x6' % mode)
       handle.ms_set_precision(1 if mode == 'bf16x6' else 0)
+    if os.environ.get('MS_BN_FUSED'):           # ablations only: MS_BN_FUSED=0 keeps BatchNorm in its own launch
+      handle.ms_debug_set_bn_fused(int(os.environ['MS_BN_FUSED']))
+    if os.environ.get('MS_BN_FUSED_MIN_WGS'):
+      handle.ms_debug_set_bn_fused_min_workgroups(int(os.environ['MS_BN_FUSED_MIN_WGS']))
     if os.environ.get('MS_PATCH_MIN_WGS'):      # tuning experiments only (ms_debug_set_patch_min_workgroups)
       handle.ms_debug_set_patch_min_workgroups(int(os.environ['MS_PATCH_MIN_WGS']))
     _lib = handle

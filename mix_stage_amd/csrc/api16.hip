@@ -64,6 +64,12 @@ Prep16Job dgrad_job(const ms_conv_desc* d, const Dgrad16& dg, const float* w, vo
   return jb;
 }
 
+// partial statistics of the in-launch BatchNorm: one (sum, M2, count, 0) per tile and (padded) channel
+size_t bn_part_bytes(const ms_conv_desc* d, const Conv16Plan& pl) {
+  const int bm = 64 * pl.wm;
+  return align_up((size_t)pl.n_tiles * cdiv(d->Cout, bm) * d->groups * bm * 16, 256);
+}
+
 }  // namespace
 
 size_t weights16_bytes(const ms_conv_desc* d, int which) {
@@ -89,6 +95,7 @@ size_t block_fwd16_workspace(const ms_conv_desc* d) {
   size_t bytes = 256;
   if (pl.ok) {
     bytes += align_up((size_t)pl.n_tiles * g.C * 2 * sizeof(float), 256) + align_up((size_t)pl.n_tiles * sizeof(float), 256);
+    if (d->mode == MS_BN_TRAIN) bytes += bn_part_bytes(d, pl);
     bytes += weights16_bytes(d, 0) + align_up((size_t)2 * g.C * sizeof(float), 256);   // per-call weight preparation
   }
   return bytes;
@@ -121,6 +128,8 @@ int block_fwd16(const ms_conv_desc* d, const void* x, const void* x2, const floa
   char* wsp = (char*)workspace;
   float* stats = (float*)wsp; wsp += align_up((size_t)pl.n_tiles * g.C * 2 * sizeof(float), 256);
   float* counts = (float*)wsp; wsp += align_up((size_t)pl.n_tiles * sizeof(float), 256);
+  float* bn_part = nullptr;
+  if (d->mode == MS_BN_TRAIN) { bn_part = (float*)wsp; wsp += bn_part_bytes(d, pl); }
   const size_t a_bytes = align_up(fwd_a_bytes(d, pl), 256);
   const void* A = w_prepared;
   const float* bias_use = bias;
@@ -166,12 +175,28 @@ int block_fwd16(const ms_conv_desc* d, const void* x, const void* x2, const floa
   a.PW = d->PW; a.o_sh = 1; a.o_sw = 1;
   a.slope = d->slope; a.eps = d->eps;
   if (outf32 && d->mode != MS_BN_TRAIN) a.out_f32 = (float*)y;
+  // train-mode BatchNorm inside the conv launch (conv16_kernel.h, EP_BN_FUSED): the workgroups of a channel tile exchange
+  // their partial statistics and normalise from registers -- taken when the whole grid is resident at once
+  bool fused = false;
+  if (d->mode == MS_BN_TRAIN && !outf32 && g_bn_fused && g_bn_sync) {
+    const int bm = 64 * pl.wm, gy = cdiv(d->Cout, bm), nwg = pl.n_tiles * gy * d->groups;
+    const int scratch = (2 * pl.nwn * bm * 2 + (128 * pl.nwn / bm) * bm * 3 * 2 + bm * 2) * 4;      // red | dred | scsh
+    // (every workgroup reads its group's n_tiles partials: beyond 64 tiles per channel tile that traffic -- n_tiles^2 x 1 KB per
+    // channel tile -- costs more than the normalising launch it replaces; measured on the 512-tile audio-encoder layers)
+    fused = pl.n_tiles <= 64 && nwg >= g_bn_fused_min_wgs && (1 + gy * d->groups) * BNF_SYNC_WORDS_PER_GROUP <= g_bn_sync_n &&
+            pl.lds_bytes >= scratch &&
+            conv16_coresident(g.dt, pl, d->KW, g.up2 != 0, nwg);
+  }
+  if (fused) {
+    a.ep = EP_BN_FUSED; a.out = y; a.out_raw = y_raw; a.bn_part = bn_part; a.bn_sync = g_bn_sync; a.save = save;
+    a.momentum = d->momentum;
+  }
   const double esz = 2.0;
   const double flops = 2.0 * d->Cout * d->Cin * d->KH * d->KW * (double)g.npix * d->groups;
   const double bytes = esz * ((double)g.C * d->Cin * d->KH * d->KW + (double)d->B * g.cin_tot * d->H * d->W) +
                        (a.out_f32 ? 4.0 : esz) * (double)g.npix * g.C;
-  rc = launch_conv16(g.dt, a, pl, d->KW, g.up2 != 0, flops, bytes, s);
-  if (rc) return rc;
+  rc = launch_conv16(g.dt, a, pl, d->KW, g.up2 != 0, flops, fused ? bytes + 2.0 * (double)g.npix * g.C : bytes, s);
+  if (rc || fused) return rc;
   if (d->mode == MS_BN_TRAIN && pl.n_tiles <= 64)      // few statistics tiles: finalize inside the normalising launch
     return launch_bn_finalize_apply16(g.dt, stats, counts, pl.n_tiles, g.npix, gamma, beta, running_mean, running_var, save, d->eps,
                                       d->momentum, y_raw, outf32 ? nullptr : y, outf32 ? (float*)y : nullptr, d->B, g.C, g.hw,
@@ -310,6 +335,22 @@ int ms_wgrad_flush(void* stream) {
   return rc ? rc : rc16;
 }
 int ms_wgrad_discard(void) { wgrad_patch_discard(); wgrad16_discard(); return 0; }
+
+int ms_set_bn_sync_buffer(int32_t* zeroed_words, int n) {
+  g_bn_sync = zeroed_words;
+  g_bn_sync_n = zeroed_words ? n : 0;
+  return 0;
+}
+int ms_debug_set_bn_fused(int on) {
+  const int prev = g_bn_fused;
+  g_bn_fused = on ? 1 : 0;
+  return prev;
+}
+int ms_debug_set_bn_fused_min_workgroups(int n) {
+  const int prev = g_bn_fused_min_wgs;
+  g_bn_fused_min_wgs = n < 0 ? 0 : n;
+  return prev;
+}
 
 size_t ms_weights16_bytes(const ms_conv_desc* d, int which) {
   if (!d || (dt_of(d) != DT_BF16 && dt_of(d) != DT_F16) || (which != 0 && which != 1)) return 0;

@@ -30,10 +30,16 @@ struct Conv16Args {
   const float* bias;
   const float* bn_g;
   const float* bn_b;
-  const float* bn_m;
-  const float* bn_v;
+  float* bn_m;          // running statistics: read by EP_BN_EVAL, updated by EP_BN_FUSED
+  float* bn_v;
   float* stats;         // EP_RAW_STATS: [n_tiles][ctot][2] = (sum, M2 about the tile mean)
   float* counts;        // EP_RAW_STATS: [n_tiles]
+  // EP_BN_FUSED (train-mode BatchNorm inside the launch, conv16_kernel.h)
+  void* out_raw;        // cb8 y_raw = conv + bias for the backward pass (NULL: not kept)
+  float* bn_part;       // [groups*gy][gx][BM] x (sum, sum of squares, count, 0): the tiles' partial statistics
+  int* bn_sync;         // word 0: error flag; per group (g*gy + by) BNF_SYNC_STRIDE words from word BNF_SYNC_STRIDE on: arrive, depart
+  float* save;          // mean | invstd | scale | shift
+  float momentum;
   int Mg, groups, Kc8g, bcast, ep;     // rows per group, groups, source channel blocks per group
   int KH, S, SV;                       // kernel rows, column stride, row stride (1 for 1-D convs: rows are batch items)
   int SRCH, SRCW, s_img, s_cblk, s_row;
@@ -58,6 +64,12 @@ Conv16Plan plan_conv16(int nd, int Mg, int groups, int Kc, int KH, int KW, int S
 size_t conv16_weight_bytes(const Conv16Plan& pl, int Mg, int groups, int Kc, int KH, int KW, int ncls);
 int launch_conv16(int dt, const Conv16Args& a, const Conv16Plan& pl, int KW, bool up2, double flops, double bytes,
                   hipStream_t s);
+bool conv16_coresident(int dt, const Conv16Plan& pl, int KW, bool up2, int nwg);
+extern int g_bn_fused;
+extern int g_bn_fused_min_wgs;
+extern int* g_bn_sync;
+extern int g_bn_sync_n;
+constexpr int BNF_SYNC_WORDS_PER_GROUP = 32;
 
 // ---- weight preparation: fp32 master weights -> 16-bit A-operand stages (once per optimizer update)
 struct Prep16Job {

@@ -255,8 +255,9 @@ int launch_prep16_multi(Prep16Batch& pb, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------------
 // dispatch
+// resident_query != NULL: no launch; *resident_query = workgroups of this instance the device holds at once
 template <typename DT, int KW, int WM, int WN, bool UP2, bool DMA, int NWN = 2, int CKX = 1>
-static int launch_one(const Conv16Args& a, int lds_bytes, int nwg, hipStream_t s) {
+static int launch_one(const Conv16Args& a, int lds_bytes, int nwg, hipStream_t s, int* resident_query) {
   static bool attr_done = false;          // kernels that stage more than 64 KiB need the limit raised once
   auto fn = conv16_kernel<DT, KW, WM, WN, UP2, DMA, NWN, CKX>;
   if (!attr_done) {
@@ -264,42 +265,75 @@ static int launch_one(const Conv16Args& a, int lds_bytes, int nwg, hipStream_t s
       return set_error("conv16: cannot raise the dynamic LDS limit");
     attr_done = true;
   }
+  if (resident_query) {
+    static int cached_lds = -1, cached = 0;
+    if (cached_lds != lds_bytes) {
+      int per_cu = 0, dev = 0, cus = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), 128 * NWN, lds_bytes) != hipSuccess ||
+          hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        per_cu = 0;
+      }
+      // the occupancy query can answer one workgroup per CU too many for kernels with 81+ SGPRs (MI355X_MICROARCH.md,
+      // "Residency and cooperative launch"): stay at or below what 112 SGPRs admit
+      per_cu = std::min(per_cu, 6 * 256 / (128 * NWN));
+      cached = per_cu * cus;
+      cached_lds = lds_bytes;
+    }
+    *resident_query = cached;
+    return 0;
+  }
   hipLaunchKernelGGL(fn, dim3(nwg), dim3(128 * NWN), lds_bytes, s, a);
   return 0;
 }
 
 template <typename DT, int KW, bool UP2>
-static int launch_tile(const Conv16Args& a, const Conv16Plan& pl, int nwg, hipStream_t s) {
+static int launch_tile(const Conv16Args& a, const Conv16Plan& pl, int nwg, hipStream_t s, int* rq) {
   if constexpr (!UP2) {
     if (pl.dma) {
-      if (pl.wm == 2 && pl.wn == 1 && pl.nwn == 4) return launch_one<DT, KW, 2, 1, false, true, 4>(a, pl.lds_bytes, nwg, s);
-      if (pl.wm == 2 && pl.wn == 2) return launch_one<DT, KW, 2, 2, false, true>(a, pl.lds_bytes, nwg, s);
+      if (pl.wm == 2 && pl.wn == 1 && pl.nwn == 4) return launch_one<DT, KW, 2, 1, false, true, 4>(a, pl.lds_bytes, nwg, s, rq);
+      if (pl.wm == 2 && pl.wn == 2) return launch_one<DT, KW, 2, 2, false, true>(a, pl.lds_bytes, nwg, s, rq);
       if (pl.wm == 1 && pl.wn == 2)
-        return pl.ck8 == 2 * conv16_ck8(KW) ? launch_one<DT, KW, 1, 2, false, true, 2, 2>(a, pl.lds_bytes, nwg, s)
-                                            : launch_one<DT, KW, 1, 2, false, true>(a, pl.lds_bytes, nwg, s);
+        return pl.ck8 == 2 * conv16_ck8(KW) ? launch_one<DT, KW, 1, 2, false, true, 2, 2>(a, pl.lds_bytes, nwg, s, rq)
+                                            : launch_one<DT, KW, 1, 2, false, true>(a, pl.lds_bytes, nwg, s, rq);
       if constexpr (KW <= 3) {
-        if (pl.ck8 == 4 * conv16_ck8(KW)) return launch_one<DT, KW, 1, 1, false, true, 2, 4>(a, pl.lds_bytes, nwg, s);
+        if (pl.ck8 == 4 * conv16_ck8(KW)) return launch_one<DT, KW, 1, 1, false, true, 2, 4>(a, pl.lds_bytes, nwg, s, rq);
       }
-      if (pl.ck8 == 2 * conv16_ck8(KW)) return launch_one<DT, KW, 1, 1, false, true, 2, 2>(a, pl.lds_bytes, nwg, s);
-      return launch_one<DT, KW, 1, 1, false, true>(a, pl.lds_bytes, nwg, s);
+      if (pl.ck8 == 2 * conv16_ck8(KW)) return launch_one<DT, KW, 1, 1, false, true, 2, 2>(a, pl.lds_bytes, nwg, s, rq);
+      return launch_one<DT, KW, 1, 1, false, true>(a, pl.lds_bytes, nwg, s, rq);
     }
   }
-  if (pl.wm == 2 && pl.wn == 2) return launch_one<DT, KW, 2, 2, UP2, false>(a, pl.lds_bytes, nwg, s);
-  if (pl.wm == 1 && pl.wn == 2) return launch_one<DT, KW, 1, 2, UP2, false>(a, pl.lds_bytes, nwg, s);
-  return launch_one<DT, KW, 1, 1, UP2, false>(a, pl.lds_bytes, nwg, s);
+  if (pl.wm == 2 && pl.wn == 2) return launch_one<DT, KW, 2, 2, UP2, false>(a, pl.lds_bytes, nwg, s, rq);
+  if (pl.wm == 1 && pl.wn == 2) return launch_one<DT, KW, 1, 2, UP2, false>(a, pl.lds_bytes, nwg, s, rq);
+  return launch_one<DT, KW, 1, 1, UP2, false>(a, pl.lds_bytes, nwg, s, rq);
 }
 
 template <typename DT>
-static int launch_kw(const Conv16Args& a, const Conv16Plan& pl, int KW, bool up2, int nwg, hipStream_t s) {
-  if (up2) return launch_tile<DT, 3, true>(a, pl, nwg, s);
+static int launch_kw(const Conv16Args& a, const Conv16Plan& pl, int KW, bool up2, int nwg, hipStream_t s, int* rq = nullptr) {
+  if (up2) return launch_tile<DT, 3, true>(a, pl, nwg, s, rq);
   switch (KW) {
-    case 1: return launch_tile<DT, 1, false>(a, pl, nwg, s);
-    case 2: return launch_tile<DT, 2, false>(a, pl, nwg, s);
-    case 3: return launch_tile<DT, 3, false>(a, pl, nwg, s);
-    case 4: return launch_tile<DT, 4, false>(a, pl, nwg, s);
-    case 8: return launch_tile<DT, 8, false>(a, pl, nwg, s);
+    case 1: return launch_tile<DT, 1, false>(a, pl, nwg, s, rq);
+    case 2: return launch_tile<DT, 2, false>(a, pl, nwg, s, rq);
+    case 3: return launch_tile<DT, 3, false>(a, pl, nwg, s, rq);
+    case 4: return launch_tile<DT, 4, false>(a, pl, nwg, s, rq);
+    case 8: return launch_tile<DT, 8, false>(a, pl, nwg, s, rq);
   }
   return set_error("conv16: no kernel for %d taps per row", KW);
+}
+
+int g_bn_fused = 1;               // tuning / test knob (ms_debug_set_bn_fused): 0 = BatchNorm always as its own launch
+int g_bn_fused_min_wgs = 0;       // ... and the smallest grid that takes the in-launch form (ms_debug_set_bn_fused_min_workgroups)
+int* g_bn_sync = nullptr;         // ms_set_bn_sync_buffer
+int g_bn_sync_n = 0;
+
+// Can EVERY workgroup of this launch be resident at once?  The in-launch BatchNorm (EP_BN_FUSED) makes the workgroups of a
+// channel tile wait for each other; with the whole grid resident that cannot deadlock under any dispatch order.
+bool conv16_coresident(int dt, const Conv16Plan& pl, int KW, bool up2, int nwg) {
+  if (!pl.ok) return false;
+  Conv16Args a = {};
+  int resident = 0;
+  const int rc = dt == DT_BF16 ? launch_kw<BF16>(a, pl, KW, up2, nwg, nullptr, &resident) : launch_kw<F16>(a, pl, KW, up2, nwg, nullptr, &resident);
+  return rc == 0 && nwg <= resident;
 }
 
 int launch_conv16(int dt, const Conv16Args& a, const Conv16Plan& pl, int KW, bool up2, double flops, double bytes,
@@ -324,7 +358,7 @@ int launch_conv16(int dt, const Conv16Args& a, const Conv16Plan& pl, int KW, boo
   TimingScope ts(s, flops, bytes, "conv16_kernel<%s,%d,%d,%d,%d,%d,%d>|conv_%s_cb8 k%dx%d s%d Mg%d Kg%d g%d tiles%d tile%dx%d tw%d%s%s",
                  dt == DT_BF16 ? "bf16" : "f16", KW, pl.wm, pl.wn, up2 ? 1 : 0, pl.dma, pl.nwn, a.is_dgrad ? "dgrad" : "fwd", a.KH, KW, a.S, a.Mg,
                  a.Kc8g * 8 * a.KH * KW, a.groups, pl.n_tiles, bm, 32 * pl.wn * pl.nwn, pl.tw, ring,
-                 a.ep == EP_RAW_STATS ? " +bnstats" : "");
+                 a.ep == EP_RAW_STATS ? " +bnstats" : a.ep == EP_BN_FUSED ? " +bnfused" : "");
   if (ts.skip()) return 0;
   const int rc = dt == DT_BF16 ? launch_kw<BF16>(b, pl, KW, up2, nwg, s) : launch_kw<F16>(b, pl, KW, up2, nwg, s);
   if (rc) return rc;

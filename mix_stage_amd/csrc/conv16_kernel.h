@@ -257,6 +257,228 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16Args& p, const f32x1
   }
 }
 
+// One 32-row x 32-pixel accumulator block -> cb8 vectors in HBM.  8 consecutive channels of a pixel sit in two lanes (l, l+32):
+// v_permlane32_swap pairs register groups so that the lower lane ends up with blocks 0,1 and the upper lane with blocks 2,3 of
+// the 32-row tile, one 16-byte store each.
+template <typename DT>
+__device__ __forceinline__ void store_block16(const Conv16Args& p, const Tile16& tl, void* out, int row_block, int oy, int ox, bool cval,
+                                              const float (&c)[16]) {
+  float vec[2][8];
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned x = __builtin_bit_cast(unsigned, c[4 * pr + e]), y = __builtin_bit_cast(unsigned, c[4 * (pr + 2) + e]);
+      const unsigned long long sw = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_permlane32_swap(x, y, false, false));
+      vec[pr][e] = __builtin_bit_cast(float, (unsigned)sw);
+      vec[pr][4 + e] = __builtin_bit_cast(float, (unsigned)(sw >> 32));
+    }
+  const int cb_tile = (tl.g * p.Mg + tl.m0 + row_block * 32) >> 3;
+  const int cb_end = (tl.g * p.Mg + p.Mg + 7) >> 3;
+  const size_t obase = (size_t)tl.img * p.o_img + (size_t)(oy * p.o_sh + tl.o_ry) * p.o_row + (size_t)(ox * p.o_sw + tl.o_rx);
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr) {
+    const int cb = cb_tile + pr + 2 * tl.h;
+    if (cval && cb < cb_end) reinterpret_cast<u32x4*>(out)[obase + (size_t)cb * p.o_cblk] = pack8<DT>(vec[pr]);
+  }
+}
+
+// ---- EP_BN_FUSED: train-mode BatchNorm + LeakyReLU applied INSIDE the conv launch (layers.py:77-78 as one HBM pass).
+// The batch statistics of a channel need every pixel tile of that channel tile: the gx workgroups (g, by, bx = 0..gx-1) form a
+// GROUP that meets once.  Each keeps its accumulators in registers, publishes its per-channel partial (sum, sum of
+// squares, count) with write-through (sc1) 16-byte stores, arrives on the group's counter, waits until all gx have arrived
+// (one lane polls with sc1 loads), reads the gx partials back (sc1 loads: served by L2 / the fabric, never by this CU's L1)
+// and sums them in tile order in fp64 -- every workgroup of the group computes bit-identical statistics --
+// then normalises, activates and stores y from registers.  y_raw (what the backward pass reads) leaves while the group
+// gathers.  No y_raw re-read, no second launch.
+// Hand-off form: MI355X_MICROARCH.md "Valid forms", table row 3 (sc1 payload stores, every storing wave's vmcnt(0), workgroup
+// barrier, one agent-scope atomic add per workgroup, sc1 poll, workgroup barrier, sc1 loads).
+// Forward progress: the launcher uses this epilogue only when the WHOLE grid is co-resident (conv16_coresident), so every
+// member of a group is running whatever the dispatch order; members of a group have consecutive logical ids, so under the
+// in-order dispatch the hardware performs at most one group per XCD is ever partially dispatched.  The spin is bounded: on
+// expiry the kernel raises word 0 of the sync buffer (ms_set_bn_sync_buffer) and finishes with whatever statistics it has.
+constexpr int BNF_SPIN_LIMIT = 1 << 21;
+constexpr int BNF_SYNC_STRIDE = BNF_SYNC_WORDS_PER_GROUP;      // int32 words per group in the sync buffer (arrive, depart on a 128-byte line of their own)
+
+template <typename DT, int WM, int WN, int NWN>
+__device__ __forceinline__ void conv16_epilogue_bnfused(const Conv16Args& p, const f32x16 (&acc)[WM][WN], const Tile16& tl, u32x4* smem,
+                                                        const float (&bias_pre)[WM][16]) {
+  constexpr int BM = 64 * WM, NT = 128 * NWN, P = NT / BM;
+  const int TW = 1 << p.ltw;
+  float* red = reinterpret_cast<float*>(smem);                         // [NWN pixel waves][BM][2]
+  double* dred = reinterpret_cast<double*>(red + NWN * BM * 2);        // [P][BM][3]
+  float* scsh = reinterpret_cast<float*>(dred + P * BM * 3);           // [BM][2]
+  const int grp = tl.g * p.gy + tl.by;
+  int* arrive = p.bn_sync + (size_t)(1 + grp) * BNF_SYNC_STRIDE;
+  int* depart = arrive + 1;
+
+  // ---- A. conv + bias stays in the accumulators; per-channel (sum, sum of squares) of this tile
+  // (the accumulators are only ever READ element-wise: this clang miscompiles constant-index element writes into a local
+  // f32x16.  The bias is added at each of the three uses; 128-row tiles re-fetch it -- an L2 hit -- instead of holding 32 more
+  // registers across the gathering)
+  auto bias_of = [&](int i, float (&bsv)[16]) {
+    const int mrow0 = tl.m0 + (tl.wm * WM + i) * 32 + 4 * tl.h;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int m = mrow0 + (q & 3) + 8 * (q >> 2);
+      const float b = WM == 2 ? (p.bias ? p.bias[tl.g * p.Mg + min(m, p.Mg - 1)] : 0.f) : bias_pre[i][q];
+      bsv[q] = m < p.Mg ? b : 0.f;
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    float bsv[16];
+    bias_of(i, bsv);
+    float s1[16], s2[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int n = (tl.wn * WN + j) * 32 + tl.r;
+      const int oy = tl.oy0 + (n >> p.ltw), ox = tl.ox0 + (n & (TW - 1));
+      const bool cval = (oy < tl.OUTH) & (ox < tl.OUTW);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float v = acc[i][j][q] + bsv[q];
+        const float vm = cval ? v : 0.f;
+        s1[q] += vm;
+        s2[q] = fmaf(vm, vm, s2[q]);
+      }
+    }
+    reduce16_over_half(s1, tl.r);
+    reduce16_over_half(s2, tl.r);
+    if (!(tl.r & 1)) {
+      const int q = (tl.r >> 1) & 15;
+      const int ml = (tl.wm * WM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * tl.h;
+      red[(tl.wn * BM + ml) * 2] = s1[0];
+      red[(tl.wn * BM + ml) * 2 + 1] = s2[0];
+    }
+  }
+  __syncthreads();
+
+  // ---- B. publish this tile's partial, arrive
+  const int th_v = min(p.TH, tl.OUTH - tl.oy0), tw_v = min(TW, tl.OUTW - tl.ox0);
+  const __amdgpu_buffer_rsrc_t rsP = buf_rsrc(p.bn_part);
+  const bool chan_ok = tl.t < BM && tl.m0 + tl.t < p.Mg;
+  const int chn = tl.g * p.Mg + min(tl.m0 + (tl.t & (BM - 1)), p.Mg - 1);
+  float gam = 0.f, bet = 0.f, rmean = 0.f, rvar = 0.f;
+  if (tl.t < BM) {
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWN; ++w) { sa += red[(w * BM + tl.t) * 2]; sb += red[(w * BM + tl.t) * 2 + 1]; }
+    const float cnt = (float)(th_v * tw_v);
+    const float4 part = {sa, sb, chan_ok ? cnt : 0.f, 0.f};
+    // one wave instruction = 64 lanes x 16 B = eight whole 128-byte lines, written through to the fabric
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, part), rsP,
+                                           (int)(16u * (unsigned)((grp * p.gx + tl.bx) * BM + tl.t)), 0, 16 /* sc1 */);
+    gam = p.bn_g[chn]; bet = p.bn_b[chn];
+    if (tl.bx == 0) { rmean = p.bn_m[chn]; rvar = p.bn_v[chn]; }
+  }
+  // (p.dbg bits 4..7: timing ablations of this epilogue -- no y_raw store / no wait / no partial loads / no publish; results are
+  // then meaningless.  ms_debug_set_conv16_ring)
+  if (!(p.dbg & 128)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave: its partial has left before the workgroup signals
+  __syncthreads();
+  if (tl.t == 0 && !(p.dbg & 128)) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // y_raw = conv + bias (what the backward pass reads) leaves while the group gathers
+  if (p.out_raw && !(p.dbg & 16)) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      float bsv[16];
+      bias_of(i, bsv);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int n = (tl.wn * WN + j) * 32 + tl.r;
+        const int oy = tl.oy0 + (n >> p.ltw), ox = tl.ox0 + (n & (TW - 1));
+        float c[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) c[q] = acc[i][j][q] + bsv[q];
+        store_block16<DT>(p, tl, p.out_raw, tl.wm * WM + i, oy, ox, (oy < tl.OUTH) & (ox < tl.OUTW), c);
+      }
+    }
+  }
+  if (tl.t == 0 && !(p.dbg & (32 | 128))) {
+    int spins = 0;
+    while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.gx) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > BNF_SPIN_LIMIT) { __hip_atomic_store(p.bn_sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+  }
+  __syncthreads();
+
+  // ---- C. the group's partials, summed in fp64 in tile order (thread = channel c, every P-th tile; then the P shares in order)
+  {
+    const int c = tl.t & (BM - 1), share = tl.t / BM;
+    const unsigned base = 16u * (unsigned)(grp * p.gx * BM + c);
+    double n = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int k0 = share; k0 < ((p.dbg & 64) ? 0 : p.gx); k0 += 4 * P) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = min(k0 + u * P, p.gx - 1);
+        v[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsP, (int)(base + 16u * (unsigned)(k * BM)), 0, 16 /* sc1 */));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (k0 + u * P < p.gx) { s1 += (double)v[u].x; s2 += (double)v[u].y; n += (double)v[u].z; }
+    }
+    dred[(share * BM + c) * 3] = n; dred[(share * BM + c) * 3 + 1] = s1; dred[(share * BM + c) * 3 + 2] = s2;
+  }
+  __syncthreads();
+  if (tl.t == 0 && !(p.dbg & 128)) {            // every load of the group's partials by this workgroup has returned: depart; the last one re-arms
+    const int old = __hip_atomic_fetch_add(depart, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == p.gx - 1) {
+      __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(depart, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (tl.t < BM) {
+    double n = dred[tl.t * 3], s1 = dred[tl.t * 3 + 1], s2 = dred[tl.t * 3 + 2];
+#pragma unroll
+    for (int s = 1; s < P; ++s) { n += dred[(s * BM + tl.t) * 3]; s1 += dred[(s * BM + tl.t) * 3 + 1]; s2 += dred[(s * BM + tl.t) * 3 + 2]; }
+    float sc = 0.f, shf = 0.f;
+    if (chan_ok && n > 0.0) {
+      // sum and sum of squares of the fp32 accumulators, exact in fp64 from here on: M2 = sum x^2 - (sum x)^2 / N
+      const double mean = s1 / n, m2 = fmax(s2 - s1 * mean, 0.0);
+      const float var = (float)(m2 / n);
+      const float invstd = 1.0f / sqrtf(var + p.eps);
+      const float fmean = (float)mean;
+      sc = gam * invstd;
+      shf = bet - fmean * sc;
+      if (tl.bx == 0) {
+        const int ctot = p.groups * p.Mg;
+        p.save[chn] = fmean; p.save[ctot + chn] = invstd; p.save[2 * ctot + chn] = sc; p.save[3 * ctot + chn] = shf;
+        const float unbiased = n > 1.0 ? (float)(m2 / (n - 1.0)) : var;
+        p.bn_m[chn] = (1.f - p.momentum) * rmean + p.momentum * fmean;
+        p.bn_v[chn] = (1.f - p.momentum) * rvar + p.momentum * unbiased;
+      }
+    }
+    scsh[tl.t * 2] = sc; scsh[tl.t * 2 + 1] = shf;
+  }
+  __syncthreads();
+
+  // ---- D. normalise + activate from registers, store y
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    float scv[16], shv[16], bsv[16];
+    bias_of(i, bsv);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int ml = (tl.wm * WM + i) * 32 + 4 * tl.h + (q & 3) + 8 * (q >> 2);
+      const float2 ss = *reinterpret_cast<const float2*>(scsh + ml * 2);
+      scv[q] = ss.x; shv[q] = fmaf(bsv[q], ss.x, ss.y);          // (acc + b) * sc + sh = acc * sc + (b * sc + sh)
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int n = (tl.wn * WN + j) * 32 + tl.r;
+      const int oy = tl.oy0 + (n >> p.ltw), ox = tl.ox0 + (n & (TW - 1));
+      float c[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) c[q] = lrelu(fmaf(acc[i][j][q], scv[q], shv[q]), p.slope);
+      store_block16<DT>(p, tl, p.out, tl.wm * WM + i, oy, ox, (oy < tl.OUTH) & (ox < tl.OUTW), c);
+    }
+  }
+}
+
 // DMA = true: the stages are filled by LDS-DMA loads into a ring of p.nstg buffers -- no staging registers, no ds_write, and
 // the loads of the next nstg-2 stages stay in flight behind the current stage's MFMAs (counted vmcnt, one raw barrier per
 // stage).  DMA = false: global -> registers -> LDS, two buffers (needed where the input is formed on the way: UP2).
@@ -286,7 +508,10 @@ __global__ __launch_bounds__(128 * NWN) void conv16_kernel(const Conv16Args p) {
 
   // logical block id: channel tile fastest, then pixel tile, then (class, group); one contiguous range per XCD
   const int vid = xcd_remap(blockIdx.x, p.gx * p.gy * p.gz);
-  const int by_ = vid % p.gy, bx_ = (vid / p.gy) % p.gx, bz_ = vid / (p.gy * p.gx);
+  // (EP_BN_FUSED: pixel tile fastest -- the gx workgroups that meet for a channel tile's statistics have consecutive ids)
+  const bool px_first = p.ep == EP_BN_FUSED;
+  const int by_ = px_first ? (vid / p.gx) % p.gy : vid % p.gy, bx_ = px_first ? vid % p.gx : (vid / p.gy) % p.gx,
+            bz_ = vid / (p.gy * p.gx);
   const int cls = p.ncls > 1 ? bz_ / p.groups : 0, g = bz_ - cls * p.groups, m0 = by_ * BM;
   const int PHc = p.ncls > 1 ? p.cls_PH[cls] : p.PH, PWc = p.ncls > 1 ? p.cls_PW[cls] : p.PW;
   const int OUTHc = p.ncls > 1 ? p.cls_OUTH[cls] : p.OUTH, OUTWc = p.ncls > 1 ? p.cls_OUTW[cls] : p.OUTW;
@@ -504,6 +729,7 @@ __global__ __launch_bounds__(128 * NWN) void conv16_kernel(const Conv16Args p) {
       case EP_LRELU: conv16_epilogue<DT, WM, WN, NWN, EP_LRELU, false>(p, acc, tl, smem, bias_pre); break;
       case EP_BN_EVAL: conv16_epilogue<DT, WM, WN, NWN, EP_BN_EVAL, false>(p, acc, tl, smem, bias_pre); break;
       case EP_RAW_STATS: conv16_epilogue<DT, WM, WN, NWN, EP_RAW_STATS, false>(p, acc, tl, smem, bias_pre); break;
+      case EP_BN_FUSED: conv16_epilogue_bnfused<DT, WM, WN, NWN>(p, acc, tl, smem, bias_pre); break;
       default: conv16_epilogue<DT, WM, WN, NWN, EP_DGRAD_UP2, false>(p, acc, tl, smem, bias_pre); break;
     }
   }

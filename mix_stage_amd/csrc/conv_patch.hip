@@ -543,7 +543,7 @@ extern "C" int ms_debug_set_patch_tuning(int intra_split, int force_splitk) {
 namespace ms { extern int g_conv16_force_wm, g_conv16_force_wn, g_conv16_dma, g_conv16_wide8, g_conv16_ring, g_conv16_dbg, g_conv16_big_stages; }
 extern "C" int ms_debug_set_conv16_ring(int nstg, int wide8) {
   ++g_tuning_epoch;
-  ms::g_conv16_ring = nstg; ms::g_conv16_wide8 = wide8 & 1; ms::g_conv16_dbg = (wide8 >> 4) & 15; ms::g_conv16_big_stages = (wide8 & 256) ? 0 : (wide8 & 512) ? 1 : 2;
+  ms::g_conv16_ring = nstg; ms::g_conv16_wide8 = wide8 & 1; ms::g_conv16_dbg = ((wide8 >> 4) & 15) | (((wide8 >> 12) & 15) << 4); ms::g_conv16_big_stages = (wide8 & 256) ? 0 : (wide8 & 512) ? 1 : 2;
   return 0;
 }
 extern "C" int ms_debug_set_conv16_tile(int wm, int wn) {

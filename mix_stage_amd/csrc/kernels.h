@@ -4,7 +4,7 @@
 
 namespace ms {
 
-enum { EP_BARE = 0, EP_LRELU = 1, EP_BN_EVAL = 2, EP_RAW_STATS = 3, EP_DGRAD = 4, EP_DGRAD_UP2 = 5 };
+enum { EP_BARE = 0, EP_LRELU = 1, EP_BN_EVAL = 2, EP_RAW_STATS = 3, EP_DGRAD = 4, EP_DGRAD_UP2 = 5, EP_BN_FUSED = 6 };
 
 struct GatherArgs {
   const float* A;     // [groups][Mg][Kg]

@@ -30,6 +30,31 @@ def _need16(*tensors):
 
 
 # ------------------------------------------------------------------------------------------------
+# In-launch BatchNorm (ms_set_bn_sync_buffer): the arrival counters through which the workgroups of a BN_TRAIN block's conv
+# launch exchange their batch statistics.  One persistent zeroed buffer per process (= per device: one process per GPU); the
+# kernels leave it zeroed.  Word 0 is raised when a workgroup gave up waiting for its peers (bn_sync_error()).
+_bn_sync = {}
+
+
+def _ensure_bn_sync(device):
+  key = (device.type, device.index)
+  buf = _bn_sync.get(key)
+  if buf is None:
+    if _bn_sync:
+      raise ops._lib.MixStageLibError('the 16-bit path serves one device per process (in-launch BatchNorm counters live on %s)'
+                                      % (list(_bn_sync)[0],))
+    buf = torch.zeros(1 << 16, dtype=torch.int32, device=device)
+    check(lib().ms_set_bn_sync_buffer(_ptr(buf), buf.numel()), 'ms_set_bn_sync_buffer')
+    _bn_sync[key] = buf
+  return buf
+
+
+def bn_sync_error():
+  """True when an in-launch BatchNorm workgroup timed out waiting for its group (synchronises the device)."""
+  return any(int(b[0].item()) != 0 for b in _bn_sync.values())
+
+
+# ------------------------------------------------------------------------------------------------
 # layout converters
 class _ToCb8Fn(torch.autograd.Function):
   @staticmethod
@@ -206,6 +231,8 @@ class _ConvBlock16Fn(torch.autograd.Function):
       y_raw = torch.empty((B, c8) + sp + (8,), dtype=x.dtype, device=x.device)
       save = torch.empty(4 * ctot, dtype=torch.float32, device=x.device)
     ws = workspace(d._fwd_ws, x.device)
+    if mode == MS_BN_TRAIN:
+      _ensure_bn_sync(x.device)
     folded = mode == MS_BN_EVAL and bool(dt_flags & MS_DT_BN_FOLDED)
     planes = _prepared16_for(w, d, 'fwd16', dict(bias=bias, gamma=gamma, beta=beta, running_mean=rm, running_var=rv)
                              if folded else None)

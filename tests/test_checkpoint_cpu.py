@@ -52,6 +52,28 @@ def test_weight_files_cannot_execute_code(tmp_path):
   with pytest.raises(Exception):
     read_weights(bad)
   assert not (tmp_path / 'pwned').exists()
+  # nested form: an allowed outer pickle whose payload goes through torch.storage._load_from_bytes, which is an
+  # unrestricted torch.load in torch 2.x -- the inner payload must be held to the same rules
+  class EvilInner:
+    def __reduce__(self):
+      return (os.system, ('echo pwned > %s' % (tmp_path / 'pwned2'),))
+  inner = io.BytesIO()
+  torch.save({'w': EvilInner()}, inner)
+
+  class Outer:
+    def __reduce__(self):
+      return (torch.storage._load_from_bytes, (inner.getvalue(),))
+  nested = tmp_path / 'nested_weights.p'
+  with open(nested, 'wb') as f:
+    pickle.dump({'model': {'w': Outer()}}, f)
+  with pytest.raises(Exception):
+    read_weights(nested)
+  assert not (tmp_path / 'pwned2').exists()
+  # the legitimate use of that hook (a tensor pickled by value) still loads
+  legit = tmp_path / 'bytes_weights.p'
+  with open(legit, 'wb') as f:
+    pickle.dump({'w': torch.arange(6.).reshape(2, 3)}, f, protocol=2)
+  assert torch.equal(read_weights(legit)['w'], torch.arange(6.).reshape(2, 3))
   good = tmp_path / 'np_weights.p'
   with open(good, 'wb') as f:
     pickle.dump({'G.eye': torch.eye(2).numpy(), 'n': torch.ones(3)}, f)

@@ -1,0 +1,176 @@
+"""GPU: train-mode BatchNorm INSIDE the conv launch (16-bit path, EP_BN_FUSED; layers.py:77-78 as one HBM pass).
+
+The workgroups that share a channel tile exchange their partial batch statistics inside the launch.  Checked here: against the
+two-launch form on the same inputs (statistics to fp32 rounding, y_raw bit for bit, y to one 16-bit rounding), bitwise
+repeatability under uneven load on the chip (a stale or torn partial would change the statistics), the counters left zeroed,
+no time-out raised."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+BN_TRAIN, PLAIN, BCAST, UP2 = 2, 0, 1, 2
+
+
+def _run_block(nd, B, cin, cout, groups, k, s, p, H, W, in_mode, fused, seed=0, dt=torch.bfloat16, reps=1, tensors=None):
+  from mix_stage_amd import ops, ops16
+  from mix_stage_amd._lib import MS_BF16, MS_F16, FwdOptions, check, lib
+  L = lib()
+  msdt = MS_BF16 if dt == torch.bfloat16 else MS_F16
+  prev = L.ms_debug_set_bn_fused(1 if fused else 0)
+  try:
+    if tensors is None:
+      g = torch.Generator().manual_seed(seed)
+      sp = (H, W) if nd == 2 else (W,)
+      cin_tot = cin if in_mode == BCAST else cin * groups
+      kt = (k, k) if (nd == 2 and not isinstance(k, tuple)) else (k if isinstance(k, tuple) else (k,))
+      fan = cin
+      for v in kt:
+        fan *= v
+      ctot = cout * groups
+      w = (torch.randn((ctot, cin) + tuple(kt), generator=g) * fan ** -0.5).to(DEV)
+      bias = (torch.randn(ctot, generator=g) * 0.1).to(DEV)
+      gamma = (0.5 + torch.rand(ctot, generator=g)).to(DEV)
+      beta = (torch.randn(ctot, generator=g) * 0.1).to(DEV)
+      rm = (torch.randn(ctot, generator=g) * 0.1).to(DEV)
+      rv = (0.5 + torch.rand(ctot, generator=g)).to(DEV)
+      if in_mode == UP2:
+        x = ops16.to_cb8(torch.randn((B, cin_tot, W // 2), generator=g).to(DEV) + 0.3, msdt)
+        x2 = ops16.to_cb8(torch.randn((B, cin_tot, W), generator=g).to(DEV), msdt)
+      else:
+        x = ops16.to_cb8(torch.randn((B, cin_tot) + sp, generator=g).to(DEV) + 0.3, msdt)
+        x2 = None
+      tensors = (w, bias, gamma, beta, rm, rv, x, x2)
+    w, bias, gamma, beta, rm, rv, x, x2 = tensors
+    rm, rv = rm.clone(), rv.clone()
+    ctot = w.shape[0]
+    geom = ops.ConvGeom(nd, groups, k, s, p)
+    d = geom.desc(B, cin, H, W, cout, BN_TRAIN, in_mode, msdt)
+    sp_out = (d.OH, d.OW) if nd == 2 else (d.OW,)
+    c8 = (ctot + 7) // 8
+    ops16._ensure_bn_sync(x.device)
+    ws = ops.workspace(d._fwd_ws, x.device)
+    outs = []
+    P = ops._ptr
+    for _ in range(reps):
+      y = torch.full((B, c8) + sp_out + (8,), float('nan'), dtype=dt, device=DEV)
+      y_raw = torch.full_like(y, float('nan'))
+      save = torch.full((4 * ctot,), float('nan'), dtype=torch.float32, device=DEV)
+      opt = FwdOptions(None)
+      check(L.ms_conv_block_fwd_ex(ctypes.byref(d), P(x), P(x2), P(w), P(bias), P(gamma), P(beta), P(rm), P(rv), P(y_raw), P(y),
+                                   P(save), P(ws), ws.numel(), ops._stream(), ctypes.byref(opt)), 'ms_conv_block_fwd_ex')
+      outs.append((y, y_raw, save))
+    torch.cuda.synchronize()
+    return outs, (rm, rv), tensors
+  finally:
+    L.ms_debug_set_bn_fused(prev)
+
+
+def _labels_of(fn):
+  from mix_stage_amd import ops
+  ops.timing_enable(True)
+  try:
+    fn()
+    torch.cuda.synchronize()
+    return [r['label'] for r in ops.timing_report()]
+  finally:
+    ops.timing_enable(False)
+
+
+GEOMS = [
+    # name, nd, B, cin, cout, groups, k, s, p, H, W, in_mode
+    ('decoder_headline', 1, 32, 256, 256, 8, 3, 1, 1, 1, 64, PLAIN),     # 512 workgroups of 64 x 128, 16 per group, 2 per CU
+    ('decoder0_bcast', 1, 32, 266, 256, 8, 3, 1, 1, 1, 64, BCAST),
+    ('unet_t64', 1, 32, 256, 256, 1, 3, 1, 1, 1, 64, PLAIN),             # 64 x 64 tiles, 32 per group
+    ('unet_down_t32', 1, 32, 256, 256, 1, 4, 2, 1, 1, 64, PLAIN),
+    ('unet_up2', 1, 32, 256, 256, 1, 3, 1, 1, 1, 32, UP2),               # register-staged kernel (no LDS-DMA)
+    ('ragged', 1, 5, 72, 40, 1, 3, 1, 1, 1, 50, PLAIN),                  # partial tiles, channels not a multiple of 8
+    ('deep_t2', 1, 6, 64, 64, 1, 4, 2, 1, 1, 4, PLAIN),                  # a single tile per channel tile
+    ('ae_deep_2d', 2, 8, 128, 256, 1, 3, 1, 1, 8, 15, PLAIN),
+    ('m4_decoder', 1, 32, 256, 256, 4, 3, 1, 1, 1, 64, PLAIN),
+]
+
+
+@pytest.mark.parametrize('geo', GEOMS, ids=[g[0] for g in GEOMS])
+def test_fused_matches_two_launch_form(geo):
+  _, nd, B, cin, cout, groups, k, s, p, H, W, in_mode = geo
+  labels = _labels_of(lambda: _run_block(nd, B, cin, cout, groups, k, s, p, H, W, in_mode, True))
+  assert any('+bnfused' in l for l in labels), labels
+  assert not any('bn_finalize' in l or 'bn_apply' in l for l in labels), labels
+  (f,), (rm_f, rv_f), tensors = _run_block(nd, B, cin, cout, groups, k, s, p, H, W, in_mode, True)
+  (u,), (rm_u, rv_u), _ = _run_block(nd, B, cin, cout, groups, k, s, p, H, W, in_mode, False, tensors=tensors)
+  y_f, raw_f, save_f = f
+  y_u, raw_u, save_u = u
+  ctot = cout * groups
+  assert not torch.isnan(save_f).any() and not torch.isnan(y_f.float()).any()
+  # y_raw: the same accumulators, the same rounding
+  assert torch.equal(raw_f.view(torch.int16), raw_u.view(torch.int16))
+  # statistics: the same per-tile partials merged in fp64 (Chan) on both sides -> fp32 rounding at most
+  mean_f, mean_u = save_f[:ctot], save_u[:ctot]
+  inv_f, inv_u = save_f[ctot:2 * ctot], save_u[ctot:2 * ctot]
+  assert (mean_f - mean_u).abs().max().item() <= 2e-6 * (1 + mean_u.abs().max().item())
+  assert ((inv_f - inv_u).abs() / inv_u.abs()).max().item() <= 2e-6
+  assert (save_f[2 * ctot:] - save_u[2 * ctot:]).abs().max().item() <= 1e-5 * (1 + save_u[2 * ctot:].abs().max().item())
+  assert (rm_f - rm_u).abs().max().item() <= 1e-6 and ((rv_f - rv_u).abs() / rv_u.abs()).max().item() <= 2e-6
+  # y: the fused form normalises the fp32 accumulators, the two-launch form the 16-bit y_raw: within one rounding of y_raw
+  # through the affine map (|scale| * |y_raw| * 2^-8) plus one rounding of y
+  sc = save_u[2 * ctot:3 * ctot].abs().max().item()
+  bound = (raw_u.float().abs().max().item() * sc + y_u.float().abs().max().item()) * 2 ** -8 + 1e-6
+  assert (y_f.float() - y_u.float()).abs().max().item() <= bound
+  # and against the definition, from the kept y_raw and the statistics, elementwise to the same bound
+  from mix_stage_amd import ops16
+  raw32 = ops16.from_cb8(raw_f, ctot)
+  shape = (1, -1) + (1,) * (raw32.dim() - 2)
+  z = raw32 * save_f[2 * ctot:3 * ctot].view(shape) + save_f[3 * ctot:].view(shape)
+  ref = torch.where(z > 0, z, 0.2 * z)
+  assert (ops16.from_cb8(y_f, ctot) - ref).abs().max().item() <= bound
+  if ctot % 8:
+    assert float(y_f[:, -1, ..., ctot % 8:].float().abs().max()) == 0.0          # pad channels stay zero
+
+
+def test_fused_is_bitwise_repeatable_under_uneven_load():
+  """The hand-off (sc1 partial stores -> counter -> sc1 loads) must deliver every workgroup the SAME, COMPLETE set of partials.
+  Three different input sets are launched in rotation, 30 times, next to a second stream that hammers HBM and the L2s; every
+  output is compared bit for bit with the first launch of its input set, and every workgroup's statistics are recovered from
+  y and compared with the block's.  A stale line (the previous launch's partials live at the same addresses and differ), a
+  torn or an early read would move the statistics of some channel tile."""
+  from mix_stage_amd import ops16
+  geo = GEOMS[0][1:]
+  nd, B, cin, cout, groups, k, s, p, H, W, in_mode = geo
+  sets = []
+  for seed in (11, 12, 13):
+    (first,), _, tensors = _run_block(nd, B, cin, cout, groups, k, s, p, H, W, in_mode, True, seed=seed)
+    sets.append((first, tensors))
+  assert not torch.equal(sets[0][0][2], sets[1][0][2])
+  side = torch.cuda.Stream()
+  big = torch.randn(64 << 20, device=DEV)
+  with torch.cuda.stream(side):
+    for i in range(16):
+      big = big * 1.0001 + 0.5            # 512 MB of traffic per pass beside the conv launches
+  for rep in range(30):
+    first, tensors = sets[rep % 3]
+    (out,), _, _ = _run_block(nd, B, cin, cout, groups, k, s, p, H, W, in_mode, True, tensors=tensors)
+    y, raw, save = out
+    assert torch.equal(save, first[2]), rep
+    assert torch.equal(y.view(torch.int16), first[0].view(torch.int16)), rep
+  torch.cuda.synchronize()
+  # every tile of y was normalised with the block's statistics (each workgroup derives them itself from the partials it read)
+  ctot = cout * groups
+  for first, _ in sets:
+    y32, raw32 = ops16.from_cb8(first[0], ctot), ops16.from_cb8(first[1], ctot)
+    z = raw32 * first[2][2 * ctot:3 * ctot].view(1, -1, 1) + first[2][3 * ctot:].view(1, -1, 1)
+    ref = torch.where(z > 0, z, 0.2 * z)
+    err = (y32 - ref).abs()
+    assert err.max().item() <= (ref.abs().max().item() + raw32.abs().max().item()) * 2 ** -8
+    assert (err / (ref.abs() + 1e-2)).mean().item() <= 2 ** -8            # no tile with shifted statistics
+  assert not ops16.bn_sync_error()
+  assert int(ops16._bn_sync[('cuda', 0)].abs().sum().item()) == 0          # arrive / depart counters re-armed
+
+
+def test_large_grids_keep_the_two_launch_form():
+  """More workgroups than the device holds at once (first audio-encoder layer): conv + statistics, then the normalising launch."""
+  labels = _labels_of(lambda: _run_block(2, 32, 1, 64, 1, 3, 1, 1, 64, 128, PLAIN, True))
+  assert not any('+bnfused' in l for l in labels), labels
+  assert any('+bnstats' in l for l in labels), labels

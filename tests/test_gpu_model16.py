@@ -98,7 +98,9 @@ def _train_compare(tag, M, S, B, T):
     assert np.isfinite(l1) and l1 <= 5e-2, vals
     assert dl <= 5e-2, vals
     assert vals['grad_cosine_main'] >= 0.6, vals
-    if 'grad_cosine_style_encoder' in vals:
+    if 'grad_cosine_style_encoder' in vals and vals.get('style_argmax_equal', True):
+      # (a clip whose style id flipped on a near-tie -- margin below the 16-bit noise, reported above -- feeds ANOTHER style
+      # embedding to the generator: the id_out gradient of the style encoder is then the gradient of a different function)
       assert vals['grad_cosine_style_encoder'] >= 0.98, vals
     if 'style_argmax_equal' in vals and vals['style_top2_margin_min'] > 2e-2:
       assert vals['style_argmax_equal'], vals            # (smaller margins than the 16-bit noise: reported only)
