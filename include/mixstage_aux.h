@@ -52,6 +52,7 @@ int ms_debug_set_conv16_ring(int nstg, int wide8);
 /* ... and the number of workgroups a 16-bit weight-gradient launch aims for when it splits the pixel reduction (default 128);
  * returns the previous value.  Scratch and slab sizes follow: set it before any step is captured. */
 int ms_debug_set_wgrad16_target(int workgroups);
+int ms_debug_set_wgrad16_ring(int buffers);           /* LDS-DMA ring depth of the 16-bit weight gradient (2..8, default 2) */
 int ms_debug_set_wgrad_target(int workgroups);      /* the same for the fp32 patch-staged weight gradient (default 768) */
 /* Test / ablation aid: 0 = 16-bit BN_TRAIN blocks never take the in-launch BatchNorm form (ms_set_bn_sync_buffer), 1 = they do
  * when eligible (default).  Returns the previous value. */

@@ -9,6 +9,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libmixstage_hip.so')
+# A/B measurements only (tools/ab_libs.py): another build of the same library; debug setters it lacks are skipped
+_ALT_LIB = os.environ.get('MS_LIB_PATH')
+if _ALT_LIB:
+  LIB_PATH = _ALT_LIB
 
 c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 
@@ -115,6 +119,7 @@ SIGNATURES = {
     'ms_debug_set_conv16_ring': (c_int, [c_int, c_int]),
     'ms_debug_set_skip': (c_int, [ctypes.c_char_p]),
     'ms_debug_set_wgrad16_target': (c_int, [c_int]),
+    'ms_debug_set_wgrad16_ring': (c_int, [c_int]),
     'ms_debug_set_wgrad_target': (c_int, [c_int]),
     'ms_selftest_mfma': (c_int, [_P, _P, _P, c_int, _P]),
 }
@@ -134,6 +139,8 @@ def lib():
                              'there is no CPU fallback' % LIB_PATH)
     handle = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+      if _ALT_LIB and name.startswith('ms_debug_') and not hasattr(handle, name):
+        continue
       fn = getattr(handle, name)          # AttributeError here = header/library drift
       fn.restype, fn.argtypes = res, args
     mode = os.environ.get('MS_PRECISION', '')

@@ -40,7 +40,7 @@ Dgrad16 dgrad_plan16(const ms_conv_desc* d) {
 }
 Wgrad16Plan wgrad_plan16(const ms_conv_desc* d) {
   const Geo16 g = geo_of(d);
-  return plan_wgrad16(g.nd, d->Cout, d->Cin, d->groups, d->KH, d->KW, d->SH, d->SW, d->B, d->OH, d->OW);
+  return plan_wgrad16(g.nd, d->Cout, d->Cin, d->groups, d->KH, d->KW, d->SH, d->SW, d->B, d->OH, d->OW, g.up2 != 0);
 }
 size_t fwd_a_bytes(const ms_conv_desc* d, const Conv16Plan& pl) {
   return conv16_weight_bytes(pl, d->Cout, d->groups, d->Cin, d->KH, d->KW, 1);
@@ -315,7 +315,7 @@ int block_bwd16(const ms_conv_desc* d, const void* x, const void* x2, const floa
     const double flops = 2.0 * d->Cout * d->Cin * d->KH * d->KW * (double)g.npix * d->groups;
     const double bytes = 2.0 * ((double)g.npix * g.C + (double)d->B * g.cin_tot * d->H * d->W) + 4.0 * (double)wsize;
     // queued form: only when nothing of this call reads the result (dw written in place, or slabs left for the caller)
-    if (defer_wgrad_launch && (wp.splits == 1 || defer)) return queue_wgrad16(g.dt, a, wp, g.up2 != 0, flops, bytes);
+    if (defer_wgrad_launch && (wp.splits == 1 || defer) && !wgrad16_c1_ok(a, g.up2 != 0)) return queue_wgrad16(g.dt, a, wp, g.up2 != 0, flops, bytes);
     rc = launch_wgrad16(g.dt, a, wp, g.up2 != 0, flops, bytes, s);
     if (rc) return rc;
     if (wp.splits > 1 && !defer) rc = launch_reduce_splits(wg_part, dw, (int)wsize, wp.splits, s);

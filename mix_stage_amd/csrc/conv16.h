@@ -97,12 +97,14 @@ struct Wgrad16Args {
   int OUTH, OUTW, o_img, o_cblk, o_row;
   int ltw, TH, PCX, tiles_x, tiles_y, n_tiles, tiles_per_split, splits;
   int ktg;              // tap groups per kernel row
+  int nstg;             // LDS-DMA form: buffers in the ring
+  int dbg;              // timing ablations (ms_debug_set_conv16_ring flag bits 4..6): no stores / no MFMAs / no tile loop
   int gx, gy, gz;
   int accumulate;       // splits == 1 only: out += result instead of out = result (queued launches)
   size_t out_split_stride;
 };
-struct Wgrad16Plan { int tp, tw, th, tiles_y, tiles_x, n_tiles, splits, tiles_per_split, ktg, pcx, lds_bytes; };
-Wgrad16Plan plan_wgrad16(int nd, int Cog, int Cig, int groups, int KH, int KW, int SH, int SW, int B, int OH, int OW);
+struct Wgrad16Plan { int tp, tw, th, tiles_y, tiles_x, n_tiles, splits, tiles_per_split, ktg, pcx, lds_bytes, nstg, npx; };
+Wgrad16Plan plan_wgrad16(int nd, int Cog, int Cig, int groups, int KH, int KW, int SH, int SW, int B, int OH, int OW, bool up2);
 int launch_wgrad16(int dt, const Wgrad16Args& a, const Wgrad16Plan& pl, bool up2, double flops, double bytes, hipStream_t s);
 // the same launch queued (process-wide queue) for wgrad16_flush: many blocks' kernels side by side in one multi-block launch
 constexpr int WG16_MAX_JOBS = 20;    // 20 x sizeof(Wgrad16Args) + the table of block ranges stays below the 4 KB of kernel arguments
@@ -112,6 +114,7 @@ struct Wgrad16Batch {
   Wgrad16Args job[WG16_MAX_JOBS];
 };
 int queue_wgrad16(int dt, const Wgrad16Args& a, const Wgrad16Plan& pl, bool up2, double flops, double bytes);
+bool wgrad16_c1_ok(const Wgrad16Args& a, bool up2);      // single-input-channel block: its own (vector-unit) kernel, launched at once
 int wgrad16_flush(hipStream_t s);
 void wgrad16_discard();
 

@@ -353,8 +353,11 @@ int launch_conv16(int dt, const Conv16Args& a, const Conv16Plan& pl, int KW, boo
   if ((double)b.a_cls_stride * std::max(1, a.ncls) * 16.0 >= 4.0e9) return set_error("conv16: prepared weights of 4 GB or more");
   if (a.groups > 1 && (a.Mg & 7)) return set_error("conv16: grouped blocks need a multiple of 8 output channels per group");
   const int nwg = b.gx * b.gy * b.gz;
-  char ring[16] = "";
-  if (pl.dma) snprintf(ring, sizeof(ring), " dma%d", pl.nstg);
+  char ring[32] = "";
+  if (pl.dma) {
+    const int nt = 128 * pl.nwn, na = (KW * pl.ck8 * bm) / nt, npd = cdiv(pl.ck8 * pl.th * pl.pc, nt);
+    snprintf(ring, sizeof(ring), " dma%d w%d", pl.nstg, (pl.nstg - 2) * (na + npd));
+  }
   TimingScope ts(s, flops, bytes, "conv16_kernel<%s,%d,%d,%d,%d,%d,%d>|conv_%s_cb8 k%dx%d s%d Mg%d Kg%d g%d tiles%d tile%dx%d tw%d%s%s",
                  dt == DT_BF16 ? "bf16" : "f16", KW, pl.wm, pl.wn, up2 ? 1 : 0, pl.dma, pl.nwn, a.is_dgrad ? "dgrad" : "fwd", a.KH, KW, a.S, a.Mg,
                  a.Kc8g * 8 * a.KH * KW, a.groups, pl.n_tiles, bm, 32 * pl.wn * pl.nwn, pl.tw, ring,

@@ -10,6 +10,8 @@
 // ragged edges by an out-of-range offset that the hardware answers with zeros); the next stage's loads are in flight while
 // the current one computes.  Weights arrive pre-arranged per (m tile, stage) by prep16_kernel, so their staging is a linear copy.
 #pragma once
+#include <type_traits>
+
 #include "conv16.h"
 
 namespace ms {
@@ -79,6 +81,12 @@ __device__ inline void wait_vmcnt(int n) {
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 #undef MS_VM
+}
+
+// the same with a compile-time count (a literal in the instruction: no branching)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_lit() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // 16 bytes per lane from a buffer straight into LDS (buffer_load_dwordx4 ... lds): the destination is the wave-uniform
@@ -643,16 +651,24 @@ __global__ __launch_bounds__(128 * NWN) void conv16_kernel(const Conv16Args p) {
   // One stage = KW*KS k-steps of WM*WN MFMAs.  The operand fragments of k-step s+2 are requested before the MFMAs of k-step s
   // (three register sets, order pinned): with one wave per SIMD nothing else hides the LDS latency, and left to the
   // scheduler the stage was a chain of ~14 read -> wait -> MFMA rounds (0.95 us per stage against 0.32 us of MFMA issue).
-  auto compute_stage = [&](int cur) {
-    const u32x4* st = smem + cur * stage_vecs;
+  // Operand addresses: one add per operand row group and stage (buffer base + per-lane constant), every read of the stage then
+  // uses an immediate offset (weight slot / tap).  Before, each of the stage's ds_reads re-formed its address (18-23 v_add per 12
+  // MFMAs on the decoder layer; one wave issues a VALU instruction every ~4 cycles, an MFMA occupies its pipe for 32).
+  auto compute_stage = [&](const u32x4* st) {
     constexpr int NSTEP = KW * KS;
+    const u32x4* ap = st + a_base;
+    const u32x4* bp[WN][KS];
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) bp[j][ks] = st + b_base[j] + 2 * ks * thpc;
     u32x4 av[3][WM], bv[3][WN];
     auto fetch = [&](int s, u32x4 (&a)[WM], u32x4 (&b)[WN]) {
       const int kw = s / KS, ks = s - kw * KS;
 #pragma unroll
-      for (int i = 0; i < WM; ++i) a[i] = st[a_base + ((kw * KS + ks) * 2) * BM + i * 32];
+      for (int i = 0; i < WM; ++i) a[i] = ap[((kw * KS + ks) * 2) * BM + i * 32];
 #pragma unroll
-      for (int j = 0; j < WN; ++j) b[j] = st[b_base[j] + 2 * ks * thpc + kw];
+      for (int j = 0; j < WN; ++j) b[j] = bp[j][ks][kw];
     };
     fetch(0, av[0], bv[0]);
     if (NSTEP > 1) fetch(1, av[1], bv[1]);
@@ -670,35 +686,66 @@ __global__ __launch_bounds__(128 * NWN) void conv16_kernel(const Conv16Args p) {
 
   if constexpr (DMA) {
     const int wave = __builtin_amdgcn_readfirstlane(wid);
-    auto issue_stage = [&](int st) {
-      const int ch = st / KH, kh = st - ch * KH;
-      u32x4* dst = smem + (st % p.nstg) * stage_vecs + wave * 64;
-      const unsigned sa = __builtin_amdgcn_readfirstlane(16u * (a_wg + (unsigned)st * NAV));
-      if (st > 0) {                                    // (stage 0's weight slab left at the top of the kernel)
+    // the stage to be issued next: (channel chunk, kernel row), its ring buffer and its weight slab, all advanced incrementally
+    // (st / KH, st % nstg as run-time scalar divisions were ~100 SALU instructions per stage)
+    int is_ch = 0, is_kh = 0, is_buf = 0;
+    unsigned is_sa = __builtin_amdgcn_readfirstlane(16u * a_wg);
+    bool first = true;
+    const unsigned t16 = 16u * (unsigned)t;
+    auto issue_stage = [&]() {
+      u32x4* dst = smem + is_buf * stage_vecs + wave * 64;
+      if (!first) {                                    // (stage 0's weight slab left at the top of the kernel)
 #pragma unroll
-        for (int i = 0; i < NA; ++i) dma16(rsA, dst + i * NT, 16u * (unsigned)(t + i * NT), sa);
+        for (int i = 0; i < NA; ++i) dma16(rsA, dst + i * NT, t16, is_sa + 16u * (unsigned)(i * NT));
       }
-      const int cb0 = ch * CK8;
+      first = false;
+      const int cb0 = is_ch * CK8;
       const int sbase = __builtin_amdgcn_readfirstlane(img * p.s_img + (cbase8 + cb0) * p.s_cblk);
-      const int khrow = kh * p.s_row;
+      const int khrow = is_kh * p.s_row;
+      const int cb_left = p.Kc8g - cb0;
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
         if (i < npd) {
-          const bool ok = pcol[i] & ((unsigned)(prow[i] + kh) < (unsigned)p.SRCH) & (cb0 + pcb[i] < p.Kc8g);
+          const bool ok = pcol[i] & ((unsigned)(prow[i] + is_kh) < (unsigned)p.SRCH) & (pcb[i] < cb_left);
           dma16(rsS, dst + NAV + i * NT, ok ? 16u * (unsigned)(poff[i] + khrow) : BUF_OOB, 16u * (unsigned)sbase);
         }
       }
+      if (++is_kh == KH) { is_kh = 0; ++is_ch; }
+      if (++is_buf == p.nstg) is_buf = 0;
+      is_sa += 16u * (unsigned)NAV;
     };
     const int per_stage = NA + npd;                    // LDS-DMA instructions a wave issues per stage
     const int ahead = p.nstg - 2;                      // stages that stay in flight behind the one being computed
-    for (int st = 0; st < p.nstg - 1 && st < nst_run; ++st) issue_stage(st);
-    for (int st = 0; st < nst_run; ++st) {
-      // stage st has landed once at most `ahead` younger stages are outstanding (in the tail fewer are: drain)
-      wait_vmcnt(st + ahead < nst_run ? ahead * per_stage : 0);
-      __builtin_amdgcn_s_barrier();                    // everyone's part of stage st is in LDS, everyone is done with stage st-1
-      asm volatile("" ::: "memory");
-      if (st + p.nstg - 1 < nst_run) issue_stage(st + p.nstg - 1);    // refills the buffer of stage st-1
-      compute_stage(st % p.nstg);
+    const int wcount = ahead * per_stage;
+    // WC >= 0: the steady-state wait is the literal vmcnt(WC).  The run-time form (WC < 0) is a 64-way switch inside the loop;
+    // around it the register allocator moved every accumulator between the AGPR and the VGPR file each stage (32 v_accvgpr
+    // moves per 12 MFMAs on the decoder layer).  The counts the path's layers produce get a loop of their own.
+    auto k_loop = [&](auto wc) {
+      constexpr int WC = decltype(wc)::value;
+      int issued = 0;
+      for (; issued < p.nstg - 1 && issued < nst_run; ++issued) issue_stage();
+      const u32x4* cur = smem;
+      int cur_i = 0;
+      for (int st = 0; st < nst_run; ++st) {
+        // stage st has landed once at most `ahead` younger stages are outstanding (in the tail fewer are: drain)
+        if (st + ahead < nst_run) {
+          if constexpr (WC >= 0) wait_vmcnt_lit<(WC >= 0 ? WC : 0)>(); else wait_vmcnt(wcount);
+        } else {
+          wait_vmcnt_lit<0>();
+        }
+        __builtin_amdgcn_s_barrier();                  // everyone's part of stage st is in LDS, everyone is done with stage st-1
+        asm volatile("" ::: "memory");
+        if (issued < nst_run) { issue_stage(); ++issued; }    // refills the buffer of stage st-1
+        compute_stage(cur);
+        cur += stage_vecs;
+        if (++cur_i == p.nstg) { cur_i = 0; cur = smem; }
+      }
+    };
+    switch (wcount) {
+#define MS_KLOOP(N) case N: k_loop(std::integral_constant<int, N>{}); break;
+      MS_KLOOP(0) MS_KLOOP(6) MS_KLOOP(8) MS_KLOOP(10) MS_KLOOP(11) MS_KLOOP(13) MS_KLOOP(18) MS_KLOOP(20) MS_KLOOP(24)
+#undef MS_KLOOP
+      default: k_loop(std::integral_constant<int, -1>{}); break;
     }
   } else {
     load_stage(0);
@@ -707,7 +754,7 @@ __global__ __launch_bounds__(128 * NWN) void conv16_kernel(const Conv16Args p) {
     for (int st = 0; st < nstages; ++st) {
       const int cur = st & 1;
       if (st + 1 < nstages) load_stage(st + 1);
-      compute_stage(cur);
+      compute_stage(smem + cur * stage_vecs);
       if (st + 1 < nstages) store_stage(cur ^ 1);
       __syncthreads();
     }

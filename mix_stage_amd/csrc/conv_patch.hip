@@ -561,6 +561,13 @@ extern "C" int ms_debug_set_wgrad_target(int workgroups) {
   ms::g_wgrad_patch_target_wgs = workgroups > 0 ? workgroups : 768;
   return old;
 }
+namespace ms { extern int g_wgrad16_ring; }
+extern "C" int ms_debug_set_wgrad16_ring(int buffers) {
+  const int old = ms::g_wgrad16_ring;
+  ++g_tuning_epoch;
+  ms::g_wgrad16_ring = buffers >= 2 ? (buffers > 8 ? 8 : buffers) : 2;
+  return old;
+}
 extern "C" int ms_debug_set_wgrad16_target(int workgroups) {
   const int old = ms::g_wgrad16_target_wgs;
   ++g_tuning_epoch;

@@ -22,35 +22,55 @@ namespace ms {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-__device__ inline u32x4 tr_read2(const u32x4* base, int vec0, int vec1, int sub8) {
-  // vecN: index of the cb8 vector (row of the 4x16 block this lane addresses), sub8: 0/8 byte offset inside it
-  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  const char* b = reinterpret_cast<const char*>(base);
-  // (whole-value bit casts: element access on a builtin's vector result is miscompiled by this clang)
-  const unsigned long long lo = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(b + (size_t)vec0 * 16 + sub8)));
-  const unsigned long long hi = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(b + (size_t)vec1 * 16 + sub8)));
-  u32x4 v;
-  v[0] = (unsigned)lo;
-  v[1] = (unsigned)(lo >> 32);
-  v[2] = (unsigned)hi;
-  v[3] = (unsigned)(hi >> 32);
-  return v;
-}
-
 // workgroups a layer's launch aims for through pixel splits (ms_debug_set_wgrad16_target).  The trainer launches the layers'
 // kernels side by side (ms_wgrad_flush), so a layer need not fill the chip alone; measured on the train step: 512 -> 3.17 ms,
 // 256 -> 3.12, 128 -> 3.06, 64 -> 3.15 per G-step (fewer, longer workgroups leave fewer partial slabs to store and reduce)
 int g_wgrad16_target_wgs = 128;
+extern int g_conv16_dbg;
 
-constexpr int WG16_NPX = 8;   // input-row vectors a thread stages per tile at most (plan_wgrad16 keeps 8*TH*PCX <= 8*256)
+// LDS pitches (16-byte vectors) of a channel block's pixels.  The transposed reads of one MFMA operand touch FOUR channel blocks
+// at once (lanes 0-31 of ds_read_b64_tr_b16: 4 rows x 16 banks each), so the block pitch must be = 16 banks (4 vectors) mod 64
+// banks: the natural pitches -- 64 vectors for dy, TH*PCX = 66 for a k3 row -- put the four blocks on the same / overlapping
+// banks (SQ_LDS_BANK_CONFLICT was 40 % of SQ_LDS_IDX_ACTIVE on the decoder layer).
+constexpr int WG16_DP = 68;   // dy: 64 pixels + 4
+__host__ __device__ inline int wg16_xpitch(int thpcx) { return ((thpcx + 11) & ~15) + 4; }   // smallest pitch >= thpcx that is 4 mod 16
+constexpr int WG16_DYV = 8 * WG16_DP;    // vectors of the dy part of a stage
+constexpr int WG16_NPX = 5;   // register-staged form (upsample-add input): input-row vectors a thread stages per tile at most
 
-template <typename DT, int TP, bool UP2>
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+// one transposed 4-row read at a byte address (constant byte offsets fold into the instruction's offset field)
+__device__ __forceinline__ unsigned long long tr_read_b64(const char* ptr) {
+  // (whole-value bit cast: element access on a builtin's vector result is miscompiled by this clang)
+  return __builtin_bit_cast(unsigned long long, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)ptr));
+}
+__device__ __forceinline__ u32x4 tr_pair(const char* p0, const char* p1) {
+  const unsigned long long lo = tr_read_b64(p0), hi = tr_read_b64(p1);
+  u32x4 v;
+  v[0] = (unsigned)lo; v[1] = (unsigned)(lo >> 32); v[2] = (unsigned)hi; v[3] = (unsigned)(hi >> 32);
+  return v;
+}
+
+// The kernel was INSTRUCTION-bound, not memory- or MFMA-bound (SQ counters on the decoder layer: 11 VALU and 11 SALU
+// instructions per MFMA, matrix pipe busy 12 % of the wave cycles): every operand read re-derived its LDS address from the tile
+// geometry, every tile re-derived eight staging slots (five of them unused for k3 rows) and two scalar divisions.  Now:
+//  * LDS operand addresses are per-lane constants formed once (9 registers); per tile they get the buffer base added (9 VALU)
+//    and every read uses an immediate offset (k-step, tap, second row group);
+//  * staging is LDS-DMA (buffer_load ... lds: no staging registers, no ds_write) from offsets that are tile-invariant per slot:
+//    per tile and slot one add + the bounds test; NPXT = slots a thread owns (3 / 5 in registers; 0 = any number, re-derived per
+//    tile: only the layers with a handful of pixels per row need more than 5);
+//  * the tile coordinates advance incrementally.
+// UP2 (x = up2(a) + r formed in registers) keeps global -> registers -> LDS staging with two buffers.
+template <typename DT, int TP, bool UP2, int NPXT>
 __device__ __forceinline__ void wgrad16_body(const Wgrad16Args& p, const int bid, u32x4* smem) {
+  constexpr bool DMA = !UP2;
+  constexpr int NREG = UP2 ? WG16_NPX : (NPXT > 0 ? NPXT : 1);
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wm = wid >> 1, wn = wid & 1, h = lane >> 5;
   const int TW = 1 << p.ltw, TH = p.TH, PCX = p.PCX, S = p.S, SV = p.SV;
-  const int xv = 8 * TH * PCX;                 // input-row vectors per tile
-  const int stage_vecs = 512 + xv + 1;
+  const int XP = wg16_xpitch(TH * PCX);        // padded pitch of a channel block's input rows
+  const int xv = 8 * XP;                       // input-row vectors per tile (pad vectors are never loaded and never read)
+  const int xv64 = (xv + 63) & ~63;            // DMA: a wave skips its 64-vector share of a slab that lies beyond the rows
+  const int stage_vecs = DMA ? WG16_DYV + xv64 : WG16_DYV + xv + 1;
 
   const int vid = xcd_remap(bid, p.gx * p.gy * p.gz);
   const int bx_ = vid % p.gx, by_ = (vid / p.gx) % p.gy, bz_ = vid / (p.gx * p.gy);
@@ -71,67 +91,83 @@ __device__ __forceinline__ void wgrad16_body(const Wgrad16Args& p, const int bid
   const __amdgpu_buffer_rsrc_t rsD = buf_rsrc(p.dyr), rsS = buf_rsrc(p.src), rsS2 = buf_rsrc(UP2 ? p.src2 : p.src);
 
   // ---- tile-invariant parts of the staging offsets
-  // dy: vector e = cb*64 + n, n = ty*TW + tx
-  int d_cb[2], d_ty[2], d_tx[2];
+  // dy: vector e = cb*64 + n, n = ty*TW + tx; element offset inside the tensor relative to the tile's first pixel
+  int d_ty[2], d_tx[2], d_off[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int e = t + i * 256;
-    d_cb[i] = e >> 6;
-    const int n = e & 63;
+    const int e = t + i * 256, cb = e >> 6, n = e & 63;
     d_ty[i] = n >> p.ltw; d_tx[i] = n & (TW - 1);
+    if ((co0 >> 3) + cb >= cog8) d_ty[i] = 1 << 28;                        // a channel block beyond the group: never in range
+    d_off[i] = cb * p.o_cblk + d_ty[i] * p.o_row + d_tx[i];
   }
-  int x_cb[WG16_NPX], x_ty[WG16_NPX], x_c[WG16_NPX], x_lds[WG16_NPX];
+  const unsigned mg_xp = 0xFFFFFFFFu / (unsigned)XP + 1u, mg_pcx = 0xFFFFFFFFu / (unsigned)PCX + 1u;   // e < 2^16, small divisors: exact
+  // input-row vector e -> (channel block, tile row, column); false for pad vectors and channel blocks beyond the group
+  auto x_decode = [&](int e, int& cb, int& ty, int& c) -> bool {
+    cb = (int)__umulhi((unsigned)e, mg_xp);
+    const int rem = e - cb * XP;
+    ty = PCX == 1 ? rem : (int)__umulhi((unsigned)rem, mg_pcx);
+    c = rem - ty * PCX;
+    return (e < xv) & (rem < TH * PCX) & ((ci0 >> 3) + cb < cig8);
+  };
+  int x_r[NREG], x_c[NREG], x_off[NREG], x_lds[UP2 ? NREG : 1];
 #pragma unroll
-  for (int i = 0; i < WG16_NPX; ++i) {
+  for (int i = 0; i < NREG; ++i) {
+    int cb, ty, c;
     const int e = t + i * 256;
-    const int cb = e / (TH * PCX), rem = e - cb * TH * PCX, ty = rem / PCX;
-    x_cb[i] = cb; x_ty[i] = ty; x_c[i] = rem - ty * PCX;
-    x_lds[i] = e < xv ? 512 + e : 512 + xv;
+    const bool ok = x_decode(e, cb, ty, c);
+    x_r[i] = ok ? ty * SV : (1 << 28);                                       // (a slot that does not exist: never in range)
+    x_c[i] = c;
+    x_off[i] = cb * p.s_cblk + ty * SV * p.s_row + c;
+    if (UP2) x_lds[UP2 ? i : 0] = ok ? WG16_DYV + e : WG16_DYV + xv;
   }
 
-  u32x4 rd[2], rx[WG16_NPX], rx2[UP2 ? WG16_NPX : 1];
-  auto load_tile = [&](int tile) {
-    const int img = tile / tiles_per_img, trem = tile - img * tiles_per_img;
-    const int tyi = trem / p.tiles_x, txi = trem - tyi * p.tiles_x;
-    const int oy0 = tyi * TH, ox0 = txi << p.ltw;
-    const int dbase = __builtin_amdgcn_readfirstlane(img * p.o_img + dy_cb0 * p.o_cblk);
+  // tile coordinates of the tile to be staged next, advanced incrementally (wave-uniform)
+  int s_img = tile_beg / tiles_per_img, s_ty, s_tx;
+  {
+    const int trem = tile_beg - s_img * tiles_per_img;
+    s_ty = trem / p.tiles_x; s_tx = trem - s_ty * p.tiles_x;
+  }
+  auto advance = [&]() {
+    if (++s_tx == p.tiles_x) { s_tx = 0; if (++s_ty == p.tiles_y) { s_ty = 0; ++s_img; } }
+  };
+
+  u32x4 rd[DMA ? 1 : 2], rx[DMA ? 1 : NREG], rx2[UP2 ? NREG : 1];
+  auto load_tile = [&]() {          // register-staged form
+    if constexpr (!DMA) {
+      const int oy0 = s_ty * TH, ox0 = s_tx << p.ltw;
+      const int dbase = __builtin_amdgcn_readfirstlane(s_img * p.o_img + dy_cb0 * p.o_cblk + oy0 * p.o_row + ox0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int oy = oy0 + d_ty[i], ox = ox0 + d_tx[i];
-      const bool ok = (oy < p.OUTH) & (ox < p.OUTW) & ((co0 >> 3) + d_cb[i] < cog8);
-      rd[i] = buf_load_v(rsD, ok ? 16u * (unsigned)(d_cb[i] * p.o_cblk + oy * p.o_row + ox) : BUF_OOB, 16u * (unsigned)dbase);
-    }
-    const int iy0 = oy0 * SV - p.PH + kh, ix0 = ox0 * S - p.PW + kw0;
-    const int sbase = __builtin_amdgcn_readfirstlane(img * p.s_img + x_cb0 * p.s_cblk);
-#pragma unroll
-    for (int i = 0; i < WG16_NPX; ++i) {
-      const int iy = iy0 + x_ty[i] * SV, ix = ix0 + x_c[i];
-      const bool ok = (x_lds[i] < 512 + xv) & ((unsigned)iy < (unsigned)p.SRCH) & ((unsigned)ix < (unsigned)p.SRCW) &
-                      ((ci0 >> 3) + x_cb[i] < cig8);
-      const int o = x_cb[i] * p.s_cblk + iy * p.s_row;
-      if (UP2) {
-        rx[i] = buf_load_v(rsS, ok ? 16u * (unsigned)((o >> 1) + (ix >> 1)) : BUF_OOB, 16u * (unsigned)(sbase >> 1));
-        rx2[UP2 ? i : 0] = buf_load_v(rsS2, ok ? 16u * (unsigned)(o + ix) : BUF_OOB, 16u * (unsigned)sbase);
-      } else {
-        rx[i] = buf_load_v(rsS, ok ? 16u * (unsigned)(o + ix) : BUF_OOB, 16u * (unsigned)sbase);
+      for (int i = 0; i < 2; ++i) {
+        const bool ok = (d_ty[i] < p.OUTH - oy0) & (d_tx[i] < p.OUTW - ox0);
+        rd[i] = buf_load_v(rsD, ok ? 16u * (unsigned)d_off[i] : BUF_OOB, 16u * (unsigned)dbase);
       }
+      const int iy0 = oy0 * SV - p.PH + kh, ix0 = ox0 * S - p.PW + kw0;
+      const int sbase = __builtin_amdgcn_readfirstlane(s_img * p.s_img + x_cb0 * p.s_cblk);
+      const int toff = iy0 * p.s_row + ix0;
+#pragma unroll
+      for (int i = 0; i < NREG; ++i) {
+        const bool ok = ((unsigned)(iy0 + x_r[i]) < (unsigned)p.SRCH) & ((unsigned)(ix0 + x_c[i]) < (unsigned)p.SRCW);
+        const int o = x_off[i] + toff, ix = ix0 + x_c[i];
+        // x = nearest_up2(a) + r: a has half the row length, hence half of every stride (all strides are even)
+        rx[i] = buf_load_v(rsS, ok ? 16u * (unsigned)(((o - ix) >> 1) + (ix >> 1)) : BUF_OOB, 16u * (unsigned)(sbase >> 1));
+        rx2[UP2 ? i : 0] = buf_load_v(rsS2, ok ? 16u * (unsigned)o : BUF_OOB, 16u * (unsigned)sbase);
+      }
+      advance();
     }
   };
   auto store_tile = [&](int buf) {
-    u32x4* st = smem + buf * stage_vecs;
+    if constexpr (!DMA) {
+      u32x4* st = smem + buf * stage_vecs;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) st[t + i * 256] = rd[i];
+      for (int i = 0; i < 2; ++i) st[((t + i * 256) >> 6) * WG16_DP + (t & 63)] = rd[i];
 #pragma unroll
-    for (int i = 0; i < WG16_NPX; ++i) {
-      if (UP2) {
+      for (int i = 0; i < NREG; ++i) {
         float fa[8], fr[8];
         unpack8<DT>(rx[i], fa);
         unpack8<DT>(rx2[UP2 ? i : 0], fr);
 #pragma unroll
         for (int j = 0; j < 8; ++j) fa[j] += fr[j];
-        st[x_lds[i]] = pack8<DT>(fa);
-      } else {
-        st[x_lds[i]] = rx[i];
+        st[x_lds[UP2 ? i : 0]] = pack8<DT>(fa);
       }
     }
   };
@@ -142,37 +178,116 @@ __device__ __forceinline__ void wgrad16_body(const Wgrad16Args& p, const int bid
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
 
-  // ---- transposed-read lane roles: group of 16 lanes = 16 channels (2 blocks); lane 4q+pp addresses row q, 4 channels pp
+  // ---- transposed-read lane roles: group of 16 lanes = 16 channels (2 blocks); lane 4q+pp addresses row q, 4 channels pp.
+  // Byte offsets inside a stage, formed once: the dy operand of k-step kk sits 256 bytes per kk further (16 pixels), its second
+  // row group 64 bytes further; the input operand's two row groups per k-step (bx0, bx1) depend on the tile shape and stride.
   const int li = lane & 15, q4 = li >> 2, pp = li & 3, half16 = (lane >> 4) & 1;
   const int sub8 = (pp & 1) * 8;
   const int a_blk = wm * 4 + half16 * 2 + (pp >> 1);     // dy block inside the 64-channel tile
   const int b_blk = wn * 4 + half16 * 2 + (pp >> 1);     // x block inside the 64-channel tile
-  const int thpcx = TH * PCX;
+  const int a_off = (a_blk * WG16_DP + 8 * h + q4) * 16 + sub8;
+  int bx0[4], bx1[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const int p0 = 16 * kk + 8 * h + q4, p1 = p0 + 4;           // this lane's rows (pixels) of the two 4-row reads
+    bx0[kk] = (WG16_DYV + b_blk * XP + (p0 >> p.ltw) * PCX + (p0 & (TW - 1)) * S) * 16 + sub8;
+    bx1[kk] = (WG16_DYV + b_blk * XP + (p1 >> p.ltw) * PCX + (p1 & (TW - 1)) * S) * 16 + sub8;
+  }
+  const int stage_bytes = stage_vecs * 16;
 
+  // One tile = 4 k-steps of 16 pixels, TP MFMAs each; the operand reads of k-step kk+1 are requested before the MFMAs of k-step kk.
   auto compute_tile = [&](int cur) {
-    const u32x4* st = smem + cur * stage_vecs;
-    const u32x4* xs = st + 512;
+    const char* stb = reinterpret_cast<const char*>(smem) + cur * stage_bytes;
+    const char* ap = stb + a_off;
+    const char* b0[4];
+    const char* b1[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { b0[kk] = stb + bx0[kk]; b1[kk] = stb + bx1[kk]; }
+    u32x4 av[2], bv[2][TP];
+    av[0] = tr_pair(ap, ap + 64);
+#pragma unroll
+    for (int q = 0; q < TP; ++q) bv[0][q] = tr_pair(b0[0] + 16 * q, b1[0] + 16 * q);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      const int p0 = 16 * kk + 8 * h + q4, p1 = p0 + 4;           // this lane's rows (pixels) of the two 4-row reads
-      const u32x4 av = tr_read2(st, a_blk * 64 + p0, a_blk * 64 + p1, sub8);
-      const int x0 = b_blk * thpcx + (p0 >> p.ltw) * PCX + (p0 & (TW - 1)) * S;
-      const int x1 = b_blk * thpcx + (p1 >> p.ltw) * PCX + (p1 & (TW - 1)) * S;
+      if (kk + 1 < 4) {
+        av[(kk + 1) & 1] = tr_pair(ap + 256 * (kk + 1), ap + 256 * (kk + 1) + 64);
 #pragma unroll
-      for (int q = 0; q < TP; ++q) {
-        const u32x4 bv = tr_read2(xs, x0 + q, x1 + q, sub8);
-        acc[q] = DT::mfma(av, bv, acc[q]);
+        for (int q = 0; q < TP; ++q) bv[(kk + 1) & 1][q] = tr_pair(b0[(kk + 1) & 3] + 16 * q, b1[(kk + 1) & 3] + 16 * q);
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < TP; ++q) acc[q] = DT::mfma(av[kk & 1], bv[kk & 1][q], acc[q]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
-  if (tile_beg < tile_end) {
-    load_tile(tile_beg);
+  if constexpr (DMA) {
+    const int wave = __builtin_amdgcn_readfirstlane(wid);
+    auto issue_tile = [&](int buf) {
+      const int oy0 = s_ty * TH, ox0 = s_tx << p.ltw;
+      u32x4* dst = smem + buf * stage_vecs;
+      const int dbase = __builtin_amdgcn_readfirstlane(s_img * p.o_img + dy_cb0 * p.o_cblk + oy0 * p.o_row + ox0);
+      const int oh_left = p.OUTH - oy0, ow_left = p.OUTW - ox0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bool ok = (d_ty[i] < oh_left) & (d_tx[i] < ow_left);
+        // (a wave's 64 lanes = the 64 pixels of channel block wave + 4*i: the destination is that block's padded row)
+        dma16(rsD, dst + (wave + 4 * i) * WG16_DP, ok ? 16u * (unsigned)d_off[i] : BUF_OOB, 16u * (unsigned)dbase);
+      }
+      const int iy0 = oy0 * SV - p.PH + kh, ix0 = ox0 * S - p.PW + kw0;
+      const int sbase = __builtin_amdgcn_readfirstlane(s_img * p.s_img + x_cb0 * p.s_cblk);
+      const int toff = iy0 * p.s_row + ix0;                          // (may be negative: it goes into the per-lane offset)
+      if constexpr (NPXT > 0) {
+#pragma unroll
+        for (int i = 0; i < NPXT; ++i) {
+          if (i * 256 + wave * 64 < xv) {                            // (wave-uniform: a slab beyond the rows is not issued)
+            const bool ok = ((unsigned)(iy0 + x_r[i]) < (unsigned)p.SRCH) & ((unsigned)(ix0 + x_c[i]) < (unsigned)p.SRCW);
+            dma16(rsS, dst + WG16_DYV + wave * 64 + i * 256, ok ? 16u * (unsigned)(x_off[i] + toff) : BUF_OOB, 16u * (unsigned)sbase);
+          }
+        }
+      } else {
+        for (int e0 = wave * 64; e0 < xv; e0 += 256) {                // any number of slots, re-derived per tile
+          int cb, ty, c;
+          const bool okc = x_decode(e0 + lane, cb, ty, c);
+          const int iy = iy0 + ty * SV, ix = ix0 + c;
+          const bool ok = okc & ((unsigned)iy < (unsigned)p.SRCH) & ((unsigned)ix < (unsigned)p.SRCW);
+          dma16(rsS, dst + WG16_DYV + e0, ok ? 16u * (unsigned)(cb * p.s_cblk + iy * p.s_row + ix) : BUF_OOB, 16u * (unsigned)sbase);
+        }
+      }
+      advance();
+    };
+    const int ntl = (p.dbg & 4) ? 0 : tile_end - tile_beg;
+    const int per_tile = 2 + max(0, (xv - wave * 64 + 255) >> 8);   // LDS-DMA instructions THIS wave issues per tile
+    const int ahead = p.nstg - 2;                      // tiles that stay in flight behind the one being multiplied
+    if (p.nstg == 2) {
+      // two buffers (the default): the wait is a literal vmcnt(0) -- the run-time count of the general form below is a 64-way
+      // switch INSIDE the loop, around which the register allocator moved all accumulators between the AGPR and VGPR files every
+      // tile (48 v_accvgpr moves per 12 MFMAs)
+      if (ntl > 0) issue_tile(0);
+      for (int i = 0; i < ntl; ++i) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                  // everyone's part of tile i is in LDS, everyone is done with tile i-1
+        asm volatile("" ::: "memory");
+        if (i + 1 < ntl) issue_tile((i + 1) & 1);
+        if (!(p.dbg & 2)) compute_tile(i & 1);
+      }
+    } else {
+      for (int i = 0; i < p.nstg - 1 && i < ntl; ++i) issue_tile(i);
+      for (int i = 0; i < ntl; ++i) {
+        wait_vmcnt(i + ahead < ntl ? ahead * per_tile : 0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (i + p.nstg - 1 < ntl) issue_tile((i + p.nstg - 1) % p.nstg);    // refills the buffer of tile i-1
+        if (!(p.dbg & 2)) compute_tile(i % p.nstg);
+      }
+    }
+  } else if (tile_beg < tile_end) {
+    load_tile();
     store_tile(0);
     __syncthreads();
     for (int tile = tile_beg; tile < tile_end; ++tile) {
       const int cur = (tile - tile_beg) & 1;
-      if (tile + 1 < tile_end) load_tile(tile + 1);
+      if (tile + 1 < tile_end) load_tile();
       compute_tile(cur);
       if (tile + 1 < tile_end) store_tile(cur ^ 1);
       __syncthreads();
@@ -186,6 +301,7 @@ __device__ __forceinline__ void wgrad16_body(const Wgrad16Args& p, const int bid
   float* out = p.out + (size_t)split * p.out_split_stride;
   const int ci = ci0 + wn * 32 + r;
   struct __attribute__((packed, aligned(4))) Taps { float v[TP]; };
+  if (p.dbg & 1) return;
   // accumulating form (queued launches that write dw themselves): all 16 read-modify-writes read first, then write
   Taps prev[16];
   if (p.accumulate && kw0 + TP <= p.KW) {
@@ -214,15 +330,15 @@ __device__ __forceinline__ void wgrad16_body(const Wgrad16Args& p, const int bid
   }
 }
 
-template <typename DT, int TP, bool UP2>
+template <typename DT, int TP, bool UP2, int NPXT>
 __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args p) {
   prefetch_kernargs<sizeof(Wgrad16Args)>();
   extern __shared__ u32x4 smem[];
-  wgrad16_body<DT, TP, UP2>(p, (int)blockIdx.x, smem);
+  wgrad16_body<DT, TP, UP2, NPXT>(p, (int)blockIdx.x, smem);
 }
 
 // many blocks' weight gradients in one launch: a workgroup finds its job in the table of block ranges
-template <typename DT, int TP, bool UP2>
+template <typename DT, int TP, bool UP2, int NPXT>
 __global__ __launch_bounds__(256) void wgrad16_multi_kernel(const Wgrad16Batch b) {
   extern __shared__ u32x4 smem[];
   prefetch_kernargs<128>();                                   // n and the table of block ranges
@@ -230,7 +346,95 @@ __global__ __launch_bounds__(256) void wgrad16_multi_kernel(const Wgrad16Batch b
   while (j + 1 < b.n && (int)blockIdx.x >= b.block_end[j]) ++j;
   const int b0 = j ? b.block_end[j - 1] : 0;
   prefetch_kernargs<sizeof(Wgrad16Args)>((int)offsetof(Wgrad16Batch, job) + j * (int)sizeof(Wgrad16Args));
-  wgrad16_body<DT, TP, UP2>(b.job[j], (int)blockIdx.x - b0, smem);
+  wgrad16_body<DT, TP, UP2, NPXT>(b.job[j], (int)blockIdx.x - b0, smem);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Single-input-channel blocks (the first audio-encoder layer: 1 -> 64 channels, 3x3): dw[co][0][kh][kw] is a handful of numbers
+// per output channel, reduced over every pixel -- on the MFMA kernel above a 64 x 64 x taps tile whose input-channel side is 63/64
+// zeros (2.7 TF, and a quarter of all tile iterations of the backward pass's weight-gradient launch).  Here it is what it is, a
+// stream over dy on the vector unit: a workgroup owns one channel block (8 output channels) and one pixel split; a thread takes one
+// pixel per step, loads its dy vector and the KH*KW input values around it (channel 0 of the cb8 input: neighbouring lanes
+// read neighbouring pixels, served by L1 / L2) and keeps 8 x KH*KW running sums.  Fixed-order reduction: lanes (DPP), the 4
+// waves through LDS, the splits by the caller's slab reduction like every other weight gradient.
+constexpr int WGC1_MAX_TAPS = 9;
+
+template <typename DT>
+__global__ __launch_bounds__(256) void wgrad16_c1_kernel(const Wgrad16Args p) {
+  prefetch_kernargs<sizeof(Wgrad16Args)>();
+  __shared__ float red[4][8 * WGC1_MAX_TAPS];
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int cb = blockIdx.x % p.gy, split = blockIdx.x / p.gy;          // gy = output channel blocks
+  const int TW = 1 << p.ltw, taps = p.KH * p.KW;
+  const int tile_beg = split * p.tiles_per_split, tile_end = min(p.n_tiles, tile_beg + p.tiles_per_split);
+  const int tiles_per_img = p.tiles_y * p.tiles_x;
+  const u32x4* dy = reinterpret_cast<const u32x4*>(p.dyr);
+  const unsigned short* xs = reinterpret_cast<const unsigned short*>(p.src);
+  float acc[8][WGC1_MAX_TAPS];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int q = 0; q < WGC1_MAX_TAPS; ++q) acc[j][q] = 0.f;
+  // 16 tiles of 64 pixels per step (4 per wave): every load of the step is issued before the first use (clamped addresses, masked
+  // values) -- one memory round trip per step instead of one per tile
+  constexpr int U = 4;
+  for (int tile0 = tile_beg; tile0 < tile_end; tile0 += 4 * U) {
+    u32x4 gv[U];
+    unsigned short raw[U][WGC1_MAX_TAPS];
+    bool okv[U][WGC1_MAX_TAPS];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int tile = tile0 + wid * U + u;
+      const int tl = min(tile, p.n_tiles - 1);
+      const int img = tl / tiles_per_img, trem = tl - img * tiles_per_img;
+      const int tyi = trem / p.tiles_x, txi = trem - tyi * p.tiles_x;
+      const int oy = tyi * p.TH + (lane >> p.ltw), ox = (txi << p.ltw) + (lane & (TW - 1));
+      const bool ok = (tile < tile_end) & (oy < p.OUTH) & (ox < p.OUTW);
+      const int oyc = min(oy, p.OUTH - 1), oxc = min(ox, p.OUTW - 1);
+      gv[u] = dy[(size_t)img * p.o_img + (size_t)cb * p.o_cblk + (size_t)oyc * p.o_row + oxc];
+      if (!ok) gv[u] = u32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < WGC1_MAX_TAPS; ++q) {
+        const int kh = q / p.KW, kw = q - kh * p.KW;
+        const int iy = oy * p.SV - p.PH + kh, ix = ox * p.S - p.PW + kw;
+        okv[u][q] = ok & (q < taps) & ((unsigned)iy < (unsigned)p.SRCH) & ((unsigned)ix < (unsigned)p.SRCW);
+        const int iyc = min(max(iy, 0), p.SRCH - 1), ixc = min(max(ix, 0), p.SRCW - 1);
+        raw[u][q] = xs[((size_t)img * p.s_img + (size_t)iyc * p.s_row + ixc) * 8];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float g[8];
+      unpack8<DT>(gv[u], g);
+#pragma unroll
+      for (int q = 0; q < WGC1_MAX_TAPS; ++q) {
+        const float xq = okv[u][q] ? DT::lo((unsigned)raw[u][q]) : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j][q] = fmaf(g[j], xq, acc[j][q]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int q = 0; q < WGC1_MAX_TAPS; ++q) {
+      const float v = wave_sum(acc[j][q]);
+      if (lane == 0) red[wid][j * WGC1_MAX_TAPS + q] = v;
+    }
+  __syncthreads();
+  if (t < 8 * WGC1_MAX_TAPS) {
+    const int j = t / WGC1_MAX_TAPS, q = t - j * WGC1_MAX_TAPS;
+    const int co = cb * 8 + j;
+    if (co < p.Cog && q < taps) {
+      const float v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+      float* out = p.out + (size_t)split * p.out_split_stride + (size_t)co * taps + q;
+      *out = p.accumulate ? *out + v : v;
+    }
+  }
+}
+
+bool wgrad16_c1_ok(const Wgrad16Args& a, bool up2) {
+  return !up2 && a.Cig == 1 && a.groups == 1 && a.KH * a.KW <= WGC1_MAX_TAPS;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -245,7 +449,9 @@ static int ilog2(int v) {
   return l;
 }
 
-Wgrad16Plan plan_wgrad16(int nd, int Cog, int Cig, int groups, int KH, int KW, int SH, int SW, int B, int OH, int OW) {
+int g_wgrad16_ring = 2;        // LDS-DMA ring depth (ms_debug_set_wgrad16_ring)
+
+Wgrad16Plan plan_wgrad16(int nd, int Cog, int Cig, int groups, int KH, int KW, int SH, int SW, int B, int OH, int OW, bool up2) {
   Wgrad16Plan pl = {};
   const int rows = nd == 1 ? B : OH, imgs = nd == 1 ? 1 : B;
   pl.tp = KW == 1 ? 1 : KW == 3 ? 3 : (KW % 4 == 0) ? 4 : (KW == 2 ? 2 : 0);
@@ -254,7 +460,10 @@ Wgrad16Plan plan_wgrad16(int nd, int Cog, int Cig, int groups, int KH, int KW, i
   pl.tw = std::min(pow2_at_least(OW), 64);
   pl.th = 64 / pl.tw;
   pl.pcx = (pl.tw - 1) * SW + pl.tp;
-  if (8 * pl.th * pl.pcx > WG16_NPX * 256) return (pl.tp = 0, pl);
+  const int xp = wg16_xpitch(pl.th * pl.pcx), xv = 8 * xp;
+  pl.npx = cdiv(xv, 256);                              // 256-vector slabs of input rows per tile
+  if (up2 && pl.npx > WG16_NPX) return (pl.tp = 0, pl);
+  if (xv > 65535) return (pl.tp = 0, pl);
   pl.tiles_y = cdiv(rows, pl.th); pl.tiles_x = cdiv(OW, pl.tw);
   pl.n_tiles = imgs * pl.tiles_y * pl.tiles_x;
   // pixel splits: fill ~2 workgroups per CU, at least 2 tiles per workgroup
@@ -263,15 +472,20 @@ Wgrad16Plan plan_wgrad16(int nd, int Cog, int Cig, int groups, int KH, int KW, i
   splits = std::min(splits, 64);
   pl.tiles_per_split = cdiv(pl.n_tiles, std::max(1, splits));
   pl.splits = cdiv(pl.n_tiles, pl.tiles_per_split);
-  pl.lds_bytes = 2 * (512 + 8 * pl.th * pl.pcx + 1) * 16;
+  // register-staged form (upsample-add input): two buffers.  LDS-DMA form: a ring of g_wgrad16_ring buffers of whole 64-vector
+  // wave slabs (17 KB for a k3 row: two buffers leave room for four workgroups per CU)
+  const int stage = (WG16_DYV + cdiv(xv, 64) * 64) * 16;
+  pl.nstg = up2 ? 2 : std::max(2, std::min(std::min(g_wgrad16_ring, pl.tiles_per_split + 1), 160 * 1024 / stage));
+  pl.lds_bytes = up2 ? 2 * (WG16_DYV + xv + 1) * 16 : pl.nstg * stage;
+  if (pl.lds_bytes > 160 * 1024) return (pl.tp = 0, pl);
   (void)SH;
   return pl;
 }
 
-template <typename DT, int TP, bool UP2>
+template <typename DT, int TP, bool UP2, int NPXT>
 static int launch_w(const Wgrad16Args& a, int lds, int nwg, hipStream_t s) {
   static bool attr_done = false;
-  auto fn = wgrad16_kernel<DT, TP, UP2>;
+  auto fn = wgrad16_kernel<DT, TP, UP2, NPXT>;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return set_error("wgrad16: cannot raise the dynamic LDS limit");
@@ -281,10 +495,10 @@ static int launch_w(const Wgrad16Args& a, int lds, int nwg, hipStream_t s) {
   return 0;
 }
 
-template <typename DT, int TP, bool UP2>
+template <typename DT, int TP, bool UP2, int NPXT>
 static int launch_wm(const Wgrad16Batch& b, int lds, hipStream_t s) {
   static bool attr_done = false;
-  auto fn = wgrad16_multi_kernel<DT, TP, UP2>;
+  auto fn = wgrad16_multi_kernel<DT, TP, UP2, NPXT>;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return set_error("wgrad16: cannot raise the dynamic LDS limit");
@@ -294,26 +508,43 @@ static int launch_wm(const Wgrad16Batch& b, int lds, hipStream_t s) {
   return 0;
 }
 
+// npxt: slots of input rows a thread keeps in registers (3, 5) or 0 = the per-tile loop (layers with a few pixels per row)
+inline int wg16_npxt(int npx) { return npx <= 3 ? 3 : npx <= 5 ? 5 : 0; }
+
+template <typename DT, int TP>
+static int launch_np_multi(const Wgrad16Batch& b, int npxt, int lds, hipStream_t s) {
+  if (npxt == 3) return launch_wm<DT, TP, false, 3>(b, lds, s);
+  if (npxt == 5) return launch_wm<DT, TP, false, 5>(b, lds, s);
+  return launch_wm<DT, TP, false, 0>(b, lds, s);
+}
+template <typename DT, int TP>
+static int launch_np(const Wgrad16Args& a, int npxt, int lds, int nwg, hipStream_t s) {
+  if (npxt == 3) return launch_w<DT, TP, false, 3>(a, lds, nwg, s);
+  if (npxt == 5) return launch_w<DT, TP, false, 5>(a, lds, nwg, s);
+  return launch_w<DT, TP, false, 0>(a, lds, nwg, s);
+}
+
 template <typename DT>
-static int launch_tp_multi(const Wgrad16Batch& b, int tp, bool up2, int lds, hipStream_t s) {
-  if (up2) return launch_wm<DT, 3, true>(b, lds, s);
+static int launch_tp_multi(const Wgrad16Batch& b, int tp, bool up2, int npxt, int lds, hipStream_t s) {
+  if (up2) return launch_wm<DT, 3, true, 0>(b, lds, s);
   switch (tp) {
-    case 1: return launch_wm<DT, 1, false>(b, lds, s);
-    case 2: return launch_wm<DT, 2, false>(b, lds, s);
-    case 3: return launch_wm<DT, 3, false>(b, lds, s);
-    case 4: return launch_wm<DT, 4, false>(b, lds, s);
+    case 1: return launch_np_multi<DT, 1>(b, npxt, lds, s);
+    case 2: return launch_np_multi<DT, 2>(b, npxt, lds, s);
+    case 3: return launch_np_multi<DT, 3>(b, npxt, lds, s);
+    case 4: return launch_np_multi<DT, 4>(b, npxt, lds, s);
   }
   return set_error("wgrad16: no kernel for %d taps", tp);
 }
 
 template <typename DT>
 static int launch_tp(const Wgrad16Args& a, const Wgrad16Plan& pl, bool up2, int nwg, hipStream_t s) {
-  if (up2) return launch_w<DT, 3, true>(a, pl.lds_bytes, nwg, s);
+  if (up2) return launch_w<DT, 3, true, 0>(a, pl.lds_bytes, nwg, s);
+  const int npxt = wg16_npxt(pl.npx);
   switch (pl.tp) {
-    case 1: return launch_w<DT, 1, false>(a, pl.lds_bytes, nwg, s);
-    case 2: return launch_w<DT, 2, false>(a, pl.lds_bytes, nwg, s);
-    case 3: return launch_w<DT, 3, false>(a, pl.lds_bytes, nwg, s);
-    case 4: return launch_w<DT, 4, false>(a, pl.lds_bytes, nwg, s);
+    case 1: return launch_np<DT, 1>(a, npxt, pl.lds_bytes, nwg, s);
+    case 2: return launch_np<DT, 2>(a, npxt, pl.lds_bytes, nwg, s);
+    case 3: return launch_np<DT, 3>(a, npxt, pl.lds_bytes, nwg, s);
+    case 4: return launch_np<DT, 4>(a, npxt, pl.lds_bytes, nwg, s);
   }
   return set_error("wgrad16: no kernel for %d taps", pl.tp);
 }
@@ -328,7 +559,7 @@ static double finish_wgrad16_args(const Wgrad16Args& a, const Wgrad16Plan& pl, b
   }
   Wgrad16Args b = a;
   b.ltw = ilog2(pl.tw); b.TH = pl.th; b.PCX = pl.pcx; b.tiles_x = pl.tiles_x; b.tiles_y = pl.tiles_y; b.n_tiles = pl.n_tiles;
-  b.tiles_per_split = pl.tiles_per_split; b.splits = pl.splits; b.ktg = pl.ktg;
+  b.tiles_per_split = pl.tiles_per_split; b.splits = pl.splits; b.ktg = pl.ktg; b.nstg = pl.nstg; b.dbg = g_conv16_dbg & 15;
   b.gx = cdiv(a.Cig, 64); b.gy = cdiv(a.Cog, 64); b.gz = a.groups * a.KH * pl.ktg * pl.splits;
   const double nwg = (double)b.gx * b.gy * b.gz;
   if (nwg > 2.0e9) { set_error("wgrad16: grid too large"); return 0; }
@@ -337,7 +568,7 @@ static double finish_wgrad16_args(const Wgrad16Args& a, const Wgrad16Plan& pl, b
 }
 
 // ---- queued launches (ms_bwd_options.defer_wgrad_launch / ms_wgrad_flush)
-struct PendingWgrad16 { int dt, tp, up2, lds, nwg; double flops, bytes; Wgrad16Args a; };
+struct PendingWgrad16 { int dt, tp, up2, npxt, lds, nwg; double flops, bytes; Wgrad16Args a; };
 // process-wide: autograd runs the blocks' backward on its device thread and the end-of-backward callback on the caller's
 static std::vector<PendingWgrad16> t_pending;
 static std::mutex t_pending_mu;
@@ -349,7 +580,7 @@ int queue_wgrad16(int dt, const Wgrad16Args& a, const Wgrad16Plan& pl, bool up2,
   // a queued kernel that writes dw itself (no pixel split) ADDS to it: by the time it runs, autograd may already have
   // accumulated the parameter's other uses of this step into the same slot (the slot starts the step zeroed)
   if (pl.splits == 1) pw.a.accumulate = 1;
-  pw.dt = dt; pw.tp = up2 ? 3 : pl.tp; pw.up2 = up2 ? 1 : 0; pw.lds = pl.lds_bytes; pw.nwg = (int)nwg; pw.flops = flops; pw.bytes = bytes;
+  pw.dt = dt; pw.tp = up2 ? 3 : pl.tp; pw.up2 = up2 ? 1 : 0; pw.npxt = up2 ? 0 : wg16_npxt(pl.npx); pw.lds = pl.lds_bytes; pw.nwg = (int)nwg; pw.flops = flops; pw.bytes = bytes;
   std::lock_guard<std::mutex> lk(t_pending_mu);
   t_pending.push_back(pw);
   return 0;
@@ -381,15 +612,15 @@ int wgrad16_flush(hipStream_t s) {
                      q[i].dt == DT_BF16 ? "bf16" : "f16", q[i].tp, q[i].up2, q[i].tp, q[i].up2, b.n, blocks);
       int rc = 0;
       if (!ts.skip()) {
-        rc = q[i].dt == DT_BF16 ? launch_tp_multi<BF16>(b, q[i].tp, q[i].up2 != 0, lds, s)
-                                : launch_tp_multi<F16>(b, q[i].tp, q[i].up2 != 0, lds, s);
+        rc = q[i].dt == DT_BF16 ? launch_tp_multi<BF16>(b, q[i].tp, q[i].up2 != 0, q[i].npxt, lds, s)
+                                : launch_tp_multi<F16>(b, q[i].tp, q[i].up2 != 0, q[i].npxt, lds, s);
         if (!rc) rc = check_launch("wgrad16_multi_kernel");
       }
       b.n = 0; lds = 0; blocks = 0; flops = bytes = 0;
       return rc;
     };
     for (size_t k = i; k < q.size(); ++k) {
-      if (done[k] || q[k].dt != q[i].dt || q[k].tp != q[i].tp || q[k].up2 != q[i].up2) continue;
+      if (done[k] || q[k].dt != q[i].dt || q[k].tp != q[i].tp || q[k].up2 != q[i].up2 || q[k].npxt != q[i].npxt) continue;
       if (b.n == WG16_MAX_JOBS || blocks + q[k].nwg > 0x3fffffff) {
         const int rc = launch();
         if (rc) return rc;
@@ -412,6 +643,15 @@ int launch_wgrad16(int dt, const Wgrad16Args& a, const Wgrad16Plan& pl, bool up2
   Wgrad16Args b;
   const double nwg = finish_wgrad16_args(a, pl, up2, &b);
   if (nwg <= 0) return -1;
+  if (wgrad16_c1_ok(a, up2)) {
+    b.gy = c8_of(a.Cog);
+    TimingScope ts(s, flops, bytes, "wgrad16_c1_kernel<%s>|conv_wgrad_cb8 c1 k%dx%d s%d Cog%d tiles%d splits%d", dt == DT_BF16 ? "bf16" : "f16",
+                   a.KH, a.KW, a.S, a.Cog, pl.n_tiles, pl.splits);
+    if (ts.skip()) return 0;
+    if (dt == DT_BF16) hipLaunchKernelGGL(wgrad16_c1_kernel<BF16>, dim3(b.gy * pl.splits), dim3(256), 0, s, b);
+    else hipLaunchKernelGGL(wgrad16_c1_kernel<F16>, dim3(b.gy * pl.splits), dim3(256), 0, s, b);
+    return check_launch("wgrad16_c1_kernel");
+  }
   TimingScope ts(s, flops, bytes, "wgrad16_kernel<%s,%d,%d>|conv_wgrad_cb8 k%dx%d s%d Cog%d Kg%d g%d tiles%d tw%d splits%d",
                  dt == DT_BF16 ? "bf16" : "f16", pl.tp, up2 ? 1 : 0, a.KH, a.KW, a.S, a.Cog, a.Cig * a.KH * a.KW, a.groups, pl.n_tiles,
                  pl.tw, pl.splits);
