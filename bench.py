@@ -29,6 +29,18 @@ if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
 B_PER_GPU, T, F_MEL, P, M, S = 32, 64, 128, 104, 8, 8
+# --config: the default is the metric's own configuration (BASELINE.json `metric`); the others are BASELINE.json configs[1], [3]
+# and [4] at their stated size and dtype on ONE GPU (profiles/r03_bench_c*.json; the driver runs the default)
+CONFIGS = {
+    'headline': dict(B=32, T=64, M=8, S=8, precision=None, kind='train',
+                     metric='train-step clips/sec (B=32, T=64, M=8)'),
+    'c2': dict(B=32, T=64, M=4, S=4, precision='bf16', kind='train',
+               metric='train-step clips/sec (configs[1]: M=4, B=32, T=64, bf16, one MI355X)'),
+    'c4': dict(B=32, T=256, M=25, S=25, precision='bf16', kind='train',
+               metric='train-step clips/sec (configs[3]: M=25, T=256, bf16; one rank\'s shard B=32 on one MI355X)'),
+    'c5': dict(B=1024, T=64, M=8, S=8, precision='fp16', kind='infer',
+               metric='inference clips/sec (configs[4]: style transfer, B=1024, M=8, fp16, BN folded, HIP-graph replay)'),
+}
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16
@@ -47,7 +59,8 @@ def parse():
   ap.add_argument('--no-per-kind', action='store_true', help='skip the separate G-step / D-step timing')
   ap.add_argument('--no-bf16-extra', action='store_true', help='skip the extra bf16-mode measurement attached to the fp32 line')
   ap.add_argument('--seed', type=int, default=4321)
-  ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16x6', 'bf16'],
+  ap.add_argument('--config', default='headline', choices=sorted(CONFIGS), help='headline (default, the metric) | c2 | c4 | c5: BASELINE configs[1], [3], [4]')
+  ap.add_argument('--precision', default=None, choices=['fp32', 'bf16x6', 'bf16'],
                   help='fp32: exact fp32 matrix products (default, the parity headline); bf16x6: both operands split exactly '
                        'into 3 bf16 parts, 6 of 9 partial products on the bf16 pipe, fp32 accumulate (same measured accuracy); '
                        'bf16: native bf16 operands and bf16 activations in HBM, fp32 accumulate and BN statistics '
@@ -55,7 +68,20 @@ def parse():
   ap.add_argument('--bn-sync', default='local', choices=['local', 'global'])
   ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL over xGMI); gloo only for smoke-testing the DP path')
   ap.add_argument('--same-device', action='store_true', help='smoke test: all ranks share cuda:0 (needs --dist-backend gloo)')
-  return ap.parse_args()
+  args = ap.parse_args()
+  cfg = CONFIGS[args.config]
+  global B_PER_GPU, T, M, S, G_STEP_GFLOP, D_STEP_GFLOP
+  B_PER_GPU, T, M, S = cfg['B'], cfg['T'], cfg['M'], cfg['S']
+  if args.precision is None:
+    args.precision = cfg['precision'] or 'fp32'
+  if args.config != 'headline':
+    # forward GFLOP of this configuration (SURVEY.md A.3 scaling: everything is linear in B*T, decoder and logits in M too)
+    bt = (B_PER_GPU * T) / (32.0 * 64.0)
+    fwd = bt * (62.31 + 4.21 + 0.50 + 4.87 + (26.02 + 0.87) * M / 8.0 + 0.215)
+    G_STEP_GFLOP, D_STEP_GFLOP = 3 * fwd, fwd + 3 * 2 * 0.215 * bt
+    args.no_bf16_extra = True
+    args.no_cpu_baseline = True     # (the CPU baseline belongs to the metric's configuration)
+  return args
 
 
 def self_launch(args):
@@ -147,8 +173,58 @@ def source_hash():
 
 
 def decoder_label_re(precision):
-  # forward + BN statistics of decoder.1-3 (JL:69-77): grouped k3 conv, 256 -> 256 channels per group, M groups
-  return re.compile(r'conv_fwd\S* k1x3 s1 Mg256 Kg768 g%d .*\+bnstats' % M)
+  # forward of decoder.1-3 (JL:69-77): grouped k3 conv, 256 -> 256 channels per group, M groups; with the batch statistics
+  # (+bnstats: the normalising launch follows) or with the whole BatchNorm + LeakyReLU inside the launch (+bnfused)
+  return re.compile(r'conv_fwd\S* k1x3 s1 Mg256 Kg768 g%d .*\+bn(stats|fused)' % M)
+
+
+def block_and_segment(rows, n_g, precision):
+  """Roofline entries of the north-star BLOCK (Conv1d + BatchNorm1d + LeakyReLU of a decoder layer, layers.py:77-78) and of
+  SURVEY section 8(d)'s unit, the decoder segment decoder.0-3 + logits + softmax mixture (JL:69-83,190-194), from the same
+  HIP-event timings: every launch that belongs to them, summed per G-step."""
+  bt = B_PER_GPU * T
+  esz = 2.0 if precision == 'bf16' else 4.0
+  mode_peak = BF16_MFMA_PEAK_TFLOPS if precision == 'bf16' else (BF16_MFMA_PEAK_TFLOPS / 6.0 if precision == 'bf16x6' else FP32_MFMA_PEAK_TFLOPS)
+
+  def avg(pattern):
+    """(average launch duration in us over the matching labels, their labels) -- the same kernel also runs in D-steps (the
+    generator's eval forward), so per-G-step sums use the launch counts of the model, not the counts of the timed steps"""
+    pat = re.compile(pattern)
+    hit = [r for r in rows if pat.search(r['label'])]
+    n = sum(r['count'] for r in hit)
+    return (sum(r['total_ms'] for r in hit) * 1e3 / n if n else 0.0), [r['label'].split('|')[-1] for r in hit]
+
+  def entry(us, flops, nbytes, what, parts):
+    t_mfma, t_hbm = flops / (mode_peak * 1e12), nbytes / (HBM_PEAK_GBS * 1e9)
+    bound = 'hbm' if t_hbm >= t_mfma else 'mfma'
+    s_ = us * 1e-6
+    return dict(what=what, us=round(us, 2), bound=bound, algorithmic_flops=round(flops), algorithmic_bytes=round(nbytes),
+                frac_hbm=round(nbytes / s_ / (HBM_PEAK_GBS * 1e9), 4), frac_mfma=round(flops / s_ / (mode_peak * 1e12), 4),
+                frac=round(max(t_mfma, t_hbm) / s_, 4), time_lower_bound_us=round(max(t_mfma, t_hbm) * 1e6, 2), launches=parts)
+
+  C = 256 * M
+  conv_us, conv_l = avg(r'conv_fwd\S* k1x3 s1 Mg256 Kg768 g%d .*\+bn(stats|fused)' % M)
+  bn_us, bn_l = avg(r'bn_finalize_apply\S* C%d N%d ' % (C, bt))     # the normalising launch, when BatchNorm is its own launch
+  if not conv_l:
+    return None, None
+  blk_us = conv_us + bn_us
+  blk_flops = 2.0 * 256 * 256 * 3 * bt * M
+  blk_bytes = esz * (2.0 * bt * C + M * 256.0 * 768.0)
+  block = entry(blk_us, blk_flops, blk_bytes,
+                'decoder.1-3 block = grouped Conv1d(k3) + BatchNorm1d(train) + LeakyReLU forward: %s' %
+                ('one launch (BatchNorm inside the conv launch)' if not bn_l else 'conv+statistics launch, then the normalising launch'),
+                conv_l + bn_l)
+  d0_us, d0_l = avg(r'conv_fwd\S* k1x3 s1 Mg256 Kg(798|816) g%d .*\+bn(stats|fused)' % M)
+  lg_us, lg_l = avg(r'conv_fwd\S* k1x1 s1 Mg104 Kg256 g%d ' % M)
+  mx_us, mx_l = avg(r'ew_softmax_mix_fwd')
+  seg_us = 3 * conv_us + d0_us + 4 * bn_us + lg_us + mx_us        # launches per G-step: decoder.1-3, decoder.0, 4 x BN, logits, mixture
+  # SURVEY 8(d): 26.89 GFLOP and 163.6 MB (fp32) / 81.8 MB (16-bit) at B=32, T=64, M=8; linear in B*T and M
+  scale = (bt / 2048.0) * (M / 8.0)
+  segment = entry(seg_us, 26.89e9 * scale, (81.8e6 if esz == 2.0 else 163.6e6) * scale,
+                  'decoder segment = decoder.0-3 (+BatchNorm, LeakyReLU) + logits + softmax mixture, forward, per G-step '
+                  '(SURVEY.md 8(d) unit): 3 x decoder.1-3 + decoder.0 + %d normalising launches + logits + mixture' % (4 if bn_l else 0),
+                  conv_l + d0_l + bn_l + lg_l + mx_l)
+  return block, segment
 
 
 def kernel_roofline(ts, batch, kinds, precision):
@@ -193,17 +269,22 @@ def kernel_roofline(ts, batch, kinds, precision):
               achieved_tflops=round(tf, 2), achieved_gbs=round(gbs, 1),
               time_lower_bound_us=round(max(t_mfma, t_hbm) * 1e6, 2),
               frac_of_lower_bound=round(max(t_mfma, t_hbm) / avg_s, 4),
-              note='north-star kernel by label: grouped decoder block forward + BN statistics (decoder.1-3: k3, %d groups, '
+              note='north-star kernel by label: grouped decoder block forward, BatchNorm statistics or the whole BatchNorm + LeakyReLU inside the launch (decoder.1-3: k3, %d groups, '
                    '256->256 channels per group, B*T = %d pixels), one launch per layer; HIP events on the launch stream over '
                    '2 G-steps + 2 D-steps (eager); bound = the larger of flops/peak and bytes/HBM-peak' % (M, B_PER_GPU * T))
+  n_g = sum(1 for k in kinds if k == 'G')
+  try:
+    roof['block'], roof['decoder_segment'] = block_and_segment(rows, max(1, n_g), precision)
+  except Exception as e:  # noqa: BLE001
+    roof['block'] = roof['decoder_segment'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
   # HBM traffic of that launch from the committed PMC passes (tools/pmc_decoder.sh; rocprofv3 cannot run inside bench.py):
   # quoted only when the file was produced by these very kernel sources
   try:
-    pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_decoder.json')))
+    pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r03_pmc_decoder.json')))
     ent = pmc.get(precision)
     if ent and ent.get('src_hash') == source_hash():
       roof['traffic'] = ent['hbm_bytes_per_launch']
-      roof['traffic_note'] = 'HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, profiles/r02_pmc_decoder.json (same sources: %s)' % ent['src_hash']
+      roof['traffic_note'] = 'HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, profiles/r03_pmc_decoder.json (same sources: %s)' % ent['src_hash']
   except (OSError, ValueError, KeyError):
     pass
   return roof, rows
@@ -256,8 +337,59 @@ def time_steps(ts, batch, n, kind, world, dist, dev):
   return elapsed, kinds
 
 
+def bench_inference(args):
+  """configs[4]: the generator's eval forward (sample_flag=1: style ids given, BatchNorm from the running statistics folded into
+  the prepared fp16 weights) on B=1024 clips, captured in a HIP graph; a step = one replay."""
+  import torch
+  import mix_stage_amd as A
+  from oracle import mixstage_oracle as O
+  dev = torch.device('cuda', 0)
+  torch.cuda.set_device(dev)
+  model = build_model(dev, 'fp32')
+  A.set_compute_dtype(model, 'fp16')
+  model.eval()
+  A.set_inference_folding(model, True)
+  audio, pose, labels, style = O.synthetic_batch(B_PER_GPU, T=T, F_=F_MEL, P=P, M=M, S=S, seed=1234)
+  style = (style + 3) % S                           # transfer to another speaker's style (trainer.py:1367-1386)
+  st = [t.to(dev) for t in (audio, labels, pose, style)]
+  kw = O.model_kwargs(st[3], T); kw['sample_flag'] = 1
+  with torch.no_grad():
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+      model([st[0], st[1]], st[2], **kw)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+      y_cap, _, _ = model([st[0], st[1]], st[2], **kw)
+    for _ in range(args.warmup):
+      g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+      g.replay()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+  fwd_gflop = (B_PER_GPU * T) / 2048.0 * 99.0
+  ms = 1e3 * elapsed / args.steps
+  out = {'metric': CONFIGS[args.config]['metric'], 'value': round(B_PER_GPU * args.steps / elapsed, 2), 'unit': 'clips/s', 'n_gpus': 1,
+         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak',
+         'vs_baseline': None, 'dtype': 'f16 (fp32 accumulate; eval BatchNorm folded into the prepared weights)', 'data': 'synthetic',
+         'config': {'workload': 'Mix-StAGE generator eval forward, style transfer (sample_flag=1), B=%d clips, T=%d, M=S=%d, HIP-graph replay'
+                                % (B_PER_GPU, T, M), 'global_batch': B_PER_GPU, 'parallelism': 'dp1', 'hip_graphs': True},
+         'output_finite': bool(torch.isfinite(y_cap).all()),
+         'roofline': {'bound': 'mfma', 'achieved': round(fwd_gflop / ms, 2), 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                      'frac': round(fwd_gflop / ms / BF16_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                      'note': 'whole forward: %.0f algorithmic GFLOP per replay (SURVEY A.3) / replay time, against the dense fp16 MFMA peak' % fwd_gflop},
+         'cpu_baseline': None}
+  print(json.dumps(out))
+
+
 def main():
   args = parse()
+  if CONFIGS[args.config]['kind'] == 'infer':
+    return bench_inference(args)
   world = int(os.environ.get('WORLD_SIZE', '1'))
   if args.gpus > 1 and 'RANK' not in os.environ:
     sys.exit(self_launch(args))
@@ -311,7 +443,7 @@ def main():
     dtype = {'fp32': 'f32', 'bf16x6': 'f32 via bf16x6 (exact 3-way bf16 split of both operands, 6 of 9 products, fp32 accumulate)',
              'bf16': 'bf16 (fp32 accumulate, fp32 BN statistics, fp32 master weights)'}[args.precision]
     out = {
-        'metric': 'train-step clips/sec (B=32, T=64, M=8)', 'value': round(world * B_PER_GPU * args.steps / elapsed, 2),
+        'metric': CONFIGS[args.config]['metric'], 'value': round(world * B_PER_GPU * args.steps / elapsed, 2),
         'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',

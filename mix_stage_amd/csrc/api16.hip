@@ -195,7 +195,7 @@ int block_fwd16(const ms_conv_desc* d, const void* x, const void* x2, const floa
   const double flops = 2.0 * d->Cout * d->Cin * d->KH * d->KW * (double)g.npix * d->groups;
   const double bytes = esz * ((double)g.C * d->Cin * d->KH * d->KW + (double)d->B * g.cin_tot * d->H * d->W) +
                        (a.out_f32 ? 4.0 : esz) * (double)g.npix * g.C;
-  rc = launch_conv16(g.dt, a, pl, d->KW, g.up2 != 0, flops, fused ? bytes + 2.0 * (double)g.npix * g.C : bytes, s);
+  rc = launch_conv16(g.dt, a, pl, d->KW, g.up2 != 0, flops, bytes, s);          // (bytes: algorithmic |x| + |w| + |y| of the block)
   if (rc || fused) return rc;
   if (d->mode == MS_BN_TRAIN && pl.n_tiles <= 64)      // few statistics tiles: finalize inside the normalising launch
     return launch_bn_finalize_apply16(g.dt, stats, counts, pl.n_tiles, g.npix, gamma, beta, running_mean, running_var, save, d->eps,

@@ -19,6 +19,39 @@ class ConstantLambdaScheduler:
   def step(self):
     return list(self.lmbdas)
 
+  def state(self):
+    return ()
+
+  def set_state(self, state):
+    pass
+
+
+class IncrementalLambdaScheduler:
+  """A RAMPING schedule with the reference's constructor arguments (gan.py:30-33: kind='incremental', max_interval=300,
+  max_lambda=2).  pycasper's own rule is not available (PARITY UNPINNED: the package is neither vendored nor version-pinned),
+  so this is an inferred reading of those arguments, provided so that a non-constant schedule can be trained and captured:
+  every `max_interval` calls of step() each lambda grows by its initial value, up to max_lambda times the initial value --
+  step() returns the current list.  Pass an instance as GAN(..., lambda_scheduler=...); the default stays constant (what the
+  golden vectors were generated with)."""
+
+  def __init__(self, lmbdas, kind='incremental', max_interval=300, max_lambda=2, **kwargs):
+    if kind != 'incremental':
+      raise NotImplementedError('lambda schedule kind %r' % (kind,))
+    self.initial = [float(v) for v in lmbdas]
+    self.max_interval, self.max_lambda = int(max_interval), float(max_lambda)
+    self.count = 0
+
+  def step(self):
+    k = 1 + self.count // self.max_interval
+    self.count += 1
+    return [min(v * k, v * self.max_lambda) if v >= 0 else max(v * k, v * self.max_lambda) for v in self.initial]
+
+  def state(self):
+    return (self.count,)
+
+  def set_state(self, state):
+    self.count, = state
+
 
 _SUPPORTED = {'L1Loss': 'l1_mean', 'MSELoss': 'l2_mean'}      # criterion -> fused mean-reduced kernel (gan.py:40,64-75)
 
@@ -34,6 +67,11 @@ class GAN(nn.Module):
     self.lambda_gan = lambda_gan
     self.lambda_scheduler = kwargs.get('lambda_scheduler') or ConstantLambdaScheduler(
         [self.lambda_D, self.lambda_gan], kind='incremental', max_interval=300, max_lambda=2)
+    # the two loss weights as seen by the kernels: a 2-float device tensor the loss ops read at run time, so that a captured
+    # step (HIP graph) follows a schedule that moves between replays.  `_lambda_host_writes`: forward() itself refreshes it
+    # (eager use); a trainer that replays captured steps switches that off and writes the values before each replay.
+    self._lambda_dev = None
+    self._lambda_host_writes = True
     self.G_flag = True
     self.fake_flag = True
     self.lr = lr
@@ -90,6 +128,22 @@ class GAN(nn.Module):
       for p, f in flags:
         p.requires_grad_(f)
 
+  def lambda_device(self, device):
+    """The (lambda_D, lambda_gan) device tensor (created on first use)."""
+    if self._lambda_dev is None or self._lambda_dev.device != device:
+      self._lambda_dev = torch.tensor([float(self.lambda_D), float(self.lambda_gan)], dtype=torch.float32, device=device)
+    return self._lambda_dev
+
+  def write_lambdas(self, device, staging=None):
+    """Current host values -> device tensor.  staging: optional pinned 2-float host tensor (asynchronous copy)."""
+    dev = self.lambda_device(device)
+    if staging is not None:
+      staging[0], staging[1] = float(self.lambda_D), float(self.lambda_gan)
+      dev.copy_(staging, non_blocking=True)
+    else:
+      dev.copy_(torch.tensor([float(self.lambda_D), float(self.lambda_gan)], dtype=torch.float32))
+    return dev
+
   def _score(self, pose):
     """D(get_velocity(pose)) with the velocity produced channel-major for D's first conv."""
     dt = getattr(self.D, '_ms_dt', 0)
@@ -110,6 +164,11 @@ class GAN(nn.Module):
 
     if self.training:
       self.lambda_D, self.lambda_gan = self.lambda_scheduler.step()
+      lam = None
+      if y_pose.is_cuda:
+        lam = self.write_lambdas(y_pose.device) if self._lambda_host_writes else self.lambda_device(y_pose.device)
+      lam_D = lam[0] if lam is not None else self.lambda_D
+      lam_gan = lam[1] if lam is not None else self.lambda_gan
       if torch.rand(1).item() < self.D_prob:                           # host RNG draw (gan.py:105)
         ## D-step: G in eval mode under no_grad, D on fake then real velocity (gan.py:106-132)
         self.G.eval()
@@ -119,7 +178,7 @@ class GAN(nn.Module):
         self.G.train(self.training)
         self.fake_flag = True
         fake_pose_score = self._score(fake_pose.detach())
-        fake_D_loss = self._loss(fake_pose_score, target=0.0, scale=self.lambda_D)
+        fake_D_loss = self._loss(fake_pose_score, target=0.0, scale=lam_D)
         real_pose_score = self._score(y_pose)
         real_D_loss = self._loss(real_pose_score, target=1.0)
         internal_losses.append(real_D_loss)
@@ -138,7 +197,7 @@ class GAN(nn.Module):
             fake_pose_score = self._score(fake_pose)
         else:
           fake_pose_score = self._score(fake_pose)
-        G_gan_loss = self._loss(fake_pose_score, target=1.0, scale=self.lambda_gan)
+        G_gan_loss = self._loss(fake_pose_score, target=1.0, scale=lam_gan)
         pose_loss = self._loss(fake_pose, y_pose)
         internal_losses.append(pose_loss)
         internal_losses.append(G_gan_loss)

@@ -761,12 +761,17 @@ class _L1MeanFn(torch.autograd.Function):
     check(fwd(_ptr(a), _ptr(b), target, _ptr(loss), _ptr(part), n, _stream()), 'ms_l2_mean_fwd' if squared else 'ms_l1_mean_fwd')
     ctx.save_for_backward(a, b)
     ctx.target, ctx.scale, ctx.squared = target, scale, squared
+    if torch.is_tensor(scale):         # a device-resident weight (gan.py: lambda schedule), read when the kernel runs
+      return loss * scale
     return loss * scale if scale != 1.0 else loss
 
   @staticmethod
   def backward(ctx, g):
     a, b = ctx.saved_tensors
-    g = (g * ctx.scale if ctx.scale != 1.0 else g).contiguous()
+    if torch.is_tensor(ctx.scale):
+      g = (g * ctx.scale).contiguous()
+    else:
+      g = (g * ctx.scale if ctx.scale != 1.0 else g).contiguous()
     da = torch.empty_like(a)
     bwd = lib().ms_l2_mean_bwd if ctx.squared else lib().ms_l1_mean_bwd
     check(bwd(_ptr(a), _ptr(b), ctx.target, _ptr(g), _ptr(da), a.numel(), _stream()), 'ms_l2_mean_bwd' if ctx.squared else 'ms_l1_mean_bwd')
@@ -776,13 +781,13 @@ class _L1MeanFn(torch.autograd.Function):
 @_bridge64
 def l1_mean(a, b=None, target=0.0, scale=1.0):
   """scale * mean|a - b| (b a tensor without grad, or the constant `target`): gan.py:64-75 with L1Loss."""
-  return _L1MeanFn.apply(a, b, float(target), float(scale), False)
+  return _L1MeanFn.apply(a, b, float(target), scale if torch.is_tensor(scale) else float(scale), False)
 
 
 @_bridge64
 def l2_mean(a, b=None, target=0.0, scale=1.0):
   """scale * mean (a - b)^2: gan.py:64-75 with MSELoss, the GAN constructor's default criterion."""
-  return _L1MeanFn.apply(a, b, float(target), float(scale), True)
+  return _L1MeanFn.apply(a, b, float(target), scale if torch.is_tensor(scale) else float(scale), True)
 
 
 # ------------------------------------------------------------------------------------------------

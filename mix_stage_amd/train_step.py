@@ -245,6 +245,7 @@ class MixStageTrainStep:
     self.losses = None       # list of 0-dim device tensors of the last step (reference order)
     # d(sum of losses)/d(loss) = 1: one constant on the default stream, made before any capture or side-stream pass
     self._seed = torch.ones((), dtype=torch.float32, device=self.optim_G.flat_p.device)
+    self._lambda_staging = torch.zeros(2, dtype=torch.float32).pin_memory()
     self.fake_pose = None
 
   # ---- the eager pieces ------------------------------------------------------------------------------------
@@ -284,11 +285,15 @@ class MixStageTrainStep:
     return peek_step_decisions(self.model.D_prob, th.value, th.iters, th.num_iters, th.end)
 
   def _consume_decisions(self, kind):
+    """What GAN.forward / G.forward do on the host per training step, for a step that is replayed from a graph: the two RNG
+    draws, the curriculum clock and the lambda schedule (gan.py:103,105; JL:127)."""
+    m = self.model
+    m.lambda_D, m.lambda_gan = m.lambda_scheduler.step()
     torch.rand(1)
     torch.rand(1)
-    self.model.G.thresh.step(kind == 'G')
-    self.model.G_flag = kind == 'G'
-    self.model.fake_flag = True
+    m.G.thresh.step(kind == 'G')
+    m.G_flag = kind == 'G'
+    m.fake_flag = True
 
   # ---- public ----------------------------------------------------------------------------------------------
   def step(self, audio, labels, pose, style, kind=None, inputs_unchanged=False):
@@ -306,6 +311,7 @@ class MixStageTrainStep:
       self.optim_G.resync_if_modified()
       self.optim_D.resync_if_modified()
       if not self.use_graphs:
+        m._lambda_host_writes = True        # (eager: forward() refreshes the device-side loss weights itself)
         self.fake_pose, self.losses = self._forward_backward(audio, labels, pose, style, k)
         opt = self.optim_G if m.G_flag else self.optim_D
         active = opt.active_params()
@@ -320,6 +326,7 @@ class MixStageTrainStep:
     return k
 
   def _graph_step(self, k, pose_branch, audio, labels, pose, style, inputs_unchanged=False):
+    self.model._lambda_host_writes = False   # the captured loss kernels read the device tensor written below
     key = (k, pose_branch, tuple(audio.shape), tuple(pose.shape))
     if self._static is None or self._static['key_shapes'] != key[2:]:
       self._static = dict(key_shapes=key[2:], audio=audio.clone(), labels=labels.clone(), pose=pose.clone(),
@@ -339,6 +346,8 @@ class MixStageTrainStep:
       entry = self._capture(key, k, st, opt)       # capture executes nothing: replay below does the step
     else:
       self._consume_decisions(k)
+    # this step's loss weights (the schedule moved on the host): into the device tensor the captured loss kernels read
+    self.model.write_lambdas(opt.flat_p.device, self._lambda_staging)
     for mod in entry['bn_tape']:
       mod._pending_batches += 1
     opt.mark_active(entry['active'])
@@ -353,11 +362,13 @@ class MixStageTrainStep:
 
   def _capture(self, key, k, st, opt):
     m = self.model
-    from .gan import ConstantLambdaScheduler
-    if not isinstance(m.lambda_scheduler, ConstantLambdaScheduler):
-      # the loss weights are baked into the captured kernels' constants and the scheduler is not stepped on replay
-      raise NotImplementedError('use_graphs=True needs the constant lambda scheduler (gan.py:30-33 stand-in); construct '
-                                'MixStageTrainStep(..., use_graphs=False) with a custom lambda_scheduler')
+    sched = m.lambda_scheduler
+    if not (hasattr(sched, 'state') and hasattr(sched, 'set_state')):
+      # the warm-up and capture passes below call scheduler.step(); their effect on the schedule has to be undone
+      raise NotImplementedError('use_graphs=True needs a lambda scheduler with state() / set_state() (see '
+                                'gan.IncrementalLambdaScheduler); or construct MixStageTrainStep(..., use_graphs=False)')
+    sched_state = sched.state()
+    m.write_lambdas(opt.flat_p.device)
     rng = torch.get_rng_state()
     thresh = (m.G.thresh.value, m.G.thresh.iters)
     bn_state = {n: b.clone() for n, b in m.named_buffers()}
@@ -380,6 +391,7 @@ class MixStageTrainStep:
       mod._pending_batches -= 1
     torch.set_rng_state(rng)
     m.G.thresh.value, m.G.thresh.iters = thresh
+    sched.set_state(sched_state)
     tape = []
     layers.set_train_tape(tape)
     # with a process group alive, RCCL's watchdog thread issues HIP calls of its own: only this thread's calls may

@@ -262,3 +262,50 @@ def test_lin_style_path_trains_the_style_embedding(use_graphs):
   assert (w_hip - w_ref).abs().max().item() <= 1.5e-4, (w_hip - w_ref).abs().max().item()
   # a parameter that never receives a gradient keeps torch's "skipped" semantics: untouched bit for bit
   assert torch.equal(hip.G.smoothen.conv.weight.detach().cpu(), ref.G.smoothen.conv.weight.detach())
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_ramping_lambda_schedule_under_graphs_equals_eager(precision):
+  """gan.py:30-33,103: the reference constructs a NON-constant LambdaScheduler(kind='incremental', max_interval=300,
+  max_lambda=2) and steps it every training forward.  The loss weights live in a device tensor the loss kernels read, so a
+  captured step follows a schedule that moves between replays: 20 steps of a fast ramp (interval 3), graph replay == eager bit
+  for bit, and the losses are the weighted ones."""
+  from mix_stage_amd.gan import IncrementalLambdaScheduler
+  from mix_stage_amd.train_step import MixStageTrainStep
+  import mix_stage_amd as A
+  M = S = 2
+  batch = [t.to(DEV) for t in O.synthetic_batch(4, M=M, S=S, seed=7)]
+  audio, pose, labels, style = batch
+  kinds = ['G', 'D', 'G', 'G', 'D'] * 4
+  results = {}
+  for use_graphs in (False, True):
+    torch.manual_seed(5)
+    model = _hip(M, S)
+    model.lambda_scheduler = IncrementalLambdaScheduler([1.0, 1.0], max_interval=3, max_lambda=4)
+    if precision == 'bf16':
+      A.set_compute_dtype(model, 'bf16')
+    ts = MixStageTrainStep(model, use_graphs=use_graphs)
+    got, lams = [], []
+    for k in kinds:
+      ts.step(audio, labels, pose, style, kind=k)
+      got.append([float(l) for l in ts.losses])
+      lams.append((model.lambda_D, model.lambda_gan))
+    results[use_graphs] = (got, lams, {n: v.clone() for n, v in model.state_dict().items()})
+  eager, graph = results[False], results[True]
+  assert eager[1] == graph[1]
+  assert eager[1][0] == (1.0, 1.0) and eager[1][3] == (2.0, 2.0) and eager[1][-1] == (4.0, 4.0)      # the ramp, capped
+  assert eager[0] == graph[0]
+  for n, v in eager[2].items():
+    assert torch.equal(v, graph[2][n]), n
+  # the weight really multiplies the GAN term: the last G-step's generator GAN loss under lambda 4 is 4 x the unweighted one
+  torch.manual_seed(5)
+  plain = _hip(M, S)
+  if precision == 'bf16':
+    A.set_compute_dtype(plain, 'bf16')
+  plain.load_state_dict({n: v for n, v in eager[2].items()})
+  from test_gpu_model import _step
+  plain.lambda_scheduler = IncrementalLambdaScheduler([3.0, 3.0], max_interval=10 ** 9)
+  _, l3 = _step(plain, O.synthetic_batch(4, M=M, S=S, seed=7), 'G', DEV)
+  plain.lambda_scheduler = IncrementalLambdaScheduler([1.0, 1.0], max_interval=10 ** 9)
+  _, l1 = _step(plain, O.synthetic_batch(4, M=M, S=S, seed=7), 'G', DEV)
+  assert abs(float(l3[1]) - 3.0 * float(l1[1])) <= 1e-5 * max(1.0, abs(float(l3[1]))) and abs(float(l3[0]) - float(l1[0])) <= 1e-6
