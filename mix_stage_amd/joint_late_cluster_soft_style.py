@@ -98,6 +98,12 @@ class JointLateClusterSoftStyle4_G(nn.Module):
     self.thresh = Curriculum(0, 1, 1000)
     self.labels_cap_soft = None
 
+  def index_select_outputs(self, x, labels, groups):
+    """JL:106-115 (API parity: forward() uses the fused softmax + mixture kernel, ops.softmax_mix): x (B, M*P, T) mixed with
+    the per-frame cluster weights labels (B, T, M) -> (B, T, P)."""
+    from .layers import Group
+    return Group.mix_groups(x, labels, groups)
+
   def forward(self, x, y, time_steps=None, **kwargs):
     internal_losses = []
     labels = x[-1]          # cluster labels ride along with the inputs (JL:119)

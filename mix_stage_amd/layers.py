@@ -383,9 +383,32 @@ class Group(nn.Module):
     self.groups = groups
     self.dim = dim
 
-  def forward(self, *args, **kwargs):
-    raise NotImplementedError('Group.forward is not on the Mix-StAGE audio path (the generator only constructs it: '
-                              'state_dict keys style_dec_gr.*)')
+  @staticmethod
+  def mix_groups(z, weights, groups):
+    """Soft mixture over the `groups` channel slices of z (B, groups*F, T) with per-frame weights (B, T, groups) ->
+    (B, T, F): out[b,t,f] = sum_g weights[b,t,g] * z[b, g*F+f, t]  (layers.py:618-627)."""
+    B, C, T = z.shape
+    w = weights.reshape(B, T, groups)
+    return torch.einsum('bgft,btg->btf', z.reshape(B, groups, C // groups, T), w)
+
+  def index_select_outputs(self, x, labels):
+    return self.mix_groups(x, labels, self.groups)
+
+  def forward(self, x, labels=None, transpose=True, **kwargs):
+    """layers.py:629-650.  Off the audio path (plain torch ops; the sub-modules run whatever kernels they own): the inputs
+    are joined along `dim`, optionally moved to channel-major, passed through the models; with `labels` the groups are mixed
+    per frame, otherwise the result is handed back as one tensor per group."""
+    if self.dim == 0:
+      self.groups = len(x)
+    if isinstance(x, (list, tuple)):
+      x = torch.cat(list(x), dim=self.dim)
+    if transpose:
+      x = x.transpose(-1, -2)
+    for model in self.models:
+      x = model(x, **kwargs) if kwargs else model(x)
+    if labels is not None:
+      return self.mix_groups(x, labels, self.groups).transpose(-1, -2)
+    return list(torch.chunk(x, self.groups, dim=self.dim % x.dim()))
 
 
 class EmbLin(nn.Module):

@@ -71,3 +71,28 @@ def test_product_package_never_imports_the_oracle():
     if fn.endswith('.py'):
       src = open(os.path.join(pkg, fn)).read()
       assert 'oracle' not in src.replace('"""', ''), fn
+
+
+def test_group_module_matches_the_reference_semantics():
+  """layers.py:593-650 (off the audio path, kept for API parity): joined inputs -> models -> per-frame soft mixture of the
+  groups, or one tensor per group; JL:106-115 index_select_outputs likewise."""
+  import torch
+  import torch.nn as nn
+  import mix_stage_amd as A
+  from mix_stage_amd.layers import Group
+  torch.manual_seed(0)
+  g = Group([nn.Conv1d(8, 12, 1, groups=2)], groups=2, dim=1)
+  xs = [torch.randn(3, 4, 5), torch.randn(3, 4, 5)]                  # (B, C, T) each, joined along the channels (dim=1)
+  labels = torch.softmax(torch.randn(3, 5, 2), -1)
+  out = g(xs, labels=labels, transpose=False)
+  z = g.models[0](torch.cat(xs, 1))                                  # (B, 12, T)
+  zz = z.transpose(2, 1).reshape(3, z.shape[2], 2, -1)
+  ref = (zz * labels.reshape(3, z.shape[2], 2).unsqueeze(-1)).sum(-2).transpose(-1, -2)
+  assert torch.allclose(out, ref, atol=1e-6)
+  parts = g(xs, transpose=False)
+  assert len(parts) == 2 and torch.equal(torch.cat(parts, 1), z)
+  G = A.JointLateClusterSoftStyle4_G(time_steps=64, out_feats=6, num_clusters=2, style_dict={0: 0, 1: 1}, style_dim=10, shape={})
+  x = torch.randn(3, 12, 5); lab = torch.softmax(torch.randn(3, 5, 2), -1)
+  got = G.index_select_outputs(x, lab, 2)
+  exp = (x.transpose(2, 1).reshape(3, 5, 2, 6) * lab.unsqueeze(-1)).sum(-2)
+  assert torch.allclose(got, exp, atol=1e-6)

@@ -393,3 +393,50 @@ def test_mse_criterion_the_constructor_default(kind):
   probe = (lambda m: m.G.logits.weight) if kind == 'G' else (lambda m: m.D.conv3.conv.weight)
   g_ref, g_hip = probe(ref).grad, probe(hip).grad.cpu().double()
   assert ((g_hip - g_ref).norm() / g_ref.norm()).item() <= 2e-2
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'float64'])
+def test_reference_format_weight_file_on_the_device(tmp_path, dtype):
+  """N4 (README.md:124-141, trainer.py:138,148): a pickled `*_weights.p` state_dict of GAN(G, D) -- fp32, or fp64 as a
+  `.double()`-cast reference model writes it, DataParallel prefix and wrapper key included -- loaded with
+  checkpoint.load_weights into the HIP modules reproduces what the oracle computes from the SAME file: train-mode G-step and
+  D-step outputs and losses, eval-mode sampling output."""
+  import pickle
+  from mix_stage_amd.checkpoint import load_weights
+  M = S = 3
+  torch.manual_seed(11)
+  src = O.build_gan(M=M, S=S)
+  with torch.no_grad():                                     # not the deterministic fill the other tests use: trained-looking weights
+    for n, p in src.named_parameters():
+      p.add_(0.02 * torch.randn_like(p))
+    for n, b in src.named_buffers():
+      if b.is_floating_point():
+        b.add_(0.05 * torch.rand_like(b))
+  if dtype == 'float64':
+    src = src.double()
+  path = tmp_path / 'exp_42_weights.p'
+  with open(path, 'wb') as f:
+    pickle.dump({'model': {'module.' + k: v.clone() for k, v in src.state_dict().items()}}, f)
+  ref = O.build_gan(M=M, S=S, dtype=getattr(torch, dtype))
+  ref.load_state_dict(src.state_dict())
+  hip = build_hip_gan(M, S)
+  if dtype == 'float64':
+    hip = hip.double()                                      # what trainer.py:138 does to the model
+  res = load_weights(hip, str(path))
+  assert not res.missing_keys and not res.unexpected_keys
+  batch = O.synthetic_batch(4, M=M, S=S, seed=3)
+  if dtype == 'float64':
+    batch = [t.double() if t.is_floating_point() else t for t in batch]
+  for kind in ('G', 'D'):
+    f_ref, l_ref = _step(ref, batch, kind, 'cpu')
+    f_hip, l_hip = _step(hip, batch, kind, DEV)
+    assert (f_hip.detach().cpu().double() - f_ref.detach().double()).abs().mean().item() <= 1e-4
+    np.testing.assert_allclose([float(l) for l in l_hip], [float(l) for l in l_ref], atol=2e-4)
+  audio, pose, labels, style = batch
+  kw = O.model_kwargs((style + 1) % S); kw['sample_flag'] = 1
+  ref.eval(); hip.eval()
+  with torch.no_grad():
+    y_ref, _, _ = ref([audio, labels], pose, **kw)
+    kw_d = dict(kw); kw_d['style'] = kw['style'].to(DEV)
+    y_hip, _, _ = hip([audio.to(DEV), labels.to(DEV)], pose.to(DEV), **kw_d)
+  assert (y_hip.cpu().double() - y_ref.double()).abs().mean().item() <= 1e-4

@@ -190,3 +190,42 @@ def test_config4_fp16_inference_b1024_graph_folded():
   _report('configs[4] inference B=1024 M=8 fp16 folded graph', pose_l1=l1, mixture_argmax_agreement=mix_agree,
           ms_per_forward=ms, clips_per_s=B / ms * 1e3)
   assert y_cap.shape == (B, 64, 104) and np.isfinite(l1) and l1 <= 2e-2
+
+
+def test_config3_full_batch_b32_m25_t256():
+  """BASELINE configs[3] at one rank's FULL shard: M = S = 25, T = 256, B = 32, bf16 -- the 52 M-element decoder activations,
+  the workspace sizing and the tile planner at the size the configuration names (the oracle comparison of this geometry runs at
+  B = 2: test_config3_bf16_train_step_m25_t256).  G-step and D-step through the captured train step: finite losses, graph
+  replay == eager bit for bit, and the bf16 step tracks the exact-fp32 HIP path (the parity path, itself checked against the
+  oracle at this geometry) on the same batch: poses and losses."""
+  from mix_stage_amd.train_step import MixStageTrainStep
+  M = S = 25
+  T, B = 256, 32
+  batch = [t.to(DEV) for t in O.synthetic_batch(B, T=T, M=M, S=S)]
+  audio, pose, labels, style = batch
+  out = {}
+  for tag, dtype, graphs in (('fp32', None, True), ('bf16_eager', 'bf16', False), ('bf16_graph', 'bf16', True)):
+    torch.manual_seed(3)
+    if dtype:
+      model = _hip_gan(M, S, T, dtype)
+    else:
+      from test_gpu_model import build_hip_gan
+      model = build_hip_gan(M, S, T)
+    ts = MixStageTrainStep(model, use_graphs=graphs, time_steps=T)
+    rec = []
+    for k in ('G', 'D', 'G'):
+      ts.step(audio, labels, pose, style, kind=k)
+      rec.append((ts.fake_pose.detach().float().clone(), [float(l) for l in ts.losses]))
+    out[tag] = rec
+    del ts, model
+    torch.cuda.empty_cache()
+  for (fe, le), (fg, lg) in zip(out['bf16_eager'], out['bf16_graph']):
+    assert torch.equal(fe, fg) and le == lg
+  for i, ((f16, l16), (f32, l32)) in enumerate(zip(out['bf16_graph'], out['fp32'])):
+    assert all(np.isfinite(l16)) and f16.shape == (B, T, 104)
+    l1 = (f16 - f32).abs().mean().item()
+    dl = max(abs(a - b) for a, b in zip(l16, l32))
+    _report('configs[3] M=25 T=256 B=32 bf16 vs fp32 HIP path, step %d' % i, pose_l1=l1, max_loss_diff=dl)
+    # (step 2 follows a clipped Adam update whose direction is the SIGN of gradients that the two arithmetic modes agree on to
+    # ~80 % only -- an L1 loss; the trajectories part by about one update's worth of motion, the losses stay together)
+    assert l1 <= (3e-2 if i < 2 else 1.5e-1) and dl <= 5e-2, (i, l1, dl)
