@@ -129,6 +129,7 @@ class JointLateClusterSoftStyle4_G(nn.Module):
     if dt:
       x = ops16.to_cb8(x, dt)
     x = self.unet(x)                                            # (B, 256, T) channel-major throughout
+    x = ops.backward_marker(x)       # (data-parallel trainers: the decoder / classifier gradients are complete here)
     B, T = x.shape[0], x.shape[2]
 
     ## Pose Style

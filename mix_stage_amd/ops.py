@@ -478,6 +478,35 @@ def conv_block(x, w, bias, geom, mode, gamma=None, beta=None, running_mean=None,
 
 
 # ------------------------------------------------------------------------------------------------
+# Backward-pass marker: an identity in the forward pass whose backward runs a callback -- the point of the backward pass at
+# which every gradient of the layers BEHIND it in the forward pass (the grouped decoder, logits, cluster classifier) is
+# complete.  A data-parallel trainer starts the gradient exchange of that bucket there, next to the rest of the backward pass
+# (train_step.MixStageTrainStep); without a callback the marker is not inserted at all.
+_marker = {'cb': None}
+
+
+def set_backward_marker(callback):
+  _marker['cb'] = callback
+
+
+class _BackwardMarkerFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x):
+    return x.view_as(x)
+
+  @staticmethod
+  def backward(ctx, g):
+    cb = _marker['cb']
+    if cb is not None:
+      cb()
+    return g
+
+
+def backward_marker(x):
+  return _BackwardMarkerFn.apply(x) if (_marker['cb'] is not None and x.requires_grad) else x
+
+
+# ------------------------------------------------------------------------------------------------
 # cross-rank ("global") BatchNorm for data-parallel training (include/mixstage.h: ms_bn_stats ...)
 _bn_sync = {'group': None, 'on': False}
 

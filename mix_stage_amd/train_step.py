@@ -80,14 +80,19 @@ def peek_step_decisions(D_prob, thresh_value, thresh_iters, thresh_num_iters, th
 class FlatAdam:
   """torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8) + clip_grad_norm_(params, max_norm) over flat buffers."""
 
-  def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0, order_last=()):
+  def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0, order_last=(), order_first=()):
     self.params = [p for p in params if p.requires_grad]
     if not self.params:
       raise ValueError('no trainable parameters')
     # used-first layout: parameters named in `order_last` (sub-networks that are idle on the path being trained) sit at
-    # the END of the flat buffers, so the live gradients form one prefix -- what the data-parallel exchange moves
+    # the END of the flat buffers, so the live gradients form one prefix -- what the data-parallel exchange moves.
+    # `order_first`: the parameters whose gradients are complete EARLIEST in the backward pass (the last layers of the forward
+    # pass) lead the buffer: one contiguous bucket that can be exchanged while the rest of the backward pass runs.
     last = set(id(p) for p in order_last)
-    self.params = [p for p in self.params if id(p) not in last] + [p for p in self.params if id(p) in last]
+    first = set(id(p) for p in order_first) - last
+    self.params = ([p for p in self.params if id(p) in first] + [p for p in self.params if id(p) not in last and id(p) not in first] +
+                   [p for p in self.params if id(p) in last])
+    self.n_first = sum(1 for p in self.params if id(p) in first)
     dev = self.params[0].device
     if dev.type != 'cuda':
       raise RuntimeError('FlatAdam runs on the MI355X only (parameters are on %s)' % dev)
@@ -96,6 +101,7 @@ class FlatAdam:
       offs.append(total)
       total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
     self.offsets, self.total = offs, total
+    self.first_elems = offs[self.n_first] if self.n_first < len(offs) else total      # length of the `order_first` bucket
     self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
     self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
     self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -211,16 +217,32 @@ class MixStageTrainStep:
   """Runs reference-equivalent training steps for GAN(G, D) on one GPU or data-parallel over ranks."""
 
   def __init__(self, model, lr=1e-4, clip=1.0, use_graphs=True, process_group=None, time_steps=64, overlap_wgrad=False,
-               bn_sync='local'):
+               bn_sync='local', overlap_allreduce=False, grad_buckets=4):
     self.model = model
     if bn_sync not in ('local', 'global'):
       raise ValueError("bn_sync must be 'local' or 'global'")
     self.bn_sync = bn_sync
+    rccl = dist.is_available() and dist.is_initialized() and dist.get_backend(process_group) == 'nccl'
     if bn_sync == 'global':
       if getattr(model, '_ms_dt', 0):
         raise NotImplementedError("bn_sync='global' is implemented for the fp32 path")
-      use_graphs = False        # the statistics exchanges run between the kernels of a block: not capturable
+      if not rccl:
+        use_graphs = False      # gloo's statistics exchanges (host side) cannot be captured; RCCL's are graph nodes like any kernel
     ops.set_bn_sync(bn_sync == 'global', process_group)
+    # Data-parallel exchange (world > 1): the live prefix of the flat gradient buffer in `grad_buckets` all-reduces, issued in
+    # REVERSE order of the forward pass.  The first of them -- the decoder / logits / classifier gradients, which lead the
+    # buffer (FlatAdam order_first) -- starts at the backward-pass marker behind the UNet, on a communication stream, next to
+    # the rest of the backward pass; the others follow the end of the backward pass.  On RCCL the collectives are captured
+    # into the step's HIP graph (one graph per step kind); gloo (CPU-side transport: the tests) keeps two graphs around an
+    # eager exchange and no overlap.
+    # overlap_allreduce is OFF by default: measured with ONE rank on the data-parallel form of the step (MS_DP_SINGLE_RANK=1, bf16
+    # G-step, all of it RCCL's local reduce-copy of 60 MB): plain 2.69 ms, exchange captured on the step's own stream 2.79-2.81,
+    # on the communication stream with the early bucket 2.97 -- the cross-stream edges inside the captured graph cost more than
+    # a one-rank exchange can give back (the same was measured for weight gradients on a side stream).  Whether it pays with 8
+    # ranks (an exchange of ~0.4 ms over xGMI) has to be measured on such a node; no N > 1 RCCL run exists so far.
+    self.capture_allreduce = rccl
+    self.overlap_allreduce = bool(overlap_allreduce) and rccl
+    self.grad_buckets = max(1, int(grad_buckets))
     # overlap_wgrad: weight gradients on a side HIP stream (ms_conv_block_bwd_overlap).  Measured on MI355X / ROCm 7.2
     # inside the captured step it is SLOWER (5.01 vs 4.67 ms/step: cross-stream edges in the HIP graph cost more than the
     # concurrency buys), so it is off by default.
@@ -230,7 +252,8 @@ class MixStageTrainStep:
     # idle on the audio path: constructed for state_dict parity, trained only by other branches / never
     idle = [p for n, p in model.G.named_parameters()
             if n.split('.')[0] in ('text_encoder', 'pose_encoder', 'style_dec', 'style_dec_gr', 'concat_encoder', 'smoothen')]
-    self.optim_G = FlatAdam(model.G.parameters(), lr=lr, max_norm=clip, order_last=idle)
+    early = [p for n, p in model.G.named_parameters() if n.split('.')[0] in ('decoder', 'logits', 'classify_cluster')]
+    self.optim_G = FlatAdam(model.G.parameters(), lr=lr, max_norm=clip, order_last=idle, order_first=early)
     self.optim_D = FlatAdam(model.D.parameters(), lr=lr, max_norm=clip)
     self.use_graphs = use_graphs
     self.time_steps = time_steps
@@ -240,6 +263,8 @@ class MixStageTrainStep:
       broadcast_from_rank0([self.optim_G.flat_p, self.optim_D.flat_p] + [b for b in model.buffers()], process_group)
     self._graphs = {}
     self._static = None
+    self._comm = torch.cuda.Stream() if (self.world > 1 and self.overlap_allreduce) else None
+    self._early_done = False            # this step's first bucket went out at the backward-pass marker
     weakref.finalize(self, ops.drop_trainer_caches, [self.optim_G.flat_p.untyped_storage().data_ptr(),
                                                      self.optim_D.flat_p.untyped_storage().data_ptr()])
     self.losses = None       # list of 0-dim device tensors of the last step (reference order)
@@ -273,12 +298,66 @@ class MixStageTrainStep:
       ops.set_backward_overlap(None)
     return fake, losses
 
+  def _with_marker(self, fn, *args):
+    """fn(*args) with the backward-pass marker armed (data-parallel G-steps with the overlapped exchange)."""
+    arm = self.world > 1 and self.overlap_allreduce
+    if arm:
+      self._early_done = False
+      ops.set_backward_marker(self._backward_marker)
+    try:
+      return fn(*args)
+    finally:
+      if arm:
+        ops.set_backward_marker(None)
+
+  def _bucket_bounds(self, opt, n):
+    """[lo, hi) element ranges of the live prefix [0, n), in the order they are exchanged: the `order_first` bucket, then the
+    rest in `grad_buckets - 1` pieces from the END of the prefix (the audio encoder, first in the forward pass, goes last)."""
+    first = min(opt.first_elems, n) if opt.n_first else 0
+    out = [(0, first)] if first else []
+    k = max(1, self.grad_buckets - (1 if first else 0))
+    step = ((n - first + k - 1) // k + _ALIGN - 1) // _ALIGN * _ALIGN if n > first else 0
+    hi = n
+    while hi > first:
+      lo = max(first, hi - step)
+      out.append((lo, hi))
+      hi = lo
+    return out
+
+  def _backward_marker(self):
+    """Runs inside the backward pass, behind the UNet (ops.backward_marker): G-steps of a data-parallel job start the exchange
+    of the first bucket here.  The weight-gradient kernels queued so far (decoder, logits, classifier) are launched first."""
+    opt = self.optim_G
+    if self.world <= 1 or not self.overlap_allreduce or not self.model.G_flag or not opt.n_first or self._early_done:
+      return
+    ops._flush_deferred_wgrad()
+    cur = torch.cuda.current_stream()
+    self._comm.wait_stream(cur)
+    with torch.cuda.stream(self._comm):
+      average_flat_gradients(opt.flat_g[:opt.first_elems], self.pg)
+    self._early_done = True
+
   def _all_reduce(self, opt, active=None):
     """The exchange step: mean over ranks of the live prefix of the flat gradient buffer (used-first layout: 59.7 MB of
-    the generator's 80.6 MB on the audio branch; everything behind it is zero on every rank)."""
-    if self.world > 1:
-      n = opt.live_elems(active) if active is not None else opt.total
-      average_flat_gradients(opt.flat_g[:n] if n < opt.total else opt.flat_g, self.pg)
+    the generator's 80.6 MB on the audio branch; everything behind it is zero on every rank), bucket by bucket."""
+    if self.world <= 1:
+      return
+    n = opt.live_elems(active) if active is not None else opt.total
+    early, self._early_done = self._early_done and opt is self.optim_G, False
+    cur = torch.cuda.current_stream()
+    comm = self._comm if self.overlap_allreduce else None
+    if comm is not None:
+      comm.wait_stream(cur)
+    for lo, hi in self._bucket_bounds(opt, n):
+      if early and lo == 0 and hi == min(opt.first_elems, n):
+        continue                          # already on its way since the backward-pass marker
+      if comm is not None:
+        with torch.cuda.stream(comm):
+          average_flat_gradients(opt.flat_g[lo:hi], self.pg)
+      else:
+        average_flat_gradients(opt.flat_g[lo:hi], self.pg)
+    if comm is not None:
+      cur.wait_stream(comm)
 
   def _peek_decisions(self):
     th = self.model.G.thresh
@@ -312,7 +391,7 @@ class MixStageTrainStep:
       self.optim_D.resync_if_modified()
       if not self.use_graphs:
         m._lambda_host_writes = True        # (eager: forward() refreshes the device-side loss weights itself)
-        self.fake_pose, self.losses = self._forward_backward(audio, labels, pose, style, k)
+        self.fake_pose, self.losses = self._with_marker(self._forward_backward, audio, labels, pose, style, k)
         opt = self.optim_G if m.G_flag else self.optim_D
         active = opt.active_params()
         opt.mark_active(active)
@@ -352,7 +431,7 @@ class MixStageTrainStep:
       mod._pending_batches += 1
     opt.mark_active(entry['active'])
     entry['fwd_bwd'].replay()
-    if self.world > 1:
+    if entry['opt'] is not None:            # (gloo: the exchange runs eagerly between the two graphs)
       self._all_reduce(opt, entry['active'])
       entry['opt'].replay()
     opt.host_step += 1
@@ -382,6 +461,7 @@ class MixStageTrainStep:
         self._forward_backward(st['audio'], st['labels'], st['pose'], st['style'], k)
     finally:
       layers.set_train_tape(None)
+    warm_active = opt.active_params()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     with torch.no_grad():
@@ -397,11 +477,17 @@ class MixStageTrainStep:
     # with a process group alive, RCCL's watchdog thread issues HIP calls of its own: only this thread's calls may
     # invalidate the capture
     mode = 'thread_local' if self.world > 1 else 'global'
+    one_graph = self.world == 1 or self.capture_allreduce
     g1 = torch.cuda.CUDAGraph()
     try:
       with torch.cuda.graph(g1, capture_error_mode=mode):
-        fake, losses = self._forward_backward(st['audio'], st['labels'], st['pose'], st['style'], k)
-        if self.world == 1:
+        if one_graph and self.world > 1:
+          fake, losses = self._with_marker(self._forward_backward, st['audio'], st['labels'], st['pose'], st['style'], k)
+          # (the warm-up pass above ran the same forward / backward: its set of parameters with gradients is this step's)
+          self._all_reduce(opt, warm_active)
+        else:
+          fake, losses = self._forward_backward(st['audio'], st['labels'], st['pose'], st['style'], k)
+        if one_graph:
           opt.clip_and_step(count=False)
     finally:
       layers.set_train_tape(None)
@@ -409,7 +495,7 @@ class MixStageTrainStep:
     for mod in tape:                      # the capture pass itself ran no kernels
       mod._pending_batches -= 1
     g2 = None
-    if self.world > 1:
+    if not one_graph:
       g2 = torch.cuda.CUDAGraph()
       with torch.cuda.graph(g2, capture_error_mode=mode):
         opt.clip_and_step(count=False)

@@ -1,6 +1,7 @@
 """Worker of tests/test_gpu_dp.py::test_rccl_path_single_rank: ONE rank on the `nccl` backend (= RCCL on ROCm) taking the
 data-parallel form of the train step (MS_DP_SINGLE_RANK=1): process-group creation on the device, the parameter broadcast, the
-split graphs and the eager RCCL all-reduce (AVG) of the live gradient prefix between them.  With one rank the mean over ranks
+the bucketed RCCL all-reduces (AVG) of the live gradient prefix captured INSIDE the step's HIP graph, the first bucket started at
+the backward-pass marker on the communication stream.  With one rank the mean over ranks
 is the identity, so the run must reproduce the plain single-process step bit for bit."""
 import json
 import os
@@ -25,7 +26,7 @@ def run(dp, precision):
   model = build_hip_gan(4, 4)
   if precision != 'fp32':
     A.set_compute_dtype(model, precision)
-  ts = MixStageTrainStep(model, use_graphs=True)
+  ts = MixStageTrainStep(model, use_graphs=True, overlap_allreduce=dp)      # (the opt-in overlapped form: the riskier path)
   assert (ts.world > 1) == dp
   losses = []
   for i in range(5):
@@ -33,7 +34,9 @@ def run(dp, precision):
     ts.step(audio.cuda(), labels.cuda(), pose.cuda(), style.cuda(), kind='G' if i % 2 == 0 else 'D')
     losses.append([float(l.detach()) for l in ts.losses])
   torch.cuda.synchronize()
-  return dict(sums=ts.state_checksums(), losses=losses)
+  one_graph = all(e['opt'] is None for e in ts._graphs.values())      # RCCL: the exchange is captured inside the step's graph
+  return dict(sums=ts.state_checksums(), losses=losses, one_graph=one_graph, overlap=bool(ts.overlap_allreduce) if dp else None,
+              buckets=[list(b) for b in ts._bucket_bounds(ts.optim_G, ts.optim_G.live_elems(ts.optim_G.active_params()))] if dp else None)
 
 
 def main():

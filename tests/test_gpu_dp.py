@@ -79,7 +79,8 @@ def test_global_bn_dp_equals_single_device():
 
 def test_rccl_path_single_rank():
   """The RCCL calls of the data-parallel step, executed on the one GPU the box has: a single `nccl` rank forced onto the
-  data-parallel form of the step (split graphs around the eager all-reduce, broadcast) reproduces the plain step bit for bit,
+  data-parallel form of the step (bucketed all-reduces captured in the step's graph, the first one started at the
+  backward-pass marker on the communication stream; broadcast) reproduces the plain step bit for bit,
   in the fp32 and the bf16 mode."""
   env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
@@ -90,3 +91,7 @@ def test_rccl_path_single_rank():
   for precision, r in res[0]['out'].items():
     assert r['plain']['sums'] == r['dp']['sums'], precision
     assert r['plain']['losses'] == r['dp']['losses'], precision
+    assert r['dp']['one_graph'] and r['dp']['overlap'], r['dp']
+    b = r['dp']['buckets']
+    assert len(b) == 4 and b[0][0] == 0 and sorted(x for lo, hi in b for x in (lo, hi))[-1] == max(hi for lo, hi in b)
+    assert sum(hi - lo for lo, hi in b) == max(hi for lo, hi in b)            # the buckets tile the live prefix
