@@ -180,7 +180,7 @@ int block_fwd16(const ms_conv_desc* d, const void* x, const void* x2, const floa
   bool fused = false;
   if (d->mode == MS_BN_TRAIN && !outf32 && g_bn_fused && g_bn_sync) {
     const int bm = 64 * pl.wm, gy = cdiv(d->Cout, bm), nwg = pl.n_tiles * gy * d->groups;
-    const int scratch = (2 * pl.nwn * bm * 2 + (128 * pl.nwn / bm) * bm * 3 * 2 + bm * 2) * 4;      // red | dred | scsh
+    const int scratch = (2 * pl.nwn * bm * 2 + (128 * pl.nwn / bm) * bm * 3 * 2 + bm * 2 + bm / 8) * 4;      // red | dred | scsh | rawflag
     // (every workgroup reads its group's n_tiles partials: beyond 64 tiles per channel tile that traffic -- n_tiles^2 x 1 KB per
     // channel tile -- costs more than the normalising launch it replaces; measured on the 512-tile audio-encoder layers)
     fused = pl.n_tiles <= 64 && nwg >= g_bn_fused_min_wgs && (1 + gy * d->groups) * BNF_SYNC_WORDS_PER_GROUP <= g_bn_sync_n &&
@@ -190,6 +190,7 @@ int block_fwd16(const ms_conv_desc* d, const void* x, const void* x2, const floa
   if (fused) {
     a.ep = EP_BN_FUSED; a.out = y; a.out_raw = y_raw; a.bn_part = bn_part; a.bn_sync = g_bn_sync; a.save = save;
     a.momentum = d->momentum;
+    a.raw_all = (long)d->B * g.hw > BN_BWD16_FUSED_MAX;      // its two-pass backward reads y_raw, not y
   }
   const double esz = 2.0;
   const double flops = 2.0 * d->Cout * d->Cin * d->KH * d->KW * (double)g.npix * d->groups;
@@ -233,7 +234,8 @@ int block_bwd16(const ms_conv_desc* d, const void* x, const void* x2, const floa
   const float* dyf = outf32 ? (const float*)dy : nullptr;
   int bias_done = 0;
   if (d->mode == MS_BN_TRAIN) {
-    rc = launch_bn_bwd16(g.dt, outf32 ? nullptr : dy, dyf, y_raw, save, gamma, bn_part, dyr, colpart, dbias, dgamma, dbeta, d->B, g.C,
+    // (y: blocks with a cb8 output read x_hat and the activation mask from it wherever the map inverts safely -- conv16.h)
+    rc = launch_bn_bwd16(g.dt, outf32 ? nullptr : dy, dyf, y_raw, outf32 ? nullptr : y, save, gamma, bn_part, dyr, colpart, dbias, dgamma, dbeta, d->B, g.C,
                          g.hw, d->slope, &bias_done, s);
     gsrc = dyr;
   } else if (d->mode == MS_LRELU) {

@@ -40,6 +40,7 @@ struct Conv16Args {
   int* bn_sync;         // word 0: error flag; per group (g*gy + by) BNF_SYNC_STRIDE words from word BNF_SYNC_STRIDE on: arrive, depart
   float* save;          // mean | invstd | scale | shift
   float momentum;
+  int raw_all;          // EP_BN_FUSED: keep y_raw for every channel block (the block's backward will not read y)
   int Mg, groups, Kc8g, bcast, ep;     // rows per group, groups, source channel blocks per group
   int KH, S, SV;                       // kernel rows, column stride, row stride (1 for 1-D convs: rows are batch items)
   int SRCH, SRCW, s_img, s_cblk, s_row;
@@ -70,6 +71,20 @@ extern int g_bn_fused_min_wgs;
 extern int* g_bn_sync;
 extern int g_bn_sync_n;
 constexpr int BNF_SYNC_WORDS_PER_GROUP = 32;
+constexpr int BN_BWD16_FUSED_MAX = 2048;     // pixels per channel up to which BatchNorm backward is one launch (launch_bn_bwd16)
+
+// ---- BN_TRAIN blocks: what the backward pass reads.  BatchNorm + LeakyReLU backward needs x_hat and the sign of z per element.
+// Both follow from the block's OUTPUT y = lrelu(z), z = x_hat * gamma + beta, when the map is invertible and well conditioned:
+//   z = y > 0 ? y : y / slope;   x_hat = (z - beta) / gamma.
+// Then the raw conv output y_raw need not be kept at all (the in-launch BatchNorm writes y only: one HBM pass, no extra store).
+// The inversion amplifies y's rounding by (|x_hat| + |beta / gamma|); a channel is UNSAFE -- y_raw is kept and read for its
+// 8-channel block -- when gamma is tiny, beta dominates gamma, or the activation is not invertible (ReLU).  Forward and
+// backward evaluate this predicate on the SAME floats (the block's save vector: mean | invstd | scale | shift) with the same
+// operations (explicit fma, single multiplies: nothing the compiler could contract differently in the two kernels).
+__host__ __device__ inline bool bn_inv_unsafe(float mean, float invstd, float scale, float shift, float slope) {
+  const float beta = fmaf(mean, scale, shift);
+  return !(slope >= 1e-3f) || !(fabsf(scale) >= 1e-3f * invstd) || (fabsf(beta) * invstd > 4.0f * fabsf(scale));
+}
 
 // ---- weight preparation: fp32 master weights -> 16-bit A-operand stages (once per optimizer update)
 struct Prep16Job {
@@ -126,7 +141,10 @@ int launch_bn_finalize_apply16(int dt, const float* stats, const float* counts, 
                                const float* beta, float* rm, float* rv, float* save, float eps, float momentum, const void* y_raw,
                                void* y, float* y_f32, int B, int C, int HW, float slope, hipStream_t s);
 // dy: cb8, or plain fp32 (B,C,HW) when dy_f32 != NULL
-int launch_bn_bwd16(int dt, const void* dy, const float* dy_f32, const void* y_raw, const float* save, const float* gamma,
+// y: the block's cb8 output, or NULL: x_hat and the activation mask always from y_raw (fp32-output blocks, callers without y).
+// Only the one-launch form (B*HW <= BN_BWD16_FUSED_MAX pixels) reads y; blocks with more pixels keep y_raw whole (block_fwd16)
+// and their two-pass backward reads it.
+int launch_bn_bwd16(int dt, const void* dy, const float* dy_f32, const void* y_raw, const void* y, const float* save, const float* gamma,
                     float* partial, void* dyr, float* colpart, float* dbias, float* dgamma, float* dbeta, int B, int C, int HW,
                     float slope, int* bias_done, hipStream_t s);
 // mode 1: dyr = dy * lrelu'(y); mode 0: dyr = dy (written only when dy arrives as fp32); colsum partials always

@@ -270,7 +270,7 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16Args& p, const f32x1
 // the 32-row tile, one 16-byte store each.
 template <typename DT>
 __device__ __forceinline__ void store_block16(const Conv16Args& p, const Tile16& tl, void* out, int row_block, int oy, int ox, bool cval,
-                                              const float (&c)[16]) {
+                                              const float (&c)[16], int pr_mask = 3) {
   float vec[2][8];
 #pragma unroll
   for (int pr = 0; pr < 2; ++pr)
@@ -287,7 +287,7 @@ __device__ __forceinline__ void store_block16(const Conv16Args& p, const Tile16&
 #pragma unroll
   for (int pr = 0; pr < 2; ++pr) {
     const int cb = cb_tile + pr + 2 * tl.h;
-    if (cval && cb < cb_end) reinterpret_cast<u32x4*>(out)[obase + (size_t)cb * p.o_cblk] = pack8<DT>(vec[pr]);
+    if (cval && cb < cb_end && ((pr_mask >> pr) & 1)) reinterpret_cast<u32x4*>(out)[obase + (size_t)cb * p.o_cblk] = pack8<DT>(vec[pr]);
   }
 }
 
@@ -297,8 +297,9 @@ __device__ __forceinline__ void store_block16(const Conv16Args& p, const Tile16&
 // squares, count) with write-through (sc1) 16-byte stores, arrives on the group's counter, waits until all gx have arrived
 // (one lane polls with sc1 loads), reads the gx partials back (sc1 loads: served by L2 / the fabric, never by this CU's L1)
 // and sums them in tile order in fp64 -- every workgroup of the group computes bit-identical statistics --
-// then normalises, activates and stores y from registers.  y_raw (what the backward pass reads) leaves while the group
-// gathers.  No y_raw re-read, no second launch.
+// then normalises, activates and stores y from registers.  The backward pass takes x_hat and the activation mask from y
+// itself (conv16.h: bn_inv_unsafe); y_raw is stored only for channel blocks where that inversion is unsafe.  One HBM pass:
+// x and w in, y out -- no y_raw write, no re-read, no second launch.
 // Hand-off form: MI355X_MICROARCH.md "Valid forms", table row 3 (sc1 payload stores, every storing wave's vmcnt(0), workgroup
 // barrier, one agent-scope atomic add per workgroup, sc1 poll, workgroup barrier, sc1 loads).
 // Forward progress: the launcher uses this epilogue only when the WHOLE grid is co-resident (conv16_coresident), so every
@@ -316,6 +317,7 @@ __device__ __forceinline__ void conv16_epilogue_bnfused(const Conv16Args& p, con
   float* red = reinterpret_cast<float*>(smem);                         // [NWN pixel waves][BM][2]
   double* dred = reinterpret_cast<double*>(red + NWN * BM * 2);        // [P][BM][3]
   float* scsh = reinterpret_cast<float*>(dred + P * BM * 3);           // [BM][2]
+  int* rawflag = reinterpret_cast<int*>(scsh + BM * 2);                // [BM / 8]
   const int grp = tl.g * p.gy + tl.by;
   int* arrive = p.bn_sync + (size_t)(1 + grp) * BNF_SYNC_STRIDE;
   int* depart = arrive + 1;
@@ -387,23 +389,6 @@ __device__ __forceinline__ void conv16_epilogue_bnfused(const Conv16Args& p, con
   if (!(p.dbg & 128)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave: its partial has left before the workgroup signals
   __syncthreads();
   if (tl.t == 0 && !(p.dbg & 128)) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // y_raw = conv + bias (what the backward pass reads) leaves while the group gathers
-  if (p.out_raw && !(p.dbg & 16)) {
-#pragma unroll
-    for (int i = 0; i < WM; ++i) {
-      float bsv[16];
-      bias_of(i, bsv);
-#pragma unroll
-      for (int j = 0; j < WN; ++j) {
-        const int n = (tl.wn * WN + j) * 32 + tl.r;
-        const int oy = tl.oy0 + (n >> p.ltw), ox = tl.ox0 + (n & (TW - 1));
-        float c[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) c[q] = acc[i][j][q] + bsv[q];
-        store_block16<DT>(p, tl, p.out_raw, tl.wm * WM + i, oy, ox, (oy < tl.OUTH) & (ox < tl.OUTW), c);
-      }
-    }
-  }
   if (tl.t == 0 && !(p.dbg & (32 | 128))) {
     int spins = 0;
     while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.gx) {
@@ -444,6 +429,7 @@ __device__ __forceinline__ void conv16_epilogue_bnfused(const Conv16Args& p, con
 #pragma unroll
     for (int s = 1; s < P; ++s) { n += dred[(s * BM + tl.t) * 3]; s1 += dred[(s * BM + tl.t) * 3 + 1]; s2 += dred[(s * BM + tl.t) * 3 + 2]; }
     float sc = 0.f, shf = 0.f;
+    bool unsafe_c = false;
     if (chan_ok && n > 0.0) {
       // sum and sum of squares of the fp32 accumulators, exact in fp64 from here on: M2 = sum x^2 - (sum x)^2 / N
       const double mean = s1 / n, m2 = fmax(s2 - s1 * mean, 0.0);
@@ -452,6 +438,7 @@ __device__ __forceinline__ void conv16_epilogue_bnfused(const Conv16Args& p, con
       const float fmean = (float)mean;
       sc = gam * invstd;
       shf = bet - fmean * sc;
+      unsafe_c = bn_inv_unsafe(fmean, invstd, sc, shf, p.slope);
       if (tl.bx == 0) {
         const int ctot = p.groups * p.Mg;
         p.save[chn] = fmean; p.save[ctot + chn] = invstd; p.save[2 * ctot + chn] = sc; p.save[3 * ctot + chn] = shf;
@@ -461,6 +448,10 @@ __device__ __forceinline__ void conv16_epilogue_bnfused(const Conv16Args& p, con
       }
     }
     scsh[tl.t * 2] = sc; scsh[tl.t * 2 + 1] = shf;
+    // 8-channel blocks whose backward cannot take x_hat from y (conv16.h: bn_inv_unsafe): their y_raw is kept.  t < BM are
+    // whole waves: the ballot holds the 64 channels of this wave, bit (t & 63)
+    const unsigned long long unsafe = __ballot(unsafe_c);
+    if (!(tl.t & 7)) rawflag[tl.t >> 3] = (int)((unsafe >> (tl.t & 63)) & 0xffull) != 0;
   }
   __syncthreads();
 
@@ -469,6 +460,9 @@ __device__ __forceinline__ void conv16_epilogue_bnfused(const Conv16Args& p, con
   for (int i = 0; i < WM; ++i) {
     float scv[16], shv[16], bsv[16];
     bias_of(i, bsv);
+    // this lane's two channel blocks of row block i: pr + 2h (store_block16)
+    const int rb = (tl.wm * WM + i) * 4 + 2 * tl.h;
+    const int raw_mask = (p.dbg & 16) ? 0 : p.raw_all ? 3 : (rawflag[rb] ? 1 : 0) | (rawflag[rb + 1] ? 2 : 0);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int ml = (tl.wm * WM + i) * 32 + 4 * tl.h + (q & 3) + 8 * (q >> 2);
@@ -483,6 +477,13 @@ __device__ __forceinline__ void conv16_epilogue_bnfused(const Conv16Args& p, con
 #pragma unroll
       for (int q = 0; q < 16; ++q) c[q] = lrelu(fmaf(acc[i][j][q], scv[q], shv[q]), p.slope);
       store_block16<DT>(p, tl, p.out, tl.wm * WM + i, oy, ox, (oy < tl.OUTH) & (ox < tl.OUTW), c);
+      // (rare: a channel block whose BatchNorm map does not invert safely.  Wave-uniform condition: assembling a vector takes
+      // lanes l and l + 32 together (v_permlane32_swap), whichever of them owns the flagged block)
+      if (p.out_raw && __ballot(raw_mask != 0) != 0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) c[q] = acc[i][j][q] + bsv[q];
+        store_block16<DT>(p, tl, p.out_raw, tl.wm * WM + i, oy, ox, (oy < tl.OUTH) & (ox < tl.OUTW), c, raw_mask);
+      }
     }
   }
 }

@@ -247,6 +247,56 @@ __device__ inline void load_dy8(const u32x4* dy, const float* dy_f32, size_t v, 
   }
 }
 
+// One form for both sources, no branch in the element loops.  v = the stored value (y_raw, or the block output y):
+//   pos = v * P1 + P0 > 0          y_raw: z = v*scale + shift       y: the sign of y itself          (P1, P0) = (scale, shift) | (1, 0)
+//   u   = pos ? v : v * NS         y_raw: v                          y: z = y / slope below zero       NS = 1 | 1 / slope
+//   x_hat = u * A + Bc             y_raw: (v - mean) * invstd        y: (z - beta) / gamma             (A, Bc) = (invstd, -mean*invstd) | (invstd/scale, -beta*invstd/scale)
+struct BnSrc { float P1, P0, NS, A, Bc; };
+__device__ __forceinline__ BnSrc bn_src(bool raw, float mean, float invstd, float sc, float sh, float slope) {
+  BnSrc k;
+  if (raw) {
+    k.P1 = sc; k.P0 = sh; k.NS = 1.f; k.A = invstd; k.Bc = -mean * invstd;
+  } else {
+    const float ios = invstd / sc;
+    k.P1 = 1.f; k.P0 = 0.f; k.NS = 1.0f / slope; k.A = ios; k.Bc = -fmaf(mean, sc, sh) * ios;
+  }
+  return k;
+}
+__device__ __forceinline__ void bn_xhat_mask(const BnSrc& k, float v, float& xh, bool& pos) {
+  pos = fmaf(v, k.P1, k.P0) > 0.f;
+  xh = fmaf(pos ? v : v * k.NS, k.A, k.Bc);
+}
+
+// Source constants of a channel block, formed ONCE per workgroup: each of the 8 channels has one thread (t < 8, same wave) that
+// fetches its four statistics, decides whether the channel inverts safely and leaves both sets of constants (for y_raw, for y) in
+// LDS; the block-wide verdict is a ballot.  One barrier; no division or predicate per data thread (with 1-4 vectors per thread
+// the per-thread form of this cost a quarter of the kernel).  Returns raw; fills ks[8].
+struct BnSrcShared { float k[2][8][5]; int raw; };
+__device__ __forceinline__ bool bn_src_block(BnSrcShared& sh_, const float* __restrict__ save, int cb, int C, float slope, bool have_y,
+                                             BnSrc (&ks)[8]) {
+  const int t = threadIdx.x;
+  if (t < 8) {
+    const int c = min(cb * 8 + t, C - 1);
+    const float mn = save[c], is = save[C + c], scv = save[2 * (size_t)C + c], shv = save[3 * (size_t)C + c];
+    const bool unsafe = (cb * 8 + t < C) && bn_inv_unsafe(mn, is, scv, shv, slope);
+    const unsigned long long any = __ballot(unsafe);
+    if (t == 0) sh_.raw = !have_y || any != 0;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const BnSrc k = bn_src(r == 0, mn, is, scv, shv, slope);
+      sh_.k[r][t][0] = k.P1; sh_.k[r][t][1] = k.P0; sh_.k[r][t][2] = k.NS; sh_.k[r][t][3] = k.A; sh_.k[r][t][4] = k.Bc;
+    }
+  }
+  __syncthreads();
+  const bool raw = sh_.raw != 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float* kp = sh_.k[raw ? 0 : 1][j];
+    ks[j].P1 = kp[0]; ks[j].P0 = kp[1]; ks[j].NS = kp[2]; ks[j].A = kp[3]; ks[j].Bc = kp[4];
+  }
+  return raw;
+}
+
 // BatchNorm + LeakyReLU backward, pass 1.  grid (C8, nchunk); chunk = contiguous range of batch items.
 //   dz = dy * lrelu'(z), z = y_raw*scale+shift;  xh = (y_raw-mean)*invstd;  partial[c][chunk] = (sum dz, sum dz*xh)
 template <typename DT, bool DYF32>
@@ -415,7 +465,8 @@ __global__ __launch_bounds__(256) void bn_bwd16_apply_kernel(const u32x4* __rest
 // in ONE launch.
 template <typename DT, bool DYF32, int NE, int NT>
 __global__ __launch_bounds__(NT) void bn_bwd16_fused_kernel(const u32x4* __restrict__ dy, const float* __restrict__ dy_f32,
-                                                             const u32x4* __restrict__ y_raw, const float* __restrict__ save,
+                                                             const u32x4* __restrict__ y_raw, const u32x4* __restrict__ y_out,
+                                                             const float* __restrict__ save,
                                                              const float* __restrict__ gamma, u32x4* __restrict__ dyr, float* dbias,
                                                              float* dgamma, float* dbeta, int B, int C, int C8, int HW, float slope) {
   prefetch_kernargs<192>();
@@ -426,9 +477,10 @@ __global__ __launch_bounds__(NT) void bn_bwd16_fused_kernel(const u32x4* __restr
   // all loads first (clamped indices, no branches): one memory round trip for the whole kernel
   // (the 40 per-channel parameters travel through LDS: as scalar loads the compiler sinks them behind the data and waits
   // for them in four more round trips)
-  __shared__ float prm[40];
-  const int tp = min(t, 39);
-  const float pv = (tp < 32 ? save + (size_t)(tp >> 3) * C : gamma)[min(cb * 8 + (tp & 7), C - 1)];
+  // The data loads go out at once from the tensor the block normally reads: its output y (conv16.h: bn_inv_unsafe).  Whether one
+  // of the 8 channels is unsafe to invert is known only once the parameters have arrived; such a block -- the exception -- then
+  // reloads from y_raw.
+  const u32x4* ysrc = y_out ? y_out : y_raw;
   u32x4 ry[NE], rg[NE];
   float gf[DYF32 ? NE : 1][8];
   size_t vofs[NE];
@@ -437,7 +489,7 @@ __global__ __launch_bounds__(NT) void bn_bwd16_fused_kernel(const u32x4* __restr
     const int e = min(t + i * NT, n - 1);
     const int bl = fdHW.div(e), pix = e - bl * HW;
     vofs[i] = ((size_t)bl * C8 + cb) * HW + pix;
-    ry[i] = y_raw[vofs[i]];
+    ry[i] = ysrc[vofs[i]];
     if (DYF32) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) gf[i][j] = dy_f32[((size_t)bl * C + min(cb * 8 + j, C - 1)) * HW + pix];
@@ -445,13 +497,17 @@ __global__ __launch_bounds__(NT) void bn_bwd16_fused_kernel(const u32x4* __restr
       rg[i] = dy[vofs[i]];
     }
   }
-  if (t < 40) prm[t] = pv;
-  __syncthreads();
-  float mean[8], invstd[8], sc[8], sh[8], gi[8];
+  __shared__ BnSrcShared kshared;
+  __shared__ float gish[8];
+  if (t < 8) gish[t] = cb * 8 + t < C ? gamma[cb * 8 + t] * save[C + cb * 8 + t] : 0.f;
+  BnSrc ks[8];
+  const bool raw = bn_src_block(kshared, save, cb, C, slope, y_out != nullptr, ks);      // (one barrier: covers gish too)
+  float gi[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    mean[j] = prm[j]; invstd[j] = prm[8 + j]; sc[j] = prm[16 + j]; sh[j] = prm[24 + j];
-    gi[j] = cb * 8 + j < C ? prm[32 + j] * invstd[j] : 0.f;
+  for (int j = 0; j < 8; ++j) gi[j] = gish[j];
+  if (raw && y_out) {
+#pragma unroll
+    for (int i = 0; i < NE; ++i) ry[i] = y_raw[vofs[i]];
   }
   float dz[NE][8], xh[NE][8];
   float s12[16] = {};
@@ -468,9 +524,10 @@ __global__ __launch_bounds__(NT) void bn_bwd16_fused_kernel(const u32x4* __restr
     unpack8<DT>(ry[i], yr);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float z = fmaf(yr[j], sc[j], sh[j]);
-      dz[i][j] = ok ? g[j] * (z > 0.f ? 1.f : slope) : 0.f;
-      xh[i][j] = ok ? (yr[j] - mean[j]) * invstd[j] : 0.f;
+      float xv; bool pos;
+      bn_xhat_mask(ks[j], yr[j], xv, pos);
+      dz[i][j] = ok ? g[j] * (pos ? 1.f : slope) : 0.f;
+      xh[i][j] = ok ? xv : 0.f;
       s12[j] += dz[i][j];
       s12[8 + j] = fmaf(dz[i][j], xh[i][j], s12[8 + j]);
     }
@@ -513,12 +570,12 @@ int bwd16_chunks(int B, int C8, int HW, int* b_per_chunk) {
   return (int)nchunk;
 }
 
-int launch_bn_bwd16(int dt, const void* dy, const float* dy_f32, const void* y_raw, const float* save, const float* gamma,
+int launch_bn_bwd16(int dt, const void* dy, const float* dy_f32, const void* y_raw, const void* y, const float* save, const float* gamma,
                     float* partial, void* dyr, float* colpart, float* dbias, float* dgamma, float* dbeta, int B, int C, int HW,
                     float slope, int* bias_done, hipStream_t s) {
   const int C8 = c8_of(C);
   *bias_done = 0;
-  if ((long)B * HW <= 2048) {
+  if ((long)B * HW <= BN_BWD16_FUSED_MAX) {
     *bias_done = 1;
     // 1024 threads per channel block when there is enough to share: few workgroups exist (C/8), so each one's latency counts
     const int n = B * HW;
@@ -528,7 +585,7 @@ int launch_bn_bwd16(int dt, const void* dy, const float* dy_f32, const void* y_r
     if (ts.skip()) return 0;
 #define MS_BNF(DT, F, NE, NT)                                                                                                      \
     hipLaunchKernelGGL((bn_bwd16_fused_kernel<DT, F, NE, NT>), dim3(C8), dim3(NT), 0, s, (const u32x4*)dy, dy_f32, (const u32x4*)y_raw, \
-                       save, gamma, (u32x4*)dyr, dbias, dgamma, dbeta, B, C, C8, HW, slope)
+                       (const u32x4*)y, save, gamma, (u32x4*)dyr, dbias, dgamma, dbeta, B, C, C8, HW, slope)
 #define MS_BNF_NE(DT, F) do { if (ne <= 1) MS_BNF(DT, F, 1, 256); else if (ne <= 2) MS_BNF(DT, F, 2, 256);                         \
                               else if (ne <= 4) MS_BNF(DT, F, 4, 256); else MS_BNF(DT, F, 8, 256); } while (0)
     if (dt == DT_BF16) { if (dy_f32) MS_BNF_NE(BF16, true); else MS_BNF_NE(BF16, false); }

@@ -14,6 +14,8 @@ from ._lib import (BwdOptions, ConvDesc, FwdOptions, MS_BARE, MS_BF16, MS_BN_EVA
                    MS_F16, MS_IN_BCAST, MS_IN_PLAIN, MS_IN_UP2ADD, MS_LRELU, Prep16Item, check, lib)
 from .ops import _grad_slot, _ptr, _stream, workspace
 
+import os as _os
+_ABL_BWD_RAW = _os.environ.get('MS_ABL_BWD_RAW') == '1'
 TORCH_DT = {MS_BF16: torch.bfloat16, MS_F16: torch.float16}
 MS_DT = {torch.bfloat16: MS_BF16, torch.float16: MS_F16}
 NAME_DT = {'bf16': MS_BF16, 'bfloat16': MS_BF16, 'fp16': MS_F16, 'f16': MS_F16, 'float16': MS_F16, 'half': MS_F16}
@@ -245,7 +247,9 @@ class _ConvBlock16Fn(torch.autograd.Function):
     ctx.has_bias = bias is not None
     ctx.params = (w, bias, gamma, beta)
     ctx.raw_shape = (B, c8) + sp + (8,)
-    ctx.save_for_backward(x, x2, w, gamma, y_raw, y if mode == MS_LRELU else None, save)
+    # (BN_TRAIN blocks with a cb8 output: the backward pass reads x_hat and the activation mask from y wherever BatchNorm +
+    # LeakyReLU invert safely -- y_raw is only written for the channel blocks where they do not, csrc/conv16.h)
+    ctx.save_for_backward(x, x2, w, gamma, y_raw, y if (mode == MS_LRELU or (mode == MS_BN_TRAIN and not out_f32)) else None, save)
     return y
 
   @staticmethod
@@ -284,6 +288,8 @@ class _ConvBlock16Fn(torch.autograd.Function):
     defer_launch = bool(D['on'] and direct_w and dw is not None and ops.DEFER_WGRAD_LAUNCH)
     opt = BwdOptions(None, None, 0, wt.data_ptr() if wt is not None else None, part.data_ptr() if part is not None else None,
                      1 if defer_launch else 0)
+    if _ABL_BWD_RAW and mode == MS_BN_TRAIN:
+      y = None                  # (timing ablation only: the backward pass reads y_raw everywhere; results are garbage)
     check(lib().ms_conv_block_bwd_ex(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(gamma), None, None, _ptr(y_raw),
                                      _ptr(y), _ptr(save), _ptr(dy), _ptr(dyr), _ptr(dx), _ptr(dx2), _ptr(dw),
                                      _ptr(dbias), _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), _stream(),
