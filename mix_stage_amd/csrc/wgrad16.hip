@@ -433,6 +433,117 @@ __global__ __launch_bounds__(256) void wgrad16_c1_kernel(const Wgrad16Args p) {
   }
 }
 
+// 3x3, stride 1 (the layer this exists for).  A workgroup owns a run of consecutive rows of the flattened (image, row) space
+// (one pixel split) x 64 output columns; a lane is one column, the 4 waves take two channel blocks each.  Every wave slides a
+// 3 x 3 window of input values down the rows (three new values per row; the four waves read the same input -- L1 hits) and
+// loads its two dy vectors per row; U rows per step with all loads of the step issued first.  dy is read exactly once from HBM
+// and the input once per workgroup: the generic form above re-read the input per channel block (9x its size beyond L2) and sat
+// at 69 % of its wave cycles waiting on memory.
+template <typename DT>
+__global__ __launch_bounds__(256) void wgrad16_c1_3x3_kernel(const Wgrad16Args p, int rows_per_split, int col_tiles) {
+  prefetch_kernargs<sizeof(Wgrad16Args) + 8>();
+  __shared__ float red[144];
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int ct = blockIdx.x % col_tiles, split = blockIdx.x / col_tiles;
+  const int ox = ct * 64 + lane;
+  const int total_rows = p.n_tiles;                               // (reused field: images x output rows)
+  const int r0 = split * rows_per_split, r1 = min(total_rows, r0 + rows_per_split);
+  const u32x4* dy = reinterpret_cast<const u32x4*>(p.dyr);
+  const unsigned short* xs = reinterpret_cast<const unsigned short*>(p.src);
+  const bool col_ok = ox < p.OUTW;
+  const int oxc = min(ox, p.OUTW - 1);
+  const int ncb = p.gy;                                           // output channel blocks
+  // the three input columns of this lane: ix = ox - PW + kw; out of range -> 0 (padding)
+  bool cok[3];
+  int cix[3];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) {
+    const int ix = ox - p.PW + kw;
+    cok[kw] = col_ok & ((unsigned)ix < (unsigned)p.SRCW);
+    cix[kw] = min(max(ix, 0), p.SRCW - 1) * 8;
+  }
+  auto load_row = [&](int img, int iy, float (&v)[3]) {
+    const bool rok = (unsigned)iy < (unsigned)p.SRCH;
+    const unsigned short* row = xs + ((size_t)img * p.s_img + (size_t)min(max(iy, 0), p.SRCH - 1) * p.s_row) * 8;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const unsigned short raw = row[cix[kw]];
+      v[kw] = (rok & cok[kw]) ? DT::lo((unsigned)raw) : 0.f;
+    }
+  };
+  for (int cbp = wid; 2 * cbp < ncb; cbp += 4) {                   // this wave's pairs of channel blocks (one pair for 64 channels)
+    const int cb0 = 2 * cbp, cb1 = min(2 * cbp + 1, ncb - 1);
+    float acc[2][8][9];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int q = 0; q < 9; ++q) acc[c][j][q] = 0.f;
+    constexpr int U = 4;
+    for (int rb = r0; rb < r1; rb += U) {
+      u32x4 gv[U][2];
+      float xin[U + 2][3];
+      int img_u[U], oy_u[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int r = min(rb + u, r1 - 1);
+        img_u[u] = r / p.OUTH; oy_u[u] = r - img_u[u] * p.OUTH;
+        const size_t base = (size_t)img_u[u] * p.o_img + (size_t)oy_u[u] * p.o_row + oxc;
+        gv[u][0] = dy[base + (size_t)cb0 * p.o_cblk];
+        gv[u][1] = dy[base + (size_t)cb1 * p.o_cblk];
+      }
+      // rows of one image are consecutive: input rows oy_0 - PH .. + U + 1 serve all U output rows unless an image boundary falls
+      // inside the step (then each row loads its own three input rows: once per image)
+      const bool same = img_u[U - 1] == img_u[0] && oy_u[U - 1] == oy_u[0] + U - 1;
+      if (same) {
+#pragma unroll
+        for (int k = 0; k < U + 2; ++k) load_row(img_u[0], oy_u[0] - p.PH + k, xin[k]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (rb + u < r1) {
+          float w3[3][3];
+          if (same) {
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+              for (int kw = 0; kw < 3; ++kw) w3[kh][kw] = xin[u + kh][kw];
+          } else {
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) load_row(img_u[u], oy_u[u] - p.PH + kh, w3[kh]);
+          }
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            float g[8];
+            unpack8<DT>(col_ok ? gv[u][c] : u32x4{0, 0, 0, 0}, g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+              for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) acc[c][j][kh * 3 + kw] = fmaf(g[j], w3[kh][kw], acc[c][j][kh * 3 + kw]);
+          }
+        }
+      }
+    }
+    // lanes -> one value per (channel, tap); the column tiles meet in the slab through the caller's fixed-order reduction: slab
+    // index = split * col_tiles + ct
+    float* out = p.out + (size_t)(split * col_tiles + ct) * p.out_split_stride;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+          const float v = wave_sum(acc[c][j][q]);
+          const int co = (2 * cbp + c) * 8 + j;
+          if (lane == 0 && co < p.Cog && (c == 0 || 2 * cbp + 1 < ncb)) out[(size_t)co * 9 + q] = p.accumulate ? out[(size_t)co * 9 + q] + v : v;
+        }
+  }
+  (void)red;
+}
+
 bool wgrad16_c1_ok(const Wgrad16Args& a, bool up2) {
   return !up2 && a.Cig == 1 && a.groups == 1 && a.KH * a.KW <= WGC1_MAX_TAPS;
 }
@@ -472,6 +583,15 @@ Wgrad16Plan plan_wgrad16(int nd, int Cog, int Cig, int groups, int KH, int KW, i
   splits = std::min(splits, 64);
   pl.tiles_per_split = cdiv(pl.n_tiles, std::max(1, splits));
   pl.splits = cdiv(pl.n_tiles, pl.tiles_per_split);
+  if (Cig == 1 && groups == 1 && KH == 3 && KW == 3 && SW == 1 && !up2) {
+    // single-input-channel 3x3 block (wgrad16_c1_3x3_kernel: a 33 MB stream over dy at the headline size): slabs = row splits x
+    // 64-column tiles, one 4-wave workgroup each -- enough of them (256) to keep the stream in flight; a slab is Cog x 9 floats
+    const int col_tiles = cdiv(OW, 64), total_rows = imgs * rows;
+    const int row_splits = std::max(1, std::min(256 / col_tiles, total_rows / 8));
+    const int rps = cdiv(total_rows, row_splits);
+    pl.splits = cdiv(total_rows, rps) * col_tiles;
+    pl.tiles_per_split = cdiv(pl.n_tiles, pl.splits);            // (the MFMA kernel is not used for this block)
+  }
   // register-staged form (upsample-add input): two buffers.  LDS-DMA form: a ring of g_wgrad16_ring buffers of whole 64-vector
   // wave slabs (17 KB for a k3 row: two buffers leave room for four workgroups per CU)
   const int stage = (WG16_DYV + cdiv(xv, 64) * 64) * 16;
@@ -648,6 +768,19 @@ int launch_wgrad16(int dt, const Wgrad16Args& a, const Wgrad16Plan& pl, bool up2
     TimingScope ts(s, flops, bytes, "wgrad16_c1_kernel<%s>|conv_wgrad_cb8 c1 k%dx%d s%d Cog%d tiles%d splits%d", dt == DT_BF16 ? "bf16" : "f16",
                    a.KH, a.KW, a.S, a.Cog, pl.n_tiles, pl.splits);
     if (ts.skip()) return 0;
+    const int col_tiles = cdiv(a.OUTW, 64);
+    if (a.KH == 3 && a.KW == 3 && a.S == 1 && a.SV == 1 && pl.splits % col_tiles == 0 && pl.splits / col_tiles >= 1) {
+      // the plan's `splits` slabs = (row splits) x (column tiles of 64): every slab is written, the caller sums them in order
+      const int imgs = pl.n_tiles / (pl.tiles_y * pl.tiles_x), row_splits = pl.splits / col_tiles;
+      b.n_tiles = imgs * a.OUTH;                                   // rows of the flattened (image, output row) space
+      const int rows_per_split = cdiv(b.n_tiles, std::max(1, std::min(256 / col_tiles, b.n_tiles / 8)));      // (as plan_wgrad16)
+      if (cdiv(b.n_tiles, rows_per_split) == row_splits) {
+        if (dt == DT_BF16) hipLaunchKernelGGL(wgrad16_c1_3x3_kernel<BF16>, dim3(pl.splits), dim3(256), 0, s, b, rows_per_split, col_tiles);
+        else hipLaunchKernelGGL(wgrad16_c1_3x3_kernel<F16>, dim3(pl.splits), dim3(256), 0, s, b, rows_per_split, col_tiles);
+        return check_launch("wgrad16_c1_3x3_kernel");
+      }
+      b.n_tiles = pl.n_tiles;
+    }
     if (dt == DT_BF16) hipLaunchKernelGGL(wgrad16_c1_kernel<BF16>, dim3(b.gy * pl.splits), dim3(256), 0, s, b);
     else hipLaunchKernelGGL(wgrad16_c1_kernel<F16>, dim3(b.gy * pl.splits), dim3(256), 0, s, b);
     return check_launch("wgrad16_c1_kernel");

@@ -95,9 +95,12 @@ def _train_compare(tag, M, S, B, T):
       if nb > 0:
         vals['grad_cosine_' + k] = dot / (na * nb) ** 0.5
     _report('%s/%s-step' % (tag, kind), **vals)
-    assert np.isfinite(l1) and l1 <= 5e-2, vals
-    assert dl <= 5e-2, vals
-    assert vals['grad_cosine_main'] >= 0.6, vals
+    # rails = 1.5 x the largest value measured over the three configurations (profiles/r03_precision_report.json: G-step pose L1
+    # 0.0086-0.0193, D-step 0.0002-0.0005; loss differences <= 0.0073; main-path gradient cosine 0.78-0.81 in G-steps -- an L1
+    # loss: sign(fake - y) flips wherever |fake - y| is below the 16-bit noise -- and >= 0.985 in D-steps)
+    assert np.isfinite(l1) and l1 <= (3e-2 if kind == 'G' else 1e-3), vals
+    assert dl <= 1.2e-2, vals
+    assert vals['grad_cosine_main'] >= (0.70 if kind == 'G' else 0.97), vals
     if 'grad_cosine_style_encoder' in vals and vals.get('style_argmax_equal', True):
       # (a clip whose style id flipped on a near-tie -- margin below the 16-bit noise, reported above -- feeds ANOTHER style
       # embedding to the generator: the id_out gradient of the style encoder is then the gradient of a different function)
