@@ -284,6 +284,9 @@ def kernel_roofline(ts, batch, kinds, precision):
     ent = pmc.get(precision)
     if ent and ent.get('src_hash') == source_hash():
       roof['traffic'] = ent['hbm_bytes_per_launch']
+      if isinstance(roof.get('block'), dict) and 'block_hbm_bytes' in ent:
+        roof['block']['traffic'] = ent['block_hbm_bytes']
+        roof['block']['traffic_over_algorithmic'] = round(ent['block_hbm_bytes'] / roof['block']['algorithmic_bytes'], 3)
       roof['traffic_note'] = 'HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, profiles/r03_pmc_decoder.json (same sources: %s)' % ent['src_hash']
   except (OSError, ValueError, KeyError):
     pass
@@ -485,6 +488,11 @@ def main():
     if args.precision == 'fp32' and not args.no_bf16_extra and not args.no_per_kind:
       try:
         out['bf16'] = bf16_extra(dev, batch, args)
+        b16 = out['bf16']
+        out['bf16_value_blend_50_50'] = b16.get('value_blend_50_50')
+        out['bf16_g_step_ms'], out['bf16_d_step_ms'] = b16.get('g_step_ms'), b16.get('d_step_ms')
+        blk = (b16.get('roofline') or {}).get('block') or {}
+        out['bf16_decoder_block_us'], out['bf16_decoder_block_frac'] = blk.get('us'), blk.get('frac')
       except Exception as e:  # noqa: BLE001
         out['bf16'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
     try:

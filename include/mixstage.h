@@ -170,8 +170,12 @@ int ms_weights16_prepare(int n, const ms_prep16_item* items, void* stream);
 /* 16-bit modes, BN_TRAIN blocks: BatchNorm INSIDE the conv launch.  layers.py:77-78 is one expression, relu(norm(conv(x))); with
  * this buffer registered, a block whose conv grid is resident on the device all at once computes it in ONE launch and one HBM
  * pass: the workgroups that share a channel tile exchange their partial batch statistics through `zeroed_words` (arrival
- * counters) and the block's scratch, and normalise + activate their accumulators from registers -- y_raw is written (the backward
- * pass reads it) but never re-read, and there is no separate normalising launch.  Larger grids keep the two-launch form.
+ * counters) and the block's scratch, and normalise + activate their accumulators from registers; there is no separate
+ * normalising launch.  The backward pass recovers the pre-activation from y (z = y > 0 ? y : y / slope, x_hat = (z - beta) /
+ * gamma), so y_raw is written only for the 8-channel blocks that hold a channel where that inversion is ill-conditioned (tiny
+ * gamma relative to beta or to 1, slope 0); `save` carries what both passes derive that decision from, and ms_conv_block_bwd
+ * must be given y as well as y_raw for these blocks.  Layers of more than 2048 pixels per channel keep y_raw whole.  Larger grids
+ * keep the two-launch form (same outputs).
  *   zeroed_words  persistent, ZERO-INITIALISED int32 device buffer of n words (65536 recommended; 32 per channel tile and
  *                 group of the largest block + 32), owned by the caller, serving ONE device and ONE stream at a time (blocks
  *                 launched concurrently on two streams must not share it); the kernels restore the zeros.  Word 0 is an error

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: the round's measurement artifacts -> gpurun_out/final_<tag>/ (copy the summaries into profiles/ afterwards)
 set -eu
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/final_$TAG
 mkdir -p "$OUT"
@@ -24,4 +24,17 @@ rm -rf gpurun_out/pmcdec
 # what each kernel family costs inside the captured step (launches of a family dropped, step re-captured and re-timed)
 python tools/ablate_step.py fp32 2>&1 | grep -v amdgpu.ids > "$OUT/ablation_fp32.txt"
 python tools/ablate_step.py bf16 2>&1 | grep -v amdgpu.ids > "$OUT/ablation_bf16.txt"
+# BASELINE configs[1], [3], [4] at their stated size and dtype (bench.py --config)
+for c in c2 c4 c5; do
+  python bench.py --config $c > "$OUT/bench_${c}_full.log" 2>&1
+  grep -o '{"metric.*' "$OUT/bench_${c}_full.log" > "$OUT/bench_$c.json"
+done
+# per-kernel timeline of one captured bf16 G-step (rocprofv3 kernel trace of a replay, tools/trace_summary.py)
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --output-format csv -d /tmp/tr16 -- python3 "$R/tools/trace_step.py" bf16 G 12 > "$OUT/trace16.log" 2>&1
+python3 "$R/tools/trace_summary.py" "$(ls /tmp/tr16/*/*kernel_trace.csv | head -1)" "$OUT/timeline_bf16_gstep.json" >> "$OUT/trace16.log" 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/tr32 -- python3 "$R/tools/trace_step.py" fp32 G 12 > "$OUT/trace32.log" 2>&1
+python3 "$R/tools/trace_summary.py" "$(ls /tmp/tr32/*/*kernel_trace.csv | head -1)" "$OUT/timeline_fp32_gstep.json" >> "$OUT/trace32.log" 2>&1
+cd "$R"
+python -m pytest tests/test_gpu_model16.py -q -m gpu > "$OUT/precision_tests.log" 2>&1; cp gpurun_out/precision_report.json "$OUT/precision_report.json"
 cut -c1-300 "$OUT/bench.json"; cut -c1-300 "$OUT/bench_bf16.json"

@@ -42,10 +42,20 @@ for prec in ('fp32', 'bf16x6', 'bf16'):
     ent['kernel'] = k[:100]
     ent[ctr.lower() + '_kb_per_launch'] = round(v / n, 1)
     ent['launches'] = n
+    # the normalising launch of the block, where BatchNorm is not inside the conv launch (fp32 modes)
+    bns = {kk: vv for kk, vv in agg.items() if 'bn_finalize_apply' in kk}
+    if bns:
+      kb = max(bns, key=lambda kk: bns[kk][ctr][1])
+      nb, vb = bns[kb][ctr]
+      ent['bn_kernel'] = kb[:100]
+      ent['bn_' + ctr.lower() + '_kb_per_launch'] = round(vb / nb, 1)
     if k in dur:
       ent['avg_us_under_pmc'] = round(dur[k][1] / dur[k][0], 2)
   if 'fetch_size_kb_per_launch' in ent and 'write_size_kb_per_launch' in ent:
     ent['hbm_bytes_per_launch'] = int((2 * ent['fetch_size_kb_per_launch'] + ent['write_size_kb_per_launch']) * 1024)
+    # the block (conv + BatchNorm + LeakyReLU): the conv launch alone when BatchNorm runs inside it
+    ent['block_hbm_bytes'] = ent['hbm_bytes_per_launch'] + int((2 * ent.get('bn_fetch_size_kb_per_launch', 0) +
+                                                                ent.get('bn_write_size_kb_per_launch', 0)) * 1024)
     ent['src_hash'] = bench.source_hash()
     traffic[prec] = ent
   for d in sorted(glob.glob(os.path.join(root, prec + '_sq*'))):
