@@ -307,6 +307,21 @@ int ms_cross_entropy_bwd(const float* score, const int64_t* target, const float*
                          int n_outer, int n_inner, int C, int stride_outer, int stride_c,
                          int stride_inner, int accumulate, void* stream);
 
+/* Loss weights folded into the loss kernels (`lambda * criterion(...)`, gan.py:64-75 with the lambda_D / lambda_gan of gan.py:103;
+ * `lambda_id * cross_entropy(...)`, joint_late_cluster_soft_style.py:159,184,203): loss_out = loss * scale [* scale_dev[0]] and the
+ * gradient uses gscale[0] * scale [* scale_dev[0]] -- the same fp32 products torch forms for `w * loss`, so results are bit-identical
+ * to scaling outside.  scale_dev (optional) is ONE float on the device, read when the kernel runs: a weight schedule that moves between
+ * replays of a captured step.  ls == NULL: weight 1. */
+typedef struct ms_loss_scale {
+  float scale;
+  const float* scale_dev;
+} ms_loss_scale;
+int ms_cross_entropy_fwd_ex(const float* score, const int64_t* target, float* loss, int n_outer, int n_inner, int C,
+                            int stride_outer, int stride_c, int stride_inner, void* stream, const ms_loss_scale* ls);
+int ms_cross_entropy_bwd_ex(const float* score, const int64_t* target, const float* gscale, float* dscore, int n_outer,
+                            int n_inner, int C, int stride_outer, int stride_c, int stride_inner, int accumulate, void* stream,
+                            const ms_loss_scale* ls);
+
 /* GAN.get_velocity (gan.py:47-52) fused with the (B,T,P)->(B,P,T) transpose D.forward does (S2G:67):
  * v[b,p,0] = 0, v[b,p,t] = x[b,t,p] - x[b,t-1,p]. */
 int ms_velocity_fwd(const float* x, float* v, int B, int T, int P, void* stream);
@@ -325,6 +340,16 @@ int ms_l1_mean_bwd(const float* a, const float* b, float target, const float* gs
 /* The same for criterion MSELoss, the GAN constructor's default (gan.py:21,40): mean (a-b)^2, da = gscale[0] * 2(a-b)/n. */
 int ms_l2_mean_fwd(const float* a, const float* b, float target, float* loss, float* partials, size_t n, void* stream);
 int ms_l2_mean_bwd(const float* a, const float* b, float target, const float* gscale, float* da, size_t n, void* stream);
+
+/* squared = 0: L1Loss, 1: MSELoss; with the loss weight folded in (ms_loss_scale above) */
+int ms_lp_mean_fwd_ex(int squared, const float* a, const float* b, float target, float* loss, float* partials, size_t n,
+                      void* stream, const ms_loss_scale* ls);
+int ms_lp_mean_bwd_ex(int squared, const float* a, const float* b, float target, const float* gscale, float* da, size_t n,
+                      void* stream, const ms_loss_scale* ls);
+
+/* n device-to-device copies (any sizes, any alignment) in one launch: the batch tensors of a step into the buffers a captured
+ * step reads (the reference hands `batch` to the model directly, trainer.py:1077-1110; a HIP graph needs fixed addresses). */
+int ms_copy_multi(int n, const void* const* src, void* const* dst, const size_t* bytes, void* stream);
 
 /* Trainer step tail (trainer.py:1138-1146): global L2 norm of a flat gradient buffer, then
  * clip_grad_norm_(., max_norm) folded into a fused Adam step (torch.optim.Adam defaults).

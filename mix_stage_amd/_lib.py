@@ -23,6 +23,11 @@ class BwdOptions(ctypes.Structure):
               ('wt_prepared', ctypes.c_void_p), ('wgrad_partials', ctypes.c_void_p), ('defer_wgrad_launch', ctypes.c_int)]
 
 
+class LossScale(ctypes.Structure):
+  """struct ms_loss_scale"""
+  _fields_ = [('scale', ctypes.c_float), ('scale_dev', ctypes.c_void_p)]
+
+
 class FwdOptions(ctypes.Structure):
   """struct ms_fwd_options"""
   _fields_ = [('w_planes', ctypes.c_void_p)]
@@ -98,6 +103,10 @@ SIGNATURES = {
     'ms_concat_style_bwd': (c_int, [_P, _P, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'ms_cross_entropy_fwd': (c_int, [_P, _P, _P, _P] + [c_int] * 6 + [_P]),
     'ms_cross_entropy_bwd': (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [_P]),
+    'ms_cross_entropy_fwd_ex': (c_int, [_P, _P, _P] + [c_int] * 6 + [_P, _P]),
+    'ms_cross_entropy_bwd_ex': (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [_P, _P]),
+    'ms_lp_mean_fwd_ex': (c_int, [c_int, _P, _P, c_float, _P, _P, c_size_t, _P, _P]),
+    'ms_lp_mean_bwd_ex': (c_int, [c_int, _P, _P, c_float, _P, _P, c_size_t, _P, _P]),
     'ms_velocity_fwd': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     'ms_velocity_bwd': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     'ms_transpose_btc': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
@@ -106,6 +115,7 @@ SIGNATURES = {
     'ms_l1_mean_bwd': (c_int, [_P, _P, c_float, _P, _P, c_size_t, _P]),
     'ms_l2_mean_fwd': (c_int, [_P, _P, c_float, _P, _P, c_size_t, _P]),
     'ms_l2_mean_bwd': (c_int, [_P, _P, c_float, _P, _P, c_size_t, _P]),
+    'ms_copy_multi': (c_int, [c_int, _P, _P, _P, _P]),
     'ms_sqnorm': (c_int, [_P, c_size_t, _P, _P, _P]),
     'ms_adam_step': (c_int, [_P, _P, _P, _P, c_size_t, _P, c_float, c_float, c_float, c_float, c_float, _P, _P]),
     'ms_adam_step_segmented': (c_int, [_P, _P, _P, _P, c_size_t, _P, c_float, c_float, c_float, c_float, c_float, _P, _P, _P, _P,

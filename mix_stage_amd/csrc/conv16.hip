@@ -1,5 +1,7 @@
 // 16-bit arithmetic mode: tile planning, weight preparation and dispatch of conv16_kernel (conv16_kernel.h).
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 #include "conv16_kernel.h"
 
@@ -277,8 +279,23 @@ static int launch_one(const Conv16Args& a, int lds_bytes, int nwg, hipStream_t s
       // the occupancy query can answer one workgroup per CU too many for kernels with 81+ SGPRs (MI355X_MICROARCH.md,
       // "Residency and cooperative launch"): stay at or below what 112 SGPRs admit
       per_cu = std::min(per_cu, 6 * 256 / (128 * NWN));
+      // ... and leave room in the register file for foreign waves: a launch whose workgroups fill the CU's registers exactly
+      // (4 x 128 per SIMD, measured with the fp32 decoder kernel) stalls for SECONDS when a second stream's kernel holds a few
+      // registers of one CU while this launch's resident workgroups spin for the member that cannot be placed.  With
+      // 96 registers per SIMD lane left over the foreign wave and the member coexist (tests/test_gpu_bnfused.py, the load test).
+      hipFuncAttributes fa = {};
+      if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(fn)) != hipSuccess || fa.numRegs <= 0) {
+        (void)hipGetLastError();
+        per_cu = 0;
+      } else {
+        const int regs = (fa.numRegs + 7) & ~7, waves_per_simd = (128 * NWN) / 256 > 0 ? (128 * NWN) / 256 : 1;
+        per_cu = std::min(per_cu, (512 - 96) / (regs * waves_per_simd));
+      }
       cached = per_cu * cus;
       cached_lds = lds_bytes;
+      if (getenv("MS_PRINT_REGS"))
+        fprintf(stderr, "conv16<KW%d WM%d WN%d UP2%d DMA%d NWN%d CKX%d> lds %d: %d workgroups per CU for the in-launch BatchNorm, %d registers\n", KW, WM,
+                WN, (int)UP2, (int)DMA, NWN, CKX, lds_bytes, per_cu, fa.numRegs);
     }
     *resident_query = cached;
     return 0;

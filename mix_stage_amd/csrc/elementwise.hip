@@ -745,11 +745,19 @@ __global__ __launch_bounds__(256) void concat_style_bwd_emb_kernel(const float* 
   if (threadIdx.x == 0) demb[(size_t)sidx * D + j] = acc;
 }
 
+// loss weights (ms_loss_scale): a host constant and / or one float on the device, applied as torch applies `loss * w` and
+// `grad * w` (fp32 products, in this order), so that folding them into the kernels changes no bit
+__device__ inline float loss_weight(float v, float mul, const float* mul_dev) {
+  if (mul != 1.0f) v *= mul;
+  if (mul_dev) v *= mul_dev[0];
+  return v;
+}
+
 // ----------------------------------------------------------------------------------------------
 // cross entropy (mean over rows); single workgroup, fixed order
 __global__ __launch_bounds__(1024) void cross_entropy_fwd_kernel(const float* __restrict__ score, const int64_t* __restrict__ target,
                                                                  float* __restrict__ loss, int n_outer, int n_inner, int C,
-                                                                 int so, int sc, int si) {
+                                                                 int so, int sc, int si, float mul, const float* __restrict__ mul_dev) {
   __shared__ float red[16];
   const int rows = n_outer * n_inner;
   float acc = 0.f;
@@ -768,13 +776,14 @@ __global__ __launch_bounds__(1024) void cross_entropy_fwd_kernel(const float* __
   if (threadIdx.x == 0) {
     float s = 0.f;
     for (int w = 0; w < 16; ++w) s += red[w];          // fixed order
-    loss[0] = s / (float)rows;
+    loss[0] = loss_weight(s / (float)rows, mul, mul_dev);
   }
 }
 
 __global__ void cross_entropy_bwd_kernel(const float* __restrict__ score, const int64_t* __restrict__ target,
                                          const float* __restrict__ gscale, float* __restrict__ dscore, int n_outer,
-                                         int n_inner, int C, int so, int sc, int si, int accumulate) {
+                                         int n_inner, int C, int so, int sc, int si, int accumulate, float mul,
+                                         const float* __restrict__ mul_dev) {
   const int rows = n_outer * n_inner;
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
@@ -786,7 +795,7 @@ __global__ void cross_entropy_bwd_kernel(const float* __restrict__ score, const 
   for (int c = 0; c < C; ++c) mx = fmaxf(mx, sp[(size_t)c * sc]);
   float den = 0.f;
   for (int c = 0; c < C; ++c) den += expf(sp[(size_t)c * sc] - mx);
-  const float g = gscale[0] / (float)rows, inv = 1.f / den;
+  const float g = loss_weight(gscale[0], mul, mul_dev) / (float)rows, inv = 1.f / den;
   const int tg = (int)target[r];
   for (int c = 0; c < C; ++c) {
     const float v = g * (expf(sp[(size_t)c * sc] - mx) * inv - (c == tg ? 1.f : 0.f));
@@ -871,7 +880,7 @@ __global__ __launch_bounds__(256) void sq_partial_kernel(const float* __restrict
 
 // mode 0: out = sum * scale ; mode 1: out = sqrt(sum)
 __global__ __launch_bounds__(256) void reduce_final_kernel(const float* __restrict__ partials, int n, float* out, float scale,
-                                                           int mode) {
+                                                           int mode, float mul = 1.0f, const float* __restrict__ mul_dev = nullptr) {
   __shared__ double red[4];
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += 256) s += (double)partials[i];
@@ -880,14 +889,15 @@ __global__ __launch_bounds__(256) void reduce_final_kernel(const float* __restri
   __syncthreads();
   if (threadIdx.x == 0) {
     const double tot = red[0] + red[1] + red[2] + red[3];
-    out[0] = mode == 1 ? (float)sqrt(tot) : (float)(tot * (double)scale);
+    out[0] = mode == 1 ? (float)sqrt(tot) : loss_weight((float)(tot * (double)scale), mul, mul_dev);
   }
 }
 
 template <int SQ>
 __global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, float target,
-                                                     const float* __restrict__ gscale, float* __restrict__ da, size_t n) {
-  const float g = gscale[0] / (float)n;
+                                                     const float* __restrict__ gscale, float* __restrict__ da, size_t n, float mul,
+                                                     const float* __restrict__ mul_dev) {
+  const float g = loss_weight(gscale[0], mul, mul_dev) / (float)n;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float d = a[i] - (b ? b[i] : target);
     da[i] = SQ ? 2.f * g * d : (d > 0.f ? g : (d < 0.f ? -g : 0.f));
@@ -1265,24 +1275,46 @@ int ms_concat_style_bwd(const float* dout, const int64_t* ids, int ids_stride_b,
   return 0;
 }
 
-int ms_cross_entropy_fwd(const float* score, const int64_t* target, float* loss, float* row_scratch, int n_outer, int n_inner,
-                         int C, int stride_outer, int stride_c, int stride_inner, void* stream) {
+static int cross_entropy_fwd(const float* score, const int64_t* target, float* loss, int n_outer, int n_inner, int C,
+                             int stride_outer, int stride_c, int stride_inner, void* stream, const ms_loss_scale* ls) {
   TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_cross_entropy_fwd");
   if (ts.skip()) return 0;
-  (void)row_scratch;
   hipLaunchKernelGGL(cross_entropy_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, score, target, loss, n_outer, n_inner,
-                     C, stride_outer, stride_c, stride_inner);
+                     C, stride_outer, stride_c, stride_inner, ls ? ls->scale : 1.0f, ls ? ls->scale_dev : nullptr);
   return check_launch("cross_entropy_fwd_kernel");
 }
-
-int ms_cross_entropy_bwd(const float* score, const int64_t* target, const float* gscale, float* dscore, int n_outer, int n_inner,
-                         int C, int stride_outer, int stride_c, int stride_inner, int accumulate, void* stream) {
+static int cross_entropy_bwd(const float* score, const int64_t* target, const float* gscale, float* dscore, int n_outer, int n_inner,
+                             int C, int stride_outer, int stride_c, int stride_inner, int accumulate, void* stream,
+                             const ms_loss_scale* ls) {
   TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_cross_entropy_bwd");
   if (ts.skip()) return 0;
   const int rows = n_outer * n_inner;
   hipLaunchKernelGGL(cross_entropy_bwd_kernel, dim3(cdiv(rows, 64)), dim3(64), 0, (hipStream_t)stream, score, target, gscale,
-                     dscore, n_outer, n_inner, C, stride_outer, stride_c, stride_inner, accumulate);
+                     dscore, n_outer, n_inner, C, stride_outer, stride_c, stride_inner, accumulate, ls ? ls->scale : 1.0f,
+                     ls ? ls->scale_dev : nullptr);
   return check_launch("cross_entropy_bwd_kernel");
+}
+
+int ms_cross_entropy_fwd(const float* score, const int64_t* target, float* loss, float* row_scratch, int n_outer, int n_inner,
+                         int C, int stride_outer, int stride_c, int stride_inner, void* stream) {
+  (void)row_scratch;
+  return cross_entropy_fwd(score, target, loss, n_outer, n_inner, C, stride_outer, stride_c, stride_inner, stream, nullptr);
+}
+int ms_cross_entropy_fwd_ex(const float* score, const int64_t* target, float* loss, int n_outer, int n_inner, int C,
+                            int stride_outer, int stride_c, int stride_inner, void* stream, const ms_loss_scale* ls) {
+  return cross_entropy_fwd(score, target, loss, n_outer, n_inner, C, stride_outer, stride_c, stride_inner, stream, ls);
+}
+
+int ms_cross_entropy_bwd(const float* score, const int64_t* target, const float* gscale, float* dscore, int n_outer, int n_inner,
+                         int C, int stride_outer, int stride_c, int stride_inner, int accumulate, void* stream) {
+  return cross_entropy_bwd(score, target, gscale, dscore, n_outer, n_inner, C, stride_outer, stride_c, stride_inner, accumulate,
+                           stream, nullptr);
+}
+int ms_cross_entropy_bwd_ex(const float* score, const int64_t* target, const float* gscale, float* dscore, int n_outer, int n_inner,
+                            int C, int stride_outer, int stride_c, int stride_inner, int accumulate, void* stream,
+                            const ms_loss_scale* ls) {
+  return cross_entropy_bwd(score, target, gscale, dscore, n_outer, n_inner, C, stride_outer, stride_c, stride_inner, accumulate,
+                           stream, ls);
 }
 
 int ms_velocity_fwd(const float* x, float* v, int B, int T, int P, void* stream) {
@@ -1315,42 +1347,101 @@ int ms_transpose_bct(const float* x, float* y, int B, int C, int T, void* stream
 
 size_t ms_reduce_partials_count(size_t n) { return (size_t)red_blocks(n); }
 
-static int lp_mean_fwd(int sq, const float* a, const float* b, float target, float* loss, float* partials, size_t n, void* stream) {
+static int lp_mean_fwd(int sq, const float* a, const float* b, float target, float* loss, float* partials, size_t n, void* stream,
+                       const ms_loss_scale* ls) {
   if (!a || !loss || !partials || n == 0) return set_error("ms_l%d_mean_fwd: bad argument", sq ? 2 : 1);
+  TimingScope ts((hipStream_t)stream, 0, 0, sq ? "ew|ew_l2_mean_fwd" : "ew|ew_l1_mean_fwd");
+  if (ts.skip()) return 0;
   const int nb = red_blocks(n);
   if (sq) hipLaunchKernelGGL(l1_partial_kernel<1>, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, b, target, partials, n);
   else hipLaunchKernelGGL(l1_partial_kernel<0>, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, b, target, partials, n);
   int rc = check_launch("l1_partial_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nb, loss, 1.0f / (float)n, 0);
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nb, loss, 1.0f / (float)n, 0,
+                     ls ? ls->scale : 1.0f, ls ? ls->scale_dev : nullptr);
   return check_launch("reduce_final_kernel");
 }
-static int lp_mean_bwd(int sq, const float* a, const float* b, float target, const float* gscale, float* da, size_t n, void* stream) {
+static int lp_mean_bwd(int sq, const float* a, const float* b, float target, const float* gscale, float* da, size_t n, void* stream,
+                       const ms_loss_scale* ls) {
   if (!a || !gscale || !da || n == 0) return set_error("ms_l%d_mean_bwd: bad argument", sq ? 2 : 1);
-  if (sq) hipLaunchKernelGGL(l1_bwd_kernel<1>, dim3(red_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, target, gscale, da, n);
-  else hipLaunchKernelGGL(l1_bwd_kernel<0>, dim3(red_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, target, gscale, da, n);
+  TimingScope ts((hipStream_t)stream, 0, 0, sq ? "ew|ew_l2_mean_bwd" : "ew|ew_l1_mean_bwd");
+  if (ts.skip()) return 0;
+  const float mul = ls ? ls->scale : 1.0f;
+  const float* mul_dev = ls ? ls->scale_dev : nullptr;
+  if (sq) hipLaunchKernelGGL(l1_bwd_kernel<1>, dim3(red_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, target, gscale, da, n, mul, mul_dev);
+  else hipLaunchKernelGGL(l1_bwd_kernel<0>, dim3(red_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, target, gscale, da, n, mul, mul_dev);
   return check_launch("l1_bwd_kernel");
 }
 
 int ms_l1_mean_fwd(const float* a, const float* b, float target, float* loss, float* partials, size_t n, void* stream) {
-  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_l1_mean_fwd");
-  if (ts.skip()) return 0;
-  return lp_mean_fwd(0, a, b, target, loss, partials, n, stream);
+  return lp_mean_fwd(0, a, b, target, loss, partials, n, stream, nullptr);
 }
 int ms_l1_mean_bwd(const float* a, const float* b, float target, const float* gscale, float* da, size_t n, void* stream) {
-  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_l1_mean_bwd");
-  if (ts.skip()) return 0;
-  return lp_mean_bwd(0, a, b, target, gscale, da, n, stream);
+  return lp_mean_bwd(0, a, b, target, gscale, da, n, stream, nullptr);
 }
 int ms_l2_mean_fwd(const float* a, const float* b, float target, float* loss, float* partials, size_t n, void* stream) {
-  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_l2_mean_fwd");
-  if (ts.skip()) return 0;
-  return lp_mean_fwd(1, a, b, target, loss, partials, n, stream);
+  return lp_mean_fwd(1, a, b, target, loss, partials, n, stream, nullptr);
 }
 int ms_l2_mean_bwd(const float* a, const float* b, float target, const float* gscale, float* da, size_t n, void* stream) {
-  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_l2_mean_bwd");
+  return lp_mean_bwd(1, a, b, target, gscale, da, n, stream, nullptr);
+}
+int ms_lp_mean_fwd_ex(int squared, const float* a, const float* b, float target, float* loss, float* partials, size_t n, void* stream,
+                      const ms_loss_scale* ls) {
+  return lp_mean_fwd(squared ? 1 : 0, a, b, target, loss, partials, n, stream, ls);
+}
+int ms_lp_mean_bwd_ex(int squared, const float* a, const float* b, float target, const float* gscale, float* da, size_t n,
+                      void* stream, const ms_loss_scale* ls) {
+  return lp_mean_bwd(squared ? 1 : 0, a, b, target, gscale, da, n, stream, ls);
+}
+
+// ---- several device-to-device copies in ONE launch (the train step's batch inputs into the captured step's static buffers)
+enum { COPY_MULTI_MAX = 8 };
+struct CopyBatch {
+  int n;
+  int block_end[COPY_MULTI_MAX];
+  const char* src[COPY_MULTI_MAX];
+  char* dst[COPY_MULTI_MAX];
+  size_t bytes[COPY_MULTI_MAX];
+};
+__global__ __launch_bounds__(256) void copy_multi_kernel(const CopyBatch cb) {
+  int j = 0;
+  while (j + 1 < cb.n && (int)blockIdx.x >= cb.block_end[j]) ++j;
+  const int b0 = j ? cb.block_end[j - 1] : 0;
+  const size_t off = ((size_t)((int)blockIdx.x - b0) * 256 + threadIdx.x) * 64;      // 64 bytes per thread
+  const char* s = cb.src[j];
+  char* d = cb.dst[j];
+  const size_t n = cb.bytes[j];
+  if (off >= n) return;
+  if (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0 && off + 64 <= n) {
+    const uint4* s4 = reinterpret_cast<const uint4*>(s + off);
+    uint4 v0 = s4[0], v1 = s4[1], v2 = s4[2], v3 = s4[3];
+    uint4* d4 = reinterpret_cast<uint4*>(d + off);
+    d4[0] = v0; d4[1] = v1; d4[2] = v2; d4[3] = v3;
+  } else {
+    for (size_t i = off; i < n && i < off + 64; ++i) d[i] = s[i];
+  }
+}
+
+int ms_copy_multi(int n, const void* const* src, void* const* dst, const size_t* bytes, void* stream) {
+  if (n < 0 || (n > 0 && (!src || !dst || !bytes))) return set_error("ms_copy_multi: bad argument");
+  TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_copy_multi");
   if (ts.skip()) return 0;
-  return lp_mean_bwd(1, a, b, target, gscale, da, n, stream);
+  for (int i0 = 0; i0 < n; i0 += COPY_MULTI_MAX) {
+    CopyBatch cb = {};
+    int blocks = 0;
+    for (int i = i0; i < n && i < i0 + COPY_MULTI_MAX; ++i) {
+      if (!bytes[i]) continue;
+      if (!src[i] || !dst[i]) return set_error("ms_copy_multi: null buffer");
+      cb.src[cb.n] = (const char*)src[i]; cb.dst[cb.n] = (char*)dst[i]; cb.bytes[cb.n] = bytes[i];
+      blocks += (int)((bytes[i] + 256 * 64 - 1) / (256 * 64));
+      cb.block_end[cb.n++] = blocks;
+    }
+    if (!cb.n) continue;
+    hipLaunchKernelGGL(copy_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, cb);
+    const int rc = check_launch("copy_multi_kernel");
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 int ms_sqnorm(const float* g, size_t n, float* norm_out, float* partials, void* stream) {

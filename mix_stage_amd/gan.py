@@ -71,6 +71,7 @@ class GAN(nn.Module):
     # step (HIP graph) follows a schedule that moves between replays.  `_lambda_host_writes`: forward() itself refreshes it
     # (eager use); a trainer that replays captured steps switches that off and writes the values before each replay.
     self._lambda_dev = None
+    self._ones_cache = {}
     self._lambda_host_writes = True
     self.G_flag = True
     self.fake_flag = True
@@ -108,8 +109,13 @@ class GAN(nn.Module):
     return self._loss(y_cap, y)
 
   def estimate_weights(self, x_audio, y_pose, **kwargs):
-    # allocated on the device directly (a host->device copy would not be capturable in a HIP graph)
-    return torch.ones(y_pose.shape[0], device=y_pose.device, dtype=y_pose.dtype), None
+    # sample weights are 1 (gan.py:77-78): one constant per (batch size, device, dtype), made on the device (a host->device copy
+    # would not be capturable in a HIP graph) and reused -- a fill kernel per step otherwise.  Treat it as read-only.
+    key = (y_pose.shape[0], y_pose.device, y_pose.dtype)
+    W = self._ones_cache.get(key)
+    if W is None:
+      W = self._ones_cache[key] = torch.ones(y_pose.shape[0], device=y_pose.device, dtype=y_pose.dtype)
+    return W, None
 
   def estimate_weights_loss(self, W):
     return W

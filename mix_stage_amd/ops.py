@@ -257,13 +257,24 @@ def _flush_deferred_wgrad():
       _deferred['keep'].clear()
   if not jobs:
     return
-  n = len(jobs)
-  parts = (ctypes.c_void_p * n)(*[j[0].data_ptr() for j in jobs])
-  outs = (ctypes.c_void_p * n)(*[j[1].data_ptr() for j in jobs])
-  elems = (ctypes.c_int * n)(*[j[1].numel() for j in jobs])
-  splits = (ctypes.c_int * n)(*[j[2] for j in jobs])
+  # one launch adds every job into its gradient slot; a slot that receives more than one job (a parameter used twice in the
+  # step: the discriminator on fake and real poses, the decoder on the audio and the pose branch) takes them in successive
+  # launches, in the order the backward pass produced them: no two workgroups of a launch add into the same words
+  rounds, seen = [], {}
+  for j in jobs:
+    k = seen.get(j[1].data_ptr(), 0)
+    seen[j[1].data_ptr()] = k + 1
+    if k == len(rounds):
+      rounds.append([])
+    rounds[k].append(j)
   try:
-    check(lib().ms_wgrad_reduce_multi(n, parts, outs, elems, splits, _stream()), 'ms_wgrad_reduce_multi')
+    for rj in rounds:
+      n = len(rj)
+      parts = (ctypes.c_void_p * n)(*[j[0].data_ptr() for j in rj])
+      outs = (ctypes.c_void_p * n)(*[j[1].data_ptr() for j in rj])
+      elems = (ctypes.c_int * n)(*[j[1].numel() for j in rj])
+      splits = (ctypes.c_int * n)(*[j[2] for j in rj])
+      check(lib().ms_wgrad_reduce_multi(n, parts, outs, elems, splits, _stream()), 'ms_wgrad_reduce_multi')
   finally:
     jobs.clear()
 
@@ -310,15 +321,27 @@ class ConvGeom:
     return d
 
 
+LATE = 'late'      # _grad_slot: truthy (autograd gets None for this gradient) but not the slot itself
+
+
 def _grad_slot(param, shape_like):
   """Direct gradient write-through: FlatAdam gives every parameter a view into the flat gradient buffer
   (`_ms_grad_slot`) and marks it fresh at zero_grad.  The first gradient of a step is written straight into the slot
-  by the kernels (autograd then gets None for it: no accumulate kernel); later contributions in the same step fall
-  back to a temporary that autograd adds."""
+  by the kernels (autograd then gets None for it: no accumulate kernel); later contributions in the same step go to a
+  temporary that the deferred reduction adds (second value LATE), or -- without the deferred reductions -- that autograd adds."""
   slot = getattr(param, '_ms_grad_slot', None) if param is not None else None
-  if slot is not None and getattr(param, '_ms_grad_fresh', False) and torch.is_grad_enabled() is False:
-    param._ms_grad_fresh = False
-    return slot, True
+  if slot is not None and torch.is_grad_enabled() is False:
+    if getattr(param, '_ms_grad_fresh', False):
+      param._ms_grad_fresh = False
+      return slot, True
+    if _deferred['on']:
+      # a later contribution of the same step (the discriminator runs on the fake and on the real poses): the kernels write a
+      # temporary, and the ONE reduction launch at the end of the backward pass adds it into the slot (autograd gets None:
+      # no accumulate kernel per parameter)
+      tmp = torch.empty_like(slot)
+      _deferred['jobs'].append((tmp, slot, 1))
+      _queue_deferred_flush()
+      return tmp, LATE
   return torch.empty_like(shape_like), False
 
 
@@ -395,11 +418,11 @@ class _ConvBlockFn(torch.autograd.Function):
       dbeta, direct_be = _grad_slot(pbeta, gamma)
     ws = workspace(d._bwd_ws, dev)
     side = _overlap['stream']
-    if side is not None and need_w and not direct_w:
+    if side is not None and need_w and direct_w is not True:
       # a second contribution to a parameter in this step (autograd will add it on this stream): the first one may
       # still be in flight on the side stream
       torch.cuda.current_stream().wait_stream(side)
-    if side is not None and direct_w and (dbias is None or direct_b):
+    if side is not None and direct_w is True and (dbias is None or direct_b is True):
       # dw goes straight into the flat gradient buffer, so nothing downstream in autograd reads it: run it on the side
       # stream.  Its inputs must outlive this function until the streams are joined.
       ws2 = side_workspace(d._bwd_ws, dev)
@@ -412,11 +435,11 @@ class _ConvBlockFn(torch.autograd.Function):
     else:
       wt = _prepared_for(w, d) if want_dx else None
       part, nsplit = (None, 1)
-      if _deferred['on'] and direct_w:
+      if _deferred['on'] and direct_w is True:
         part, nsplit = _wgrad_partials_for(w, d)
       # the weight-gradient kernel itself is queued (ms_wgrad_flush at the end of the backward pass) when nothing downstream
       # reads dw: it lands in the flat gradient buffer
-      defer_launch = bool(_deferred['on'] and direct_w and dw is not None and DEFER_WGRAD_LAUNCH)
+      defer_launch = bool(_deferred['on'] and direct_w is True and dw is not None and DEFER_WGRAD_LAUNCH)
       if wt is not None or part is not None or defer_launch:
         opt = BwdOptions(None, None, 0, wt.data_ptr() if wt is not None else None,
                          part.data_ptr() if part is not None else None, 1 if defer_launch else 0)
@@ -684,6 +707,15 @@ def concat_style(x, emb_weight, ids):
   return _ConcatStyleFn.apply(x, emb_weight, ids)
 
 
+def _loss_scale(scale):
+  """struct ms_loss_scale for a host constant or a one-float device tensor."""
+  if torch.is_tensor(scale):
+    if not scale.is_cuda or scale.dtype != torch.float32 or scale.numel() != 1:
+      raise TypeError('a tensor loss weight is one float32 on the device')
+    return _lib.LossScale(1.0, scale.data_ptr())
+  return _lib.LossScale(float(scale), None)
+
+
 class _CrossEntropyFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, score, target, layout, scale):
@@ -700,19 +732,21 @@ class _CrossEntropyFn(torch.autograd.Function):
       dims = (N, 1, C, C, 1, 1)
     assert target.numel() == dims[0] * dims[1]
     loss = torch.empty((), dtype=torch.float32, device=score.device)
-    check(lib().ms_cross_entropy_fwd(_ptr(score), _ptr(target), _ptr(loss), None, *dims, _stream()),
-          'ms_cross_entropy_fwd')
+    ls = _loss_scale(scale)          # the weight is applied inside the kernels (bit-identical to `loss * scale`, one launch less)
+    check(lib().ms_cross_entropy_fwd_ex(_ptr(score), _ptr(target), _ptr(loss), *dims, _stream(), ctypes.byref(ls)),
+          'ms_cross_entropy_fwd_ex')
     ctx.save_for_backward(score, target)
     ctx.dims, ctx.scale = dims, scale
-    return loss * scale if scale != 1.0 else loss
+    return loss
 
   @staticmethod
   def backward(ctx, g):
     score, target = ctx.saved_tensors
-    g = (g * ctx.scale if ctx.scale != 1.0 else g).contiguous()
+    g = g.contiguous()
     dscore = torch.empty_like(score)
-    check(lib().ms_cross_entropy_bwd(_ptr(score), _ptr(target), _ptr(g), _ptr(dscore), *ctx.dims, 0, _stream()),
-          'ms_cross_entropy_bwd')
+    ls = _loss_scale(ctx.scale)
+    check(lib().ms_cross_entropy_bwd_ex(_ptr(score), _ptr(target), _ptr(g), _ptr(dscore), *ctx.dims, 0, _stream(),
+                                        ctypes.byref(ls)), 'ms_cross_entropy_bwd_ex')
     return dscore, None, None, None
 
 
@@ -786,24 +820,23 @@ class _L1MeanFn(torch.autograd.Function):
     n = a.numel()
     loss = torch.empty((), dtype=torch.float32, device=a.device)
     part = torch.empty(lib().ms_reduce_partials_count(n), dtype=torch.float32, device=a.device)
-    fwd = lib().ms_l2_mean_fwd if squared else lib().ms_l1_mean_fwd
-    check(fwd(_ptr(a), _ptr(b), target, _ptr(loss), _ptr(part), n, _stream()), 'ms_l2_mean_fwd' if squared else 'ms_l1_mean_fwd')
-    ctx.save_for_backward(a, b)
-    ctx.target, ctx.scale, ctx.squared = target, scale, squared
-    if torch.is_tensor(scale):         # a device-resident weight (gan.py: lambda schedule), read when the kernel runs
-      return loss * scale
-    return loss * scale if scale != 1.0 else loss
+    # `scale`: a host constant, or a device-resident weight (gan.py: lambda schedule) read when the kernels run; either way it
+    # is applied inside the kernels (bit-identical to `loss * scale` / `g * scale`, without their launches)
+    ls = _loss_scale(scale)
+    check(lib().ms_lp_mean_fwd_ex(1 if squared else 0, _ptr(a), _ptr(b), target, _ptr(loss), _ptr(part), n, _stream(),
+                                  ctypes.byref(ls)), 'ms_lp_mean_fwd_ex')
+    ctx.save_for_backward(a, b, scale if torch.is_tensor(scale) else None)
+    ctx.target, ctx.scale, ctx.squared = target, (None if torch.is_tensor(scale) else scale), squared
+    return loss
 
   @staticmethod
   def backward(ctx, g):
-    a, b = ctx.saved_tensors
-    if torch.is_tensor(ctx.scale):
-      g = (g * ctx.scale).contiguous()
-    else:
-      g = (g * ctx.scale if ctx.scale != 1.0 else g).contiguous()
+    a, b, scale_t = ctx.saved_tensors
+    g = g.contiguous()
     da = torch.empty_like(a)
-    bwd = lib().ms_l2_mean_bwd if ctx.squared else lib().ms_l1_mean_bwd
-    check(bwd(_ptr(a), _ptr(b), ctx.target, _ptr(g), _ptr(da), a.numel(), _stream()), 'ms_l2_mean_bwd' if ctx.squared else 'ms_l1_mean_bwd')
+    ls = _loss_scale(scale_t if scale_t is not None else ctx.scale)
+    check(lib().ms_lp_mean_bwd_ex(1 if ctx.squared else 0, _ptr(a), _ptr(b), ctx.target, _ptr(g), _ptr(da), a.numel(), _stream(),
+                                  ctypes.byref(ls)), 'ms_lp_mean_bwd_ex')
     return da, None, None, None, None
 
 
@@ -817,6 +850,21 @@ def l1_mean(a, b=None, target=0.0, scale=1.0):
 def l2_mean(a, b=None, target=0.0, scale=1.0):
   """scale * mean (a - b)^2: gan.py:64-75 with MSELoss, the GAN constructor's default criterion."""
   return _L1MeanFn.apply(a, b, float(target), scale if torch.is_tensor(scale) else float(scale), True)
+
+
+def copy_multi(pairs):
+  """dst.copy_(src) for every (dst, src) pair of contiguous device tensors of equal size and dtype, in ONE launch."""
+  pairs = [(d, s) for d, s in pairs if d.numel()]
+  if not pairs:
+    return
+  for d, s in pairs:
+    if not (d.is_cuda and s.is_cuda and d.is_contiguous() and s.is_contiguous() and d.dtype == s.dtype and d.shape == s.shape):
+      raise TypeError('copy_multi: contiguous device tensors of equal shape and dtype')
+  n = len(pairs)
+  srcs = (ctypes.c_void_p * n)(*[s.data_ptr() for _, s in pairs])
+  dsts = (ctypes.c_void_p * n)(*[d.data_ptr() for d, _ in pairs])
+  sizes = (ctypes.c_size_t * n)(*[d.numel() * d.element_size() for d, _ in pairs])
+  check(lib().ms_copy_multi(n, srcs, dsts, sizes, _stream()), 'ms_copy_multi')
 
 
 # ------------------------------------------------------------------------------------------------

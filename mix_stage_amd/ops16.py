@@ -15,7 +15,6 @@ from ._lib import (BwdOptions, ConvDesc, FwdOptions, MS_BARE, MS_BF16, MS_BN_EVA
 from .ops import _grad_slot, _ptr, _stream, workspace
 
 import os as _os
-_ABL_BWD_RAW = _os.environ.get('MS_ABL_BWD_RAW') == '1'
 TORCH_DT = {MS_BF16: torch.bfloat16, MS_F16: torch.float16}
 MS_DT = {torch.bfloat16: MS_BF16, torch.float16: MS_F16}
 NAME_DT = {'bf16': MS_BF16, 'bfloat16': MS_BF16, 'fp16': MS_F16, 'f16': MS_F16, 'float16': MS_F16, 'half': MS_F16}
@@ -282,14 +281,12 @@ class _ConvBlock16Fn(torch.autograd.Function):
     wt = _prepared16_for(w, d, 'dgrad16') if want_dx else None
     part, nsplit = (None, 1)
     D = ops._deferred
-    if D['on'] and direct_w:
+    if D['on'] and direct_w is True:
       part, nsplit = ops._wgrad_partials_for(w, d)
     # the weight-gradient kernel itself is queued too when nothing downstream reads dw (it lands in the flat buffer)
-    defer_launch = bool(D['on'] and direct_w and dw is not None and ops.DEFER_WGRAD_LAUNCH)
+    defer_launch = bool(D['on'] and direct_w is True and dw is not None and ops.DEFER_WGRAD_LAUNCH)
     opt = BwdOptions(None, None, 0, wt.data_ptr() if wt is not None else None, part.data_ptr() if part is not None else None,
                      1 if defer_launch else 0)
-    if _ABL_BWD_RAW and mode == MS_BN_TRAIN:
-      y = None                  # (timing ablation only: the backward pass reads y_raw everywhere; results are garbage)
     check(lib().ms_conv_block_bwd_ex(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(gamma), None, None, _ptr(y_raw),
                                      _ptr(y), _ptr(save), _ptr(dy), _ptr(dyr), _ptr(dx), _ptr(dx2), _ptr(dw),
                                      _ptr(dbias), _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), _stream(),

@@ -1,3 +1,4 @@
+"""In-launch BatchNorm on / off inside the captured train step, same process, alternating (argument: bf16 | fp32)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -27,7 +28,8 @@ def measure(fused, skip='', reps=40, minw=0, precision='bf16'):
   L.ms_debug_set_skip(None)
   del ts, model
   return out
+PREC = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
 for rnd in range(3):
-  for fused, minw in ((0, 0), (1, 0), (1, 300)):
-    m = measure(fused, minw=minw)
-    print('round %d fused=%d minw=%d  G %.3f D %.3f' % (rnd, fused, minw, m['G'], m['D']))
+  for fused, minw in ((0, 0), (1, 0)) + (((1, 300),) if PREC == 'bf16' else ()):
+    m = measure(fused, minw=minw, precision=PREC)
+    print('%s round %d fused=%d minw=%d  G %.3f D %.3f' % (PREC, rnd, fused, minw, m['G'], m['D']), flush=True)
