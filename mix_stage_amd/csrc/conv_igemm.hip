@@ -477,6 +477,36 @@ __global__ __launch_bounds__(256) void reduce_splits_multi_kernel(const ReduceBa
     for (int k = lane; k < jb.splits; k += 64) s += jb.part[(size_t)k * jb.n + i];
     s = wave_sum(s);
     if (lane == 0) jb.out[i] += s;
+  } else if ((jb.n & 3) == 0 && ((reinterpret_cast<uintptr_t>(jb.part) | reinterpret_cast<uintptr_t>(jb.out)) & 15) == 0) {
+    // 16-byte form: four neighbouring outputs per thread, up to eight slabs in flight (per output the same ascending sum as below)
+    const int n4 = jb.n >> 2;
+    const float4* part4 = reinterpret_cast<const float4*>(jb.part);
+    float4* out4 = reinterpret_cast<float4*>(jb.out);
+    for (int i = b * 256 + threadIdx.x; i < n4; i += nb * 256) {
+      float4 o = out4[i];
+      float4 s = {0.f, 0.f, 0.f, 0.f};
+      int k = 0;
+      for (; k + 8 <= jb.splits; k += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = part4[(size_t)(k + j) * n4 + i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s.x += v[j].x; s.y += v[j].y; s.z += v[j].z; s.w += v[j].w; }
+      }
+      for (; k + 4 <= jb.splits; k += 4) {
+        float4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = part4[(size_t)(k + j) * n4 + i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s.x += v[j].x; s.y += v[j].y; s.z += v[j].z; s.w += v[j].w; }
+      }
+      for (; k < jb.splits; ++k) {
+        const float4 v = part4[(size_t)k * n4 + i];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+      out4[i] = o;
+    }
   } else {
     for (int i = b * 256 + threadIdx.x; i < jb.n; i += nb * 256) {
       jb.out[i] += sum_splits_in_order(jb.part + i, (size_t)jb.n, jb.splits);
@@ -881,7 +911,7 @@ int launch_reduce_splits_multi(ReduceBatch& rb, hipStream_t s) {
   for (int j = 0; j < rb.n; ++j) {
     ReduceJob& jb = rb.job[j];
     jb.wave = (jb.splits >= 32 && jb.n <= 65536) ? 1 : 0;          // as launch_reduce_splits
-    blocks += jb.wave ? cdiv(jb.n, 4) : std::max(1, std::min(cdiv(jb.n, 256), 512));
+    blocks += jb.wave ? cdiv(jb.n, 4) : std::max(1, std::min(cdiv(jb.n, 1024), 512));
     jb.block_end = blocks;
     bytes += 4.0 * jb.n * (jb.splits + 2);
   }

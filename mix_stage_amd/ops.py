@@ -223,9 +223,18 @@ def reset_deferred_wgrad():
 
 
 def _queue_deferred_flush():
+  """The queues (here and in the library: wgrad_patch.hip / wgrad16.hip) are process-wide and flushed on ONE stream at the end
+  of ONE backward pass: every block that queues work during a backward pass must run on the device and stream of the first
+  one.  (The queued kernels ACCUMULATE into the gradient slots: FlatAdam.zero_grad of the same step is a precondition.)"""
+  owner = (torch.cuda.current_device(), _stream().value)
   if not _deferred['queued']:
     _deferred['queued'] = True
+    _deferred['owner'] = owner
     torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred_wgrad)
+  elif _deferred.get('owner') != owner:
+    raise _lib.MixStageLibError('deferred weight-gradient work was queued from two devices or streams in one backward pass '
+                                '(%s, then %s): run concurrent trainers in separate processes or with '
+                                'ops.enable_deferred_wgrad(False)' % (_deferred.get('owner'), owner))
 
 
 def _wgrad_partials_for(w, d):

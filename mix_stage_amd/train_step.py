@@ -21,7 +21,7 @@ import weakref
 import torch
 import torch.distributed as dist
 
-from . import layers, ops
+from . import layers, ops, ops16
 
 _ALIGN = 64  # elements: every parameter starts 256-B aligned inside the flat buffer
 
@@ -228,6 +228,11 @@ class MixStageTrainStep:
         raise NotImplementedError("bn_sync='global' is implemented for the fp32 path")
       if not rccl:
         use_graphs = False      # gloo's statistics exchanges (host side) cannot be captured; RCCL's are graph nodes like any kernel
+    if getattr(model, '_ms_dt', 0) == ops16.MS_F16:
+      # loss-mean gradients of ~1/(B*T*P) = 5e-6 sit in the fp16 subnormal range: without a loss scale (not implemented) the
+      # activation gradients underflow.  fp16 is the inference arithmetic (BASELINE configs[4]); train in bf16 or fp32.
+      raise NotImplementedError("training in fp16 needs loss scaling, which this path does not implement: use 'bf16' or 'fp32'")
+    self.process_group = process_group
     ops.set_bn_sync(bn_sync == 'global', process_group)
     # Data-parallel exchange (world > 1): the live prefix of the flat gradient buffer in `grad_buckets` all-reduces, issued in
     # REVERSE order of the forward pass.  The first of them -- the decoder / logits / classifier gradients, which lead the
@@ -382,6 +387,8 @@ class MixStageTrainStep:
     copies into the captured step's static buffers are skipped."""
     m = self.model
     m.train()
+    # (module-level switch of the ops: another trainer built in this process may have set it differently)
+    ops.set_bn_sync(self.bn_sync == 'global', self.process_group)
     if kind is not None:
       saved = m.D_prob
       m.D_prob = 1.1 if kind == 'D' else -1.0

@@ -309,3 +309,23 @@ def test_ramping_lambda_schedule_under_graphs_equals_eager(precision):
   plain.lambda_scheduler = IncrementalLambdaScheduler([1.0, 1.0], max_interval=10 ** 9)
   _, l1 = _step(plain, O.synthetic_batch(4, M=M, S=S, seed=7), 'G', DEV)
   assert abs(float(l3[1]) - 3.0 * float(l1[1])) <= 1e-5 * max(1.0, abs(float(l3[1]))) and abs(float(l3[0]) - float(l1[0])) <= 1e-6
+
+
+def test_fp16_training_is_refused_and_bn_sync_is_per_trainer():
+  """fp16 has no loss scaling here (activation gradients would underflow): the trainer refuses it instead of training
+  silently wrong.  The module-level bn_sync switch follows the trainer that steps, not the one built last."""
+  import mix_stage_amd as A
+  from mix_stage_amd import ops
+  from mix_stage_amd.train_step import MixStageTrainStep
+  model = _hip(4, 4)
+  A.set_compute_dtype(model, 'fp16')
+  with pytest.raises(NotImplementedError):
+    MixStageTrainStep(model, use_graphs=False)
+  a = MixStageTrainStep(_hip(4, 4), use_graphs=False, bn_sync='global')
+  b = MixStageTrainStep(_hip(4, 4), use_graphs=False, bn_sync='local')
+  assert ops._bn_sync['on'] is False          # b was built last
+  audio, pose, labels, style = O.synthetic_batch(4, M=4, S=4, seed=3)
+  a.step(audio.to(DEV), labels.to(DEV), pose.to(DEV), style.to(DEV), kind='D')
+  assert ops._bn_sync['on'] is True           # ... but a's step runs with a's setting (one rank: same arithmetic as local)
+  b.step(audio.to(DEV), labels.to(DEV), pose.to(DEV), style.to(DEV), kind='D')
+  assert ops._bn_sync['on'] is False
