@@ -245,7 +245,9 @@ class MixStageTrainStep:
     # on the communication stream with the early bucket 2.97 -- the cross-stream edges inside the captured graph cost more than
     # a one-rank exchange can give back (the same was measured for weight gradients on a side stream).  Whether it pays with 8
     # ranks (an exchange of ~0.4 ms over xGMI) has to be measured on such a node; no N > 1 RCCL run exists so far.
-    self.capture_allreduce = rccl
+    # MS_CAPTURE_ALLREDUCE=0: keep the gradient exchange outside the graphs (two graphs per step with an eager all-reduce between
+    # them), should capturing the collective fail on some stack
+    self.capture_allreduce = rccl and os.environ.get('MS_CAPTURE_ALLREDUCE', '1') != '0'
     self.overlap_allreduce = bool(overlap_allreduce) and rccl
     self.grad_buckets = max(1, int(grad_buckets))
     # overlap_wgrad: weight gradients on a side HIP stream (ms_conv_block_bwd_overlap).  Measured on MI355X / ROCm 7.2
@@ -492,6 +494,8 @@ class MixStageTrainStep:
     one_graph = self.world == 1 or self.capture_allreduce
     g1 = torch.cuda.CUDAGraph()
     try:
+      # (a capture that fails half-way cannot be retried in this process -- the stream stays in capture mode -- so there is no
+      # automatic fallback here: MS_CAPTURE_ALLREDUCE=0 selects the two-graph form with the eager exchange up front)
       with torch.cuda.graph(g1, capture_error_mode=mode):
         if one_graph and self.world > 1:
           fake, losses = self._with_marker(self._forward_backward, st['audio'], st['labels'], st['pose'], st['style'], k)
