@@ -5,6 +5,12 @@ TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/final_$TAG
 mkdir -p "$OUT"
+# HBM traffic (FETCH_SIZE / WRITE_SIZE in separate passes) and SQ counters of the north-star launch, every arithmetic mode --
+# first, and into profiles/ of this copy of the tree, so that the bench lines below carry roofline.traffic
+cd "$R" && bash tools/pmc_decoder.sh fp32 bf16x6 bf16 > "$OUT/pmc_decoder.log" 2>&1
+cp gpurun_out/pmc_decoder.json "$OUT/pmc_decoder.json"; cp gpurun_out/sq_counters.json "$OUT/sq_counters.json"
+cp gpurun_out/pmc_decoder.json profiles/r03_pmc_decoder.json
+rm -rf gpurun_out/pmcdec
 cd "$R" && python bench.py > "$OUT/bench_full.log" 2>&1
 grep -o '{"metric.*' "$OUT/bench_full.log" > "$OUT/bench.json"
 python bench.py --precision bf16 --no-cpu-baseline > "$OUT/bench_bf16_full.log" 2>&1
@@ -17,10 +23,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 
 cp "$OUT"/stats/*/*kernel_stats.csv "$OUT/kernel_stats.csv"; rm -rf "$OUT/stats"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats16" -- python3 "$R/bench.py" --precision bf16 --no-cpu-baseline > "$OUT/stats16_bench.log" 2>&1
 cp "$OUT"/stats16/*/*kernel_stats.csv "$OUT/kernel_stats_bf16.csv"; rm -rf "$OUT/stats16"
-# HBM traffic (FETCH_SIZE / WRITE_SIZE in separate passes) and SQ counters of the north-star launch, every arithmetic mode
-cd "$R" && bash tools/pmc_decoder.sh fp32 bf16x6 bf16 > "$OUT/pmc_decoder.log" 2>&1
-cp gpurun_out/pmc_decoder.json "$OUT/pmc_decoder.json"; cp gpurun_out/sq_counters.json "$OUT/sq_counters.json"
-rm -rf gpurun_out/pmcdec
 # what each kernel family costs inside the captured step (launches of a family dropped, step re-captured and re-timed)
 python tools/ablate_step.py fp32 2>&1 | grep -v amdgpu.ids > "$OUT/ablation_fp32.txt"
 python tools/ablate_step.py bf16 2>&1 | grep -v amdgpu.ids > "$OUT/ablation_bf16.txt"
