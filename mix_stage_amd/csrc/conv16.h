@@ -87,17 +87,17 @@ __host__ __device__ inline bool bn_inv_unsafe(float mean, float invstd, float sc
 }
 
 // ---- weight preparation: fp32 master weights -> 16-bit A-operand stages (once per optimizer update)
-struct Prep16Job {
+struct Prep16Job {          // (narrow fields: 72 jobs fit the 4 KB of kernel arguments -- a generator's ~90 operands take 2 launches)
   const float* w;        // (groups*Cog, Cig, KH, KW) fp32
   void* out;
   const float* scale;    // optional per-output-channel factor (eval BatchNorm folded into the weights), forward only
-  int dgrad;             // 0: forward rows = output channels; 1: data gradient rows = input channels, taps reversed, classes
-  int groups, Cog, Cig, KH, KW, SH, SW, PH, PW, bcast;
-  int BM, CK8, nchunks, n_mt;
-  int dt;
+  short groups, Cog, Cig, BM, nchunks, n_mt;
+  unsigned char dgrad;   // 0: forward rows = output channels; 1: data gradient rows = input channels, taps reversed, classes
+  unsigned char KH, KW, SH, SW, PH, PW, bcast, CK8, dt;
   int block_end;
 };
-enum { PREP16_BATCH_MAX = 24 };
+enum { PREP16_BATCH_MAX = 72 };
+static_assert(sizeof(Prep16Job) * PREP16_BATCH_MAX + 8 <= 4096, "Prep16Batch exceeds the kernel-argument segment");
 struct Prep16Batch { int n; Prep16Job job[PREP16_BATCH_MAX]; };
 int launch_prep16_multi(Prep16Batch& pb, hipStream_t s);
 

@@ -143,9 +143,46 @@ __device__ inline void prep16_unit(const Prep16Job& jb, int unit, float* lds) {
   const int m0 = mt * BM + rb * R, k0 = ch * jb.CK8 * 8;
   const int nk = jb.CK8 * 8;                                   // reduction channels of a chunk
   __syncthreads();                                             // the previous unit's gathers are done
+  const bool w16 = (reinterpret_cast<uintptr_t>(jb.w) & 15) == 0 && ((jb.Cig * KHW) & 3) == 0;
   if (!dg) {
     // lds[row][kk*KHW + tap], row pitch nk*KHW + 1
     const int run = nk * KHW, pitch = run + 1;
+    if (w16 && (run & 3) == 0) {
+      // 16-byte loads: 4 consecutive elements of a row's run per lane, 4 loads in flight per thread (the index arithmetic once
+      // per vector); a vector that reaches past the layer's channels (last chunk only) falls back to masked scalar loads
+      const int nv = R * (run >> 2);
+      for (int v0 = t; v0 < nv; v0 += 4 * 256) {
+        float4 val[4];
+        int dst[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int v = v0 + q * 256;
+          const int vc = min(v, nv - 1);
+          const int row = vc / (run >> 2), off = (vc - row * (run >> 2)) << 2;
+          const int m = m0 + row;
+          const bool rowok = v < nv && m < jb.Cog;
+          const int co = g * jb.Cog + min(m, jb.Cog - 1);
+          const size_t src = ((size_t)co * jb.Cig + k0) * KHW + off;
+          const bool full = rowok && k0 + (off + 3) / KHW < jb.Cig;
+          float4 x = {0.f, 0.f, 0.f, 0.f};
+          if (full) {
+            x = *reinterpret_cast<const float4*>(jb.w + src);
+          } else if (rowok) {
+            if (k0 + (off + 0) / KHW < jb.Cig) x.x = jb.w[src + 0];
+            if (k0 + (off + 1) / KHW < jb.Cig) x.y = jb.w[src + 1];
+            if (k0 + (off + 2) / KHW < jb.Cig) x.z = jb.w[src + 2];
+            if (k0 + (off + 3) / KHW < jb.Cig) x.w = jb.w[src + 3];
+          }
+          if (jb.scale) { const float sc = jb.scale[co]; x.x *= sc; x.y *= sc; x.z *= sc; x.w *= sc; }
+          if (!rowok) x = float4{0.f, 0.f, 0.f, 0.f};
+          val[q] = x;
+          dst[q] = v < nv ? row * pitch + off : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (dst[q] >= 0) { lds[dst[q]] = val[q].x; lds[dst[q] + 1] = val[q].y; lds[dst[q] + 2] = val[q].z; lds[dst[q] + 3] = val[q].w; }
+      }
+    } else {
     // 8 loads in flight per thread (clamped addresses, masked values): the unit is a latency chain otherwise
     for (int e0 = t; e0 < R * run; e0 += 8 * 256) {
       float val[8];
@@ -168,10 +205,43 @@ __device__ inline void prep16_unit(const Prep16Job& jb, int unit, float* lds) {
       for (int q = 0; q < 8; ++q)
         if (dst[q] >= 0) lds[dst[q]] = val[q];
     }
+    }
   } else {
     // lds[kk][row*KHW + tap], pitch R*KHW + 1; reduction channel k = output channel (bcast: of any group)
     const int run = R * KHW, pitch = run + 1;
     const int tcog = jb.bcast ? jb.groups * jb.Cog : jb.Cog;
+    if (w16 && (run & 3) == 0 && ((m0 * KHW) & 3) == 0) {
+      const int nv = nk * (run >> 2);
+      for (int v0 = t; v0 < nv; v0 += 4 * 256) {
+        float4 val[4];
+        int dst[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int v = v0 + q * 256;
+          const int vc = min(v, nv - 1);
+          const int kk = vc / (run >> 2), off = (vc - kk * (run >> 2)) << 2;
+          const int k = k0 + kk;
+          const bool kok = v < nv && k < tcog;
+          const int co = jb.bcast ? min(k, tcog - 1) : g * jb.Cog + min(k, tcog - 1);
+          const size_t src = ((size_t)co * jb.Cig + m0) * KHW + off;
+          const bool full = kok && m0 + (off + 3) / KHW < jb.Cig;
+          float4 x = {0.f, 0.f, 0.f, 0.f};
+          if (full) {
+            x = *reinterpret_cast<const float4*>(jb.w + src);
+          } else if (kok) {
+            if (m0 + (off + 0) / KHW < jb.Cig) x.x = jb.w[src + 0];
+            if (m0 + (off + 1) / KHW < jb.Cig) x.y = jb.w[src + 1];
+            if (m0 + (off + 2) / KHW < jb.Cig) x.z = jb.w[src + 2];
+            if (m0 + (off + 3) / KHW < jb.Cig) x.w = jb.w[src + 3];
+          }
+          val[q] = x;
+          dst[q] = v < nv ? kk * pitch + off : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (dst[q] >= 0) { lds[dst[q]] = val[q].x; lds[dst[q] + 1] = val[q].y; lds[dst[q] + 2] = val[q].z; lds[dst[q] + 3] = val[q].w; }
+      }
+    } else {
     for (int e0 = t; e0 < nk * run; e0 += 8 * 256) {
       float val[8];
       int dst[8];
@@ -190,6 +260,7 @@ __device__ inline void prep16_unit(const Prep16Job& jb, int unit, float* lds) {
 #pragma unroll
       for (int q = 0; q < 8; ++q)
         if (dst[q] >= 0) lds[dst[q]] = val[q];
+    }
     }
   }
   __syncthreads();
