@@ -282,7 +282,8 @@ def kernel_roofline(ts, batch, kinds, precision):
   try:
     pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r03_pmc_decoder.json')))
     ent = pmc.get(precision)
-    if ent and ent.get('src_hash') == source_hash():
+    # (the passes measure the HEADLINE decoder layer: 8 groups, 2048 pixels -- other configs get no traffic figure)
+    if ent and ent.get('src_hash') == source_hash() and M == 8 and B_PER_GPU * T == 2048:
       roof['traffic'] = ent['hbm_bytes_per_launch']
       if isinstance(roof.get('block'), dict) and 'block_hbm_bytes' in ent:
         roof['block']['traffic'] = ent['block_hbm_bytes']

@@ -23,6 +23,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 
 cp "$OUT"/stats/*/*kernel_stats.csv "$OUT/kernel_stats.csv"; rm -rf "$OUT/stats"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats16" -- python3 "$R/bench.py" --precision bf16 --no-cpu-baseline > "$OUT/stats16_bench.log" 2>&1
 cp "$OUT"/stats16/*/*kernel_stats.csv "$OUT/kernel_stats_bf16.csv"; rm -rf "$OUT/stats16"
+cd "$R"
 # what each kernel family costs inside the captured step (launches of a family dropped, step re-captured and re-timed)
 python tools/ablate_step.py fp32 2>&1 | grep -v amdgpu.ids > "$OUT/ablation_fp32.txt"
 python tools/ablate_step.py bf16 2>&1 | grep -v amdgpu.ids > "$OUT/ablation_bf16.txt"
