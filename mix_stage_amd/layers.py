@@ -167,6 +167,15 @@ class ConvNormRelu(nn.Module):
       if was_plain:
         x = ops16.to_cb8(x, dt)
         x2 = ops16.to_cb8(x2, dt) if x2 is not None else None
+      if mode == MS_BN_TRAIN and ops.bn_sync_active():
+        # data parallel with bn_sync='global' in the 16-bit modes: the conv leaves its fp32 accumulators as a plain fp32 tensor,
+        # BatchNorm over the batch of ALL ranks runs on that (fp32 statistics, two small collectives, as in the fp32 mode), and
+        # the activation goes back to 16 bits for the next block.  Not the one-launch block: a meeting across ranks inside a
+        # launch would need device-initiated communication.
+        g = self._geometry()
+        y_raw = ops16.conv_block16(x, self.conv.weight, self.conv.bias, g, MS_BARE, x2=x2, in_mode=in_mode, out_f32=True)
+        y = ops.sync_bn_act(y_raw, n.weight, n.bias, n.running_mean, n.running_var, g.slope, g.eps, g.momentum)
+        return y if (was_plain or out_f32) else ops16.to_cb8(y, dt)
       y = ops16.conv_block16(x, self.conv.weight, self.conv.bias, self._geometry(), mode, n.weight, n.bias, n.running_mean,
                              n.running_var, x2=x2, in_mode=in_mode, out_f32=out_f32,
                              bn_folded=getattr(self, '_bn_folded', False))

@@ -224,8 +224,6 @@ class MixStageTrainStep:
     self.bn_sync = bn_sync
     rccl = dist.is_available() and dist.is_initialized() and dist.get_backend(process_group) == 'nccl'
     if bn_sync == 'global':
-      if getattr(model, '_ms_dt', 0):
-        raise NotImplementedError("bn_sync='global' is implemented for the fp32 path")
       if not rccl:
         use_graphs = False      # gloo's statistics exchanges (host side) cannot be captured; RCCL's are graph nodes like any kernel
     if getattr(model, '_ms_dt', 0) == ops16.MS_F16:

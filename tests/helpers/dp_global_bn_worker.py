@@ -35,6 +35,9 @@ def main():
   Bl = 2
   torch.manual_seed(77)
   model = build_hip_gan(M, S)
+  if os.environ.get('DP_PRECISION', 'fp32') != 'fp32':
+    import mix_stage_amd as A
+    A.set_compute_dtype(model, os.environ['DP_PRECISION'])
   ts = MixStageTrainStep(model, use_graphs=True, bn_sync='global')
   assert ts.use_graphs is False
   audio, pose, labels, style = O.synthetic_batch(Bl * world, M=M, S=S, seed=321)

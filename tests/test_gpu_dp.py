@@ -77,6 +77,51 @@ def test_global_bn_dp_equals_single_device():
     assert abs(v - float(sd[k].double().sum())) <= 2e-4 * max(1.0, sd[k].numel() ** 0.5), k
 
 
+def test_global_bn_dp_bf16_equals_single_device_bf16():
+  """bn_sync='global' in the bf16 mode (conv -> fp32 -> BatchNorm over all ranks -> 16 bits): two ranks with 2 clips each
+  against ONE device stepping on the 4 clips in bf16 (same weights, same arithmetic mode: the difference is the fp32 detour of
+  the normalisation and the summation order of the statistics), and against the fp64 oracle within the bf16 rails."""
+  import numpy as np
+  import torch
+  import mix_stage_amd as A
+  from oracle import mixstage_oracle as O
+  from test_gpu_model import build_hip_gan
+  from mix_stage_amd.train_step import MixStageTrainStep
+  env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0', DP_PRECISION='bf16')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+         '--master-port', '29549', os.path.join(ROOT, 'tests', 'helpers', 'dp_global_bn_worker.py')]
+  out, res = _run_ranks(cmd, env)
+  assert out.returncode == 0 and len(res) == 2, (out.stdout[-2000:], out.stderr[-4000:])
+  a, b = sorted(res, key=lambda r: r['rank'])
+  M = S = 2
+  audio, pose, labels, style = O.synthetic_batch(4, M=M, S=S, seed=321)
+  ref = O.build_gan(M=M, S=S)
+  og = torch.optim.Adam(ref.G.parameters(), lr=1e-4)
+  od = torch.optim.Adam(ref.D.parameters(), lr=1e-4)
+  torch.manual_seed(77)
+  single = build_hip_gan(M, S)
+  A.set_compute_dtype(single, 'bf16')
+  ts = MixStageTrainStep(single, use_graphs=False)
+  for kind in ('G', 'D'):
+    torch.manual_seed(77)
+    fake64, losses64, _ = O.oracle_train_step(ref, og, od, audio, pose, labels, style, kind)
+    ts.step(audio.cuda(), labels.cuda(), pose.cuda(), style.cuda(), kind=kind)
+    one = ts.fake_pose.detach().cpu().numpy().reshape(-1)
+    got = np.concatenate([np.array(a['out'][kind]['pose']), np.array(b['out'][kind]['pose'])])
+    f64 = fake64.numpy().reshape(-1)
+    e_dp, e_one, e_pair = np.abs(got - f64).mean(), np.abs(one - f64).mean(), np.abs(got - one).mean()
+    print('bf16 global BN %s-step: dp vs fp64 %.4f, single bf16 vs fp64 %.4f, dp vs single %.4f' % (kind, e_dp, e_one, e_pair))
+    # both are bf16 roundings of the same fp64 step (different ones: the data-parallel form normalises the fp32 accumulators
+    # outside the conv launch): each within the bf16 rail of the oracle, and no further from each other than those two errors
+    assert e_dp <= 3e-2 and e_one <= 3e-2, (kind, e_dp, e_one)
+    assert e_dp <= 1.5 * e_one + 2e-3, (kind, e_dp, e_one)
+    assert e_pair <= e_dp + e_one, (kind, e_pair, e_dp, e_one)
+    mean_losses = (np.array(a['out'][kind]['losses']) + np.array(b['out'][kind]['losses'])) / 2
+    np.testing.assert_allclose(mean_losses, [float(l) for l in ts.losses], atol=2e-2)
+  for k, v in a['probe'].items():
+    assert b['probe'][k] == v                                            # replicas identical
+
+
 def test_rccl_path_single_rank():
   """The RCCL calls of the data-parallel step, executed on the one GPU the box has: a single `nccl` rank forced onto the
   data-parallel form of the step (bucketed all-reduces captured in the step's graph, the first one started at the
