@@ -423,7 +423,8 @@ def main():
   model = build_model(dev, args.precision)
   ts = MixStageTrainStep(model, use_graphs=not args.no_graphs, time_steps=T, bn_sync=args.bn_sync,
                          grad_buckets=int(os.environ.get('MS_GRAD_BUCKETS', '4')),
-                         overlap_allreduce=os.environ.get('MS_OVERLAP_ALLREDUCE', '0') == '1')
+                         overlap_allreduce=os.environ.get('MS_OVERLAP_ALLREDUCE', '0') == '1',
+                         grad_exchange=os.environ.get('MS_GRAD_EXCHANGE', 'fp32'))
   # every rank gets its own shard of synthetic clips (pure data parallel, weak scaling: 32 clips per GPU)
   audio, pose, labels, style = O.synthetic_batch(B_PER_GPU, T=T, F_=F_MEL, P=P, M=M, S=S, seed=1234 + rank)
   batch = [t.to(dev) for t in (audio, labels, pose, style)]

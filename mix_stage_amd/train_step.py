@@ -40,19 +40,29 @@ def _dp_world(process_group=None):
   return 2 if (world == 1 and _single_rank_dp()) else world
 
 
-def average_flat_gradients(flat_g, process_group=None):
+def average_flat_gradients(flat_g, process_group=None, wire=None):
   """The data-parallel exchange step: one all-reduce (RCCL over xGMI on the GPUs; gloo in the CPU tests) of the flat
   gradient buffer, leaving the mean over ranks -- what a single device would have computed on the global batch of
-  equally sized shards (up to per-rank BatchNorm statistics)."""
+  equally sized shards (up to per-rank BatchNorm statistics).
+  wire: optional 16-bit buffer of the same length -- the gradients travel in its dtype (half the bytes on the links; every
+  rank ends with the same values, so the replicas stay identical, but they are the rounded means)."""
   if not (dist.is_available() and dist.is_initialized()):
     return flat_g
   world = dist.get_world_size(process_group)
   if world == 1 and not _single_rank_dp():
     return flat_g
+  buf = flat_g
+  if wire is not None:
+    wire.copy_(flat_g)
+    buf = wire
   if dist.get_backend(process_group) == 'nccl':
-    dist.all_reduce(flat_g, op=dist.ReduceOp.AVG, group=process_group)
+    dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=process_group)
+    if wire is not None:
+      flat_g.copy_(wire)
   else:
-    dist.all_reduce(flat_g, op=dist.ReduceOp.SUM, group=process_group)
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=process_group)
+    if wire is not None:
+      flat_g.copy_(wire)
     flat_g.mul_(1.0 / world)
   return flat_g
 
@@ -217,7 +227,7 @@ class MixStageTrainStep:
   """Runs reference-equivalent training steps for GAN(G, D) on one GPU or data-parallel over ranks."""
 
   def __init__(self, model, lr=1e-4, clip=1.0, use_graphs=True, process_group=None, time_steps=64, overlap_wgrad=False,
-               bn_sync='local', overlap_allreduce=False, grad_buckets=4):
+               bn_sync='local', overlap_allreduce=False, grad_buckets=4, grad_exchange='fp32'):
     self.model = model
     if bn_sync not in ('local', 'global'):
       raise ValueError("bn_sync must be 'local' or 'global'")
@@ -231,6 +241,12 @@ class MixStageTrainStep:
       # activation gradients underflow.  fp16 is the inference arithmetic (BASELINE configs[4]); train in bf16 or fp32.
       raise NotImplementedError("training in fp16 needs loss scaling, which this path does not implement: use 'bf16' or 'fp32'")
     self.process_group = process_group
+    if grad_exchange not in ('fp32', 'bf16'):
+      raise ValueError("grad_exchange must be 'fp32' or 'bf16'")
+    # 'bf16': the gradient all-reduce moves bf16 values (an option for the xGMI-bound exchange of the 16-bit mode; the optimizer
+    # then sees the bf16-rounded mean gradient on every rank).  Default: fp32, the exchange whose result equals a single device's.
+    self.grad_exchange = grad_exchange
+    self._wire = {}
     ops.set_bn_sync(bn_sync == 'global', process_group)
     # Data-parallel exchange (world > 1): the live prefix of the flat gradient buffer in `grad_buckets` all-reduces, issued in
     # REVERSE order of the forward pass.  The first of them -- the decoder / logits / classifier gradients, which lead the
@@ -339,7 +355,8 @@ class MixStageTrainStep:
     cur = torch.cuda.current_stream()
     self._comm.wait_stream(cur)
     with torch.cuda.stream(self._comm):
-      average_flat_gradients(opt.flat_g[:opt.first_elems], self.pg)
+      average_flat_gradients(opt.flat_g[:opt.first_elems], self.pg,
+                             self._wire_buffer(opt)[:opt.first_elems] if self.grad_exchange == 'bf16' else None)
     self._early_done = True
 
   def _all_reduce(self, opt, active=None):
@@ -356,13 +373,20 @@ class MixStageTrainStep:
     for lo, hi in self._bucket_bounds(opt, n):
       if early and lo == 0 and hi == min(opt.first_elems, n):
         continue                          # already on its way since the backward-pass marker
+      wire = self._wire_buffer(opt)[lo:hi] if self.grad_exchange == 'bf16' else None
       if comm is not None:
         with torch.cuda.stream(comm):
-          average_flat_gradients(opt.flat_g[lo:hi], self.pg)
+          average_flat_gradients(opt.flat_g[lo:hi], self.pg, wire)
       else:
-        average_flat_gradients(opt.flat_g[lo:hi], self.pg)
+        average_flat_gradients(opt.flat_g[lo:hi], self.pg, wire)
     if comm is not None:
       cur.wait_stream(comm)
+
+  def _wire_buffer(self, opt):
+    buf = self._wire.get(id(opt))
+    if buf is None:
+      buf = self._wire[id(opt)] = torch.empty(opt.total, dtype=torch.bfloat16, device=opt.flat_g.device)
+    return buf
 
   def _peek_decisions(self):
     th = self.model.G.thresh

@@ -36,7 +36,7 @@ def main():
     with torch.no_grad():
       for p in model.parameters():
         p.mul_(1.5)
-  ts = MixStageTrainStep(model, use_graphs=True)
+  ts = MixStageTrainStep(model, use_graphs=True, grad_exchange=os.environ.get('DP_GRAD_EXCHANGE', 'fp32'))
   kinds = []
   losses = []
   for i in range(6):

@@ -34,6 +34,14 @@ def _worker(rank, world, port, out):
     dist.all_gather(gathered, mine)
     expect = sum(gathered) / world
     ok_mean = torch.allclose(flat, expect, atol=1e-6)
+    # the 16-bit exchange: the mean of the bf16-rounded gradients, identical on every rank
+    flat16 = mine.clone()
+    wire = torch.empty(flat16.numel(), dtype=torch.bfloat16)
+    average_flat_gradients(flat16, wire=wire)
+    expect16 = sum(t.to(torch.bfloat16).float() for t in gathered) / world
+    both = [torch.zeros_like(flat16) for _ in range(world)]
+    dist.all_gather(both, flat16)
+    ok_mean = ok_mean and torch.allclose(flat16, expect16, rtol=2 ** -7, atol=1e-6) and torch.equal(both[0], both[1])
     # identical host seeds -> identical D/G and curriculum decisions on every rank, RNG left untouched by the peek
     torch.manual_seed(4321)
     kinds = []

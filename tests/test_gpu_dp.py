@@ -46,6 +46,26 @@ def test_two_ranks_stay_bit_identical():
   assert all(abs(v) < 1e3 for step in a['losses'] for v in step)
 
 
+def test_two_ranks_bf16_gradient_exchange():
+  """grad_exchange='bf16': the all-reduce moves bf16 values; the replicas still end bit-identical (every rank receives the same
+  means), and the parameters differ from the fp32 exchange only by the rounding of the gradients."""
+  outs = {}
+  for mode, port in (('fp32', '29551'), ('bf16', '29553')):
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0', DP_GRAD_EXCHANGE=mode)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', port, os.path.join(ROOT, 'tests', 'helpers', 'dp_worker.py')]
+    out, res = _run_ranks(cmd, env)
+    assert out.returncode == 0 and len(res) == 2, (out.stdout[-2000:], out.stderr[-4000:])
+    a, b = sorted(res, key=lambda r: r['rank'])
+    assert a['sums'] == b['sums'], (mode, a['sums'], b['sums'])
+    outs[mode] = a
+  assert outs['fp32']['kinds'] == outs['bf16']['kinds']
+  assert outs['fp32']['sums'] != outs['bf16']['sums']                       # the 16-bit wire is really in use
+  for net in ('G', 'D'):
+    (s32, n32), (s16, n16) = outs['fp32']['sums'][net], outs['bf16']['sums'][net]
+    assert abs(n32 - n16) <= 1e-4 * n32, (net, n32, n16)                    # six Adam steps of 1e-4: the same weights to 1e-4
+
+
 def test_global_bn_dp_equals_single_device():
   """bn_sync='global': two ranks with 2 clips each reproduce what ONE device computes on the 4 clips (the reference trains on
   one device, layers.py:65-70): poses and losses of a G-step and a D-step against the oracle at B=4, within the fp32 bar."""
