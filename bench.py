@@ -422,7 +422,7 @@ def main():
   from mix_stage_amd.train_step import MixStageTrainStep
   model = build_model(dev, args.precision)
   ts = MixStageTrainStep(model, use_graphs=not args.no_graphs, time_steps=T, bn_sync=args.bn_sync,
-                         grad_buckets=int(os.environ.get('MS_GRAD_BUCKETS', '4')),
+                         grad_buckets=int(os.environ['MS_GRAD_BUCKETS']) if os.environ.get('MS_GRAD_BUCKETS') else None,
                          overlap_allreduce=os.environ.get('MS_OVERLAP_ALLREDUCE', '0') == '1',
                          grad_exchange=os.environ.get('MS_GRAD_EXCHANGE', 'fp32'))
   # every rank gets its own shard of synthetic clips (pure data parallel, weak scaling: 32 clips per GPU)
