@@ -298,6 +298,66 @@ def test_velocity_transposes_l1(B, T, P):
   assert abs(l.item() - (x.double() - 1).abs().mean().item()) < 1e-6
 
 
+def test_loss_weights_inside_the_kernels_equal_scaling_outside():
+  """ms_loss_scale: a host constant or ONE float on the device applied inside the loss kernels -- bit-identical to torch's
+  `w * loss` on the unweighted kernel result, forward and gradient; the device weight is read when the kernel RUNS."""
+  from mix_stage_amd import ops
+  gen = torch.Generator().manual_seed(9)
+  a = torch.randn(5, 64, 104, generator=gen).to(DEV)
+  b = torch.randn(5, 64, 104, generator=gen).to(DEV)
+  lam = torch.tensor([0.37, 1.83], device=DEV)
+  for squared in (False, True):
+    fn = ops.l2_mean if squared else ops.l1_mean
+    for scale in (0.37, lam[1]):
+      x = a.clone().requires_grad_()
+      base = fn(x, b)                                   # weight 1
+      (g_base,) = torch.autograd.grad(base, x)
+      x2 = a.clone().requires_grad_()
+      l = fn(x2, b, scale=scale)
+      l.backward()
+      w = scale if torch.is_tensor(scale) else torch.tensor(scale, device=DEV)
+      assert torch.equal(l.detach(), base.detach() * w)
+      # gradient: (1 * w) / n * sign(.) in the kernel == the unweighted gradient times w up to one rounding of the product
+      assert torch.allclose(x2.grad, g_base * w, rtol=2e-7, atol=0)
+  sc = torch.randn(32, 8, generator=gen).to(DEV)
+  tg = torch.randint(0, 8, (32,), generator=gen).to(DEV)
+  s1 = sc.clone().requires_grad_(); s2 = sc.clone().requires_grad_()
+  l1 = ops.cross_entropy(s1, tg); l2 = ops.cross_entropy(s2, tg, scale=0.1)
+  assert torch.equal(l2.detach(), l1.detach() * 0.1)
+  l1.backward(); l2.backward()
+  assert torch.allclose(s2.grad, s1.grad * 0.1, rtol=2e-7, atol=0)
+  # a device weight that changes between two launches of the same call is honoured (what a captured step relies on)
+  x = a.clone()
+  v1 = ops.l1_mean(x, b, scale=lam[0]).item()
+  lam[0] = 2.0
+  v2 = ops.l1_mean(x, b, scale=lam[0]).item()
+  assert abs(v2 / v1 - 2.0 / 0.37) < 1e-5
+
+
+def test_copy_multi_any_sizes_and_dtypes():
+  """ms_copy_multi: many device-to-device copies in one launch (more than the 8 a launch holds; odd byte counts; unaligned
+  views; int64)."""
+  from mix_stage_amd import ops
+  gen = torch.Generator().manual_seed(10)
+  pairs, expect = [], []
+  for i, n in enumerate([1, 3, 17, 255, 256, 4097, 65536 + 5, 104 * 64 * 32, 2, 7, 1 << 20]):
+    if i % 3 == 2:
+      src = torch.randint(-9, 9, (n,), generator=gen, dtype=torch.int64).to(DEV)
+    elif i % 3 == 1:
+      src = torch.randn(n + 1, generator=gen).to(DEV)[1:]          # 4-byte aligned only
+    else:
+      src = torch.randn(n, generator=gen).to(DEV)
+    dst = torch.zeros_like(src) if i % 3 != 1 else torch.zeros(n + 3, device=DEV)[3:]
+    pairs.append((dst, src)); expect.append(src.clone())
+  guard = [torch.zeros(n + 3, device=DEV) for n in (255,)]
+  ops.copy_multi(pairs)
+  torch.cuda.synchronize()
+  for (dst, _), e in zip(pairs, expect):
+    assert torch.equal(dst, e)
+  with pytest.raises(TypeError):
+    ops.copy_multi([(torch.zeros(4, device=DEV), torch.zeros(5, device=DEV))])
+
+
 def test_cpu_tensor_fails_loudly():
   from mix_stage_amd import ops, _lib
   with pytest.raises(_lib.MixStageLibError):
