@@ -32,4 +32,6 @@ for precision in ('fp32', 'bf16'):
     assert ok and mem[1] <= mem[0] + 8 and not ops._deferred['keep'] and not ops._deferred['jobs']
     del ts, model
     torch.cuda.empty_cache()
+from mix_stage_amd import ops16
+assert not ops16.bn_sync_error(), 'an in-launch BatchNorm meeting timed out during the soak'
 print('soak ok')
