@@ -502,6 +502,12 @@ class MixStageTrainStep:
     finally:
       layers.set_train_tape(None)
     warm_active = opt.active_params()
+    if self.world > 1 and self.capture_allreduce:
+      # the collective library sets up channels / buffers the first time it sees a message size: let that happen in an eager
+      # exchange of exactly the slices the captured step will exchange (the warm-up gradients are discarded anyway)
+      with torch.cuda.stream(side):
+        self._early_done = False
+        self._all_reduce(opt, warm_active)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     with torch.no_grad():
