@@ -68,13 +68,17 @@ def parse():
   ap.add_argument('--bn-sync', default='local', choices=['local', 'global'])
   ap.add_argument('--dist-backend', default='nccl', help='nccl (= RCCL over xGMI); gloo only for smoke-testing the DP path')
   ap.add_argument('--same-device', action='store_true', help='smoke test: all ranks share cuda:0 (needs --dist-backend gloo)')
+  ap.add_argument('--worker', action='store_true', help='(internal) this process is a rank worker started by the supervising rank process')
+  ap.add_argument('--batch', type=int, default=None, help='diagnostic: clips per GPU instead of the configuration\'s (profiles/r04_frac_vs_batch.json); the default invocation is the metric\'s B=32')
   args = ap.parse_args()
   cfg = CONFIGS[args.config]
   global B_PER_GPU, T, M, S, G_STEP_GFLOP, D_STEP_GFLOP
   B_PER_GPU, T, M, S = cfg['B'], cfg['T'], cfg['M'], cfg['S']
+  if args.batch:
+    B_PER_GPU = args.batch
   if args.precision is None:
     args.precision = cfg['precision'] or 'fp32'
-  if args.config != 'headline':
+  if args.config != 'headline' or args.batch:
     # forward GFLOP of this configuration (SURVEY.md A.3 scaling: everything is linear in B*T, decoder and logits in M too)
     bt = (B_PER_GPU * T) / (32.0 * 64.0)
     fwd = bt * (62.31 + 4.21 + 0.50 + 4.87 + (26.02 + 0.87) * M / 8.0 + 0.215)
@@ -96,6 +100,85 @@ def self_launch(args):
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
          '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
   return subprocess.run(cmd, env=env).returncode
+
+
+class Watchdog:
+  """Rank worker: exits non-zero (code 3) when no progress was reported for `limit` seconds -- a hung collective must end the run
+  with an error line, not hang the node.  beat(phase, limit) re-arms it."""
+
+  def __init__(self):
+    import threading
+    self.last, self.limit, self.phase = time.time(), 900.0, 'start'
+    t = threading.Thread(target=self._run, daemon=True)
+    t.start()
+
+  def beat(self, phase=None, limit=None):
+    self.last = time.time()
+    if phase:
+      self.phase = phase
+    if limit:
+      self.limit = float(limit)
+
+  def _run(self):
+    while True:
+      time.sleep(2.0)
+      if time.time() - self.last > self.limit:
+        sys.stderr.write('bench watchdog: no progress for %.0f s in phase %r -- exiting\n' % (self.limit, self.phase))
+        sys.stderr.flush()
+        os._exit(3)
+
+
+def supervise(args):
+  """One rank under the launcher (world > 1), BEFORE anything touches the GPU: runs the real rank as a fresh child process, so that a
+  failed or hung first attempt -- this is the first code path of the repository to move bytes between GPUs -- can be repeated once
+  in a more conservative form instead of losing the measurement.  The supervisors of all ranks agree over a gloo group (CPU) on
+  whether the attempt succeeded.  Attempt 1: the default step (HIP graphs around an eager RCCL all-reduce).  Attempt 2 (only if any
+  rank failed): no HIP graphs at all (`"dp_fallback": "no-graphs"` in the line).  The supervisor never initialises HIP."""
+  import tempfile
+  import torch.distributed as dist
+  import datetime
+  rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+  dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=1800))
+  attempts = [({}, None), ({'MS_BENCH_NO_GRAPHS': '1'}, 'no-graphs')]
+  tails = []
+  for extra, tag in attempts:
+    port = [0]
+    if rank == 0:
+      with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port[0] = sk.getsockname()[1]
+    dist.broadcast_object_list(port, src=0)
+    env = dict(os.environ, MASTER_PORT=str(port[0]), **extra)
+    if tag:
+      env['MS_DP_FALLBACK'] = tag
+    errf = tempfile.TemporaryFile(mode='w+')
+    child = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != '--worker'] + ['--worker'],
+                             env=env, stdout=subprocess.PIPE, stderr=errf, text=True)
+    try:
+      out, _ = child.communicate(timeout=1500)
+      ok = child.returncode == 0
+    except subprocess.TimeoutExpired:
+      child.kill()
+      out, _ = child.communicate()
+      ok = False
+    errf.seek(0)
+    err_tail = errf.read()[-1500:]
+    flags = [None] * world
+    dist.all_gather_object(flags, (bool(ok), child.returncode, err_tail if not ok else ''))
+    if all(f[0] for f in flags):
+      if rank == 0:
+        sys.stdout.write(out)
+        sys.stdout.flush()
+      dist.barrier()
+      dist.destroy_process_group()
+      return 0
+    tails.append({'attempt': tag or 'default', 'ranks': [{'rank': i, 'rc': f[1], 'stderr_tail': f[2]} for i, f in enumerate(flags) if not f[0]]})
+    sys.stderr.write('bench supervisor rank %d: attempt %r failed on %d rank(s)\n' % (rank, tag or 'default', sum(1 for f in flags if not f[0])))
+  if rank == 0:
+    print(json.dumps({'metric': CONFIGS[args.config]['metric'], 'value': None, 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps,
+                      'warmup': args.warmup, 'error': 'every attempt failed', 'attempts': tails}))
+  dist.destroy_process_group()
+  return 1
 
 
 def build_model(dev, precision='fp32'):
@@ -399,6 +482,12 @@ def main():
     sys.exit(self_launch(args))
   if world != args.gpus:
     raise SystemExit('WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
+  if world > 1 and not args.worker and os.environ.get('MS_BENCH_SUPERVISE', '1') != '0':
+    sys.exit(supervise(args))
+  if os.environ.get('MS_BENCH_NO_GRAPHS') == '1':
+    args.no_graphs = True
+  wd = Watchdog()
+  wd.beat('import', 900)
   import torch
   import torch.distributed as dist
   rank = int(os.environ.get('RANK', '0'))
@@ -430,9 +519,14 @@ def main():
   batch = [t.to(dev) for t in (audio, labels, pose, style)]
   torch.manual_seed(args.seed)          # identical host generators on all ranks -> identical D/G decisions
 
+  wd.beat('warmup', 300)                # (the first steps capture the graphs and set up RCCL's channels)
   for _ in range(args.warmup):
     ts.step(*batch)
+    torch.cuda.synchronize()
+    wd.beat('warmup', 300)
+  wd.beat('timed', 120)
   elapsed, kinds = time_steps(ts, batch, args.steps, None, world, dist, dev)
+  wd.beat('per-kind', 120)
   losses = [float(l.detach()) for l in ts.losses]
   finite = all(l == l and abs(l) < 1e6 for l in losses)
   per_kind = None
@@ -443,6 +537,9 @@ def main():
       for _ in range(2):
         ts.step(*batch, kind=kind)
       per_kind[kind] = time_steps(ts, batch, n_k, kind, world, dist, dev)[0] / n_k
+      wd.beat('per-kind', 120)
+  ts.check_health()                    # raises if a launch whose workgroups meet in-launch timed out (outputs would be NaN)
+  wd.beat('report', 1200)
 
   out = None
   if rank == 0:
@@ -461,6 +558,9 @@ def main():
                    'bn_sync': args.bn_sync},
         'last_losses': [round(l, 5) for l in losses], 'losses_finite': finite,
     }
+    if world > 1:
+      out['dp_fallback'] = os.environ.get('MS_DP_FALLBACK') or False
+      out['config']['grad_exchange'] = 'captured in the step graph' if ts.capture_allreduce else ('eager RCCL all-reduce between two graphs' if not args.no_graphs else 'eager')
     if per_kind:
       g_ms, d_ms = 1e3 * per_kind['G'], 1e3 * per_kind['D']
       peak = {'fp32': FP32_MFMA_PEAK_TFLOPS, 'bf16x6': FP32_MFMA_PEAK_TFLOPS, 'bf16': BF16_MFMA_PEAK_TFLOPS}[args.precision]

@@ -102,6 +102,12 @@ int ms_conv_block_fwd(const ms_conv_desc* d, const float* x, const float* x2, co
  * three bf16 planes); NULL = split them per call into the scratch. */
 typedef struct ms_fwd_options {
   const void* w_planes;
+  /* 16-bit BN_TRAIN blocks: zero-initialised int32 words through which the workgroups of the launch meet for the batch statistics
+   * (BatchNorm inside the conv launch).  Give every (device, stream) that runs such blocks concurrently a buffer of its own;
+   * NULL = the process-wide buffer of ms_set_bn_sync_buffer.  Word 0 is raised when a workgroup gave up waiting (the block's
+   * output is then NaN, the running statistics are left alone). */
+  int32_t* bn_sync;
+  int32_t bn_sync_words;
 } ms_fwd_options;
 int ms_conv_block_fwd_ex(const ms_conv_desc* d, const float* x, const float* x2, const float* w,
                          const float* bias, const float* gamma, const float* beta, float* running_mean,
@@ -350,6 +356,10 @@ int ms_lp_mean_bwd_ex(int squared, const float* a, const float* b, float target,
 /* n device-to-device copies (any sizes, any alignment) in one launch: the batch tensors of a step into the buffers a captured
  * step reads (the reference hands `batch` to the model directly, trainer.py:1077-1110; a HIP graph needs fixed addresses). */
 int ms_copy_multi(int n, const void* const* src, void* const* dst, const size_t* bytes, void* stream);
+
+/* n <= 8 host floats -> device, by value through the kernel arguments (no asynchronous read of host memory): the GAN loss
+ * weights of a step (gan.py:103, lambda_scheduler.step()) into the 2-float tensor the captured loss kernels read. */
+int ms_write_floats(float* dst, const float* host_values, int n, void* stream);
 
 /* Trainer step tail (trainer.py:1138-1146): global L2 norm of a flat gradient buffer, then
  * clip_grad_norm_(., max_norm) folded into a fused Adam step (torch.optim.Adam defaults).

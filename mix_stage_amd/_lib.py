@@ -30,7 +30,7 @@ class LossScale(ctypes.Structure):
 
 class FwdOptions(ctypes.Structure):
   """struct ms_fwd_options"""
-  _fields_ = [('w_planes', ctypes.c_void_p)]
+  _fields_ = [('w_planes', ctypes.c_void_p), ('bn_sync', ctypes.c_void_p), ('bn_sync_words', ctypes.c_int32)]
 
 
 class ConvDesc(ctypes.Structure):
@@ -116,6 +116,7 @@ SIGNATURES = {
     'ms_l2_mean_fwd': (c_int, [_P, _P, c_float, _P, _P, c_size_t, _P]),
     'ms_l2_mean_bwd': (c_int, [_P, _P, c_float, _P, _P, c_size_t, _P]),
     'ms_copy_multi': (c_int, [c_int, _P, _P, _P, _P]),
+    'ms_write_floats': (c_int, [_P, _P, c_int, _P]),
     'ms_sqnorm': (c_int, [_P, c_size_t, _P, _P, _P]),
     'ms_adam_step': (c_int, [_P, _P, _P, _P, c_size_t, _P, c_float, c_float, c_float, c_float, c_float, _P, _P]),
     'ms_adam_step_segmented': (c_int, [_P, _P, _P, _P, c_size_t, _P, c_float, c_float, c_float, c_float, c_float, _P, _P, _P, _P,

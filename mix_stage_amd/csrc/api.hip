@@ -128,7 +128,7 @@ int ms_conv_block_fwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
   if (d->in_mode == MS_IN_UP2ADD && !x2) return set_error("ms_conv_block_fwd: UP2ADD needs x2");
   if (dt_of(d) != DT_F32)     // 16-bit modes: the tensor pointers are cb8 buffers (include/mixstage.h, ms_dtype)
     return block_fwd16(d, x, x2, w, bias, gamma, beta, running_mean, running_var, y_raw, y, save, workspace, workspace_bytes,
-                       (hipStream_t)stream, w_planes);
+                       (hipStream_t)stream, w_planes, opt ? opt->bn_sync : nullptr, opt ? opt->bn_sync_words : 0);
   if (workspace_bytes < ms_conv_block_fwd_workspace(d)) return set_error("ms_conv_block_fwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   const int C = ctot_of(d), npix = d->B * d->OH * d->OW, hw = d->OH * d->OW;

@@ -116,9 +116,10 @@ size_t block_bwd16_workspace(const ms_conv_desc* d) {
 
 int block_fwd16(const ms_conv_desc* d, const void* x, const void* x2, const float* w, const float* bias, const float* gamma,
                 const float* beta, float* running_mean, float* running_var, void* y_raw, void* y, float* save, void* workspace,
-                size_t workspace_bytes, hipStream_t s, const void* w_prepared) {
+                size_t workspace_bytes, hipStream_t s, const void* w_prepared, int32_t* bn_sync, int bn_sync_words) {
   const Geo16 g = geo_of(d);
   if (g.dt != DT_BF16 && g.dt != DT_F16) return set_error("ms_conv_block_fwd: dtype %d", d->dtype);
+  if (!bn_sync) { bn_sync = g_bn_sync; bn_sync_words = g_bn_sync_n; }      // (the process-wide buffer of ms_set_bn_sync_buffer)
   const Conv16Plan pl = fwd_plan16(d);
   if (!pl.ok) return set_error("ms_conv_block_fwd: no 16-bit kernel for a %dx%d stride (%d,%d) block", d->KH, d->KW, d->SH, d->SW);
   if (d->groups > 1 && ((d->Cout & 7) || (!g.bcast && (d->Cin & 7))))
@@ -178,17 +179,17 @@ int block_fwd16(const ms_conv_desc* d, const void* x, const void* x2, const floa
   // train-mode BatchNorm inside the conv launch (conv16_kernel.h, EP_BN_FUSED): the workgroups of a channel tile exchange
   // their partial statistics and normalise from registers -- taken when the whole grid is resident at once
   bool fused = false;
-  if (d->mode == MS_BN_TRAIN && !outf32 && g_bn_fused && g_bn_sync) {
+  if (d->mode == MS_BN_TRAIN && !outf32 && g_bn_fused && bn_sync) {
     const int bm = 64 * pl.wm, gy = cdiv(d->Cout, bm), nwg = pl.n_tiles * gy * d->groups;
-    const int scratch = (2 * pl.nwn * bm * 2 + (128 * pl.nwn / bm) * bm * 3 * 2 + bm * 2 + bm / 8) * 4;      // red | dred | scsh | rawflag
+    const int scratch = (pl.nwn * bm * 4 + (128 * pl.nwn / bm) * bm * 3 * 2 + bm * 2 + bm / 8 + pl.nwn + 1) * 4;      // red | dred | scsh | rawflag | wcnt
     // (every workgroup reads its group's n_tiles partials: beyond 64 tiles per channel tile that traffic -- n_tiles^2 x 1 KB per
     // channel tile -- costs more than the normalising launch it replaces; measured on the 512-tile audio-encoder layers)
-    fused = pl.n_tiles <= 64 && nwg >= g_bn_fused_min_wgs && (1 + gy * d->groups) * BNF_SYNC_WORDS_PER_GROUP <= g_bn_sync_n &&
+    fused = pl.n_tiles <= 64 && nwg >= g_bn_fused_min_wgs && (1 + gy * d->groups) * BNF_SYNC_WORDS_PER_GROUP <= bn_sync_words &&
             pl.lds_bytes >= scratch &&
             conv16_coresident(g.dt, pl, d->KW, g.up2 != 0, nwg);
   }
   if (fused) {
-    a.ep = EP_BN_FUSED; a.out = y; a.out_raw = y_raw; a.bn_part = bn_part; a.bn_sync = g_bn_sync; a.save = save;
+    a.ep = EP_BN_FUSED; a.out = y; a.out_raw = y_raw; a.bn_part = bn_part; a.bn_sync = bn_sync; a.save = save;
     a.momentum = d->momentum;
     a.raw_all = (long)d->B * g.hw > BN_BWD16_FUSED_MAX;      // its two-pass backward reads y_raw, not y
   }

@@ -160,7 +160,7 @@ size_t block_fwd16_workspace(const ms_conv_desc* d);
 size_t block_bwd16_workspace(const ms_conv_desc* d);
 int block_fwd16(const ms_conv_desc* d, const void* x, const void* x2, const float* w, const float* bias, const float* gamma,
                 const float* beta, float* running_mean, float* running_var, void* y_raw, void* y, float* save, void* workspace,
-                size_t workspace_bytes, hipStream_t s, const void* w_prepared);
+                size_t workspace_bytes, hipStream_t s, const void* w_prepared, int32_t* bn_sync = nullptr, int bn_sync_words = 0);
 int block_bwd16(const ms_conv_desc* d, const void* x, const void* x2, const float* w, const float* gamma, const void* y_raw,
                 const void* y, const float* save, const void* dy, void* dyr, void* dx, void* dx2, float* dw, float* dbias,
                 float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, hipStream_t s, const void* wt_prepared,

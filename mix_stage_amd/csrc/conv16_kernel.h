@@ -314,15 +314,18 @@ __device__ __forceinline__ void conv16_epilogue_bnfused(const Conv16Args& p, con
                                                         const float (&bias_pre)[WM][16]) {
   constexpr int BM = 64 * WM, NT = 128 * NWN, P = NT / BM;
   const int TW = 1 << p.ltw;
-  float* red = reinterpret_cast<float*>(smem);                         // [NWN pixel waves][BM][2]
-  double* dred = reinterpret_cast<double*>(red + NWN * BM * 2);        // [P][BM][3]
+  float* red = reinterpret_cast<float*>(smem);                         // [NWN pixel waves][BM][4] = (sum, sum of squares about the pivot, pivot, -)
+  double* dred = reinterpret_cast<double*>(red + NWN * BM * 4);        // [P][BM][3]
   float* scsh = reinterpret_cast<float*>(dred + P * BM * 3);           // [BM][2]
   int* rawflag = reinterpret_cast<int*>(scsh + BM * 2);                // [BM / 8]
+  int* wcnt = rawflag + BM / 8;                                        // [NWN] valid pixels of each pixel wave; [NWN]: spin expired
   const int grp = tl.g * p.gy + tl.by;
   int* arrive = p.bn_sync + (size_t)(1 + grp) * BNF_SYNC_STRIDE;
   int* depart = arrive + 1;
 
-  // ---- A. conv + bias stays in the accumulators; per-channel (sum, sum of squares) of this tile
+  // ---- A. conv + bias stays in the accumulators; per-channel sums of this tile ABOUT A PIVOT (the channel's value at the wave's
+  // first pixel): sum (x - K) and sum (x - K)^2 lose nothing when |mean| >> sigma, where sum x^2 - (sum x)^2 / n in fp32 loses the
+  // variance.  The tile's partial is published as (mean, M2 about that mean, count) and combined by Chan's rule.
   // (the accumulators are only ever READ element-wise: this clang miscompiles constant-index element writes into a local
   // f32x16.  The bias is added at each of the three uses; 128-row tiles re-fetch it -- an L2 hit -- instead of holding 32 more
   // registers across the gathering)
@@ -335,33 +338,50 @@ __device__ __forceinline__ void conv16_epilogue_bnfused(const Conv16Args& p, con
       bsv[q] = m < p.Mg ? b : 0.f;
     }
   };
-#pragma unroll
-  for (int i = 0; i < WM; ++i) {
-    float bsv[16];
-    bias_of(i, bsv);
-    float s1[16], s2[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+  {
+    int cnt = 0;
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
       const int n = (tl.wn * WN + j) * 32 + tl.r;
       const int oy = tl.oy0 + (n >> p.ltw), ox = tl.ox0 + (n & (TW - 1));
-      const bool cval = (oy < tl.OUTH) & (ox < tl.OUTW);
+      cnt += __popc((unsigned)__ballot((oy < tl.OUTH) & (ox < tl.OUTW)));      // lanes 0-31 = the 32 pixels of block j
+    }
+    if (tl.lane == 0 && tl.wm == 0) wcnt[tl.wn] = cnt;
+    if (tl.t == 0) wcnt[NWN] = 0;
+  }
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const float v = acc[i][j][q] + bsv[q];
-        const float vm = cval ? v : 0.f;
-        s1[q] += vm;
-        s2[q] = fmaf(vm, vm, s2[q]);
+  for (int i = 0; i < WM; ++i) {
+    float bsv[16];
+    bias_of(i, bsv);
+    float s1[16], s2[16], kk[16];
+    const int n0 = tl.wn * WN * 32;
+    const bool pivot_ok = (tl.oy0 + (n0 >> p.ltw) < tl.OUTH) & (tl.ox0 + (n0 & (TW - 1)) < tl.OUTW);     // wave-uniform
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      // the value of this half's lane 0 (pixel block 0): one per (q, h)
+      const float v0 = acc[i][0][q] + bsv[q];
+      const float k0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v0), 0));
+      const float k1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v0), 32));
+      const float k = pivot_ok ? (tl.h ? k1 : k0) : 0.f;
+      kk[q] = tl.r == 0 ? k : 0.f;           // (summed over the half below: lands next to the channel's totals)
+      s1[q] = 0.f; s2[q] = 0.f;
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int n = (tl.wn * WN + j) * 32 + tl.r;
+        const int oy = tl.oy0 + (n >> p.ltw), ox = tl.ox0 + (n & (TW - 1));
+        const bool cval = (oy < tl.OUTH) & (ox < tl.OUTW);
+        const float dv = cval ? (acc[i][j][q] + bsv[q]) - k : 0.f;
+        s1[q] += dv;
+        s2[q] = fmaf(dv, dv, s2[q]);
       }
     }
     reduce16_over_half(s1, tl.r);
     reduce16_over_half(s2, tl.r);
+    reduce16_over_half(kk, tl.r);
     if (!(tl.r & 1)) {
       const int q = (tl.r >> 1) & 15;
       const int ml = (tl.wm * WM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * tl.h;
-      red[(tl.wn * BM + ml) * 2] = s1[0];
-      red[(tl.wn * BM + ml) * 2 + 1] = s2[0];
+      *reinterpret_cast<float4*>(red + (tl.wn * BM + ml) * 4) = float4{s1[0], s2[0], kk[0], 0.f};
     }
   }
   __syncthreads();
@@ -373,14 +393,22 @@ __device__ __forceinline__ void conv16_epilogue_bnfused(const Conv16Args& p, con
   const int chn = tl.g * p.Mg + min(tl.m0 + (tl.t & (BM - 1)), p.Mg - 1);
   float gam = 0.f, bet = 0.f, rmean = 0.f, rvar = 0.f;
   if (tl.t < BM) {
-    float sa = 0.f, sb = 0.f;
+    // the pixel waves of this tile in fixed order (Chan): (count, mean, M2 about the mean)
+    float cn = 0.f, cmean = 0.f, cm2 = 0.f;
 #pragma unroll
-    for (int w = 0; w < NWN; ++w) { sa += red[(w * BM + tl.t) * 2]; sb += red[(w * BM + tl.t) * 2 + 1]; }
-    const float cnt = (float)(th_v * tw_v);
-    const float4 part = {sa, sb, chan_ok ? cnt : 0.f, 0.f};
-    // one wave instruction = 64 lanes x 16 B = eight whole 128-byte lines, written through to the fabric
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, part), rsP,
-                                           (int)(16u * (unsigned)((grp * p.gx + tl.bx) * BM + tl.t)), 0, 16 /* sc1 */);
+    for (int w = 0; w < NWN; ++w) {
+      const float4 rv = *reinterpret_cast<const float4*>(red + (w * BM + tl.t) * 4);
+      const float nw = (float)wcnt[w];
+      if (nw > 0.f) {
+        const float mw = rv.z + rv.x / nw, m2w = fmaxf(rv.y - rv.x * rv.x / nw, 0.f);
+        const float tot = cn + nw, dl = mw - cmean;
+        cmean += dl * (nw / tot);
+        cm2 += m2w + dl * dl * (cn * nw / tot);
+        cn = tot;
+      }
+    }
+    (void)th_v; (void)tw_v;
+    const float4 part = {cmean, cm2, chan_ok ? cn : 0.f, 0.f};
     gam = p.bn_g[chn]; bet = p.bn_b[chn];
     if (tl.bx == 0) { rmean = p.bn_m[chn]; rvar = p.bn_v[chn]; }
   }
@@ -393,7 +421,7 @@ __device__ __forceinline__ void conv16_epilogue_bnfused(const Conv16Args& p, con
     int spins = 0;
     while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.gx) {
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > BNF_SPIN_LIMIT) { __hip_atomic_store(p.bn_sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      if (++spins > BNF_SPIN_LIMIT) { __hip_atomic_store(p.bn_sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); wcnt[NWN] = 1; break; }
     }
   }
   __syncthreads();
@@ -402,7 +430,7 @@ __device__ __forceinline__ void conv16_epilogue_bnfused(const Conv16Args& p, con
   {
     const int c = tl.t & (BM - 1), share = tl.t / BM;
     const unsigned base = 16u * (unsigned)(grp * p.gx * BM + c);
-    double n = 0.0, s1 = 0.0, s2 = 0.0;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
     for (int k0 = share; k0 < ((p.dbg & 64) ? 0 : p.gx); k0 += 4 * P) {
       float4 v[4];
 #pragma unroll
@@ -412,9 +440,14 @@ __device__ __forceinline__ void conv16_epilogue_bnfused(const Conv16Args& p, con
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
-        if (k0 + u * P < p.gx) { s1 += (double)v[u].x; s2 += (double)v[u].y; n += (double)v[u].z; }
+        if (k0 + u * P < p.gx && v[u].z > 0.f) {
+          const double nw = (double)v[u].z, tot = n + nw, dl = (double)v[u].x - mean;
+          mean += dl * (nw / tot);
+          m2 += (double)v[u].y + dl * dl * (n * nw / tot);
+          n = tot;
+        }
     }
-    dred[(share * BM + c) * 3] = n; dred[(share * BM + c) * 3 + 1] = s1; dred[(share * BM + c) * 3 + 2] = s2;
+    dred[(share * BM + c) * 3] = n; dred[(share * BM + c) * 3 + 1] = mean; dred[(share * BM + c) * 3 + 2] = m2;
   }
   __syncthreads();
   if (tl.t == 0 && !(p.dbg & 128)) {            // every load of the group's partials by this workgroup has returned: depart; the last one re-arms
@@ -425,14 +458,25 @@ __device__ __forceinline__ void conv16_epilogue_bnfused(const Conv16Args& p, con
     }
   }
   if (tl.t < BM) {
-    double n = dred[tl.t * 3], s1 = dred[tl.t * 3 + 1], s2 = dred[tl.t * 3 + 2];
+    double n = dred[tl.t * 3], mean = dred[tl.t * 3 + 1], m2 = dred[tl.t * 3 + 2];
 #pragma unroll
-    for (int s = 1; s < P; ++s) { n += dred[(s * BM + tl.t) * 3]; s1 += dred[(s * BM + tl.t) * 3 + 1]; s2 += dred[(s * BM + tl.t) * 3 + 2]; }
+    for (int s = 1; s < P; ++s) {
+      const double nw = dred[(s * BM + tl.t) * 3];
+      if (nw > 0.0) {
+        const double tot = n + nw, dl = dred[(s * BM + tl.t) * 3 + 1] - mean;
+        mean += dl * (nw / tot);
+        m2 += dred[(s * BM + tl.t) * 3 + 2] + dl * dl * (n * nw / tot);
+        n = tot;
+      }
+    }
     float sc = 0.f, shf = 0.f;
     bool unsafe_c = false;
-    if (chan_ok && n > 0.0) {
-      // sum and sum of squares of the fp32 accumulators, exact in fp64 from here on: M2 = sum x^2 - (sum x)^2 / N
-      const double mean = s1 / n, m2 = fmax(s2 - s1 * mean, 0.0);
+    const bool expired = wcnt[NWN] != 0;
+    if (expired) {
+      // this workgroup gave up waiting for its group (word 0 of the sync buffer is raised): statistics are incomplete.  Poison the
+      // output instead of normalising with them, and leave the running statistics and the saved vector alone.
+      sc = __builtin_nanf(""); shf = sc;
+    } else if (chan_ok && n > 0.0) {
       const float var = (float)(m2 / n);
       const float invstd = 1.0f / sqrtf(var + p.eps);
       const float fmean = (float)mean;

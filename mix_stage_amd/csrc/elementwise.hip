@@ -1465,6 +1465,21 @@ int ms_copy_multi(int n, const void* const* src, void* const* dst, const size_t*
   return 0;
 }
 
+// up to 8 floats handed over BY VALUE (kernel arguments are copied when the launch is enqueued): a host-side schedule value reaches
+// the device without an asynchronous read of host memory that a later host write could overtake
+struct FloatsArg { float v[8]; };
+__global__ void write_floats_kernel(float* dst, FloatsArg a, int n) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = a.v[threadIdx.x];
+}
+
+int ms_write_floats(float* dst, const float* host_values, int n, void* stream) {
+  if (!dst || !host_values || n < 1 || n > 8) return set_error("ms_write_floats: 1..8 values");
+  FloatsArg a = {};
+  for (int i = 0; i < n; ++i) a.v[i] = host_values[i];
+  hipLaunchKernelGGL(write_floats_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dst, a, n);
+  return check_launch("write_floats_kernel");
+}
+
 int ms_sqnorm(const float* g, size_t n, float* norm_out, float* partials, void* stream) {
   TimingScope ts((hipStream_t)stream, 0, 0, "ew|ew_sqnorm");
   if (ts.skip()) return 0;

@@ -141,13 +141,14 @@ class GAN(nn.Module):
     return self._lambda_dev
 
   def write_lambdas(self, device, staging=None):
-    """Current host values -> device tensor.  staging: optional pinned 2-float host tensor (asynchronous copy)."""
+    """Current host values -> device tensor, BY VALUE through a kernel's arguments (ms_write_floats): the values are copied when
+    the launch is enqueued, so a host that runs ahead of the device (replayed graphs never synchronise) cannot overwrite them
+    before the device has read them -- an asynchronous copy from one pinned staging tensor could (`staging` is ignored)."""
+    import ctypes
     dev = self.lambda_device(device)
-    if staging is not None:
-      staging[0], staging[1] = float(self.lambda_D), float(self.lambda_gan)
-      dev.copy_(staging, non_blocking=True)
-    else:
-      dev.copy_(torch.tensor([float(self.lambda_D), float(self.lambda_gan)], dtype=torch.float32))
+    vals = (ctypes.c_float * 2)(float(self.lambda_D), float(self.lambda_gan))
+    with torch.cuda.device(dev.device):
+      ops.check(ops.lib().ms_write_floats(ops._ptr(dev), vals, 2, ops._stream()), 'ms_write_floats')
     return dev
 
   def _score(self, pose):

@@ -55,8 +55,9 @@ def _ensure_counters(device):
 
 
 def workspace(nbytes, device):
-  """Per-device scratch, grown geometrically; all users are serialised by the stream."""
-  key = (device.type, device.index)
+  """Scratch of the CURRENT stream on `device`, grown geometrically.  Users on one stream are serialised by it; two streams
+  that run blocks concurrently get a buffer each (partial tiles, BatchNorm partials and split reductions live here)."""
+  key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
   if USE_IN_LAUNCH_SPLIT_REDUCTION:
     _ensure_counters(device)
   ws = _workspaces.get(key)
@@ -385,7 +386,7 @@ class _ConvBlockFn(torch.autograd.Function):
     ws = workspace(d._fwd_ws, x.device)
     planes = _prepared_for(w, d, 'fwd')
     if planes is not None:
-      opt = FwdOptions(planes.data_ptr())
+      opt = FwdOptions(planes.data_ptr(), None, 0)
       check(lib().ms_conv_block_fwd_ex(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(bias), _ptr(gamma), _ptr(beta),
                                        _ptr(rm), _ptr(rv), _ptr(y_raw), _ptr(y), _ptr(save), _ptr(ws), ws.numel(),
                                        _stream(), ctypes.byref(opt)), 'ms_conv_block_fwd_ex')

@@ -31,28 +31,47 @@ def _need16(*tensors):
 
 
 # ------------------------------------------------------------------------------------------------
-# In-launch BatchNorm (ms_set_bn_sync_buffer): the arrival counters through which the workgroups of a BN_TRAIN block's conv
-# launch exchange their batch statistics.  One persistent zeroed buffer per process (= per device: one process per GPU); the
-# kernels leave it zeroed.  Word 0 is raised when a workgroup gave up waiting for its peers (bn_sync_error()).
+# In-launch BatchNorm / chained decoder (ms_fwd_options.bn_sync): the arrival counters through which the workgroups of a launch
+# exchange their batch statistics.  One persistent zeroed buffer per (device, stream): launches on one stream are serialised and
+# leave the counters re-armed; two streams never share counters.  Word 0 is raised when a workgroup gave up waiting for its
+# peers -- the block's output is then NaN and bn_sync_error() reports it (MixStageTrainStep.check_health raises).
+# The in-launch forms assume the launch has the device to itself (all its workgroups resident at once): a second process on the
+# same GPU, or a large kernel on another stream, can make a launch wait until its bound expires.
 _bn_sync = {}
+BN_SYNC_WORDS = 1 << 16
+
+
+_in_launch = {'on': True}
+
+
+def set_in_launch_meetings(on):
+  """False: no launch of this process waits for its own workgroups (in-launch BatchNorm, chained decoder) -- for set-ups in which a
+  launch does not have the device to itself (several ranks on one GPU)."""
+  _in_launch['on'] = bool(on)
+
+
+def in_launch_meetings():
+  return _in_launch['on']
 
 
 def _ensure_bn_sync(device):
-  key = (device.type, device.index)
+  if not _in_launch['on']:
+    return None
+  key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
   buf = _bn_sync.get(key)
   if buf is None:
-    if _bn_sync:
-      raise ops._lib.MixStageLibError('the 16-bit path serves one device per process (in-launch BatchNorm counters live on %s)'
-                                      % (list(_bn_sync)[0],))
-    buf = torch.zeros(1 << 16, dtype=torch.int32, device=device)
-    check(lib().ms_set_bn_sync_buffer(_ptr(buf), buf.numel()), 'ms_set_bn_sync_buffer')
-    _bn_sync[key] = buf
+    buf = _bn_sync[key] = torch.zeros(BN_SYNC_WORDS, dtype=torch.int32, device=device)
   return buf
 
 
 def bn_sync_error():
   """True when an in-launch BatchNorm workgroup timed out waiting for its group (synchronises the device)."""
   return any(int(b[0].item()) != 0 for b in _bn_sync.values())
+
+
+def bn_sync_clear():
+  for b in _bn_sync.values():
+    b.zero_()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -232,12 +251,12 @@ class _ConvBlock16Fn(torch.autograd.Function):
       y_raw = torch.empty((B, c8) + sp + (8,), dtype=x.dtype, device=x.device)
       save = torch.empty(4 * ctot, dtype=torch.float32, device=x.device)
     ws = workspace(d._fwd_ws, x.device)
-    if mode == MS_BN_TRAIN:
-      _ensure_bn_sync(x.device)
+    sync = _ensure_bn_sync(x.device) if mode == MS_BN_TRAIN else None
     folded = mode == MS_BN_EVAL and bool(dt_flags & MS_DT_BN_FOLDED)
     planes = _prepared16_for(w, d, 'fwd16', dict(bias=bias, gamma=gamma, beta=beta, running_mean=rm, running_var=rv)
                              if folded else None)
-    opt = FwdOptions(planes.data_ptr() if planes is not None else None)
+    opt = FwdOptions(planes.data_ptr() if planes is not None else None, sync.data_ptr() if sync is not None else None,
+                     sync.numel() if sync is not None else 0)
     check(lib().ms_conv_block_fwd_ex(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(bias), _ptr(gamma), _ptr(beta),
                                      _ptr(rm), _ptr(rv), _ptr(y_raw), _ptr(y), _ptr(save), _ptr(ws), ws.numel(),
                                      _stream(), ctypes.byref(opt)), 'ms_conv_block_fwd_ex')

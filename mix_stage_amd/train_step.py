@@ -261,11 +261,20 @@ class MixStageTrainStep:
     # ranks (an exchange of ~0.4 ms over xGMI) has to be measured on such a node; no N > 1 RCCL run exists so far.
     # MS_CAPTURE_ALLREDUCE=0: keep the gradient exchange outside the graphs (two graphs per step with an eager all-reduce between
     # them), should capturing the collective fail on some stack
-    self.capture_allreduce = rccl and os.environ.get('MS_CAPTURE_ALLREDUCE', '1') != '0'
-    self.overlap_allreduce = bool(overlap_allreduce) and rccl
+    # DEFAULT: the exchange stays OUTSIDE the graphs (two graphs per step around an eager all-reduce -- the form every multi-rank
+    # test has exercised).  MS_CAPTURE_ALLREDUCE=1 opts into the captured form; it has only ever run with one RCCL rank.
+    self.capture_allreduce = rccl and os.environ.get('MS_CAPTURE_ALLREDUCE', '0') == '1'
+    # (the overlapped exchange forks a communication stream off the backward pass: only inside the one captured graph; and its
+    # early bucket must not race weight gradients still running on a side stream)
+    self.overlap_allreduce = bool(overlap_allreduce) and rccl and self.capture_allreduce
+    if self.overlap_allreduce and overlap_wgrad:
+      raise ValueError('overlap_allreduce and overlap_wgrad are exclusive: the early bucket would be exchanged while its weight '
+                       'gradients are still in flight on the side stream')
     # (buckets only pay when the exchange overlaps the backward pass; without the overlap ONE all-reduce of the live prefix has the
     # fewest launches and the longest transfers: one rank on RCCL, G-step +0.095 ms with 4 captured collectives)
     self.grad_buckets = max(1, int(grad_buckets)) if grad_buckets is not None else (4 if self.overlap_allreduce else 1)
+    if self.overlap_allreduce and self.grad_buckets < 2:
+      self.grad_buckets = 2       # the early bucket is a bucket of its own: with one bucket it would be exchanged twice
     # overlap_wgrad: weight gradients on a side HIP stream (ms_conv_block_bwd_overlap).  Measured on MI355X / ROCm 7.2
     # inside the captured step it is SLOWER (5.01 vs 4.67 ms/step: cross-stream edges in the HIP graph cost more than the
     # concurrency buys), so it is off by default.
@@ -284,6 +293,17 @@ class MixStageTrainStep:
     self.world = _dp_world(process_group)          # > 1: the data-parallel form of the step (see _single_rank_dp)
     if self.world > 1:
       broadcast_from_rank0([self.optim_G.flat_p, self.optim_D.flat_p] + [b for b in model.buffers()], process_group)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+      # ranks that share a GPU (test set-ups): a launch whose workgroups wait for each other needs the device to itself
+      import socket
+      mine = (socket.gethostname(), torch.cuda.current_device())
+      seen = [None] * dist.get_world_size(process_group)
+      dist.all_gather_object(seen, mine, group=process_group)
+      if len(set(seen)) < len(seen):
+        ops16.set_in_launch_meetings(False)
+    self._capture_stream = torch.cuda.Stream()      # warm-up and capture of every step kind: its scratch / counters are the graphs'
+    self.health_every = 256                         # steps between check_health() calls (one device synchronisation each; 0: never)
+    self._steps = 0
     self._graphs = {}
     self._static = None
     self._comm = torch.cuda.Stream() if (self.world > 1 and self.overlap_allreduce) else None
@@ -293,7 +313,6 @@ class MixStageTrainStep:
     self.losses = None       # list of 0-dim device tensors of the last step (reference order)
     # d(sum of losses)/d(loss) = 1: one constant on the default stream, made before any capture or side-stream pass
     self._seed = torch.ones((), dtype=torch.float32, device=self.optim_G.flat_p.device)
-    self._lambda_staging = torch.zeros(2, dtype=torch.float32).pin_memory()
     self.fake_pose = None
 
   # ---- the eager pieces ------------------------------------------------------------------------------------
@@ -437,7 +456,19 @@ class MixStageTrainStep:
     finally:
       if kind is not None:
         m.D_prob = saved
+    self._steps += 1
+    if self.health_every and self._steps % self.health_every == 0:
+      self.check_health()
     return k
+
+  def check_health(self):
+    """Raises if a launch whose workgroups meet inside the launch (in-launch BatchNorm, chained decoder) gave up waiting: its
+    outputs were poisoned with NaN.  Synchronises the device.  Causes: another process or a large kernel on another stream held
+    compute units the launch needed -- run one trainer per GPU, or switch the forms off (ops16.set_in_launch_meetings(False))."""
+    if ops16.bn_sync_error():
+      ops16.bn_sync_clear()
+      raise RuntimeError('an in-launch BatchNorm meeting timed out (the launch did not have the GPU to itself): the step produced '
+                         'NaN; see MixStageTrainStep.check_health')
 
   def _graph_step(self, k, pose_branch, audio, labels, pose, style, inputs_unchanged=False):
     self.model._lambda_host_writes = False   # the captured loss kernels read the device tensor written below
@@ -466,7 +497,7 @@ class MixStageTrainStep:
     else:
       self._consume_decisions(k)
     # this step's loss weights (the schedule moved on the host): into the device tensor the captured loss kernels read
-    self.model.write_lambdas(opt.flat_p.device, self._lambda_staging)
+    self.model.write_lambdas(opt.flat_p.device)
     for mod in entry['bn_tape']:
       mod._pending_batches += 1
     opt.mark_active(entry['active'])
@@ -492,7 +523,7 @@ class MixStageTrainStep:
     thresh = (m.G.thresh.value, m.G.thresh.iters)
     bn_state = {n: b.clone() for n, b in m.named_buffers()}
     # one eager pass on a side stream sizes the workspace and warms the allocator, then undo its side effects
-    side = torch.cuda.Stream()
+    side = self._capture_stream
     side.wait_stream(torch.cuda.current_stream())
     warm_tape = []
     layers.set_train_tape(warm_tape)
@@ -528,7 +559,7 @@ class MixStageTrainStep:
     try:
       # (a capture that fails half-way cannot be retried in this process -- the stream stays in capture mode -- so there is no
       # automatic fallback here: MS_CAPTURE_ALLREDUCE=0 selects the two-graph form with the eager exchange up front)
-      with torch.cuda.graph(g1, capture_error_mode=mode):
+      with torch.cuda.graph(g1, stream=side, capture_error_mode=mode):
         if one_graph and self.world > 1:
           fake, losses = self._with_marker(self._forward_backward, st['audio'], st['labels'], st['pose'], st['style'], k)
           # (the warm-up pass above ran the same forward / backward: its set of parameters with gradients is this step's)
@@ -545,7 +576,7 @@ class MixStageTrainStep:
     g2 = None
     if not one_graph:
       g2 = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(g2, capture_error_mode=mode):
+      with torch.cuda.graph(g2, stream=side, capture_error_mode=mode):
         opt.clip_and_step(count=False)
     entry = dict(fwd_bwd=g1, opt=g2, fake=fake, losses=losses, bn_tape=tape, active=active,
                  n_prepared=ops.prepared_count(opt.flat_p))

@@ -17,16 +17,17 @@ import torch.distributed as dist
 from oracle import mixstage_oracle as O
 
 
-def run(dp, precision):
+def run(dp, precision, captured=False):
   from test_gpu_model import build_hip_gan
   import mix_stage_amd as A
   from mix_stage_amd.train_step import MixStageTrainStep
   os.environ['MS_DP_SINGLE_RANK'] = '1' if dp else '0'
+  os.environ['MS_CAPTURE_ALLREDUCE'] = '1' if captured else '0'      # default form: two graphs around an eager RCCL exchange
   torch.manual_seed(1234)
   model = build_hip_gan(4, 4)
   if precision != 'fp32':
     A.set_compute_dtype(model, precision)
-  ts = MixStageTrainStep(model, use_graphs=True, overlap_allreduce=dp)      # (the opt-in overlapped form: the riskier path)
+  ts = MixStageTrainStep(model, use_graphs=True, overlap_allreduce=dp and captured)   # (captured + overlapped: the opt-in form)
   assert (ts.world > 1) == dp
   losses = []
   for i in range(5):
@@ -44,7 +45,7 @@ def main():
   dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
   out = {}
   for precision in ('fp32', 'bf16'):
-    out[precision] = dict(plain=run(False, precision), dp=run(True, precision))
+    out[precision] = dict(plain=run(False, precision), dp=run(True, precision), dp_captured=run(True, precision, captured=True))
   rec = dict(rank=0, out=out, backend=dist.get_backend())
   d = os.environ.get('DP_RESULT_DIR')
   if d:

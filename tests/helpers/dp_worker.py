@@ -36,7 +36,11 @@ def main():
     with torch.no_grad():
       for p in model.parameters():
         p.mul_(1.5)
+  if os.environ.get('DP_PRECISION', 'fp32') != 'fp32':
+    import mix_stage_amd as A
+    A.set_compute_dtype(model, os.environ['DP_PRECISION'])
   ts = MixStageTrainStep(model, use_graphs=True, grad_exchange=os.environ.get('DP_GRAD_EXCHANGE', 'fp32'))
+  from mix_stage_amd import ops16
   kinds = []
   losses = []
   for i in range(6):
@@ -44,7 +48,8 @@ def main():
     kinds.append(ts.step(audio.cuda(), labels.cuda(), pose.cuda(), style.cuda()))
     losses.append([float(l.detach()) for l in ts.losses])
   torch.cuda.synchronize()
-  _emit(dict(rank=rank, kinds=kinds, sums=ts.state_checksums(), losses=losses,
+  ts.check_health()                            # raises if an in-launch meeting timed out
+  _emit(dict(rank=rank, kinds=kinds, sums=ts.state_checksums(), losses=losses, in_launch=ops16.in_launch_meetings(),
                                       g_step=ts.optim_G.step_count, d_step=ts.optim_D.step_count))
   dist.barrier()
   dist.destroy_process_group()

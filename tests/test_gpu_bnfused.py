@@ -14,7 +14,8 @@ DEV = 'cuda:0'
 BN_TRAIN, PLAIN, BCAST, UP2 = 2, 0, 1, 2
 
 
-def _run_block(nd, B, cin, cout, groups, k, s, p, H, W, in_mode, fused, seed=0, dt=torch.bfloat16, reps=1, tensors=None):
+def _run_block(nd, B, cin, cout, groups, k, s, p, H, W, in_mode, fused, seed=0, dt=torch.bfloat16, reps=1, tensors=None, sync=True,
+               big_bias=None):
   from mix_stage_amd import ops, ops16
   from mix_stage_amd._lib import MS_BF16, MS_F16, FwdOptions, check, lib
   L = lib()
@@ -32,6 +33,8 @@ def _run_block(nd, B, cin, cout, groups, k, s, p, H, W, in_mode, fused, seed=0, 
       ctot = cout * groups
       w = (torch.randn((ctot, cin) + tuple(kt), generator=g) * fan ** -0.5).to(DEV)
       bias = (torch.randn(ctot, generator=g) * 0.1).to(DEV)
+      if big_bias is not None:
+        bias[big_bias[0]] = big_bias[1]
       gamma = (0.5 + torch.rand(ctot, generator=g)).to(DEV)
       beta = (torch.randn(ctot, generator=g) * 0.1).to(DEV)
       rm = (torch.randn(ctot, generator=g) * 0.1).to(DEV)
@@ -50,7 +53,7 @@ def _run_block(nd, B, cin, cout, groups, k, s, p, H, W, in_mode, fused, seed=0, 
     d = geom.desc(B, cin, H, W, cout, BN_TRAIN, in_mode, msdt)
     sp_out = (d.OH, d.OW) if nd == 2 else (d.OW,)
     c8 = (ctot + 7) // 8
-    ops16._ensure_bn_sync(x.device)
+    syncbuf = ops16._ensure_bn_sync(x.device)
     ws = ops.workspace(d._fwd_ws, x.device)
     outs = []
     P = ops._ptr
@@ -58,11 +61,12 @@ def _run_block(nd, B, cin, cout, groups, k, s, p, H, W, in_mode, fused, seed=0, 
       y = torch.full((B, c8) + sp_out + (8,), float('nan'), dtype=dt, device=DEV)
       y_raw = torch.full_like(y, float('nan'))
       save = torch.full((4 * ctot,), float('nan'), dtype=torch.float32, device=DEV)
-      opt = FwdOptions(None)
+      opt = FwdOptions(None, syncbuf.data_ptr(), syncbuf.numel())
       check(L.ms_conv_block_fwd_ex(ctypes.byref(d), P(x), P(x2), P(w), P(bias), P(gamma), P(beta), P(rm), P(rv), P(y_raw), P(y),
                                    P(save), P(ws), ws.numel(), ops._stream(), ctypes.byref(opt)), 'ms_conv_block_fwd_ex')
       outs.append((y, y_raw, save))
-    torch.cuda.synchronize()
+    if sync:
+      torch.cuda.synchronize()
     return outs, (rm, rv), tensors
   finally:
     L.ms_debug_set_bn_fused(prev)
@@ -169,7 +173,7 @@ def test_fused_is_bitwise_repeatable_under_uneven_load():
     assert err.max().item() <= (ref.abs().max().item() + raw32.abs().max().item()) * 2 ** -8
     assert (err / (ref.abs() + 1e-2)).mean().item() <= 2 ** -8            # no tile with shifted statistics
   assert not ops16.bn_sync_error()
-  assert int(ops16._bn_sync[('cuda', 0)].abs().sum().item()) == 0          # arrive / depart counters re-armed
+  assert all(int(b.abs().sum().item()) == 0 for b in ops16._bn_sync.values())          # arrive / depart counters re-armed
 
 
 def test_large_grids_keep_the_two_launch_form():
@@ -198,3 +202,63 @@ def test_unsafe_channel_blocks_keep_y_raw():
   assert per_block.nonzero().flatten().tolist() == [0, 5]
   for cb in (0, 5):
     assert torch.equal(f[1][:, cb].view(torch.int16), u[1][:, cb].view(torch.int16))
+
+
+def test_channel_with_mean_far_above_sigma_keeps_its_variance():
+  """A channel whose mean is 1000 sigma (a large bias): the tile partials are sums about a pivot, published as (mean, M2, count)
+  and combined by Chan's rule -- sum x^2 - (sum x)^2 / n in fp32 would lose the variance entirely.  Reference: the same 16-bit
+  operands in float64."""
+  from mix_stage_amd import ops16
+  nd, B, cin, cout, groups, k, s, p, H, W, in_mode = GEOMS[0][1:]
+  ch = 517
+  (f,), (rm, rv), tensors = _run_block(nd, B, cin, cout, groups, k, s, p, H, W, in_mode, True, seed=5, big_bias=(ch, 1000.0))
+  w, bias, gamma, beta, rm0, rv0, x, x2 = tensors
+  ctot = cout * groups
+  x64 = ops16.from_cb8(x, cin * groups).double()
+  w64 = w.to(torch.bfloat16).double()
+  ref = torch.nn.functional.conv1d(x64, w64, bias.double(), stride=s, padding=p, groups=groups)
+  mean = ref.mean((0, 2)); var = ref.var((0, 2), unbiased=False)
+  save = f[2].double()
+  assert abs(float(mean[ch]) - 1000.0) < 5 and float(var[ch].sqrt()) < 2.0              # mean / sigma ~ 1e3
+  assert (save[:ctot] - mean).abs().max().item() <= 1e-4 * (1 + mean.abs().max().item())
+  inv_ref = 1.0 / torch.sqrt(var + 1e-5)
+  rel = ((save[ctot:2 * ctot] - inv_ref).abs() / inv_ref)
+  assert rel.max().item() <= 2e-3, (rel.max().item(), int(rel.argmax()))
+  assert rel[ch].item() <= 2e-3
+  # the normalised output of that channel has unit variance (it would be garbage with a lost variance)
+  y = ops16.from_cb8(f[0], ctot)[:, ch].double()
+  z = torch.where(y > 0, y, y / 0.2)
+  xhat = (z - float(beta[ch])) / float(gamma[ch])
+  assert abs(float(xhat.var(unbiased=False)) - 1.0) < 0.1
+  assert not ops16.bn_sync_error()
+
+
+def test_two_streams_run_fused_blocks_concurrently():
+  """Two HIP streams launching in-launch-BatchNorm blocks at the same time: each stream has its own counters and scratch
+  (ms_fwd_options.bn_sync, ops.workspace per stream), so neither sees the other's arrivals or partials.  Every output must equal
+  the block's single-stream result bit for bit, and no meeting may time out."""
+  from mix_stage_amd import ops16
+  geo_a, geo_b = GEOMS[2][1:], GEOMS[8][1:]            # 128 + 256 workgroups: both launches fit on the chip together
+  firsts = []
+  for geo, seed in ((geo_a, 21), (geo_b, 22)):
+    nd, B, cin, cout, groups, k, s, p, H, W, in_mode = geo
+    (first,), _, tensors = _run_block(nd, B, cin, cout, groups, k, s, p, H, W, in_mode, True, seed=seed)
+    firsts.append((geo, first, tensors))
+  sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+  torch.cuda.synchronize()
+  outs = {0: [], 1: []}
+  for rep in range(20):
+    for i, st in enumerate((sa, sb)):
+      geo, first, tensors = firsts[i]
+      nd, B, cin, cout, groups, k, s, p, H, W, in_mode = geo
+      with torch.cuda.stream(st):
+        (o,), _, _ = _run_block(nd, B, cin, cout, groups, k, s, p, H, W, in_mode, True, tensors=tensors, sync=False)
+      outs[i].append(o)
+  torch.cuda.synchronize()
+  assert len(ops16._bn_sync) >= 3                      # the default stream's buffer and one per side stream
+  for i in (0, 1):
+    first = firsts[i][1]
+    for o in outs[i]:
+      assert torch.equal(o[2], first[2])
+      assert torch.equal(o[0].view(torch.int16), first[0].view(torch.int16))
+  assert not ops16.bn_sync_error()

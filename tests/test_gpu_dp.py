@@ -46,6 +46,21 @@ def test_two_ranks_stay_bit_identical():
   assert all(abs(v) < 1e3 for step in a['losses'] for v in step)
 
 
+def test_two_processes_on_one_gpu_in_bf16():
+  """Two ranks share cuda:0 in the bf16 mode: a launch whose workgroups meet inside the launch (in-launch BatchNorm, chained
+  decoder) assumes it has the device to itself, which two processes on one GPU violate -- the trainer detects the shared device
+  and keeps those forms off; the replicas end bit-identical, finite, and no meeting timed out (check_health in the worker)."""
+  env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0', DP_PRECISION='bf16')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+         '--master-port', '29557', os.path.join(ROOT, 'tests', 'helpers', 'dp_worker.py')]
+  out, res = _run_ranks(cmd, env)
+  assert out.returncode == 0 and len(res) == 2, (out.stdout[-2000:], out.stderr[-4000:])
+  a, b = sorted(res, key=lambda r: r['rank'])
+  assert a['in_launch'] is False and b['in_launch'] is False
+  assert a['kinds'] == b['kinds'] and a['sums'] == b['sums'], (a['sums'], b['sums'])
+  assert all(v == v and abs(v) < 1e3 for step in a['losses'] for v in step)
+
+
 def test_two_ranks_bf16_gradient_exchange():
   """grad_exchange='bf16': the all-reduce moves bf16 values; the replicas still end bit-identical (every rank receives the same
   means), and the parameters differ from the fp32 exchange only by the rounding of the gradients."""
@@ -154,9 +169,15 @@ def test_rccl_path_single_rank():
   assert out.returncode == 0 and len(res) == 1, (out.stdout[-2000:], out.stderr[-4000:])
   assert res[0]['backend'] == 'nccl'
   for precision, r in res[0]['out'].items():
+    # default form: two graphs per step around an EAGER RCCL all-reduce (the captured form is opt-in until an N > 1 run proves it)
     assert r['plain']['sums'] == r['dp']['sums'], precision
     assert r['plain']['losses'] == r['dp']['losses'], precision
-    assert r['dp']['one_graph'] and r['dp']['overlap'], r['dp']
-    b = r['dp']['buckets']
+    assert not r['dp']['one_graph'] and not r['dp']['overlap'], r['dp']
+    assert len(r['dp']['buckets']) == 1
+    # opt-in form (MS_CAPTURE_ALLREDUCE=1 + overlap_allreduce): the exchange inside the step's graph, first bucket at the marker
+    assert r['plain']['sums'] == r['dp_captured']['sums'], precision
+    assert r['plain']['losses'] == r['dp_captured']['losses'], precision
+    assert r['dp_captured']['one_graph'] and r['dp_captured']['overlap'], r['dp_captured']
+    b = r['dp_captured']['buckets']
     assert len(b) == 4 and b[0][0] == 0 and sorted(x for lo, hi in b for x in (lo, hi))[-1] == max(hi for lo, hi in b)
     assert sum(hi - lo for lo, hi in b) == max(hi for lo, hi in b)            # the buckets tile the live prefix
