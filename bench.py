@@ -148,7 +148,8 @@ def supervise(args):
         sk.bind(('127.0.0.1', 0))
         port[0] = sk.getsockname()[1]
     dist.broadcast_object_list(port, src=0)
-    env = dict(os.environ, MASTER_PORT=str(port[0]), **extra)
+    # (a rendezvous of their own: under torchrun the agent hosts the store of the ORIGINAL port; the children's rank 0 hosts theirs)
+    env = dict(os.environ, MASTER_PORT=str(port[0]), TORCHELASTIC_USE_AGENT_STORE='False', **extra)
     if tag:
       env['MS_DP_FALLBACK'] = tag
     errf = tempfile.TemporaryFile(mode='w+')
@@ -310,6 +311,55 @@ def block_and_segment(rows, n_g, precision):
   return block, segment
 
 
+def chain_roofline(chain, rows, precision):
+  """Roofline entry when the north-star unit runs as ONE launch (ms_decoder_chain_fwd: decoder.0-3 + logits + softmax mixture,
+  SURVEY 8(d)'s unit): the train-mode launch of the G-steps (BatchNorm meetings, y_raw / y / z written for the backward pass) is the
+  entry; the eval-mode launch of the D-steps (gan.py:106-110) is listed beside it."""
+  native16 = precision in ('bf16', 'fp16')
+  peak_tf = BF16_MFMA_PEAK_TFLOPS if native16 else FP32_MFMA_PEAK_TFLOPS
+
+  def entry(r):
+    avg_s = r['total_ms'] / r['count'] * 1e-3
+    tf, gbs = r['flops'] / avg_s / 1e12, r['bytes'] / avg_s / 1e9
+    t_mfma, t_hbm = r['flops'] / (peak_tf * 1e12), r['bytes'] / (HBM_PEAK_GBS * 1e9)
+    bound = 'hbm' if t_hbm >= t_mfma else 'mfma'
+    return dict(bound=bound, achieved=round(gbs if bound == 'hbm' else tf, 2), peak=HBM_PEAK_GBS if bound == 'hbm' else round(peak_tf, 1),
+                unit='GB/s' if bound == 'hbm' else 'TFLOP/s', frac=round(max(t_mfma, t_hbm) / avg_s, 4), traffic=None,
+                kernel=r['label'].split('|')[0], label=r['label'].split('|')[-1], avg_us=round(avg_s * 1e6, 2), launches=r['count'],
+                algorithmic_flops_per_launch=round(r['flops']), algorithmic_bytes_per_launch=round(r['bytes']),
+                frac_mfma=round(tf / peak_tf, 4), frac_hbm=round(gbs / HBM_PEAK_GBS, 4), achieved_tflops=round(tf, 2),
+                achieved_gbs=round(gbs, 1), time_lower_bound_us=round(max(t_mfma, t_hbm) * 1e6, 2))
+
+  train = [r for r in chain if r['label'].rstrip().endswith('train')]
+  evalr = [r for r in chain if r['label'].rstrip().endswith('eval')]
+  roof = entry((train or evalr)[0])
+  roof['note'] = ('north-star unit as ONE launch: decoder.0-3 (grouped Conv1d k3 + BatchNorm1d + LeakyReLU) + logits + softmax mixture '
+                  '(JL:69-83,106-115,186-194), M=%d groups, B*T = %d pixels; a workgroup carries one clip of one sub-generator through all blocks '
+                  '(activations resident in LDS, weights streamed straight into registers); HIP events on the launch stream over 2 G-steps + 2 '
+                  'D-steps (eager); algorithmic flops / bytes per SURVEY 8(d)' % (M, B_PER_GPU * T))
+  seg = dict(roof)
+  seg['what'] = 'decoder segment = the same single launch (SURVEY.md 8(d) unit), train mode, per G-step'
+  seg['us'] = roof['avg_us']
+  seg['launches'] = [roof['label']]
+  roof['decoder_segment'] = seg
+  roof['block'] = None        # the Conv+BN+LeakyReLU block is no launch of its own any more: a quarter of the chain's K loops + one meeting
+  if train and evalr:
+    roof['eval_launch'] = {k: v for k, v in entry(evalr[0]).items() if k in ('label', 'avg_us', 'frac', 'achieved_tflops', 'achieved_gbs', 'launches')}
+  prep = [r for r in rows if 'chain_prep' in r['label']]
+  if prep:
+    roof['weight_stream_prep_us'] = round(prep[0]['total_ms'] / prep[0]['count'] * 1e3, 2)
+  try:
+    pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r04_pmc_decoder.json')))
+    ent = pmc.get(precision)
+    if ent and ent.get('src_hash') == source_hash() and M == 8 and B_PER_GPU * T == 2048:
+      roof['traffic'] = ent['hbm_bytes_per_launch']
+      roof['traffic_over_algorithmic'] = round(ent['hbm_bytes_per_launch'] / roof['algorithmic_bytes_per_launch'], 3)
+      roof['traffic_note'] = 'HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, profiles/r04_pmc_decoder.json (same sources: %s)' % ent['src_hash']
+  except (OSError, ValueError, KeyError):
+    pass
+  return roof
+
+
 def kernel_roofline(ts, batch, kinds, precision):
   """Per-kernel launch durations from HIP events recorded on the launch stream by the library itself
   (ms_timing_*), over eager replays of the same steps as the timed region.  The roofline entry is the north-star kernel
@@ -330,6 +380,9 @@ def kernel_roofline(ts, batch, kinds, precision):
   if not rows:
     return None, []
   rows.sort(key=lambda r: -r['total_ms'])
+  chain = [r for r in rows if 'decoder_chain_fwd' in r['label']]
+  if chain:
+    return chain_roofline(chain, rows, precision), rows
   pat = decoder_label_re(precision)
   dec = [r for r in rows if pat.search(r['label'])]
   if not dec:
@@ -595,6 +648,8 @@ def main():
         out['bf16_g_step_ms'], out['bf16_d_step_ms'] = b16.get('g_step_ms'), b16.get('d_step_ms')
         blk = (b16.get('roofline') or {}).get('block') or {}
         out['bf16_decoder_block_us'], out['bf16_decoder_block_frac'] = blk.get('us'), blk.get('frac')
+        seg16 = (b16.get('roofline') or {}).get('decoder_segment') or {}
+        out['bf16_decoder_segment_us'], out['bf16_decoder_segment_frac'] = seg16.get('us'), seg16.get('frac')
       except Exception as e:  # noqa: BLE001
         out['bf16'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
     try:

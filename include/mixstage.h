@@ -262,6 +262,65 @@ int ms_softmax_mix_fwd(const float* z, const float* score, float* soft, float* o
 int ms_softmax_mix_bwd(const float* z, const float* soft, const float* dout, float* dz, float* dscore,
                        int B, int M, int P, int T, void* stream);
 
+/* The pose decoder as ONE launch: decoder.0-3 (grouped Conv1d k3 + BatchNorm1d + LeakyReLU, JL:69-77,190-192, layers.py:77-78) +
+ * the grouped 1x1 `logits` conv (JL:83,193) + softmax over the cluster scores and the mixture of the M sub-generators
+ * (JL:106-115,186-187,194).  A workgroup carries ONE clip of ONE sub-generator through all blocks with the activations resident
+ * in LDS (a k3 / pad 1 conv never looks across a clip); only BatchNorm's batch statistics (train mode) and the mixture's
+ * per-group terms cross workgroups, inside the launch.  The (B, M*P, T) logits tensor of JL:193 is never needed by the forward
+ * pass (z is an optional output for callers whose backward pass reads it).
+ *   geometry      T = 64 frames, C = 256 channels per group and block, n_blocks = 4, block 0 reads cin0 in (256, 272] channels
+ *                 shared by all groups (the broadcast of JL:190), P <= 128; B*M <= compute units of the device (all workgroups
+ *                 resident at once: ms_decoder_chain_supported says whether this device / shape qualifies -- else run the blocks
+ *                 one by one with ms_conv_block_fwd).
+ *   mode          MS_BN_TRAIN: batch statistics over all B clips, running statistics updated, `save` written; MS_BN_EVAL: running
+ *                 statistics as they are.
+ *   dtype         MS_F32: x (B, cin0, T), y_raw / y (B, M*C, T) fp32.
+ *   x             block 0's input.  score (B, M, T): the cluster scores.  w[l] (M*C, cin_l, 3), w_logits (M*P, C, 1): the
+ *                 modules' own weights -- read by ms_decoder_chain_prepare only; the launch streams `prepared`.
+ *   y_raw, y, save  per block, or NULL: conv + bias, block output, mean|invstd|scale|shift (what ms_conv_block_bwd reads).
+ *   z             (B, M*P, T) or NULL.  soft (B, T, M) or NULL: softmax of the scores.  out (B, T, P): the mixture.
+ *   prepared      ms_decoder_chain_prepared_bytes bytes filled by ms_decoder_chain_prepare (once per optimizer update).
+ *   sync          zero-initialised int32 words owned by one (device, stream) AND one (B, M): ms_decoder_chain_sync_words of them
+ *                 from sync_first_word on.  The meeting counters are monotonic (every launch adds the same amount to each word
+ *                 it uses, nothing is reset, a replayed graph needs nothing from the host), which holds only among launches of
+ *                 one shape.  Word 0 of the buffer is raised when a workgroup gave up waiting (outputs NaN; zero the buffer
+ *                 before the next launch). */
+#define MS_CHAIN_MAX_BLOCKS 4
+typedef struct ms_chain_desc {
+  int32_t B, M, T, cin0, C, P, n_blocks;
+  int32_t mode;             /* MS_BN_TRAIN | MS_BN_EVAL */
+  int32_t dtype;            /* ms_dtype */
+  int32_t sync_first_word;  /* first word of `sync` this launch may use (>= 32: word 0 is the error flag) */
+  float slope, eps, momentum;
+} ms_chain_desc;
+typedef struct ms_chain_tensors {
+  const void* x;
+  const float* score;
+  const float* w[MS_CHAIN_MAX_BLOCKS];
+  const float* bias[MS_CHAIN_MAX_BLOCKS];
+  const float* gamma[MS_CHAIN_MAX_BLOCKS];
+  const float* beta[MS_CHAIN_MAX_BLOCKS];
+  float* running_mean[MS_CHAIN_MAX_BLOCKS];
+  float* running_var[MS_CHAIN_MAX_BLOCKS];
+  void* y_raw[MS_CHAIN_MAX_BLOCKS];
+  void* y[MS_CHAIN_MAX_BLOCKS];
+  float* save[MS_CHAIN_MAX_BLOCKS];
+  const float* w_logits;
+  const float* bias_logits;
+  float* z;
+  float* soft;
+  float* out;
+  const void* prepared;
+  int32_t* sync;
+  int32_t sync_words;
+} ms_chain_tensors;
+int ms_decoder_chain_supported(const ms_chain_desc* d);
+size_t ms_decoder_chain_prepared_bytes(const ms_chain_desc* d);
+size_t ms_decoder_chain_workspace(const ms_chain_desc* d);
+int ms_decoder_chain_sync_words(const ms_chain_desc* d);
+int ms_decoder_chain_prepare(const ms_chain_desc* d, const float* const* w, const float* w_logits, void* prepared, void* stream);
+int ms_decoder_chain_fwd(const ms_chain_desc* d, const ms_chain_tensors* t, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Pre-step in front of the path ("next" row N1; src/data/transform.py, src/model/trainer.py:1290-1308), on device:
  * ms_kmeans_labels: KMeans.predict (transform.py:352-410) on RemoveJoints(pose): the feature blocks of KMeans.get_feats
  *   selected by `feats` (bit 0 pose (PK columns), bit 1 velocity (PK), bit 2 speed = |(vx, vy)| per kept joint (PK/2)), in

@@ -41,6 +41,20 @@ class ConvDesc(ctypes.Structure):
              [('slope', c_float), ('eps', c_float), ('momentum', c_float), ('dtype', ctypes.c_int32)]
 
 
+class ChainDesc(ctypes.Structure):
+  """struct ms_chain_desc"""
+  _fields_ = [(n, ctypes.c_int32) for n in ('B', 'M', 'T', 'cin0', 'C', 'P', 'n_blocks', 'mode', 'dtype', 'sync_first_word')] + \
+             [('slope', c_float), ('eps', c_float), ('momentum', c_float)]
+
+
+class ChainTensors(ctypes.Structure):
+  """struct ms_chain_tensors"""
+  _fields_ = [('x', ctypes.c_void_p), ('score', ctypes.c_void_p)] + \
+             [(n, ctypes.c_void_p * 4) for n in ('w', 'bias', 'gamma', 'beta', 'running_mean', 'running_var', 'y_raw', 'y', 'save')] + \
+             [(n, ctypes.c_void_p) for n in ('w_logits', 'bias_logits', 'z', 'soft', 'out', 'prepared', 'sync')] + \
+             [('sync_words', ctypes.c_int32)]
+
+
 class Prep16Item(ctypes.Structure):
   """struct ms_prep16_item"""
   _fields_ = [('desc', ctypes.POINTER(ConvDesc))] + [(n, ctypes.c_void_p) for n in
@@ -117,6 +131,12 @@ SIGNATURES = {
     'ms_l2_mean_bwd': (c_int, [_P, _P, c_float, _P, _P, c_size_t, _P]),
     'ms_copy_multi': (c_int, [c_int, _P, _P, _P, _P]),
     'ms_write_floats': (c_int, [_P, _P, c_int, _P]),
+    'ms_decoder_chain_supported': (c_int, [_P]),
+    'ms_decoder_chain_prepared_bytes': (c_size_t, [_P]),
+    'ms_decoder_chain_workspace': (c_size_t, [_P]),
+    'ms_decoder_chain_sync_words': (c_int, [_P]),
+    'ms_decoder_chain_prepare': (c_int, [_P, _P, _P, _P, _P]),
+    'ms_decoder_chain_fwd': (c_int, [_P, _P, _P, c_size_t, _P]),
     'ms_sqnorm': (c_int, [_P, c_size_t, _P, _P, _P]),
     'ms_adam_step': (c_int, [_P, _P, _P, _P, c_size_t, _P, c_float, c_float, c_float, c_float, c_float, _P, _P]),
     'ms_adam_step_segmented': (c_int, [_P, _P, _P, _P, c_size_t, _P, c_float, c_float, c_float, c_float, c_float, _P, _P, _P, _P,

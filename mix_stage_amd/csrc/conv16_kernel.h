@@ -409,6 +409,9 @@ __device__ __forceinline__ void conv16_epilogue_bnfused(const Conv16Args& p, con
     }
     (void)th_v; (void)tw_v;
     const float4 part = {cmean, cm2, chan_ok ? cn : 0.f, 0.f};
+    // one wave instruction = 64 lanes x 16 B = eight whole 128-byte lines, written through to the fabric
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, part), rsP,
+                                           (int)(16u * (unsigned)((grp * p.gx + tl.bx) * BM + tl.t)), 0, 16 /* sc1 */);
     gam = p.bn_g[chn]; bet = p.bn_b[chn];
     if (tl.bx == 0) { rmean = p.bn_m[chn]; rvar = p.bn_v[chn]; }
   }

@@ -177,11 +177,16 @@ class JointLateClusterSoftStyle4_G(nn.Module):
     internal_losses.append(ops.cross_entropy(labels_score, labels, layout='bct'))
 
     ## M sub-generators on the same input, mixed by softmax(labels_score) (JL:190-194)
-    z = self.decoder[0].forward_broadcast(x)
-    for m in list(self.decoder)[1:]:
-      z = m(z)
-    z = bare_conv(self.logits, z, out_f32=True)                 # (B, M*P, T), fp32 in every mode
-    x, self.labels_cap_soft = ops.softmax_mix(z, labels_score, self.out_feats)   # (B,T,P), (B,T,M)
+    chained = ops.decoder_chain(x, list(self.decoder), self.logits, labels_score, self.out_feats) if not dt else None
+    if chained is not None:
+      # decoder.0-3 + logits + softmax mixture as ONE launch (a workgroup carries a clip of a sub-generator through all blocks)
+      x, self.labels_cap_soft = chained
+    else:
+      z = self.decoder[0].forward_broadcast(x)
+      for m in list(self.decoder)[1:]:
+        z = m(z)
+      z = bare_conv(self.logits, z, out_f32=True)                 # (B, M*P, T), fp32 in every mode
+      x, self.labels_cap_soft = ops.softmax_mix(z, labels_score, self.out_feats)   # (B,T,P), (B,T,M)
 
     if pose_style_encoder_flag:
       if self.some_grad_flag:

@@ -149,15 +149,19 @@ class ConvNormRelu(nn.Module):
                                 eps=n.eps, momentum=0.1 if n.momentum is None else n.momentum)
     return self._geom
 
+  def _note_train_pass(self):
+    """Bookkeeping of one forward pass with batch statistics (nn.BatchNorm's num_batches_tracked, see __init__)."""
+    self._pending_batches += 1
+    if _train_tape is not None:
+      _train_tape.append(self)
+
   def _run(self, x, x2=None, in_mode=MS_IN_PLAIN, out_f32=False):
     if self._p and self.training:
       raise NotImplementedError('dropout p>0 is not on the Mix-StAGE path (p=0 everywhere, JL:26)')
     n = self.norm
     if self.training and n.track_running_stats:
       mode = MS_BN_TRAIN
-      self._pending_batches += 1           # nn.BatchNorm's num_batches_tracked (see __init__)
-      if _train_tape is not None:
-        _train_tape.append(self)
+      self._note_train_pass()
     else:
       mode = MS_BN_EVAL
     dt = getattr(self, '_ms_dt', 0)

@@ -127,6 +127,11 @@ def _prepare_entries(entries):
   if e16:                                # 16-bit mode operands (ops16): one ms_weights16_prepare launch per 24 blocks
     from . import ops16
     ops16._prepare16(e16)
+  for e in entries:
+    if e['kind'] == 'chain32':           # the chained decoder's weight streams (decoder_chain): one launch for its five convs
+      wl = (ctypes.c_void_p * 4)(*[x.data_ptr() for x in e['ws'][:4]])
+      check(L.ms_decoder_chain_prepare(ctypes.byref(e['d']), wl, _ptr(e['ws'][4]), _ptr(e['wt']), _stream()), 'ms_decoder_chain_prepare')
+      e['version'], e['tune'] = sum(x._version for x in e['ws']), tune
   for kind, fn in (('dgrad', L.ms_dgrad_weights_prepare), ('fwd', L.ms_fwd_weights_prepare)):
     es = [e for e in entries if e['kind'] == kind]
     if not es:
@@ -357,7 +362,7 @@ def _grad_slot(param, shape_like):
 
 class _ConvBlockFn(torch.autograd.Function):
   @staticmethod
-  def forward(ctx, x, x2, w, bias, gamma, beta, geom, mode, in_mode, stats):
+  def forward(ctx, x, x2, w, bias, gamma, beta, geom, mode, in_mode, stats, pre=None):
     rm, rv = stats if stats is not None else (None, None)
     _need_hip(x, x2, w, bias, gamma, beta, rm, rv)
     x = x.contiguous()
@@ -378,14 +383,23 @@ class _ConvBlockFn(torch.autograd.Function):
       raise RuntimeError('UP2ADD: a %s and residual %s do not match' % (tuple(x.shape), tuple(x2.shape)))
     d = geom.desc(B, Cin_g, H, W, Cout_g, mode, in_mode)
     oshape = (B, ctot, d.OH, d.OW) if nd == 2 else (B, ctot, d.OW)
-    y = torch.empty(oshape, dtype=torch.float32, device=x.device)
-    y_raw = save = None
-    if mode == MS_BN_TRAIN:
-      y_raw = torch.empty_like(y)
-      save = torch.empty(4 * ctot, dtype=torch.float32, device=x.device)
-    ws = workspace(d._fwd_ws, x.device)
-    planes = _prepared_for(w, d, 'fwd')
-    if planes is not None:
+    if pre is not None:
+      # the block's results were produced by a launch that chains several blocks (decoder_chain): nothing to run here, this
+      # node only carries the block's backward pass
+      y_raw, y, save = pre
+      if tuple(y.shape) != oshape:
+        raise RuntimeError('precomputed block output has shape %s, expected %s' % (tuple(y.shape), oshape))
+    else:
+      y = torch.empty(oshape, dtype=torch.float32, device=x.device)
+      y_raw = save = None
+      if mode == MS_BN_TRAIN:
+        y_raw = torch.empty_like(y)
+        save = torch.empty(4 * ctot, dtype=torch.float32, device=x.device)
+    ws = workspace(d._fwd_ws, x.device) if pre is None else None
+    planes = _prepared_for(w, d, 'fwd') if pre is None else None
+    if pre is not None:
+      pass
+    elif planes is not None:
       opt = FwdOptions(planes.data_ptr(), None, 0)
       check(lib().ms_conv_block_fwd_ex(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(bias), _ptr(gamma), _ptr(beta),
                                        _ptr(rm), _ptr(rv), _ptr(y_raw), _ptr(y), _ptr(save), _ptr(ws), ws.numel(),
@@ -470,7 +484,7 @@ class _ConvBlockFn(torch.autograd.Function):
                                       _ptr(dbias), _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), _stream()),
               'ms_conv_block_bwd')
     return (dx, dx2, None if direct_w else dw, None if direct_b else dbias, None if direct_g else dgamma,
-            None if direct_be else dbeta, None, None, None, None)
+            None if direct_be else dbeta, None, None, None, None, None)
 
 
 def _f32(t):
@@ -616,6 +630,132 @@ def sync_bn_act(y_raw, gamma, beta, running_mean, running_var, slope, eps, momen
 
 
 # ------------------------------------------------------------------------------------------------
+# Chained pose decoder (include/mixstage.h: ms_decoder_chain_fwd): decoder.0-3 + logits + softmax mixture in one launch.
+CHAIN_SYNC_FIRST_WORD = 32             # (word 0 of the chain's sync buffer is the error flag: ops16.chain_sync)
+USE_DECODER_CHAIN = os.environ.get('MS_DECODER_CHAIN', '1') != '0'       # ablations: MS_DECODER_CHAIN=0 runs the blocks one by one
+
+
+def _chain_desc(B, M, T, cin0, P, mode, blk, dtype=0):
+  g = blk._geometry()
+  return _lib.ChainDesc(B, M, T, cin0, 256, P, 4, mode, dtype, CHAIN_SYNC_FIRST_WORD, g.slope, g.eps, g.momentum)
+
+
+_chain_scratch = {}
+
+
+def _chain_prepared(d, ws):
+  """The chain's weight streams for these five weights.  Under a trainer that owns the parameter updates
+  (enable_prepared_weights): built on first use, rebuilt when torch changed a weight (version counters) or when the trainer says
+  so after an update it made through raw pointers (refresh_prepared_weights).  Otherwise: rebuilt on every call (nobody
+  vouches for the weights between calls), into a buffer that is reused."""
+  key = (ws[0].data_ptr(), d.M, d.cin0, d.P, 'chain32')
+  if not _prepared['on']:
+    n = (lib().ms_decoder_chain_prepared_bytes(ctypes.byref(d)) + 3) // 4
+    buf = _chain_scratch.get(key)
+    if buf is None or buf.numel() != n:
+      _chain_scratch.clear()
+      buf = _chain_scratch[key] = torch.empty(n, dtype=torch.float32, device=ws[0].device)
+    _prepare_entries([dict(w=ws[0], ws=list(ws), d=d, n=n, wt=buf, version=-1, tune=-1, kind='chain32')])
+    return buf
+  e = _prepared['entries'].get(key)
+  if e is None:
+    n = (lib().ms_decoder_chain_prepared_bytes(ctypes.byref(d)) + 3) // 4
+    e = dict(w=ws[0], ws=list(ws), d=d, n=n, wt=torch.empty(n, dtype=torch.float32, device=ws[0].device), version=-1, tune=-1,
+             kind='chain32')
+    _prepared['entries'][key] = e
+    _prepared['by_storage'].setdefault(ws[0].untyped_storage().data_ptr(), []).append(e)
+  e['ws'] = list(ws)
+  if e['version'] != sum(x._version for x in ws):
+    _prepare_entries([e])
+  return e['wt']
+
+
+def decoder_chain(x, blocks, logits, score, P):
+  """(out (B,T,P), soft (B,T,M)) = softmax mixture of logits(decoder(x)) for the M sub-generators (JL:190-194) in ONE launch, or
+  None when this shape / mode / device is not served by the chained kernel (the caller then runs the blocks one by one).
+  blocks: the four ConvNormRelu modules of the grouped decoder; logits: the grouped 1x1 nn.Conv1d; x (B, cin0, T) fp32 shared by
+  all groups; score (B, M, T)."""
+  if not USE_DECODER_CHAIN or len(blocks) != 4 or x.dim() != 3 or not x.is_cuda or x.dtype != torch.float32 or bn_sync_active():
+    return None
+  from . import ops16
+  if not ops16.in_launch_meetings():
+    return None
+  blk0 = blocks[0]
+  M = blk0.conv.groups
+  B, cin0, T = x.shape
+  if any(getattr(m, '_ms_dt', 0) for m in blocks) or any(m._p and m.training for m in blocks):
+    return None
+  if any(m._forward_hooks or m._forward_pre_hooks for m in list(blocks) + [logits]):
+    return None                            # (someone observes the blocks' own forward calls: run them)
+  if any(m.conv.groups != M or m.conv.kernel_size != (3,) or m.conv.stride != (1,) or m.conv.padding != (1,) or
+         m.conv.weight.shape[0] != 256 * M or m.conv.weight.dtype != torch.float32 or m._slope != blk0._slope for m in blocks):
+    return None
+  if blocks[0].conv.weight.shape[1] != cin0 or any(m.conv.weight.shape[1] != 256 for m in blocks[1:]):
+    return None
+  if logits.groups != M or logits.kernel_size != (1,) or logits.weight.shape[0] != M * P or logits.weight.shape[1] != 256 or logits.bias is None:
+    return None
+  if tuple(score.shape) != (B, M, T) or score.dtype != torch.float32:
+    return None
+  training = all(m.training and m.norm.track_running_stats for m in blocks)
+  if not training and any(m.training for m in blocks):
+    return None
+  mode = MS_BN_TRAIN if training else MS_BN_EVAL
+  params = [t for m in blocks for t in (m.conv.weight, m.conv.bias, m.norm.weight, m.norm.bias)] + [logits.weight, logits.bias]
+  need_grad = torch.is_grad_enabled() and (x.requires_grad or score.requires_grad or any(t is not None and t.requires_grad for t in params))
+  if need_grad and not training:
+    return None                            # (eval-mode blocks are never differentiated on the path)
+  d = _chain_desc(B, M, T, cin0, P, mode, blk0)
+  if not lib().ms_decoder_chain_supported(ctypes.byref(d)):
+    return None
+  _need_hip(x, score, *[t for t in params if t is not None])
+  x, score = x.contiguous(), score.contiguous()
+  dev = x.device
+  ws = [m.conv.weight for m in blocks] + [logits.weight]
+  prepared = _chain_prepared(d, ws)
+  sync = ops16.chain_sync(dev, B, M, CHAIN_SYNC_FIRST_WORD + lib().ms_decoder_chain_sync_words(ctypes.byref(d)))
+  C = 256 * M
+  keep = need_grad
+  y_raw = [torch.empty((B, C, T), dtype=torch.float32, device=dev) if keep else None for _ in blocks]
+  y = [torch.empty((B, C, T), dtype=torch.float32, device=dev) if keep else None for _ in blocks]
+  save = [torch.empty(4 * C, dtype=torch.float32, device=dev) if keep else None for _ in blocks]
+  z = torch.empty((B, M * P, T), dtype=torch.float32, device=dev) if keep else None
+  soft = torch.empty((B, T, M), dtype=torch.float32, device=dev)
+  out = torch.empty((B, T, P), dtype=torch.float32, device=dev)
+  tn = _lib.ChainTensors()
+  tn.x, tn.score = x.data_ptr(), score.data_ptr()
+  for l, m in enumerate(blocks):
+    tn.w[l], tn.bias[l] = m.conv.weight.data_ptr(), (m.conv.bias.data_ptr() if m.conv.bias is not None else None)
+    tn.gamma[l], tn.beta[l] = m.norm.weight.data_ptr(), m.norm.bias.data_ptr()
+    tn.running_mean[l], tn.running_var[l] = m.norm.running_mean.data_ptr(), m.norm.running_var.data_ptr()
+    tn.y_raw[l] = y_raw[l].data_ptr() if keep else None
+    tn.y[l] = y[l].data_ptr() if keep else None
+    tn.save[l] = save[l].data_ptr() if keep else None
+  tn.w_logits, tn.bias_logits = logits.weight.data_ptr(), logits.bias.data_ptr()
+  tn.z = z.data_ptr() if keep else None
+  tn.soft, tn.out, tn.prepared = soft.data_ptr(), out.data_ptr(), prepared.data_ptr()
+  tn.sync, tn.sync_words = sync.data_ptr(), sync.numel()
+  wsp = workspace(lib().ms_decoder_chain_workspace(ctypes.byref(d)), dev)
+  check(lib().ms_decoder_chain_fwd(ctypes.byref(d), ctypes.byref(tn), _ptr(wsp), wsp.numel(), _stream()), 'ms_decoder_chain_fwd')
+  if training:
+    for m in blocks:
+      m._note_train_pass()
+  if not need_grad:
+    return out, soft
+  # the autograd graph of the unchained forward pass, every node carrying results the chain already produced: the backward
+  # pass is the blocks' own (ms_conv_block_bwd, ms_softmax_mix_bwd)
+  h = x
+  for l, m in enumerate(blocks):
+    n = m.norm
+    h = _ConvBlockFn.apply(h, None, m.conv.weight, m.conv.bias, n.weight, n.bias, m._geometry(), MS_BN_TRAIN,
+                           MS_IN_BCAST if l == 0 else MS_IN_PLAIN, (n.running_mean, n.running_var), (y_raw[l], y[l], save[l]))
+  geom = getattr(logits, '_ms_geom', None)
+  if geom is None:
+    geom = logits._ms_geom = ConvGeom(1, logits.groups, logits.kernel_size, logits.stride, logits.padding, slope=0.0)
+  zt = _ConvBlockFn.apply(h, None, logits.weight, logits.bias, None, None, geom, MS_BARE, MS_IN_PLAIN, None, (None, z, None))
+  return _SoftmaxMixFn.apply(zt, score, int(P), (out, soft))
+
+
+# ------------------------------------------------------------------------------------------------
 class _LerpTimeFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, x, t_out):
@@ -644,15 +784,18 @@ def lerp_time(x, t_out):
 
 class _SoftmaxMixFn(torch.autograd.Function):
   @staticmethod
-  def forward(ctx, z, score, P):
+  def forward(ctx, z, score, P, pre=None):
     _need_hip(z, score)
     z, score = z.contiguous(), score.contiguous()
     B, M, T = score.shape
     assert z.shape == (B, M * P, T), (z.shape, score.shape, P)
-    soft = torch.empty((B, T, M), dtype=torch.float32, device=z.device)
-    out = torch.empty((B, T, P), dtype=torch.float32, device=z.device)
-    check(lib().ms_softmax_mix_fwd(_ptr(z), _ptr(score), _ptr(soft), _ptr(out), B, M, P, T, _stream()),
-          'ms_softmax_mix_fwd')
+    if pre is not None:
+      out, soft = pre                     # produced by the chained decoder launch (decoder_chain)
+    else:
+      soft = torch.empty((B, T, M), dtype=torch.float32, device=z.device)
+      out = torch.empty((B, T, P), dtype=torch.float32, device=z.device)
+      check(lib().ms_softmax_mix_fwd(_ptr(z), _ptr(score), _ptr(soft), _ptr(out), B, M, P, T, _stream()),
+            'ms_softmax_mix_fwd')
     ctx.save_for_backward(z, soft)
     ctx.dims = (B, M, P, T)
     ctx.mark_non_differentiable(soft)
@@ -667,7 +810,7 @@ class _SoftmaxMixFn(torch.autograd.Function):
     dscore = torch.empty((B, M, T), dtype=torch.float32, device=z.device)
     check(lib().ms_softmax_mix_bwd(_ptr(z), _ptr(soft), _ptr(dout), _ptr(dz), _ptr(dscore), B, M, P, T, _stream()),
           'ms_softmax_mix_bwd')
-    return dz, dscore, None
+    return dz, dscore, None, None
 
 
 @_bridge64

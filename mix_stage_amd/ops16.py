@@ -64,9 +64,26 @@ def _ensure_bn_sync(device):
   return buf
 
 
+def chain_sync(device, B, M, words):
+  """The chained decoder's meeting counters: a zeroed buffer per (device, stream, B, M) -- the counters are monotonic, which needs
+  every launch that shares them to have the same member counts."""
+  if not _in_launch['on']:
+    return None
+  key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream, 'chain', B, M)
+  buf = _bn_sync.get(key)
+  if buf is None or buf.numel() < words:
+    buf = _bn_sync[key] = torch.zeros(words, dtype=torch.int32, device=device)
+  return buf
+
+
 def bn_sync_error():
   """True when an in-launch BatchNorm workgroup timed out waiting for its group (synchronises the device)."""
   return any(int(b[0].item()) != 0 for b in _bn_sync.values())
+
+
+def bn_sync_words():
+  """Diagnostics: the first words of every sync buffer (word 0 = error code)."""
+  return [b[:3].tolist() for b in _bn_sync.values()]
 
 
 def bn_sync_clear():

@@ -466,9 +466,10 @@ class MixStageTrainStep:
     outputs were poisoned with NaN.  Synchronises the device.  Causes: another process or a large kernel on another stream held
     compute units the launch needed -- run one trainer per GPU, or switch the forms off (ops16.set_in_launch_meetings(False))."""
     if ops16.bn_sync_error():
+      words = ops16.bn_sync_words()
       ops16.bn_sync_clear()
-      raise RuntimeError('an in-launch BatchNorm meeting timed out (the launch did not have the GPU to itself): the step produced '
-                         'NaN; see MixStageTrainStep.check_health')
+      raise RuntimeError('(sync words %s) an in-launch BatchNorm meeting timed out (the launch did not have the GPU to itself): the step produced '
+                         'NaN; see MixStageTrainStep.check_health' % (words,))
 
   def _graph_step(self, k, pose_branch, audio, labels, pose, style, inputs_unchanged=False):
     self.model._lambda_host_writes = False   # the captured loss kernels read the device tensor written below
