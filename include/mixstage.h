@@ -274,7 +274,9 @@ int ms_softmax_mix_bwd(const float* z, const float* soft, const float* dout, flo
  *                 one by one with ms_conv_block_fwd).
  *   mode          MS_BN_TRAIN: batch statistics over all B clips, running statistics updated, `save` written; MS_BN_EVAL: running
  *                 statistics as they are.
- *   dtype         MS_F32: x (B, cin0, T), y_raw / y (B, M*C, T) fp32.
+ *   dtype         MS_F32: x (B, cin0, T), y_raw / y (B, M*C, T) fp32.  MS_BF16 / MS_F16: x, y_raw, y are cb8 tensors
+ *                 ((B, ceil(cin0/8), T, 8) and (B, M*C/8, T, 8)), 16-bit operands with fp32 accumulation and fp32 statistics;
+ *                 y_raw is written only where the backward pass reads it (keep_all_raw); z, soft, out stay fp32.
  *   x             block 0's input.  score (B, M, T): the cluster scores.  w[l] (M*C, cin_l, 3), w_logits (M*P, C, 1): the
  *                 modules' own weights -- read by ms_decoder_chain_prepare only; the launch streams `prepared`.
  *   y_raw, y, save  per block, or NULL: conv + bias, block output, mean|invstd|scale|shift (what ms_conv_block_bwd reads).
@@ -291,6 +293,8 @@ typedef struct ms_chain_desc {
   int32_t mode;             /* MS_BN_TRAIN | MS_BN_EVAL */
   int32_t dtype;            /* ms_dtype */
   int32_t sync_first_word;  /* first word of `sync` this launch may use (>= 32: word 0 is the error flag) */
+  int32_t keep_all_raw;     /* 16-bit modes, BN_TRAIN: y_raw for every channel block (0: only where ms_conv_block_bwd will read it --
+                             * blocks whose BatchNorm + LeakyReLU map does not invert safely from y, see ms_set_bn_sync_buffer) */
   float slope, eps, momentum;
 } ms_chain_desc;
 typedef struct ms_chain_tensors {

@@ -63,6 +63,10 @@ int ms_debug_set_bn_fused_min_workgroups(int n);
  * then meaningless); NULL or "" restores normal operation.  Returns the number of patterns. */
 int ms_debug_set_skip(const char* patterns);
 
+/* Ablations: 0 = the clip-resident 1-D conv kernels (clip32.hip: conv + BatchNorm + LeakyReLU of a UNet / classifier / style-encoder /
+ * discriminator block in one launch) are not used; returns the previous value. */
+int ms_debug_set_clip32(int on);
+
 /* Self-test kernel: C(32x32) = A(32xK) * B(Kx32) through the fp32 MFMA path (checks fragment maps). */
 int ms_selftest_mfma(const float* A, const float* B, float* C, int K, void* stream);
 

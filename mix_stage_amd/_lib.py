@@ -43,7 +43,7 @@ class ConvDesc(ctypes.Structure):
 
 class ChainDesc(ctypes.Structure):
   """struct ms_chain_desc"""
-  _fields_ = [(n, ctypes.c_int32) for n in ('B', 'M', 'T', 'cin0', 'C', 'P', 'n_blocks', 'mode', 'dtype', 'sync_first_word')] + \
+  _fields_ = [(n, ctypes.c_int32) for n in ('B', 'M', 'T', 'cin0', 'C', 'P', 'n_blocks', 'mode', 'dtype', 'sync_first_word', 'keep_all_raw')] + \
              [('slope', c_float), ('eps', c_float), ('momentum', c_float)]
 
 
@@ -149,6 +149,7 @@ SIGNATURES = {
     'ms_debug_set_conv16_tile': (c_int, [c_int, c_int]),
     'ms_debug_set_conv16_ring': (c_int, [c_int, c_int]),
     'ms_debug_set_skip': (c_int, [ctypes.c_char_p]),
+    'ms_debug_set_clip32': (c_int, [c_int]),
     'ms_debug_set_wgrad16_target': (c_int, [c_int]),
     'ms_debug_set_wgrad16_ring': (c_int, [c_int]),
     'ms_debug_set_wgrad_target': (c_int, [c_int]),
@@ -183,6 +184,8 @@ def lib():
       handle.ms_debug_set_bn_fused(int(os.environ['MS_BN_FUSED']))
     if os.environ.get('MS_BN_FUSED_MIN_WGS'):
       handle.ms_debug_set_bn_fused_min_workgroups(int(os.environ['MS_BN_FUSED_MIN_WGS']))
+    if os.environ.get('MS_CLIP32'):             # ablations only: MS_CLIP32=0 keeps the per-layer patch / gather kernels
+      handle.ms_debug_set_clip32(int(os.environ['MS_CLIP32']))
     if os.environ.get('MS_PATCH_MIN_WGS'):      # tuning experiments only (ms_debug_set_patch_min_workgroups)
       handle.ms_debug_set_patch_min_workgroups(int(os.environ['MS_PATCH_MIN_WGS']))
     _lib = handle

@@ -76,6 +76,8 @@ size_t ms_conv_block_fwd_workspace(const ms_conv_desc* d) {
   }
   bytes = align_up(bytes, 256) + 256;
   if (pp.ok && pp.p6) bytes += align_up((size_t)3 * ctot_of(d) * patch6_row_elems(d->Cin, d->KH, d->KW) * 2, 256);   // split weights
+  if (g_precision == 0 && clip32_fwd_ok(d))      // clip-resident kernel: statistics partials | weight stream (when not prepared)
+    bytes = std::max(bytes, clip32_part_bytes(d->Cout, d->B * d->OW / 32) + align_up(clip32_fwd_weight_bytes(d), 256) + 256);
   return bytes;
 }
 
@@ -89,7 +91,7 @@ size_t ms_conv_block_bwd_workspace(const ms_conv_desc* d) {
   size_t bytes = 0;
   bytes += align_up((size_t)ctot_of(d) * nchunk * 2 * sizeof(float), 256);  // bn partials
   bytes += align_up((size_t)ctot_of(d) * nchunk * sizeof(float), 256);      // colsum partials
-  bytes += align_up(dgrad_weight_elems(d->groups, d->Cout, d->Cin, d->KH, d->KW, d->SH, d->SW) * sizeof(float), 256);
+  bytes += align_up(std::max(dgrad_weight_elems(d->groups, d->Cout, d->Cin, d->KH, d->KW, d->SH, d->SW), clip32_dgrad_weight_floats(d)) * sizeof(float), 256);
   bytes += align_up(wsize_of(d) * sizeof(float) * (splits > 1 ? splits : 0), 256);
   {
     const bool bc = d->in_mode == MS_IN_BCAST;
@@ -132,6 +134,23 @@ int ms_conv_block_fwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
   if (workspace_bytes < ms_conv_block_fwd_workspace(d)) return set_error("ms_conv_block_fwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   const int C = ctot_of(d), npix = d->B * d->OH * d->OW, hw = d->OH * d->OW;
+
+  if (g_precision == 0 && clip32_fwd_ok(d)) {
+    // 1-D blocks whose whole reduction fits a workgroup (clip32.hip): conv, statistics, meeting, normalisation in ONE launch
+    char* wsp = (char*)workspace;
+    float* part = (float*)wsp; wsp += clip32_part_bytes(d->Cout, d->B * d->OW / 32);
+    const float* wp = (const float*)w_planes;
+    if (!wp) {
+      rc = clip32_prep_queue(w, (float*)wsp, d->Cout, d->Cin, d->KW, 0, d->Cin, s);
+      if (!rc) rc = clip32_prep_flush(s);
+      if (rc) return rc;
+      wp = (const float*)wsp;
+    }
+    rc = clip32_block_fwd(d, x, x2, wp, bias, gamma, beta, running_mean, running_var, y_raw, y, save, part, opt ? opt->bn_sync : nullptr,
+                          opt ? opt->bn_sync_words : 0, s);
+    if (rc != -2) return rc;          // (-2: BN_TRAIN without counters, or a grid that is not resident at once: the kernels below)
+    rc = 0;
+  }
 
   GatherArgs a = {};
   a.A = w; a.src = x; a.src2 = x2;
@@ -242,6 +261,10 @@ struct DgradWeights { int need, flip, tg, tcog, p6; size_t elems; };
 static DgradWeights dgrad_weights_of(const ms_conv_desc* d, const float* w) {
   const bool bcast = d->in_mode == MS_IN_BCAST;
   DgradWeights r;
+  if (g_precision == 0 && clip32_dgrad_ok(d)) {     // clip-resident kernel: the transposed, tap-reversed weight stream
+    r.need = 2; r.flip = 1; r.tg = 1; r.tcog = d->Cout; r.p6 = 0; r.elems = clip32_dgrad_weight_floats(d);
+    return r;
+  }
   r.tg = bcast ? 1 : d->groups;
   r.tcog = bcast ? d->groups * d->Cout : d->Cout;
   const int jh = cdiv(d->KH, d->SH), jw = cdiv(d->KW, d->SW);
@@ -307,6 +330,7 @@ size_t ms_dgrad_weights_elems(const ms_conv_desc* d, const float* w) {
 size_t ms_fwd_weights_bytes(const ms_conv_desc* d) {
   if (validate(d, "ms_fwd_weights_bytes")) return 0;
   if (dt_of(d) != DT_F32) return 0;          // 16-bit modes: ms_weights16_bytes / ms_weights16_prepare
+  if (g_precision == 0 && clip32_fwd_ok(d)) return clip32_fwd_weight_bytes(d);       // clip-resident kernel: its weight stream
   const PatchPlan pp = fwd_patch_plan(d);
   return (pp.ok && pp.p6) ? (size_t)3 * ctot_of(d) * patch6_row_elems(d->Cin, d->KH, d->KW) * 2 : 0;
 }
@@ -321,6 +345,11 @@ int ms_fwd_weights_prepare(int n, const ms_conv_desc* descs, const float* const*
     if (rc) return rc;
     if (!ms_fwd_weights_bytes(d)) continue;
     if (!planes[i]) return set_error("ms_fwd_weights_prepare: block %d needs a buffer of ms_fwd_weights_bytes bytes", i);
+    if (g_precision == 0 && clip32_fwd_ok(d)) {
+      rc = clip32_prep_queue(w[i], (float*)planes[i], d->Cout, d->Cin, d->KW, 0, d->Cin, (hipStream_t)stream);
+      if (rc) return rc;
+      continue;
+    }
     SplitJob jb = {w[i], (unsigned short*)planes[i], ctot_of(d), d->Cin, d->KH * d->KW, 0, 0, 0};
     sb.job[sb.n++] = jb;
     if (sb.n == SPLIT_BATCH_MAX) {
@@ -329,6 +358,7 @@ int ms_fwd_weights_prepare(int n, const ms_conv_desc* descs, const float* const*
       sb.n = 0;
     }
   }
+  { const int rcq = clip32_prep_flush((hipStream_t)stream); if (rcq) return rcq; }
   return sb.n ? launch_split_weights_multi(sb, (hipStream_t)stream) : 0;
 }
 
@@ -343,6 +373,11 @@ int ms_dgrad_weights_prepare(int n, const ms_conv_desc* descs, const float* cons
     const DgradWeights dw = dgrad_weights_of(d, w[i]);
     if (!dw.need) continue;
     if (!wt[i]) return set_error("ms_dgrad_weights_prepare: block %d needs a buffer of ms_dgrad_weights_elems floats", i);
+    if (dw.need == 2) {
+      rc = clip32_prep_queue(w[i], wt[i], d->Cin, d->Cout, 3, 1, d->Cin, (hipStream_t)stream);
+      if (rc) return rc;
+      continue;
+    }
     TransposeJob jb = {w[i], wt[i], dw.tg, dw.tcog, d->Cin, d->KH, d->KW, d->SH, d->SW, d->PH, d->PW, dw.flip, 0};
     tb.job[tb.n++] = jb;
     if (tb.n == TRANSPOSE_BATCH_MAX) {
@@ -355,6 +390,7 @@ int ms_dgrad_weights_prepare(int n, const ms_conv_desc* descs, const float* cons
     const int rc = launch_transpose_weight_multi(tb, (hipStream_t)stream);
     if (rc) return rc;
   }
+  { const int rcq = clip32_prep_flush((hipStream_t)stream); if (rcq) return rcq; }
   // bf16x6 mode: the planes of the fp32 copies just built, behind them
   SplitBatch sb;
   sb.n = 0;
@@ -438,7 +474,7 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
   char* wsp = (char*)workspace;
   float* bn_part = (float*)wsp; wsp += align_up((size_t)C * nchunk * 2 * sizeof(float), 256);
   float* colpart = (float*)wsp; wsp += align_up((size_t)C * nchunk * sizeof(float), 256);
-  float* wt = (float*)wsp; wsp += align_up(dgrad_weight_elems(d->groups, d->Cout, d->Cin, d->KH, d->KW, d->SH, d->SW) * sizeof(float), 256);
+  float* wt = (float*)wsp; wsp += align_up(std::max(dgrad_weight_elems(d->groups, d->Cout, d->Cin, d->KH, d->KW, d->SH, d->SW), clip32_dgrad_weight_floats(d)) * sizeof(float), 256);
   float* wg_part = (float*)wsp;
   {
     const int sp = wgrad_total_splits(d);
@@ -482,7 +518,22 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
   }
 
   // 2. data gradient: transposed gather over dyr with wt[g][ci][co][khw]
-  if (dx) {
+  bool dx_done = false;
+  if (dx && g_precision == 0 && clip32_dgrad_ok(d)) {
+    // k3 s1 blocks whose reduction fits a workgroup: one launch of the clip-resident kernel (clip32.hip), no split-K slab
+    const float* wp = wt_prepared;
+    if (!wp) {
+      rc = clip32_prep_queue(w, wt, d->Cin, d->Cout, 3, 1, d->Cin, s);
+      if (!rc) rc = clip32_prep_flush(s);
+      if (rc) return rc;
+      wp = wt;
+    }
+    rc = clip32_block_dgrad(d, g, wp, dx, dx2, s);
+    if (rc && rc != -2) return rc;
+    dx_done = rc == 0;
+    rc = 0;
+  }
+  if (dx && !dx_done) {
     const int tg = bcast ? 1 : d->groups;          // broadcast input: all groups sum into the same channels
     const int tcog = bcast ? C : d->Cout;
     const int jh = cdiv(d->KH, d->SH), jw = cdiv(d->KW, d->SW);

@@ -48,7 +48,8 @@ constexpr int CH_LOGIT_Q = 32;            // k-groups of the 1x1 logits conv (25
 constexpr size_t CH_WAVE_STREAM = (size_t)CH_CONV_BLOCKS * CH_BLK * 2 * 256 + (size_t)CH_LOGIT_Q * 256 + 2 * CH_BLK * 2 * 256;   // floats per (group, wave), + 2 blocks of slack for the ring's read-ahead
 constexpr int CH_SPIN_LIMIT = 1 << 21;
 constexpr int CH_PPAD = 128;              // rows of the logits tile (P <= 128)
-constexpr int CH_LDS_FLOATS = CH_BUF0 + CH_BUF1 + 3 * 256 + 64 + 8;
+constexpr int CH_MAXM = 32;               // groups (the softmax of a frame is formed in registers)
+constexpr int CH_LDS_FLOATS = CH_BUF0 + CH_BUF1 + 3 * CH_NL * 256 + 2 * 256 + 64 + 8;
 
 struct Chain32Args {
   const float* x;             // (B, cin0, 64)
@@ -101,8 +102,12 @@ __global__ __launch_bounds__(256, 1) void chain32_kernel(const Chain32Args p) {
   extern __shared__ float smem[];
   float* bufA = smem;
   float* bufB = bufA + CH_BUF0;
-  float* pb = bufB + CH_BUF1;               // [256] bias of the current block
-  float* psc = pb + 256;                    // [256] scale
+  // per-block parameter tables, filled once at the start (no global load sits between two blocks' K loops: a wait for it would
+  // also wait for every weight load issued before it).  train: bias | gamma | beta; eval: bias | scale | shift
+  float* tb0 = bufB + CH_BUF1;              // [NL][256]
+  float* tb1 = tb0 + CH_NL * 256;
+  float* tb2 = tb1 + CH_NL * 256;
+  float* psc = tb2 + CH_NL * 256;           // [256] scale of the current block (train: after the meeting)
   float* psh = psc + 256;                   // [256] shift
   float* sg = psh + 256;                    // [64] this group's softmax weight per frame
   int* lflag = reinterpret_cast<int*>(sg + 64);   // [0]: a meeting expired
@@ -114,14 +119,8 @@ __global__ __launch_bounds__(256, 1) void chain32_kernel(const Chain32Args p) {
   // ---- this wave's weight stream: 16 bytes per lane and (k-group, row block); two stream blocks ahead of their use
   const float4* ws = reinterpret_cast<const float4*>(p.wp + ((size_t)g * 4 + w) * CH_WAVE_STREAM) + lane;
   float4 ra0[CH_BLK][2], ra1[CH_BLK][2];
-#pragma unroll
-  for (int u = 0; u < CH_BLK; ++u)
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-      ra0[u][mb] = ld_global_f4(ws + ((0 * CH_BLK + u) * 2 + mb) * 64);
-      ra1[u][mb] = ld_global_f4(ws + ((1 * CH_BLK + u) * 2 + mb) * 64);
-    }
-
+  // (their first loads go out behind the prologue's own loads, below: loads return in order, and the input image must not wait
+  // for 50 KB of weights per wave)
   // ---- LDS: zero the halos (pixel slots 0 and 65..67 of every plane), stage the clip's input, this group's softmax weights
   if (t == 0) lflag[0] = 0;
   for (int e = t; e < (CH_K8_0 + 32) * 2 * 4; e += 256) {
@@ -130,41 +129,95 @@ __global__ __launch_bounds__(256, 1) void chain32_kernel(const Chain32Args p) {
     *reinterpret_cast<float4*>(pl + (s == 0 ? 0 : 64 + s) * 4) = float4{0.f, 0.f, 0.f, 0.f};
   }
   {
-    // plane (k8, hh) = channels 8*k8 + 4*hh + 0..3; a wave takes every 4th plane, a lane one frame: 4 coalesced row loads, one
-    // 16-byte LDS store
+    // every global load of the prologue goes out before the first LDS store (each wait would otherwise be a round trip of its own).
+    // Input image: plane (k8, hh) = channels 8*k8 + 4*hh + 0..3; a wave takes every 4th plane, a lane one frame: coalesced row
+    // loads, one 16-byte LDS store per plane
+    constexpr int NPL = (CH_K8_0 * 2 + 3) / 4;                  // planes per wave
     const float* xb = p.x + (size_t)b * p.cin0 * CH_T + lane;
-    for (int pl0 = w; pl0 < CH_K8_0 * 2; pl0 += 16) {
-      float v[4][4];
+    float xv[NPL][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int pl = pl0 + 4 * i;
+    for (int i = 0; i < NPL; ++i) {
+      const int pl = w + 4 * i;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int c = 4 * pl + j;
-          v[i][j] = (pl < CH_K8_0 * 2 && c < p.cin0) ? xb[(size_t)c * CH_T] : 0.f;
-        }
+      for (int j = 0; j < 4; ++j) {
+        const int c = 4 * pl + j;
+        xv[i][j] = xb[(size_t)min(c, p.cin0 - 1) * CH_T];
       }
+    }
+    float q0[CH_NL], q1[CH_NL], q2[CH_NL], q3[CH_NL], q4[CH_NL];
+    const int cgp = g * CH_C + t;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int pl = pl0 + 4 * i;
-        if (pl < CH_K8_0 * 2) *reinterpret_cast<float4*>(bufA + pl * CH_PLANE + (1 + lane) * 4) = float4{v[i][0], v[i][1], v[i][2], v[i][3]};
+    for (int l = 0; l < CH_NL; ++l) {
+      q0[l] = p.bias[l] ? p.bias[l][cgp] : 0.f;
+      q1[l] = p.gamma[l][cgp];
+      q2[l] = p.beta[l][cgp];
+      q3[l] = p.train ? 0.f : p.rm[l][cgp];
+      q4[l] = p.train ? 1.f : p.rv[l][cgp];
+    }
+    float sv[CH_MAXM];
+    {
+      const float* sp = p.score + (size_t)b * p.M * CH_T + lane;
+#pragma unroll
+      for (int m = 0; m < CH_MAXM; ++m) sv[m] = sp[(size_t)min(m, p.M - 1) * CH_T];
+    }
+    // the weight ring's first fill, behind the loads above
+#pragma unroll
+  for (int u = 0; u < CH_BLK; ++u)
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      ra0[u][mb] = ld_global_f4(ws + ((0 * CH_BLK + u) * 2 + mb) * 64);
+      ra1[u][mb] = ld_global_f4(ws + ((1 * CH_BLK + u) * 2 + mb) * 64);
+    }
+
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int pl = w + 4 * i;
+      if (pl < CH_K8_0 * 2) {
+        float4 v;
+        v.x = 4 * pl < p.cin0 ? xv[i][0] : 0.f;
+        v.y = 4 * pl + 1 < p.cin0 ? xv[i][1] : 0.f;
+        v.z = 4 * pl + 2 < p.cin0 ? xv[i][2] : 0.f;
+        v.w = 4 * pl + 3 < p.cin0 ? xv[i][3] : 0.f;
+        *reinterpret_cast<float4*>(bufA + pl * CH_PLANE + (1 + lane) * 4) = v;
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < CH_NL; ++l) {
+      tb0[l * 256 + t] = q0[l];
+      if (p.train) { tb1[l * 256 + t] = q1[l]; tb2[l * 256 + t] = q2[l]; }
+      else {
+        const float sc = q1[l] * (1.0f / sqrtf(q4[l] + p.eps));
+        tb1[l * 256 + t] = sc;
+        tb2[l * 256 + t] = q2[l] - q3[l] * sc;
+      }
+    }
+    if (t < CH_T) {
+      // softmax over the M cluster scores of frame t (JL:186-187); group 0's workgroup of the clip writes the monitor tensor
+      float mx = sv[0];
+#pragma unroll
+      for (int m = 1; m < CH_MAXM; ++m) mx = m < p.M ? fmaxf(mx, sv[m]) : mx;
+      float den = 0.f, mine = 0.f;
+#pragma unroll
+      for (int m = 0; m < CH_MAXM; ++m) {
+        sv[m] = m < p.M ? __expf(sv[m] - mx) : 0.f;
+        den += sv[m];
+        mine = m == g ? sv[m] : mine;
+      }
+      sg[t] = mine / den;
+      if (g == 0 && p.soft) {
+#pragma unroll
+        for (int m = 0; m < CH_MAXM; ++m)
+          if (m < p.M) p.soft[((size_t)b * CH_T + t) * p.M + m] = sv[m] / den;
       }
     }
   }
-  if (t < CH_T) {
-    // softmax over the M cluster scores of frame t (JL:186-187); group 0's workgroup of the clip writes the monitor tensor
-    const float* sp = p.score + (size_t)b * p.M * CH_T + t;
-    float mx = sp[0];
-    for (int m = 1; m < p.M; ++m) mx = fmaxf(mx, sp[(size_t)m * CH_T]);
-    float den = 0.f, mine = 0.f;
-    for (int m = 0; m < p.M; ++m) {
-      const float e = __expf(sp[(size_t)m * CH_T] - mx);
-      den += e;
-      if (m == g) mine = e;
-    }
-    sg[t] = mine / den;
-    if (g == 0 && p.soft)
-      for (int m = 0; m < p.M; ++m) p.soft[((size_t)b * CH_T + t) * p.M + m] = __expf(sp[(size_t)m * CH_T] - mx) / den;
+  // the leader of a group (clip 0) updates the running statistics: their old values, fetched now
+  float rm_old[CH_NL], rv_old[CH_NL];
+#pragma unroll
+  for (int l = 0; l < CH_NL; ++l) {
+    const bool lead = p.train && b == 0;
+    rm_old[l] = lead ? p.rm[l][g * CH_C + t] : 0.f;
+    rv_old[l] = lead ? p.rv[l][g * CH_C + t] : 0.f;
   }
 
   f32x16 acc[2][2];
@@ -203,16 +256,8 @@ __global__ __launch_bounds__(256, 1) void chain32_kernel(const Chain32Args p) {
   };
 
   for (int l = 0; l < CH_NL; ++l) {
-    // ---- per-channel parameters of this block into LDS (read after the K loop)
-    {
-      const int cg = g * CH_C + t;
-      pb[t] = p.bias[l] ? p.bias[l][cg] : 0.f;
-      if (!p.train) {
-        const float sc = p.gamma[l][cg] * (1.0f / sqrtf(p.rv[l][cg] + p.eps));
-        psc[t] = sc;
-        psh[t] = p.beta[l][cg] - p.rm[l][cg] * sc;
-      }
-    }
+    const float* pb = tb0 + l * 256;
+    if (!p.train) { psc = tb1 + l * 256; psh = tb2 + l * 256; }
     if (l == 0) __syncthreads();           // the input image is complete
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
@@ -318,34 +363,43 @@ __global__ __launch_bounds__(256, 1) void chain32_kernel(const Chain32Args p) {
       {
         // thread = channel: the B clips' partials in clip order (Chan, fp64): every workgroup of the group computes the same bits
         const unsigned base = 8u * (unsigned)(((l * p.M + g) * p.B) * CH_C + t);
-        double n = 0.0, mean = 0.0, m2 = 0.0;
-        for (int b0 = 0; b0 < p.B; b0 += 8) {
-          float2 pv[8];
+        // equal counts (64 frames per clip): mean = average of the clips' means, M2 = sum of their M2 + 64 * sum (mean_i - mean)^2
+        // -- two passes over the partials in clip order, fp64, no division in the loops
+        double msum = 0.0, m2 = 0.0, dev = 0.0;
+        float2 pv[32];
+        const int nb32 = min(p.B, 32);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int bb2 = min(b0 + i, p.B - 1);
-            pv[i] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsPart, (int)(base + 8u * (unsigned)(bb2 * CH_C)), 0, 16));
-          }
-#pragma unroll
-          for (int i = 0; i < 8; ++i)
-            if (b0 + i < p.B) {
-              const double nw = (double)CH_T, tot = n + nw, dl = (double)pv[i].x - mean;
-              mean += dl * (nw / tot);
-              m2 += (double)pv[i].y + dl * dl * (n * nw / tot);
-              n = tot;
-            }
+        for (int i = 0; i < 32; ++i) {
+          const int bb2 = min(i, p.B - 1);
+          pv[i] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsPart, (int)(base + 8u * (unsigned)(bb2 * CH_C)), 0, 16));
         }
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+          if (i < nb32) { msum += (double)pv[i].x; m2 += (double)pv[i].y; }
+        for (int bb2 = 32; bb2 < p.B; ++bb2) {
+          const float2 q = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsPart, (int)(base + 8u * (unsigned)(bb2 * CH_C)), 0, 16));
+          msum += (double)q.x; m2 += (double)q.y;
+        }
+        const double n = (double)p.B * CH_T, mean = msum / (double)p.B;
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+          if (i < nb32) { const double dl = (double)pv[i].x - mean; dev += dl * dl; }
+        for (int bb2 = 32; bb2 < p.B; ++bb2) {
+          const float2 q = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsPart, (int)(base + 8u * (unsigned)(bb2 * CH_C)), 0, 16));
+          const double dl = (double)q.x - mean; dev += dl * dl;
+        }
+        m2 += (double)CH_T * dev;
         const int cg = g * CH_C + t;
         const float var = (float)(m2 / n), fmean = (float)mean;
         const float invstd = 1.0f / sqrtf(var + p.eps);
-        float sc = p.gamma[l][cg] * invstd;
-        float sh = p.beta[l][cg] - fmean * sc;
+        float sc = tb1[l * 256 + t] * invstd;
+        float sh = tb2[l * 256 + t] - fmean * sc;
         if (lflag[0]) { sc = __builtin_nanf(""); sh = sc; }
         else if (b == 0) {
           if (p.save[l]) { float* sv = p.save[l]; sv[cg] = fmean; sv[C + cg] = invstd; sv[2 * C + cg] = sc; sv[3 * C + cg] = sh; }
           const float unbiased = n > 1.0 ? (float)(m2 / (n - 1.0)) : var;
-          p.rm[l][cg] = (1.f - p.momentum) * p.rm[l][cg] + p.momentum * fmean;
-          p.rv[l][cg] = (1.f - p.momentum) * p.rv[l][cg] + p.momentum * unbiased;
+          p.rm[l][cg] = (1.f - p.momentum) * rm_old[l] + p.momentum * fmean;
+          p.rv[l][cg] = (1.f - p.momentum) * rv_old[l] + p.momentum * unbiased;
         }
         psc[t] = sc;
         psh[t] = sh;
@@ -431,10 +485,16 @@ __global__ __launch_bounds__(256, 1) void chain32_kernel(const Chain32Args p) {
     for (int e = t; e < nq * p.P; e += 256) {
       const int tq = e / p.P, pp = e - tq * p.P;
       float4 s = {0.f, 0.f, 0.f, 0.f};
-      for (int m = 0; m < p.M; ++m) {
-        const unsigned off = 4u * (unsigned)((((b * p.M + m) * CH_PPAD) + pp) * CH_T + t0 + 4 * tq);
-        const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsMix, (int)off, 0, 16));
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      for (int m0 = 0; m0 < p.M; m0 += 8) {              // 8 groups' terms in flight, added in group order
+        float4 v4[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const unsigned off = 4u * (unsigned)((((b * p.M + min(m0 + i, p.M - 1)) * CH_PPAD) + pp) * CH_T + t0 + 4 * tq);
+          v4[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsMix, (int)off, 0, 16));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (m0 + i < p.M) { s.x += v4[i].x; s.y += v4[i].y; s.z += v4[i].z; s.w += v4[i].w; }
       }
       if (lflag[0]) s = float4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
       float* o = p.out + ((size_t)b * CH_T + t0 + 4 * tq) * p.P + pp;
@@ -519,7 +579,7 @@ __global__ __launch_bounds__(256) void chain32_prep_kernel(const ChainPrepArgs p
 
 static int chain32_shape_ok(const ms_chain_desc* d) {
   return d && d->T == CH_T && d->C == CH_C && d->n_blocks == CH_NL && d->cin0 > CH_C && d->cin0 <= 8 * CH_K8_0 && d->P >= 1 &&
-         d->P <= CH_PPAD && d->B >= 1 && d->M >= 1 && (d->mode == MS_BN_TRAIN || d->mode == MS_BN_EVAL) && d->dtype == MS_F32;
+         d->P <= CH_PPAD && d->B >= 1 && d->M >= 1 && d->M <= CH_MAXM && (d->mode == MS_BN_TRAIN || d->mode == MS_BN_EVAL) && d->dtype == MS_F32;
 }
 
 size_t chain32_prepared_bytes(const ms_chain_desc* d) { return (size_t)d->M * 4 * CH_WAVE_STREAM * sizeof(float); }
@@ -597,18 +657,21 @@ int chain32_fwd(const ms_chain_desc* d, const ms_chain_tensors* tn, void* worksp
 }  // namespace ms
 
 using namespace ms;
+static inline bool chain_is16(const ms_chain_desc* d) { return d->dtype == MS_BF16 || d->dtype == MS_F16; }
 extern "C" {
-int ms_decoder_chain_supported(const ms_chain_desc* d) { return chain32_supported(d); }
-size_t ms_decoder_chain_prepared_bytes(const ms_chain_desc* d) { return d && d->dtype == MS_F32 ? chain32_prepared_bytes(d) : 0; }
-size_t ms_decoder_chain_workspace(const ms_chain_desc* d) { return d ? chain32_workspace(d) : 256; }
-int ms_decoder_chain_sync_words(const ms_chain_desc* d) { return d ? chain32_sync_words(d) : 0; }
+int ms_decoder_chain_supported(const ms_chain_desc* d) { return !d ? 0 : chain_is16(d) ? chain16_supported(d) : chain32_supported(d); }
+size_t ms_decoder_chain_prepared_bytes(const ms_chain_desc* d) {
+  return !d ? 0 : chain_is16(d) ? chain16_prepared_bytes(d) : d->dtype == MS_F32 ? chain32_prepared_bytes(d) : 0;
+}
+size_t ms_decoder_chain_workspace(const ms_chain_desc* d) { return !d ? 256 : chain_is16(d) ? chain16_workspace(d) : chain32_workspace(d); }
+int ms_decoder_chain_sync_words(const ms_chain_desc* d) { return !d ? 0 : chain_is16(d) ? chain16_sync_words(d) : chain32_sync_words(d); }
 int ms_decoder_chain_prepare(const ms_chain_desc* d, const float* const* w, const float* w_logits, void* prepared, void* stream) {
   if (!d || !w || !w_logits || !prepared) return set_error("ms_decoder_chain_prepare: null argument");
   for (int l = 0; l < CH_NL; ++l) if (!w[l]) return set_error("ms_decoder_chain_prepare: null weight");
-  return chain32_prepare(d, w, w_logits, prepared, (hipStream_t)stream);
+  return chain_is16(d) ? chain16_prepare(d, w, w_logits, prepared, (hipStream_t)stream) : chain32_prepare(d, w, w_logits, prepared, (hipStream_t)stream);
 }
 int ms_decoder_chain_fwd(const ms_chain_desc* d, const ms_chain_tensors* t, void* workspace, size_t workspace_bytes, void* stream) {
   if (!d || !t) return set_error("ms_decoder_chain_fwd: null argument");
-  return chain32_fwd(d, t, workspace, workspace_bytes, (hipStream_t)stream);
+  return chain_is16(d) ? chain16_fwd(d, t, workspace, workspace_bytes, (hipStream_t)stream) : chain32_fwd(d, t, workspace, workspace_bytes, (hipStream_t)stream);
 }
 }

@@ -1,0 +1,486 @@
+// Clip-resident 1-D conv block, fp32 (exact fp32 matrix products): Conv1d (k3 s1 p1, optionally on nearest_up2(a) + r; or k4 s2 p1)
+// [+ BatchNorm1d + LeakyReLU] for the layers of the path whose whole reduction fits a workgroup: ConvNormRelu (layers.py:32-78)
+// inside UNet1D (layers.py:80-157), ClusterClassify (layers.py:446-467), PoseStyleEncoder (layers.py:246-289), D.conv1 / D.conv2
+// (speech2gesture.py:50-57).  Same recipe as the chained decoder (chain32.hip), one block per launch:
+//   * a workgroup owns 32 output channels x 64 (stride 2: 32) output frames = whole clips; the clips' COMPLETE input -- all input
+//     channels, frames + halo -- is staged once into LDS as [8-channel group][half][slot][4 channels];
+//   * the reduction is split over the four waves by channel groups; every wave's weight rows come from HBM / L2 straight into
+//     registers in MFMA operand order (prepared once per optimizer update: ms_fwd_weights_prepare / ms_dgrad_weights_prepare) -- the
+//     whole K slice of a wave is in flight at once, there is no weight staging, no barrier and no split-K slab in HBM;
+//   * the four partial accumulators meet in LDS; thread (channel, 8-lane frame slice) then finishes the block: bias, the clips'
+//     partial batch statistics, ONE in-launch meeting of the workgroups that share the channel tile (BN_TRAIN), normalise,
+//     activate, store y_raw / y -- no statistics launch, no normalising launch.
+// Replaces, per block: patch conv (intra-workgroup split) or im2col-gather conv + split-K epilogue + bn_finalize_apply.
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace ms {
+
+typedef unsigned int cl_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int cl_u32x2 __attribute__((ext_vector_type(2)));
+constexpr int CL_SPIN_LIMIT = 1 << 21;
+constexpr int CL_MAXK8W = 9;              // channel groups of 8 per wave at most (Cin <= 288)
+
+struct Clip32Args {
+  const float* x;        // (B, Cin, Ti) -- UP2: a (B, Cin, Ti/2)
+  const float* x2;       // UP2: r (B, Cin, Ti)
+  const float* wp;       // prepared: [channel tile][wave][k8w][KW][64 lanes][4]
+  const float* bias;
+  const float* gamma;
+  const float* beta;
+  float* rm;
+  float* rv;
+  float* y_raw;          // BN_TRAIN: conv + bias (B, Cout, To), or null
+  float* y;              // block output (B, Cout, To)
+  float* y2;             // EP_DGRAD_UP2: gradient of r (full resolution); y then is the gradient of a (half resolution)
+  float* save;
+  float* part;           // [channel tiles][pixel workgroups][32][2]
+  int* sync;
+  int cnt_base;
+  int B, Cin, Cout, To, Ti, ep, k8w, npw, rows_valid, nct;      // Cout: output channels (addressing) = rows_valid; nct = ceil(Cout / 32)
+  float slope, eps, momentum;
+};
+
+__device__ __forceinline__ float cl_f4e(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
+
+template <int CTRL>
+__device__ __forceinline__ double cl_dpp_d(double x) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)u, CTRL, 0xf, 0xf, true);
+  const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double cl_sum8_d(double v) {
+  v += cl_dpp_d<0xB1>(v);
+  v += cl_dpp_d<0x4E>(v);
+  v += cl_dpp_d<0x141>(v);
+  return v;
+}
+
+__device__ __forceinline__ float cl_sum8(float v) {
+  v += dpp_rot<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += dpp_rot<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += dpp_rot<0x141>(v);     // row_half_mirror
+  return v;
+}
+
+// KW taps, stride S; NB = 32-frame blocks of output per workgroup (2, stride 2: 1); UP2: the input is nearest_up2(a) + r
+template <int KW, int S, int NB, bool UP2>
+__global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
+  prefetch_kernargs<sizeof(Clip32Args)>();
+  extern __shared__ float cl_smem[];
+  constexpr int NPX = 32 * NB;                       // output frames per workgroup
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, n0 = lane & 31, h = lane >> 5;
+  const int nct = p.nct;
+  const int ct = blockIdx.x % nct, pw = blockIdx.x / nct;      // channel tile, pixel workgroup
+  const int To = p.To, Ti = p.Ti;
+  const int ncl = NPX / To;                          // clips per workgroup (To <= NPX, a power of two)
+  const int b0 = pw * ncl;
+  const int row = Ti + 2;                            // slots per clip: halo + Ti + halo
+  const int pslots = (ncl * row + 3) & ~3;           // slots per plane
+  const int k8w = p.k8w, nk8 = 4 * k8w;              // channel groups per wave / staged in all (zero beyond Cin)
+
+  // ---- this wave's weights: the whole slice in flight (k8w * KW loads of 16 B per lane)
+  float4 wr[CL_MAXK8W * KW];
+  {
+    const float4* ws = reinterpret_cast<const float4*>(p.wp) + ((size_t)(ct * 4 + w) * k8w * KW) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < CL_MAXK8W * KW; ++i) wr[i] = ws[(size_t)min(i, k8w * KW - 1) * 64];
+  }
+
+  // ---- the clips' input image: plane (k8, hh) = channels 8*k8 + 4*hh + 0..3, slot = clip * row + 1 + frame.
+  // Positions (clip, frame) are spread over the lanes, 4 coalesced loads + one 16-byte LDS store per position and plane.
+  {
+    const int npos = ncl * Ti;                       // input frames of this workgroup (64 at every depth)
+    for (int e = t; e < ncl * 2; e += 256) {         // halos
+      const int cl = e >> 1, s = (e & 1) ? Ti + 1 : 0;
+      for (int pl = 0; pl < nk8 * 2; ++pl) *reinterpret_cast<float4*>(cl_smem + ((size_t)pl * pslots + cl * row + s) * 4) = float4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int pos = t % npos, pl0 = t / npos, pstep = 256 / npos;      // npos divides 256 (npos = 64)
+    const int cl = pos / Ti, ti = pos - cl * Ti;
+    const size_t xoff = (size_t)(b0 + cl) * p.Cin * (UP2 ? Ti / 2 : Ti) + (UP2 ? ti / 2 : ti);
+    const size_t x2off = (size_t)(b0 + cl) * p.Cin * Ti + ti;
+    const int cstride = UP2 ? Ti / 2 : Ti;
+    for (int plb = pl0; plb < nk8 * 2; plb += 8 * pstep) {
+      float v[8][4];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int pl = plb + i * pstep;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = min(4 * pl + j, p.Cin - 1);
+          float val = p.x[xoff + (size_t)c * cstride];
+          if (UP2) val += p.x2[x2off + (size_t)c * Ti];
+          v[i][j] = val;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int pl = plb + i * pstep;
+        if (pl < nk8 * 2) {
+          float4 o;
+          o.x = 4 * pl < p.Cin ? v[i][0] : 0.f;
+          o.y = 4 * pl + 1 < p.Cin ? v[i][1] : 0.f;
+          o.z = 4 * pl + 2 < p.Cin ? v[i][2] : 0.f;
+          o.w = 4 * pl + 3 < p.Cin ? v[i][3] : 0.f;
+          *reinterpret_cast<float4*>(cl_smem + ((size_t)pl * pslots + cl * row + 1 + ti) * 4) = o;
+        }
+      }
+    }
+  }
+  // per-channel parameters of the finishing thread (channel = t >> 3), fetched now
+  const int chl = t >> 3, pq = t & 7;
+  const int cgl = ct * 32 + chl;
+  const bool rowok = cgl < p.rows_valid;
+  const int cgc = min(cgl, p.rows_valid - 1);
+  const float bias_c = p.bias ? p.bias[cgc] : 0.f;
+  float gam = 1.f, bet = 0.f, rmo = 0.f, rvo = 1.f;
+  if (p.ep == EP_RAW_STATS || p.ep == EP_BN_EVAL) { gam = p.gamma[cgc]; bet = p.beta[cgc]; rmo = p.rm[cgc]; rvo = p.rv[cgc]; }
+  __syncthreads();
+
+  // ---- K loop: this wave's channel groups x taps, no barrier
+  f32x16 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[nb][q] = 0.f;
+  int bbase[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int n = 32 * nb + n0, cl = n / To, tt = n - cl * To;
+    bbase[nb] = cl * row + tt * S;
+  }
+  {
+    const float* img = cl_smem + ((size_t)(w * k8w) * 2 + h) * pslots * 4;
+#pragma unroll
+    for (int i = 0; i < CL_MAXK8W; ++i) {
+      if (i < k8w) {
+#pragma unroll
+        for (int tap = 0; tap < KW; ++tap) {
+          float4 bf[NB];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) bf[nb] = *reinterpret_cast<const float4*>(img + ((size_t)i * 2 * pslots + bbase[nb] + tap) * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+              acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(cl_f4e(wr[i * KW + tap], j), cl_f4e(bf[nb], j), acc[nb], 0, 0, 0);
+        }
+      }
+    }
+  }
+  __syncthreads();                                   // every wave is done with the image: it becomes the exchange buffer
+
+  // ---- the four partial tiles meet in LDS: red[wave][channel 32][frame NPX + 4]
+  constexpr int RP = NPX + 4;
+  float* red = cl_smem;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) red[(w * 32 + 8 * (q >> 2) + 4 * h + (q & 3)) * RP + 32 * nb + n0] = acc[nb][q];
+  __syncthreads();
+
+  // ---- thread (channel, slice of NPX / 8 frames): sum of the waves in wave order + bias
+  constexpr int FPT = NPX / 8;                       // frames per thread: 8 (stride 2: 4)
+  float v[FPT];
+  {
+    const float* rp = red + chl * RP + FPT * pq;
+#pragma unroll
+    for (int k = 0; k < FPT; k += 4) {
+      float4 s = *reinterpret_cast<const float4*>(rp + k);
+#pragma unroll
+      for (int ww = 1; ww < 4; ++ww) {
+        const float4 u = *reinterpret_cast<const float4*>(rp + ww * 32 * RP + k);
+        s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w;
+      }
+      v[k] = s.x + bias_c; v[k + 1] = s.y + bias_c; v[k + 2] = s.z + bias_c; v[k + 3] = s.w + bias_c;
+    }
+  }
+  // frame f = FPT * pq + k of the workgroup -> (clip, frame inside the clip); To >= FPT keeps a thread inside one clip
+  const int f0 = FPT * pq;
+  auto store_frames = [&](float* dst, const float (&val)[FPT]) {
+    if (To >= FPT) {
+      const int cl = f0 / To, tt = f0 - cl * To;
+      float* d = dst + ((size_t)(b0 + cl) * p.Cout + cgl) * To + tt;
+#pragma unroll
+      for (int k = 0; k < FPT; k += 4) *reinterpret_cast<float4*>(d + k) = float4{val[k], val[k + 1], val[k + 2], val[k + 3]};
+    } else {
+#pragma unroll
+      for (int k = 0; k < FPT; ++k) {
+        const int f = f0 + k, cl = f / To, tt = f - cl * To;
+        dst[((size_t)(b0 + cl) * p.Cout + cgl) * To + tt] = val[k];
+      }
+    }
+  };
+
+  float sc = 1.f, sh = 0.f;
+  if (p.ep == EP_RAW_STATS) {
+    // this workgroup's partial statistics of the channel: (mean, M2) over its NPX frames
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < FPT; ++k) s += v[k];
+    const float mean_w = cl_sum8(s) * (1.0f / NPX);
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < FPT; ++k) { const float d = v[k] - mean_w; q = fmaf(d, d, q); }
+    const float m2_w = cl_sum8(q);
+    double mean = (double)mean_w, m2 = (double)m2_w;
+    const double n = (double)p.npw * NPX;
+    if (p.npw > 1) {
+      const __amdgpu_buffer_rsrc_t rsPart = buf_rsrc(p.part);
+      if (pq == 0)
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cl_u32x2, float2{mean_w, m2_w}), rsPart,
+                                              (int)(8u * (unsigned)((ct * p.npw + pw) * 32 + chl)), 0, 16);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      int* lflag = reinterpret_cast<int*>(cl_smem + 4 * 32 * RP);
+      if (t == 0) {
+        int* counter = p.sync + p.cnt_base + 32 * ct;
+        const unsigned old = (unsigned)__hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = (old / (unsigned)p.npw + 1u) * (unsigned)p.npw;
+        int spins = 0, bad = 0;
+        while ((int)((unsigned)__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > CL_SPIN_LIMIT) { __hip_atomic_store(p.sync, 20, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); bad = 1; break; }
+        }
+        lflag[0] = bad;
+      }
+      __syncthreads();
+      // the channel's partials, every 8th one per lane (up to 4 in flight), in fp64: sum of means, sum of M2, then the spread
+      // of the means about the mean (equal counts) -- lane sums in lane order, then the 8 lanes by a fixed tree
+      float2 pv[4];
+      const unsigned base = 8u * (unsigned)(ct * p.npw * 32 + chl);
+      double ms = 0.0, qs = 0.0, dv = 0.0;
+      for (int i0 = pq; i0 < p.npw; i0 += 32) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = min(i0 + 8 * u, p.npw - 1);
+          pv[u] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsPart, (int)(base + 8u * (unsigned)(i * 32)), 0, 16));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (i0 + 8 * u < p.npw) { ms += (double)pv[u].x; qs += (double)pv[u].y; }
+      }
+      mean = cl_sum8_d(ms) / (double)p.npw;
+      for (int i0 = pq; i0 < p.npw; i0 += 32) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = min(i0 + 8 * u, p.npw - 1);
+          pv[u] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsPart, (int)(base + 8u * (unsigned)(i * 32)), 0, 16));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (i0 + 8 * u < p.npw) { const double dl = (double)pv[u].x - mean; dv += dl * dl; }
+      }
+      m2 = cl_sum8_d(qs) + (double)NPX * cl_sum8_d(dv);
+      if (lflag[0]) { mean = __builtin_nan(""); }
+    }
+    const float var = (float)(m2 / n), fmean = (float)mean;
+    const float invstd = 1.0f / sqrtf(var + p.eps);
+    sc = gam * invstd;
+    sh = bet - fmean * sc;
+    if (pw == 0 && pq == 0 && rowok && fmean == fmean) {
+      if (p.save) { p.save[cgl] = fmean; p.save[p.Cout + cgl] = invstd; p.save[2 * p.Cout + cgl] = sc; p.save[3 * p.Cout + cgl] = sh; }
+      const float unbiased = n > 1.0 ? (float)(m2 / (n - 1.0)) : var;
+      p.rm[cgl] = (1.f - p.momentum) * rmo + p.momentum * fmean;
+      p.rv[cgl] = (1.f - p.momentum) * rvo + p.momentum * unbiased;
+    }
+    if (p.y_raw && rowok) store_frames(p.y_raw, v);
+  } else if (p.ep == EP_BN_EVAL) {
+    sc = gam * (1.0f / sqrtf(rvo + p.eps));
+    sh = bet - rmo * sc;
+  }
+  if (!rowok) return;
+  if (p.ep == EP_DGRAD_UP2) {
+    // data gradient of an upsample-add input: y2 = gradient of r (full resolution), y = gradient of a = sums of frame pairs
+    store_frames(p.y2, v);
+    float hv[FPT / 2];
+#pragma unroll
+    for (int k = 0; k < FPT / 2; ++k) hv[k] = v[2 * k] + v[2 * k + 1];
+    const int Th = To / 2, fh = f0 / 2;
+    if (Th >= FPT / 2) {
+      const int cl = fh / Th, tt = fh - cl * Th;
+      float* d = p.y + ((size_t)(b0 + cl) * p.Cout + cgl) * Th + tt;
+#pragma unroll
+      for (int k = 0; k < FPT / 2; ++k) d[k] = hv[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < FPT / 2; ++k) {
+        const int f = fh + k, cl = f / Th, tt = f - cl * Th;
+        p.y[((size_t)(b0 + cl) * p.Cout + cgl) * Th + tt] = hv[k];
+      }
+    }
+    return;
+  }
+  if (p.ep != EP_BARE) {
+#pragma unroll
+    for (int k = 0; k < FPT; ++k) v[k] = lrelu(p.ep == EP_LRELU ? v[k] : fmaf(v[k], sc, sh), p.slope);
+  }
+  store_frames(p.y, v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// weights in stream order: [channel tile][wave][k8 local][tap][lane][4] = row 32*ct + (lane & 31), channels
+// 8*(wave*k8w + k8 local) + 4*(lane >> 5) + 0..3.  transposed = 0: w (Cout, Cin, KW), row = output channel;
+// transposed = 1 (data gradient of a k3 s1 conv): row = input channel ci, reduction over co, taps reversed: w[co][ci][KW-1-tap]
+struct ClipPrepJob {
+  const float* w;
+  float* out;
+  int rows, red, KW, k8w, transposed, w_rows, w_cols, block_end;
+};
+enum { CLIP_PREP_MAX = 40 };
+struct ClipPrepBatch { int n; ClipPrepJob job[CLIP_PREP_MAX]; };
+
+__global__ void clip32_prep_kernel(const ClipPrepBatch pb) {
+  int j = 0;
+  while (j + 1 < pb.n && (int)blockIdx.x >= pb.job[j].block_end) ++j;
+  const ClipPrepJob& jb = pb.job[j];
+  const int blk = blockIdx.x - (j ? pb.job[j - 1].block_end : 0);
+  const size_t gid = (size_t)blk * 256 + threadIdx.x;
+  const int nct = (jb.rows + 31) / 32;
+  const size_t total = (size_t)nct * 4 * jb.k8w * jb.KW * 64;
+  if (gid >= total) return;
+  const int lane = (int)(gid & 63);
+  size_t r = gid >> 6;
+  const int tap = (int)(r % jb.KW); r /= jb.KW;
+  const int k8l = (int)(r % jb.k8w); r /= jb.k8w;
+  const int wv = (int)(r & 3), ct = (int)(r >> 2);
+  const int rowi = 32 * ct + (lane & 31), c0 = 8 * (wv * jb.k8w + k8l) + 4 * (lane >> 5);
+  float vv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = c0 + q;
+    float val = 0.f;
+    if (rowi < jb.rows && c < jb.red)
+      val = jb.transposed ? jb.w[((size_t)c * jb.w_cols + rowi) * jb.KW + (jb.KW - 1 - tap)] : jb.w[((size_t)rowi * jb.w_cols + c) * jb.KW + tap];
+    vv[q] = val;
+  }
+  reinterpret_cast<float4*>(jb.out)[gid] = float4{vv[0], vv[1], vv[2], vv[3]};
+}
+
+// ---------------------------------------------------------------------------------------------
+int g_clip32 = 1;       // ms_debug_set_clip32 / MS_CLIP32=0: the clip-resident kernels off (ablations)
+
+static int clip_k8w(int red) { return (cdiv(red, 8) + 3) / 4; }
+
+// rows: output rows of the launch (forward: Cout; data gradient: Cin); red: reduction channels (forward: Cin; dgrad: Cout)
+static bool clip_geom_ok(int B, int rows, int red, int To, int KW, int S, int groups, int nb) {
+  if (!g_clip32 || groups != 1) return false;
+  if (!((KW == 3 && S == 1) || (KW == 4 && S == 2))) return false;
+  if (To < 2 || To > 32 * nb || (To & (To - 1))) return false;
+  if ((B * To) % (32 * nb)) return false;
+  if (red > 8 * 4 * CL_MAXK8W || rows < 1) return false;
+  return true;
+}
+
+bool clip32_fwd_ok(const ms_conv_desc* d) {
+  if ((d->dtype & 0xff) != 0) return false;
+  if (!(d->H == 1 && d->KH == 1 && d->PW == 1 && d->in_mode != MS_IN_BCAST)) return false;
+  const int nb = d->SW == 2 ? 1 : 2;
+  if (d->in_mode == MS_IN_UP2ADD && !(d->KW == 3 && d->SW == 1)) return false;
+  if (d->Cout % 32) return false;
+  if (d->OW * d->SW != d->W) return false;
+  return clip_geom_ok(d->B, d->Cout, d->Cin, d->OW, d->KW, d->SW, d->groups, nb);
+}
+
+// data gradient of a k3 s1 p1 block as a k3 s1 conv of dy_raw with the transposed, tap-reversed weights
+bool clip32_dgrad_ok(const ms_conv_desc* d) {
+  if ((d->dtype & 0xff) != 0) return false;
+  if (!(d->H == 1 && d->KH == 1 && d->PW == 1 && d->KW == 3 && d->SW == 1 && d->in_mode != MS_IN_BCAST)) return false;
+  return clip_geom_ok(d->B, d->Cin, d->Cout, d->W, 3, 1, d->groups, 2);
+}
+
+size_t clip32_weight_floats(int rows, int red, int KW) { return (size_t)cdiv(rows, 32) * 4 * clip_k8w(red) * KW * 256; }
+
+size_t clip32_fwd_weight_bytes(const ms_conv_desc* d) { return clip32_fwd_ok(d) ? clip32_weight_floats(d->Cout, d->Cin, d->KW) * 4 : 0; }
+size_t clip32_dgrad_weight_floats(const ms_conv_desc* d) { return clip32_dgrad_ok(d) ? clip32_weight_floats(d->Cin, d->Cout, 3) : 0; }
+
+static ClipPrepBatch g_prep;
+static int g_prep_blocks = 0;
+int clip32_prep_queue(const float* w, float* out, int rows, int red, int KW, int transposed, int w_cols, hipStream_t s) {
+  if (g_prep.n == CLIP_PREP_MAX) { const int rc = clip32_prep_flush(s); if (rc) return rc; }
+  ClipPrepJob jb = {w, out, rows, red, KW, clip_k8w(red), transposed, 0, w_cols, 0};
+  g_prep_blocks += (int)((clip32_weight_floats(rows, red, KW) / 4 + 255) / 256);
+  jb.block_end = g_prep_blocks;
+  g_prep.job[g_prep.n++] = jb;
+  return 0;
+}
+int clip32_prep_flush(hipStream_t s) {
+  if (!g_prep.n) return 0;
+  TimingScope ts(s, 0, 0, "clip32_prep_kernel|clip_prep jobs%d", g_prep.n);
+  const int blocks = g_prep_blocks;
+  ClipPrepBatch pb = g_prep;
+  g_prep.n = 0; g_prep_blocks = 0;
+  if (ts.skip()) return 0;
+  hipLaunchKernelGGL(clip32_prep_kernel, dim3(blocks), dim3(256), 0, s, pb);
+  return check_launch("clip32_prep_kernel");
+}
+
+size_t clip32_part_bytes(int rows, int npw) { return align_up((size_t)cdiv(rows, 32) * npw * 32 * 2 * sizeof(float), 256); }
+int clip32_sync_words(int rows) { return 32 * (cdiv(rows, 32) + 1); }
+
+template <int KW, int S, int NB, bool UP2>
+static int clip32_launch_t(const Clip32Args& a, int nwg, int lds_bytes, hipStream_t s) {
+  auto fn = clip32_kernel<KW, S, NB, UP2>;
+  static int attr_done = 0;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return set_error("clip32: cannot raise the dynamic LDS limit");
+    attr_done = 1;
+  }
+  hipLaunchKernelGGL(fn, dim3(nwg), dim3(256), lds_bytes, s, a);
+  return check_launch("clip32_kernel");
+}
+
+// ep: EP_BARE / EP_LRELU / EP_BN_EVAL / EP_RAW_STATS (= BN_TRAIN, everything in this launch) / EP_DGRAD_UP2
+int clip32_launch(Clip32Args a, int KW, int S, bool up2, const char* what, hipStream_t s) {
+  const int nb = S == 2 ? 1 : 2, npx = 32 * nb;
+  a.k8w = clip_k8w(a.Cin);
+  a.npw = a.B * a.To / npx;
+  const int nct = cdiv(a.Cout, 32);
+  a.nct = nct;
+  const int ncl = npx / a.To, pslots = (ncl * (a.Ti + 2) + 3) & ~3;
+  const int img = 4 * a.k8w * 2 * pslots * 16, red = (4 * 32 * (npx + 4) + 4) * 4;
+  const int lds = std::max(img, red);
+  if (lds > 160 * 1024) return set_error("clip32: image of %d bytes", lds);
+  const int nwg = nct * a.npw;
+  // the workgroups of a channel tile meet inside the launch (BN_TRAIN): all of them resident at once
+  int cus = 256;
+  { static int ccus = -1; if (ccus < 0) { hipDeviceProp_t pr; int dv = 0; ccus = (hipGetDevice(&dv) == hipSuccess && hipGetDeviceProperties(&pr, dv) == hipSuccess) ? pr.multiProcessorCount : 256; } cus = ccus; }
+  const int per_cu = std::max(1, (160 * 1024) / lds);
+  if (a.ep == EP_RAW_STATS && a.npw > 1 && nwg > cus * std::min(per_cu, 2)) return -2;      // caller falls back
+  const double flops = 2.0 * a.rows_valid * a.Cin * KW * (double)a.B * a.To;
+  const double bytes = 4.0 * ((double)a.rows_valid * a.Cin * KW + (double)a.B * a.Cin * a.Ti + (double)a.B * a.rows_valid * a.To);
+  TimingScope ts(s, flops, bytes, "clip32_kernel<%d,%d,%d,%d>|conv_%s_clip k1x%d s%d rows%d red%d T%d B%d ep%d", KW, S, nb, up2 ? 1 : 0, what, KW,
+                 S, a.rows_valid, a.Cin, a.To, a.B, a.ep);
+  if (ts.skip()) return 0;
+  if (KW == 3 && S == 1) return up2 ? clip32_launch_t<3, 1, 2, true>(a, nwg, lds, s) : clip32_launch_t<3, 1, 2, false>(a, nwg, lds, s);
+  return clip32_launch_t<4, 2, 1, false>(a, nwg, lds, s);
+}
+
+int clip32_block_fwd(const ms_conv_desc* d, const float* x, const float* x2, const float* wp, const float* bias, const float* gamma,
+                     const float* beta, float* rm, float* rv, float* y_raw, float* y, float* save, float* part, int* sync,
+                     int sync_words, hipStream_t s) {
+  Clip32Args a = {};
+  a.x = x; a.x2 = x2; a.wp = wp; a.bias = bias; a.gamma = gamma; a.beta = beta; a.rm = rm; a.rv = rv;
+  a.y_raw = d->mode == MS_BN_TRAIN ? y_raw : nullptr; a.y = y; a.save = save; a.part = part; a.sync = sync; a.cnt_base = 32;
+  a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.rows_valid = d->Cout; a.To = d->OW; a.Ti = d->W;
+  a.ep = d->mode == MS_BARE ? EP_BARE : d->mode == MS_LRELU ? EP_LRELU : d->mode == MS_BN_EVAL ? EP_BN_EVAL : EP_RAW_STATS;
+  a.slope = d->slope; a.eps = d->eps; a.momentum = d->momentum;
+  if (a.ep == EP_RAW_STATS && (!sync || sync_words < 32 + clip32_sync_words(d->Cout) || !part)) return -2;
+  return clip32_launch(a, d->KW, d->SW, d->in_mode == MS_IN_UP2ADD, "fwd", s);
+}
+
+int clip32_block_dgrad(const ms_conv_desc* d, const float* g, const float* wp, float* dx, float* dx2, hipStream_t s) {
+  Clip32Args a = {};
+  const bool up2 = d->in_mode == MS_IN_UP2ADD;
+  a.x = g; a.wp = wp;
+  a.y = dx; a.y2 = dx2;
+  a.B = d->B; a.Cin = d->Cout; a.Cout = d->Cin; a.rows_valid = d->Cin; a.To = d->W; a.Ti = d->W;
+  a.ep = up2 ? EP_DGRAD_UP2 : EP_BARE;
+  return clip32_launch(a, 3, 1, false, "dgrad", s);
+}
+
+}  // namespace ms
+

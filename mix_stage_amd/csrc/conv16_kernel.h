@@ -433,7 +433,10 @@ __device__ __forceinline__ void conv16_epilogue_bnfused(const Conv16Args& p, con
   {
     const int c = tl.t & (BM - 1), share = tl.t / BM;
     const unsigned base = 16u * (unsigned)(grp * p.gx * BM + c);
-    double n = 0.0, mean = 0.0, m2 = 0.0;
+    // fp64 moments of the group's tiles in tile order: N = sum n_i, S = sum n_i mean_i, Q = sum (M2_i + n_i mean_i^2); then
+    // mean = S / N, M2 = Q - S mean.  (The subtraction is harmless in fp64 -- a relative 1e-16 (mean / sigma)^2 -- and the loop holds
+    // no division: Chan's pairwise update costs two fp64 divisions per tile, ~3 us of every launch at 16-32 tiles per thread.)
+    double n = 0.0, sm = 0.0, sq = 0.0;
     for (int k0 = share; k0 < ((p.dbg & 64) ? 0 : p.gx); k0 += 4 * P) {
       float4 v[4];
 #pragma unroll
@@ -443,14 +446,12 @@ __device__ __forceinline__ void conv16_epilogue_bnfused(const Conv16Args& p, con
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
-        if (k0 + u * P < p.gx && v[u].z > 0.f) {
-          const double nw = (double)v[u].z, tot = n + nw, dl = (double)v[u].x - mean;
-          mean += dl * (nw / tot);
-          m2 += (double)v[u].y + dl * dl * (n * nw / tot);
-          n = tot;
+        if (k0 + u * P < p.gx) {
+          const double nw = (double)v[u].z, mw = (double)v[u].x;
+          n += nw; sm += nw * mw; sq += (double)v[u].y + nw * mw * mw;
         }
     }
-    dred[(share * BM + c) * 3] = n; dred[(share * BM + c) * 3 + 1] = mean; dred[(share * BM + c) * 3 + 2] = m2;
+    dred[(share * BM + c) * 3] = n; dred[(share * BM + c) * 3 + 1] = sm; dred[(share * BM + c) * 3 + 2] = sq;
   }
   __syncthreads();
   if (tl.t == 0 && !(p.dbg & 128)) {            // every load of the group's partials by this workgroup has returned: depart; the last one re-arms
@@ -461,17 +462,10 @@ __device__ __forceinline__ void conv16_epilogue_bnfused(const Conv16Args& p, con
     }
   }
   if (tl.t < BM) {
-    double n = dred[tl.t * 3], mean = dred[tl.t * 3 + 1], m2 = dred[tl.t * 3 + 2];
+    double n = dred[tl.t * 3], sm = dred[tl.t * 3 + 1], sq = dred[tl.t * 3 + 2];
 #pragma unroll
-    for (int s = 1; s < P; ++s) {
-      const double nw = dred[(s * BM + tl.t) * 3];
-      if (nw > 0.0) {
-        const double tot = n + nw, dl = dred[(s * BM + tl.t) * 3 + 1] - mean;
-        mean += dl * (nw / tot);
-        m2 += dred[(s * BM + tl.t) * 3 + 2] + dl * dl * (n * nw / tot);
-        n = tot;
-      }
-    }
+    for (int s = 1; s < P; ++s) { n += dred[(s * BM + tl.t) * 3]; sm += dred[(s * BM + tl.t) * 3 + 1]; sq += dred[(s * BM + tl.t) * 3 + 2]; }
+    const double mean = n > 0.0 ? sm / n : 0.0, m2 = fmax(sq - sm * mean, 0.0);
     float sc = 0.f, shf = 0.f;
     bool unsafe_c = false;
     const bool expired = wcnt[NWN] != 0;

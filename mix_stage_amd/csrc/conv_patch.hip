@@ -575,6 +575,14 @@ extern "C" int ms_debug_set_wgrad16_target(int workgroups) {
   return old;
 }
 
+namespace ms { extern int g_clip32; }
+extern "C" int ms_debug_set_clip32(int on) {
+  const int prev = ms::g_clip32;
+  if (prev != (on ? 1 : 0)) ++g_tuning_epoch;
+  ms::g_clip32 = on ? 1 : 0;
+  return prev;
+}
+
 extern "C" int ms_debug_set_patch_min_workgroups(int n) {
   const int old = ms::g_patch_min_wgs;
   ++g_tuning_epoch;

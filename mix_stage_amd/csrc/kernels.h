@@ -147,6 +147,37 @@ int launch_wgrad_patch(const WgradPatchArgs& a, const WgradPatchPlan& pl, int KH
                        double bytes, hipStream_t s);
 int launch_reduce_splits(const float* part, float* out, int n, int splits, hipStream_t s);
 
+// ---- clip-resident 1-D conv blocks, fp32 (clip32.hip)
+struct Clip32Args;
+bool clip32_fwd_ok(const ms_conv_desc* d);
+bool clip32_dgrad_ok(const ms_conv_desc* d);
+size_t clip32_fwd_weight_bytes(const ms_conv_desc* d);
+size_t clip32_dgrad_weight_floats(const ms_conv_desc* d);
+size_t clip32_weight_floats(int rows, int red, int KW);
+int clip32_prep_queue(const float* w, float* out, int rows, int red, int KW, int transposed, int w_cols, hipStream_t s);
+int clip32_prep_flush(hipStream_t s);
+size_t clip32_part_bytes(int rows, int npw);
+int clip32_sync_words(int rows);
+// forward of block d (ep by mode) / data gradient of a k3 s1 block; -2: not resident at once, use the other kernels
+int clip32_block_fwd(const ms_conv_desc* d, const float* x, const float* x2, const float* wp, const float* bias, const float* gamma,
+                     const float* beta, float* rm, float* rv, float* y_raw, float* y, float* save, float* part, int* sync,
+                     int sync_words, hipStream_t s);
+int clip32_block_dgrad(const ms_conv_desc* d, const float* g, const float* wp, float* dx, float* dx2, hipStream_t s);
+
+// ---- chained pose decoder (chain32.hip: fp32; chain16.hip: bf16 / fp16), behind ms_decoder_chain_*
+int chain32_supported(const ms_chain_desc* d);
+size_t chain32_prepared_bytes(const ms_chain_desc* d);
+size_t chain32_workspace(const ms_chain_desc* d);
+int chain32_sync_words(const ms_chain_desc* d);
+int chain32_prepare(const ms_chain_desc* d, const float* const* w, const float* wl, void* prepared, hipStream_t s);
+int chain32_fwd(const ms_chain_desc* d, const ms_chain_tensors* tn, void* workspace, size_t workspace_bytes, hipStream_t s);
+int chain16_supported(const ms_chain_desc* d);
+size_t chain16_prepared_bytes(const ms_chain_desc* d);
+size_t chain16_workspace(const ms_chain_desc* d);
+int chain16_sync_words(const ms_chain_desc* d);
+int chain16_prepare(const ms_chain_desc* d, const float* const* w, const float* wl, void* prepared, hipStream_t s);
+int chain16_fwd(const ms_chain_desc* d, const ms_chain_tensors* tn, void* workspace, size_t workspace_bytes, hipStream_t s);
+
 struct GatherPlan { int tm, tn, splitk, k_per_split, n_tiles; };
 // tile shape + split-K factor for an (Mg x npix) output per z-slice (z = groups * parity classes), reduction Kg
 GatherPlan plan_gather(int Mg, int npix, int zcount, int Kg);

@@ -177,7 +177,7 @@ class JointLateClusterSoftStyle4_G(nn.Module):
     internal_losses.append(ops.cross_entropy(labels_score, labels, layout='bct'))
 
     ## M sub-generators on the same input, mixed by softmax(labels_score) (JL:190-194)
-    chained = ops.decoder_chain(x, list(self.decoder), self.logits, labels_score, self.out_feats) if not dt else None
+    chained = (ops16.decoder_chain16 if dt else ops.decoder_chain)(x, list(self.decoder), self.logits, labels_score, self.out_feats)
     if chained is not None:
       # decoder.0-3 + logits + softmax mixture as ONE launch (a workgroup carries a clip of a sub-generator through all blocks)
       x, self.labels_cap_soft = chained

@@ -397,17 +397,17 @@ class _ConvBlockFn(torch.autograd.Function):
         save = torch.empty(4 * ctot, dtype=torch.float32, device=x.device)
     ws = workspace(d._fwd_ws, x.device) if pre is None else None
     planes = _prepared_for(w, d, 'fwd') if pre is None else None
-    if pre is not None:
-      pass
-    elif planes is not None:
-      opt = FwdOptions(planes.data_ptr(), None, 0)
+    if pre is None:
+      # BN_TRAIN blocks may finish inside the conv launch (clip-resident kernels): their workgroups meet through these counters
+      sync = None
+      if mode == MS_BN_TRAIN and nd == 1:
+        from . import ops16
+        sync = ops16.block_sync(x.device, d)
+      opt = FwdOptions(planes.data_ptr() if planes is not None else None, sync.data_ptr() if sync is not None else None,
+                       sync.numel() if sync is not None else 0)
       check(lib().ms_conv_block_fwd_ex(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(bias), _ptr(gamma), _ptr(beta),
                                        _ptr(rm), _ptr(rv), _ptr(y_raw), _ptr(y), _ptr(save), _ptr(ws), ws.numel(),
                                        _stream(), ctypes.byref(opt)), 'ms_conv_block_fwd_ex')
-    else:
-      check(lib().ms_conv_block_fwd(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(bias), _ptr(gamma), _ptr(beta),
-                                    _ptr(rm), _ptr(rv), _ptr(y_raw), _ptr(y), _ptr(save), _ptr(ws), ws.numel(),
-                                    _stream()), 'ms_conv_block_fwd')
     ctx.geom_desc = d
     ctx.mode, ctx.in_mode = mode, in_mode
     ctx.has_bias = bias is not None
@@ -637,7 +637,7 @@ USE_DECODER_CHAIN = os.environ.get('MS_DECODER_CHAIN', '1') != '0'       # ablat
 
 def _chain_desc(B, M, T, cin0, P, mode, blk, dtype=0):
   g = blk._geometry()
-  return _lib.ChainDesc(B, M, T, cin0, 256, P, 4, mode, dtype, CHAIN_SYNC_FIRST_WORD, g.slope, g.eps, g.momentum)
+  return _lib.ChainDesc(B, M, T, cin0, 256, P, 4, mode, dtype, CHAIN_SYNC_FIRST_WORD, 0, g.slope, g.eps, g.momentum)
 
 
 _chain_scratch = {}
@@ -648,7 +648,7 @@ def _chain_prepared(d, ws):
   (enable_prepared_weights): built on first use, rebuilt when torch changed a weight (version counters) or when the trainer says
   so after an update it made through raw pointers (refresh_prepared_weights).  Otherwise: rebuilt on every call (nobody
   vouches for the weights between calls), into a buffer that is reused."""
-  key = (ws[0].data_ptr(), d.M, d.cin0, d.P, 'chain32')
+  key = (ws[0].data_ptr(), d.M, d.cin0, d.P, d.dtype, 'chain32')
   if not _prepared['on']:
     n = (lib().ms_decoder_chain_prepared_bytes(ctypes.byref(d)) + 3) // 4
     buf = _chain_scratch.get(key)

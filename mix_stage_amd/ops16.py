@@ -76,6 +76,22 @@ def chain_sync(device, B, M, words):
   return buf
 
 
+def block_sync(device, desc, words=1024):
+  """Meeting counters of ONE conv block (fp32 clip-resident kernels): a zeroed buffer per (device, stream, block descriptor) -- the
+  counters are monotonic, so every launch that shares them must have the same member counts: one block, one shape."""
+  if not _in_launch['on']:
+    return None
+  key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream, 'block', id(desc))
+  buf = _bn_sync.get(key)
+  if buf is None:
+    buf = _bn_sync[key] = torch.zeros(words, dtype=torch.int32, device=device)
+    _block_sync_keep.append(desc)          # (id(desc) stays unique while the buffer lives)
+  return buf
+
+
+_block_sync_keep = []
+
+
 def bn_sync_error():
   """True when an in-launch BatchNorm workgroup timed out waiting for its group (synchronises the device)."""
   return any(int(b[0].item()) != 0 for b in _bn_sync.values())
@@ -231,7 +247,7 @@ def _prepared16_for(w, d, kind, bn=None):
 # ------------------------------------------------------------------------------------------------
 class _ConvBlock16Fn(torch.autograd.Function):
   @staticmethod
-  def forward(ctx, x, x2, w, bias, gamma, beta, geom, mode, in_mode, stats, dt_flags):
+  def forward(ctx, x, x2, w, bias, gamma, beta, geom, mode, in_mode, stats, dt_flags, pre=None):
     rm, rv = stats if stats is not None else (None, None)
     _need16(x, x2, w, bias, gamma, beta, rm, rv)
     if not is_cb8(x) or (x2 is not None and not is_cb8(x2)):
@@ -259,24 +275,28 @@ class _ConvBlock16Fn(torch.autograd.Function):
     out_f32 = bool(dt_flags & MS_DT_OUT_F32)
     sp = (d.OH, d.OW) if nd == 2 else (d.OW,)
     c8 = (ctot + 7) // 8
-    if out_f32:
-      y = torch.empty((B, ctot) + sp, dtype=torch.float32, device=x.device)
+    if pre is not None:
+      # results produced by the chained decoder launch (decoder_chain16): this node only carries the block's backward pass
+      y_raw, y, save = pre
     else:
-      y = torch.empty((B, c8) + sp + (8,), dtype=x.dtype, device=x.device)
-    y_raw = save = None
-    if mode == MS_BN_TRAIN:
-      y_raw = torch.empty((B, c8) + sp + (8,), dtype=x.dtype, device=x.device)
-      save = torch.empty(4 * ctot, dtype=torch.float32, device=x.device)
-    ws = workspace(d._fwd_ws, x.device)
-    sync = _ensure_bn_sync(x.device) if mode == MS_BN_TRAIN else None
-    folded = mode == MS_BN_EVAL and bool(dt_flags & MS_DT_BN_FOLDED)
-    planes = _prepared16_for(w, d, 'fwd16', dict(bias=bias, gamma=gamma, beta=beta, running_mean=rm, running_var=rv)
-                             if folded else None)
-    opt = FwdOptions(planes.data_ptr() if planes is not None else None, sync.data_ptr() if sync is not None else None,
-                     sync.numel() if sync is not None else 0)
-    check(lib().ms_conv_block_fwd_ex(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(bias), _ptr(gamma), _ptr(beta),
-                                     _ptr(rm), _ptr(rv), _ptr(y_raw), _ptr(y), _ptr(save), _ptr(ws), ws.numel(),
-                                     _stream(), ctypes.byref(opt)), 'ms_conv_block_fwd_ex')
+      if out_f32:
+        y = torch.empty((B, ctot) + sp, dtype=torch.float32, device=x.device)
+      else:
+        y = torch.empty((B, c8) + sp + (8,), dtype=x.dtype, device=x.device)
+      y_raw = save = None
+      if mode == MS_BN_TRAIN:
+        y_raw = torch.empty((B, c8) + sp + (8,), dtype=x.dtype, device=x.device)
+        save = torch.empty(4 * ctot, dtype=torch.float32, device=x.device)
+      ws = workspace(d._fwd_ws, x.device)
+      sync = _ensure_bn_sync(x.device) if mode == MS_BN_TRAIN else None
+      folded = mode == MS_BN_EVAL and bool(dt_flags & MS_DT_BN_FOLDED)
+      planes = _prepared16_for(w, d, 'fwd16', dict(bias=bias, gamma=gamma, beta=beta, running_mean=rm, running_var=rv)
+                               if folded else None)
+      opt = FwdOptions(planes.data_ptr() if planes is not None else None, sync.data_ptr() if sync is not None else None,
+                       sync.numel() if sync is not None else 0)
+      check(lib().ms_conv_block_fwd_ex(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(bias), _ptr(gamma), _ptr(beta),
+                                       _ptr(rm), _ptr(rv), _ptr(y_raw), _ptr(y), _ptr(save), _ptr(ws), ws.numel(),
+                                       _stream(), ctypes.byref(opt)), 'ms_conv_block_fwd_ex')
     ctx.geom_desc = d
     ctx.mode, ctx.in_mode = mode, in_mode
     ctx.has_bias = bias is not None
@@ -335,7 +355,7 @@ class _ConvBlock16Fn(torch.autograd.Function):
       D['jobs'].append((part, dw, nsplit))
       ops._queue_deferred_flush()
     return (dx, dx2, None if direct_w else dw, None if direct_b else dbias, None if direct_g else dgamma,
-            None if direct_be else dbeta, None, None, None, None, None)
+            None if direct_be else dbeta, None, None, None, None, None, None)
 
 
 def conv_block16(x, w, bias, geom, mode, gamma=None, beta=None, running_mean=None, running_var=None, x2=None,
@@ -344,3 +364,89 @@ def conv_block16(x, w, bias, geom, mode, gamma=None, beta=None, running_mean=Non
   stats = (running_mean, running_var) if running_mean is not None else None
   flags = MS_DT[x.dtype] | (MS_DT_OUT_F32 if out_f32 else 0) | (MS_DT_BN_FOLDED if (bn_folded and mode == MS_BN_EVAL) else 0)
   return _ConvBlock16Fn.apply(x, x2, w, bias, gamma, beta, geom, mode, in_mode, stats, flags)
+
+
+# ------------------------------------------------------------------------------------------------
+def decoder_chain16(x, blocks, logits, score, P):
+  """16-bit form of ops.decoder_chain: x cb8 (B, 34, T, 8) shared by all groups; (out (B,T,P) fp32, soft (B,T,M)) or None."""
+  if not ops.USE_DECODER_CHAIN or len(blocks) != 4 or not is_cb8(x) or x.dim() != 4 or ops.bn_sync_active() or not in_launch_meetings():
+    return None
+  dt = MS_DT[x.dtype]
+  blk0 = blocks[0]
+  M = blk0.conv.groups
+  B, cb0, T = x.shape[0], x.shape[1], x.shape[2]
+  cin0 = blk0.conv.weight.shape[1]
+  if (cin0 + 7) // 8 != cb0:
+    return None
+  if any(getattr(m, '_ms_dt', 0) != dt for m in blocks) or getattr(logits, '_ms_dt', 0) != dt or any(m._p and m.training for m in blocks):
+    return None
+  if any(getattr(m, '_bn_folded', False) for m in blocks):
+    return None
+  if any(m._forward_hooks or m._forward_pre_hooks for m in list(blocks) + [logits]):
+    return None
+  if any(m.conv.groups != M or m.conv.kernel_size != (3,) or m.conv.stride != (1,) or m.conv.padding != (1,) or
+         m.conv.weight.shape[0] != 256 * M or m.conv.weight.dtype != torch.float32 or m._slope != blk0._slope for m in blocks):
+    return None
+  if any(m.conv.weight.shape[1] != 256 for m in blocks[1:]):
+    return None
+  if logits.groups != M or logits.kernel_size != (1,) or logits.weight.shape[0] != M * P or logits.weight.shape[1] != 256 or logits.bias is None:
+    return None
+  if tuple(score.shape) != (B, M, T) or score.dtype != torch.float32:
+    return None
+  training = all(m.training and m.norm.track_running_stats for m in blocks)
+  if not training and any(m.training for m in blocks):
+    return None
+  mode = MS_BN_TRAIN if training else MS_BN_EVAL
+  params = [t for m in blocks for t in (m.conv.weight, m.conv.bias, m.norm.weight, m.norm.bias)] + [logits.weight, logits.bias]
+  need_grad = torch.is_grad_enabled() and (x.requires_grad or score.requires_grad or any(t is not None and t.requires_grad for t in params))
+  if need_grad and not training:
+    return None
+  d = ops._chain_desc(B, M, T, cin0, P, mode, blk0, dt)
+  if not lib().ms_decoder_chain_supported(ctypes.byref(d)):
+    return None
+  _need16(x, score, *[t for t in params if t is not None])
+  x, score = x.contiguous(), score.contiguous()
+  dev = x.device
+  wts = [m.conv.weight for m in blocks] + [logits.weight]
+  prepared = ops._chain_prepared(d, wts)
+  sync = chain_sync(dev, B, M, ops.CHAIN_SYNC_FIRST_WORD + lib().ms_decoder_chain_sync_words(ctypes.byref(d)))
+  C = 256 * M
+  keep = need_grad
+  act = lambda: torch.empty((B, C // 8, T, 8), dtype=x.dtype, device=dev)
+  y_raw = [act() if keep else None for _ in blocks]
+  y = [act() if keep else None for _ in blocks]
+  save = [torch.empty(4 * C, dtype=torch.float32, device=dev) if keep else None for _ in blocks]
+  z = torch.empty((B, M * P, T), dtype=torch.float32, device=dev) if keep else None
+  soft = torch.empty((B, T, M), dtype=torch.float32, device=dev)
+  out = torch.empty((B, T, P), dtype=torch.float32, device=dev)
+  tn = ops._lib.ChainTensors()
+  tn.x, tn.score = x.data_ptr(), score.data_ptr()
+  for l, m in enumerate(blocks):
+    tn.w[l], tn.bias[l] = m.conv.weight.data_ptr(), (m.conv.bias.data_ptr() if m.conv.bias is not None else None)
+    tn.gamma[l], tn.beta[l] = m.norm.weight.data_ptr(), m.norm.bias.data_ptr()
+    tn.running_mean[l], tn.running_var[l] = m.norm.running_mean.data_ptr(), m.norm.running_var.data_ptr()
+    tn.y_raw[l] = y_raw[l].data_ptr() if keep else None
+    tn.y[l] = y[l].data_ptr() if keep else None
+    tn.save[l] = save[l].data_ptr() if keep else None
+  tn.w_logits, tn.bias_logits = logits.weight.data_ptr(), logits.bias.data_ptr()
+  tn.z = z.data_ptr() if keep else None
+  tn.soft, tn.out, tn.prepared = soft.data_ptr(), out.data_ptr(), prepared.data_ptr()
+  tn.sync, tn.sync_words = sync.data_ptr(), sync.numel()
+  wsp = workspace(lib().ms_decoder_chain_workspace(ctypes.byref(d)), dev)
+  check(lib().ms_decoder_chain_fwd(ctypes.byref(d), ctypes.byref(tn), _ptr(wsp), wsp.numel(), _stream()), 'ms_decoder_chain_fwd')
+  if training:
+    for m in blocks:
+      m._note_train_pass()
+  if not need_grad:
+    return out, soft
+  h = x
+  for l, m in enumerate(blocks):
+    n = m.norm
+    h = _ConvBlock16Fn.apply(h, None, m.conv.weight, m.conv.bias, n.weight, n.bias, m._geometry(), MS_BN_TRAIN,
+                             MS_IN_BCAST if l == 0 else MS_IN_PLAIN, (n.running_mean, n.running_var), dt, (y_raw[l], y[l], save[l]))
+  geom = getattr(logits, '_ms_geom', None)
+  if geom is None:
+    geom = logits._ms_geom = ops.ConvGeom(1, logits.groups, logits.kernel_size, logits.stride, logits.padding, slope=0.0)
+  zt = _ConvBlock16Fn.apply(h, None, logits.weight, logits.bias, None, None, geom, MS_BARE, MS_IN_PLAIN, None, dt | MS_DT_OUT_F32,
+                            (None, z, None))
+  return ops._SoftmaxMixFn.apply(zt, score, int(P), (out, soft))

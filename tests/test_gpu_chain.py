@@ -231,3 +231,124 @@ def test_shapes_outside_the_chain_fall_back():
     assert ops.decoder_chain(x, blocks, logits, torch.randn(4, 4, 64, device=DEV), 104) is None
     h.remove()
     assert ops.decoder_chain(x, blocks, logits, torch.randn(4, 4, 64, device=DEV), 104) is not None
+
+
+# ------------------------------------------------------------------------------------------------ 16-bit modes
+def _run16(blocks, logits, x32, score, P, chain, dt_name, train=True, grad=True, dout=None):
+  import mix_stage_amd as A
+  from mix_stage_amd import ops, ops16
+  from mix_stage_amd.layers import bare_conv
+  mods = nn.ModuleList(list(blocks) + [logits])
+  A.set_compute_dtype(mods, dt_name)
+  dt = ops16.NAME_DT[dt_name]
+  for m in blocks:
+    m.train(train)
+  state = [(m.norm.running_mean.clone(), m.norm.running_var.clone()) for m in blocks]
+  params = [p for m in blocks for p in m.parameters()] + list(logits.parameters())
+  for p in params:
+    p.grad = None
+  x32 = x32.clone().requires_grad_(grad)
+  score = score.clone().requires_grad_(grad)
+  prev = ops.USE_DECODER_CHAIN
+  ops.USE_DECODER_CHAIN = chain
+  try:
+    with torch.set_grad_enabled(grad):
+      x = ops16.to_cb8(x32, dt)
+      res = ops16.decoder_chain16(x, blocks, logits, score, P)
+      assert (res is not None) == chain
+      if res is None:
+        z = blocks[0].forward_broadcast(x)
+        for m in blocks[1:]:
+          z = m(z)
+        z = bare_conv(logits, z, out_f32=True)
+        res = ops.softmax_mix(z, score, P)
+      out, soft = res
+      if grad:
+        out.backward(dout)
+  finally:
+    ops.USE_DECODER_CHAIN = prev
+  torch.cuda.synchronize()
+  rec = dict(out=out.detach().clone(), soft=soft.detach().clone(),
+             running=[(m.norm.running_mean.clone(), m.norm.running_var.clone()) for m in blocks])
+  if grad:
+    rec['dx'], rec['dscore'] = x32.grad.clone(), score.grad.clone()
+    rec['grads'] = [p.grad.clone() for p in params]
+  for m, (rm, rv) in zip(blocks, state):
+    with torch.no_grad():
+      m.norm.running_mean.copy_(rm)
+      m.norm.running_var.copy_(rv)
+  return rec
+
+
+def _segment_float64(blocks, logits, x, score, M, P, round_to):
+  """The segment in float64 on operands rounded to the 16-bit type (weights and input), exact arithmetic in between."""
+  import torch.nn.functional as F
+  r = lambda t: t.detach().to(round_to).double().cpu()
+  B = x.shape[0]
+  h = torch.cat([r(x)] * M, 1)
+  for m in blocks:
+    c, n = m.conv, m.norm
+    h = F.conv1d(h, r(c.weight), c.bias.double().cpu(), padding=1, groups=M)
+    mean, var = h.mean((0, 2), keepdim=True), h.var((0, 2), unbiased=False, keepdim=True)
+    h = (h - mean) / torch.sqrt(var + n.eps) * n.weight.double().cpu().view(1, -1, 1) + n.bias.double().cpu().view(1, -1, 1)
+    h = F.leaky_relu(h, 0.2)
+  z = F.conv1d(h, r(logits.weight), logits.bias.double().cpu(), groups=M)
+  soft = torch.softmax(score.double().cpu().transpose(1, 2), -1)
+  return torch.einsum('bgpt,btg->btp', z.view(B, M, P, 64), soft)
+
+
+@pytest.mark.parametrize('dt_name', ['bf16', 'fp16'])
+@pytest.mark.parametrize('case', [('headline', 32, 8, 104, 10), ('m4_b4', 4, 4, 104, 10), ('m3_p16_extra16', 5, 3, 16, 16)], ids=lambda c: c[0])
+def test_chain16_against_blocks_and_float64(case, dt_name):
+  """16-bit chain: the same roundings as the blocks one by one (16-bit operands, fp32 accumulators normalised from registers, one
+  rounding of every block output) -- both sides within the same distance of exact arithmetic on the rounded operands, and the
+  gradients (computed by the blocks' own backward pass from what the chain stored) agree."""
+  _, B, M, P, extra = case
+  tdt = torch.bfloat16 if dt_name == 'bf16' else torch.float16
+  blocks, logits = _build(M, P, extra, seed=21)
+  x, score = _inputs(B, M, 256 + extra, seed=21)
+  dout = torch.randn(B, 64, P, generator=torch.Generator().manual_seed(6)).to(DEV)
+  a = _run16(blocks, logits, x, score, P, True, dt_name, dout=dout)
+  b = _run16(blocks, logits, x, score, P, False, dt_name, dout=dout)
+  ref = _segment_float64(blocks, logits, x, score, M, P, tdt)
+  ea = float((a['out'].cpu().double() - ref).abs().mean())
+  eb = float((b['out'].cpu().double() - ref).abs().mean())
+  scale = float(ref.abs().mean())
+  print('%s %s: chain %.3e, blocks %.3e of mean |out| %.3e' % (case[0], dt_name, ea, eb, scale))
+  assert torch.isfinite(a['out']).all()
+  assert ea <= 1.5 * eb + 1e-4 * scale and ea <= (3e-2 if dt_name == 'bf16' else 5e-3) * scale
+  _close(a['soft'], b['soft'], 1e-6, 'softmax')
+  for l, ((rm_a, rv_a), (rm_b, rv_b)) in enumerate(zip(a['running'], b['running'])):
+    _close(rm_a, rm_b, 2e-2, 'running mean %d' % l)
+    _close(rv_a, rv_b, 2e-2, 'running var %d' % l)
+  tol = 6e-2 if dt_name == 'bf16' else 1.5e-2
+  _close_l2(a['dx'], b['dx'], tol, 'dx')
+  _close_l2(a['dscore'], b['dscore'], tol, 'dscore')
+  gmax = max(float(g.abs().max()) for g in b['grads'])
+  for i, (ga, gb) in enumerate(zip(a['grads'], b['grads'])):
+    if i % 4 == 1 and i < 16:
+      assert float(ga.abs().max()) <= 2e-2 * gmax, i            # bias in front of BatchNorm: zero up to rounding
+    else:
+      _close_l2(ga, gb, tol, 'gradient of parameter %d' % i)
+
+
+def test_chain16_eval_and_repeatability():
+  from mix_stage_amd import ops16
+  B, M, P = 32, 8, 104
+  blocks, logits = _build(M, P, 10, seed=23)
+  x, score = _inputs(B, M, 266, seed=23)
+  a = _run16(blocks, logits, x, score, P, True, 'bf16', train=False, grad=False)
+  b = _run16(blocks, logits, x, score, P, False, 'bf16', train=False, grad=False)
+  ref_scale = float(b['out'].abs().mean())
+  assert float((a['out'] - b['out']).abs().mean()) <= 2e-2 * ref_scale
+  first = _run16(blocks, logits, x, score, P, True, 'bf16', grad=False)
+  side = torch.cuda.Stream()
+  big = torch.randn(32 << 20, device=DEV)
+  with torch.cuda.stream(side):
+    for _ in range(8):
+      big = big * 1.0001 + 0.5
+  for rep in range(12):
+    r = _run16(blocks, logits, x, score, P, True, 'bf16', grad=False)
+    assert torch.equal(r['out'], first['out']), rep
+  torch.cuda.synchronize()
+  assert not ops16.bn_sync_error()

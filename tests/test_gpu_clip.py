@@ -1,0 +1,116 @@
+"""GPU: the clip-resident 1-D conv blocks (csrc/clip32.hip) -- Conv1d k3 s1 p1 (plain input or nearest_up2(a) + r) and k4 s2 p1,
+[+ BatchNorm1d(train / eval) + LeakyReLU], whole block in one launch with the batch statistics met inside the launch -- against the
+fp64 oracle block (reference layers.py:32-78) at the depths of the UNet (T = 64 ... 2), the classifier, the style encoder and the
+discriminator, forward and backward (data gradient by the same kernel with transposed weights; weight gradient by the existing
+kernels from what the block stored)."""
+import zlib
+
+import pytest
+import torch
+
+from test_gpu_kernels import _conv_block_case, _mk_block, rel_err, DEV
+from oracle import mixstage_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+# (name, type, cin, cout, kernel, stride, groups, input spatial, in_mode)
+CASES = [
+    ('k3_t64', '1d', 256, 256, None, None, 1, (64,), 'plain'),
+    ('k3_t32', '1d', 256, 256, None, None, 1, (32,), 'plain'),
+    ('k3_t8', '1d', 256, 256, None, None, 1, (8,), 'plain'),
+    ('k3_t2', '1d', 256, 256, None, None, 1, (2,), 'plain'),
+    ('k3_cin266', '1d', 266, 256, None, None, 1, (64,), 'plain'),
+    ('k3_104_64', '1d', 104, 64, None, None, 1, (64,), 'plain'),
+    ('up2_t64', '1d', 256, 256, None, None, 1, (64,), 'up2'),
+    ('up2_t16', '1d', 256, 256, None, None, 1, (16,), 'up2'),
+    ('up2_t4', '1d', 256, 256, None, None, 1, (4,), 'up2'),
+    ('s2_t64', '1d', 256, 256, 4, 2, 1, (64,), 'plain'),
+    ('s2_t16', '1d', 256, 256, 4, 2, 1, (16,), 'plain'),
+    ('s2_t4', '1d', 256, 256, 4, 2, 1, (4,), 'plain'),
+    ('s2_64_128', '1d', 64, 128, 4, 2, 1, (32,), 'plain'),
+    ('s2_128_256', '1d', 128, 256, 4, 2, 1, (8,), 'plain'),
+]
+
+
+def _labels(fn):
+  from mix_stage_amd import ops
+  ops.timing_enable(True)
+  try:
+    fn()
+    torch.cuda.synchronize()
+    return [r['label'] for r in ops.timing_report()]
+  finally:
+    ops.timing_enable(False)
+
+
+@pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
+def test_clip_block_train_fwd_bwd_vs_oracle(case):
+  B = 32
+  labels = _labels(lambda: _conv_block_case(case, B, 7))
+  assert any('conv_fwd_clip' in l for l in labels), labels
+  assert not any('bn_finalize' in l or 'splitk_fwd_epilogue' in l for l in labels), labels
+  if case[4] is None:                                    # k3 s1: the data gradient runs on the clip kernel as well
+    assert any('conv_dgrad_clip' in l for l in labels), labels
+  for attempt in range(4):
+    if _conv_block_case(case, B, zlib.crc32(case[0].encode()) % 1000 + attempt):
+      return
+  raise AssertionError('no draw without a sign flip at a LeakyReLU kink')
+
+
+@pytest.mark.parametrize('case', [CASES[0], CASES[4], CASES[9], CASES[12]], ids=lambda c: c[0])
+def test_clip_block_eval_mode(case):
+  import mix_stage_amd as A
+  name, typ, cin, cout, k, s, g, sp, in_mode = case
+  gen = torch.Generator().manual_seed(5)
+  ref = _mk_block(O, case).double().eval()
+  hip = _mk_block(A, case).to(DEV).eval()
+  x = torch.randn(32, cin * g, *sp, generator=gen)
+  with torch.no_grad():
+    labels = _labels(lambda: hip(x.to(DEV)))
+    y = hip(x.to(DEV))
+    y_ref = ref(x.double())
+  assert any('conv_fwd_clip' in l for l in labels), labels
+  assert rel_err(y, y_ref) < 2e-5
+  assert rel_err(hip.norm.running_mean, ref.norm.running_mean) == 0.0
+
+
+def test_clip_block_is_bitwise_repeatable_and_replays_in_a_graph():
+  """20 launches of a BN_TRAIN block on two input sets in rotation beside a stream that hammers HBM: bit-identical outputs per
+  set (the in-launch meeting hands every workgroup the same complete partials; monotonic counters), the same from a HIP graph,
+  and no meeting timed out."""
+  import mix_stage_amd as A
+  from mix_stage_amd import ops16
+  case = CASES[0]
+  hip = _mk_block(A, case).to(DEV).train()
+  xs = [torch.randn(32, 256, 64, generator=torch.Generator().manual_seed(s)).to(DEV) for s in (1, 2)]
+  state = (hip.norm.running_mean.clone(), hip.norm.running_var.clone())
+
+  def run(x):
+    with torch.no_grad():
+      hip.norm.running_mean.copy_(state[0]); hip.norm.running_var.copy_(state[1])
+      return hip(x).clone(), hip.norm.running_mean.clone()
+  firsts = [run(x) for x in xs]
+  assert not torch.equal(firsts[0][0], firsts[1][0])
+  side = torch.cuda.Stream()
+  big = torch.randn(32 << 20, device=DEV)
+  with torch.cuda.stream(side):
+    for _ in range(8):
+      big = big * 1.0001 + 0.5
+  for rep in range(20):
+    y, rm = run(xs[rep % 2])
+    assert torch.equal(y, firsts[rep % 2][0]) and torch.equal(rm, firsts[rep % 2][1]), rep
+  torch.cuda.synchronize()
+  cs = torch.cuda.Stream()
+  cs.wait_stream(torch.cuda.current_stream())
+  with torch.cuda.stream(cs), torch.no_grad():
+    hip(xs[0])
+  torch.cuda.current_stream().wait_stream(cs)
+  torch.cuda.synchronize()
+  g = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(g, stream=cs), torch.no_grad():
+    yg = hip(xs[0])
+  for _ in range(3):
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(yg, firsts[0][0])
+  assert not ops16.bn_sync_error()

@@ -84,8 +84,11 @@ def kernel_path(request):
   workgroups); 'gather' forces the im2col-gather MFMA kernels with split-K (normally the fallback)."""
   from mix_stage_amd import _lib
   old = _lib.lib().ms_debug_set_patch_min_workgroups({'patch': 0, 'gather': 1 << 30}.get(request.param, 32))
+  # ('auto' also takes the clip-resident 1-D kernels where a block qualifies, tests/test_gpu_clip.py; the forced paths keep them off)
+  old_clip = _lib.lib().ms_debug_set_clip32(1 if request.param == 'auto' else 0)
   yield request.param
   _lib.lib().ms_debug_set_patch_min_workgroups(old)
+  _lib.lib().ms_debug_set_clip32(old_clip)
 
 
 @pytest.mark.parametrize('case', BLOCK_CASES, ids=[c[0] for c in BLOCK_CASES])

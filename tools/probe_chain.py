@@ -40,16 +40,23 @@ def main():
   from mix_stage_amd.layers import bare_conv
   B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
   M = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+  dtn = sys.argv[3] if len(sys.argv) > 3 else 'fp32'
   P = 104
   blocks, logits = _build(M, P, 10)
   x, score = _inputs(B, M, 266)
+  if dtn != 'fp32':
+    import torch.nn as nn
+    import mix_stage_amd as A
+    from mix_stage_amd import ops16
+    A.set_compute_dtype(nn.ModuleList(list(blocks) + [logits]), dtn)
+    x = ops16.to_cb8(x, ops16.NAME_DT[dtn])
   gflop = 2.0 * B * 64 * M * (256 * 3 * (266 + 3 * 256) + P * 256) / 1e9
   for train in (True, False):
     for m in blocks:
       m.train(train)
 
     def chain():
-      return ops.decoder_chain(x, blocks, logits, score, P)
+      return (ops.decoder_chain if dtn == 'fp32' else ops16.decoder_chain16)(x, blocks, logits, score, P)
 
     def one_by_one():
       z = blocks[0].forward_broadcast(x)
@@ -62,8 +69,9 @@ def main():
     ops.USE_DECODER_CHAIN = False
     t_b = timed(one_by_one)
     ops.USE_DECODER_CHAIN = True
-    print('%s B=%d M=%d: chain %.1f us = %.1f TF (%.3f of 157.3); blocks one by one %.1f us = %.1f TF' %
-          ('train' if train else 'eval', B, M, t_c, gflop / t_c * 1e3, gflop / t_c * 1e3 / 157.3, t_b, gflop / t_b * 1e3))
+    peak = 157.3 if dtn == 'fp32' else 2500.0
+    print('%s %s B=%d M=%d: chain %.1f us = %.1f TF (%.3f of peak); blocks one by one %.1f us = %.1f TF' %
+          (dtn, 'train' if train else 'eval', B, M, t_c, gflop / t_c * 1e3, gflop / t_c * 1e3 / peak, t_b, gflop / t_b * 1e3))
 
 
 if __name__ == '__main__':
