@@ -332,31 +332,50 @@ struct ClipPrepJob {
 enum { CLIP_PREP_MAX = 40 };
 struct ClipPrepBatch { int n; ClipPrepJob job[CLIP_PREP_MAX]; };
 
-__global__ void clip32_prep_kernel(const ClipPrepBatch pb) {
+// One workgroup per (job, channel tile, wave): the weights it needs are staged through LDS as they lie in the weight tensor
+// (contiguous row segments, coalesced) and leave in stream order (1 KB per (channel group, tap)).
+constexpr int CLP_LDS = 32 * 289;
+__global__ __launch_bounds__(256) void clip32_prep_kernel(const ClipPrepBatch pb) {
+  __shared__ float lds[CLP_LDS];
   int j = 0;
   while (j + 1 < pb.n && (int)blockIdx.x >= pb.job[j].block_end) ++j;
   const ClipPrepJob& jb = pb.job[j];
   const int blk = blockIdx.x - (j ? pb.job[j - 1].block_end : 0);
-  const size_t gid = (size_t)blk * 256 + threadIdx.x;
-  const int nct = (jb.rows + 31) / 32;
-  const size_t total = (size_t)nct * 4 * jb.k8w * jb.KW * 64;
-  if (gid >= total) return;
-  const int lane = (int)(gid & 63);
-  size_t r = gid >> 6;
-  const int tap = (int)(r % jb.KW); r /= jb.KW;
-  const int k8l = (int)(r % jb.k8w); r /= jb.k8w;
-  const int wv = (int)(r & 3), ct = (int)(r >> 2);
-  const int rowi = 32 * ct + (lane & 31), c0 = 8 * (wv * jb.k8w + k8l) + 4 * (lane >> 5);
-  float vv[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int c = c0 + q;
-    float val = 0.f;
-    if (rowi < jb.rows && c < jb.red)
-      val = jb.transposed ? jb.w[((size_t)c * jb.w_cols + rowi) * jb.KW + (jb.KW - 1 - tap)] : jb.w[((size_t)rowi * jb.w_cols + c) * jb.KW + tap];
-    vv[q] = val;
+  const int wv = blk & 3, ct = blk >> 2, t = threadIdx.x;
+  const int KW = jb.KW, k8w = jb.k8w;
+  const int c_lo = wv * k8w * 8, nc = min(k8w * 8, max(0, jb.red - c_lo));       // reduction channels of this wave
+  const int r_lo = 32 * ct, nr = min(32, jb.rows - r_lo);                          // rows of this tile
+  int pitch;
+  if (!jb.transposed) {
+    // source rows = output rows: w[(r_lo + rr) * w_cols + c_lo ..][tap], nc * KW contiguous floats each
+    const int seg = nc * KW;
+    pitch = (k8w * 8 * KW) | 1;
+    for (int k = t; k < seg; k += 256)
+      for (int rr = 0; rr < nr; ++rr) lds[rr * pitch + k] = jb.w[((size_t)(r_lo + rr) * jb.w_cols + c_lo) * KW + k];
+  } else {
+    // source rows = reduction channels co: w[(c_lo + cc) * w_cols + r_lo ..][tap], nr * KW contiguous floats each
+    const int seg = nr * KW;
+    pitch = (32 * KW) | 1;
+    for (int e = t; e < nc * seg; e += 256) {
+      const int cc = e / seg, k = e - cc * seg;
+      lds[cc * pitch + k] = jb.w[((size_t)(c_lo + cc) * jb.w_cols + r_lo) * KW + k];
+    }
   }
-  reinterpret_cast<float4*>(jb.out)[gid] = float4{vv[0], vv[1], vv[2], vv[3]};
+  __syncthreads();
+  float4* dst = reinterpret_cast<float4*>(jb.out) + ((size_t)(ct * 4 + wv) * k8w * KW) * 64;
+  const int lane = t & 63, rr = lane & 31, h = lane >> 5;
+  for (int u = t >> 6; u < k8w * KW; u += 4) {
+    const int k8l = u / KW, tap = u - k8l * KW;
+    float vv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int cl = 8 * k8l + 4 * h + q;
+      float val = 0.f;
+      if (rr < nr && cl < nc) val = jb.transposed ? lds[cl * pitch + rr * KW + (KW - 1 - tap)] : lds[rr * pitch + cl * KW + tap];
+      vv[q] = val;
+    }
+    dst[(size_t)u * 64 + lane] = float4{vv[0], vv[1], vv[2], vv[3]};
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -401,7 +420,7 @@ static int g_prep_blocks = 0;
 int clip32_prep_queue(const float* w, float* out, int rows, int red, int KW, int transposed, int w_cols, hipStream_t s) {
   if (g_prep.n == CLIP_PREP_MAX) { const int rc = clip32_prep_flush(s); if (rc) return rc; }
   ClipPrepJob jb = {w, out, rows, red, KW, clip_k8w(red), transposed, 0, w_cols, 0};
-  g_prep_blocks += (int)((clip32_weight_floats(rows, red, KW) / 4 + 255) / 256);
+  g_prep_blocks += cdiv(rows, 32) * 4;
   jb.block_end = g_prep_blocks;
   g_prep.job[g_prep.n++] = jb;
   return 0;
@@ -448,8 +467,9 @@ int clip32_launch(Clip32Args a, int KW, int S, bool up2, const char* what, hipSt
   // the workgroups of a channel tile meet inside the launch (BN_TRAIN): all of them resident at once
   int cus = 256;
   { static int ccus = -1; if (ccus < 0) { hipDeviceProp_t pr; int dv = 0; ccus = (hipGetDevice(&dv) == hipSuccess && hipGetDeviceProperties(&pr, dv) == hipSuccess) ? pr.multiProcessorCount : 256; } cus = ccus; }
-  const int per_cu = std::max(1, (160 * 1024) / lds);
-  if (a.ep == EP_RAW_STATS && a.npw > 1 && nwg > cus * std::min(per_cu, 2)) return -2;      // caller falls back
+  // (one workgroup per CU is what every instance of the kernel is sure to get: LDS would allow two of the smaller images, the
+  // register file of the upsample-add instance does not)
+  if (a.ep == EP_RAW_STATS && a.npw > 1 && nwg > cus) return -2;      // caller falls back to the per-layer kernels
   const double flops = 2.0 * a.rows_valid * a.Cin * KW * (double)a.B * a.To;
   const double bytes = 4.0 * ((double)a.rows_valid * a.Cin * KW + (double)a.B * a.Cin * a.Ti + (double)a.B * a.rows_valid * a.To);
   TimingScope ts(s, flops, bytes, "clip32_kernel<%d,%d,%d,%d>|conv_%s_clip k1x%d s%d rows%d red%d T%d B%d ep%d", KW, S, nb, up2 ? 1 : 0, what, KW,

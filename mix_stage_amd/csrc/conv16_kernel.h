@@ -323,11 +323,14 @@ __device__ __forceinline__ void conv16_epilogue_bnfused(const Conv16Args& p, con
   int* arrive = p.bn_sync + (size_t)(1 + grp) * BNF_SYNC_STRIDE;
   int* depart = arrive + 1;
 
-  // ---- A. conv + bias stays in the accumulators; per-channel sums of this tile ABOUT A PIVOT (the channel's value at the wave's
-  // first pixel): sum (x - K) and sum (x - K)^2 lose nothing when |mean| >> sigma, where sum x^2 - (sum x)^2 / n in fp32 loses the
-  // variance.  The tile's partial is published as (mean, M2 about that mean, count) and combined by Chan's rule.
+  // ---- A. conv + bias stays in the accumulators; per-channel sums of this tile ABOUT THE CHANNEL'S BIAS -- the part of the mean
+  // the kernel knows beforehand: sum acc and sum acc^2 of the bias-free accumulators, the tile's partial is published as
+  // (mean = bias + sum / n, M2 = sum acc^2 - (sum acc)^2 / n, n) and the tiles are combined in fp64.  A channel whose mean is
+  // large BECAUSE OF ITS BIAS keeps its variance (fp32 sum (acc + b)^2 - (sum (acc + b))^2 / n would lose it); what remains is
+  // the conv output's own mean against its spread, O(1) behind a normalised input.  (A per-tile pivot taken from the data --
+  // readlane + a third reduction -- was measured: +1.4 us per launch, 50 us per G-step.)
   // (the accumulators are only ever READ element-wise: this clang miscompiles constant-index element writes into a local
-  // f32x16.  The bias is added at each of the three uses; 128-row tiles re-fetch it -- an L2 hit -- instead of holding 32 more
+  // f32x16.  The bias is added at each use; 128-row tiles re-fetch it -- an L2 hit -- instead of holding 32 more
   // registers across the gathering)
   auto bias_of = [&](int i, float (&bsv)[16]) {
     const int mrow0 = tl.m0 + (tl.wm * WM + i) * 32 + 4 * tl.h;
@@ -338,6 +341,8 @@ __device__ __forceinline__ void conv16_epilogue_bnfused(const Conv16Args& p, con
       bsv[q] = m < p.Mg ? b : 0.f;
     }
   };
+  // this thread's channel of the tile (t < BM): its bias, requested now, used after the reduction
+  const float bias_t = (p.bias && tl.t < BM) ? p.bias[tl.g * p.Mg + min(tl.m0 + tl.t, p.Mg - 1)] : 0.f;
   {
     int cnt = 0;
 #pragma unroll
@@ -351,37 +356,27 @@ __device__ __forceinline__ void conv16_epilogue_bnfused(const Conv16Args& p, con
   }
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
-    float bsv[16];
-    bias_of(i, bsv);
-    float s1[16], s2[16], kk[16];
-    const int n0 = tl.wn * WN * 32;
-    const bool pivot_ok = (tl.oy0 + (n0 >> p.ltw) < tl.OUTH) & (tl.ox0 + (n0 & (TW - 1)) < tl.OUTW);     // wave-uniform
+    float s1[16], s2[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      // the value of this half's lane 0 (pixel block 0): one per (q, h)
-      const float v0 = acc[i][0][q] + bsv[q];
-      const float k0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v0), 0));
-      const float k1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v0), 32));
-      const float k = pivot_ok ? (tl.h ? k1 : k0) : 0.f;
-      kk[q] = tl.r == 0 ? k : 0.f;           // (summed over the half below: lands next to the channel's totals)
-      s1[q] = 0.f; s2[q] = 0.f;
+    for (int q = 0; q < 16; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
 #pragma unroll
-      for (int j = 0; j < WN; ++j) {
-        const int n = (tl.wn * WN + j) * 32 + tl.r;
-        const int oy = tl.oy0 + (n >> p.ltw), ox = tl.ox0 + (n & (TW - 1));
-        const bool cval = (oy < tl.OUTH) & (ox < tl.OUTW);
-        const float dv = cval ? (acc[i][j][q] + bsv[q]) - k : 0.f;
+    for (int j = 0; j < WN; ++j) {
+      const int n = (tl.wn * WN + j) * 32 + tl.r;
+      const int oy = tl.oy0 + (n >> p.ltw), ox = tl.ox0 + (n & (TW - 1));
+      const bool cval = (oy < tl.OUTH) & (ox < tl.OUTW);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float dv = cval ? acc[i][j][q] : 0.f;
         s1[q] += dv;
         s2[q] = fmaf(dv, dv, s2[q]);
       }
     }
     reduce16_over_half(s1, tl.r);
     reduce16_over_half(s2, tl.r);
-    reduce16_over_half(kk, tl.r);
     if (!(tl.r & 1)) {
       const int q = (tl.r >> 1) & 15;
       const int ml = (tl.wm * WM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * tl.h;
-      *reinterpret_cast<float4*>(red + (tl.wn * BM + ml) * 4) = float4{s1[0], s2[0], kk[0], 0.f};
+      *reinterpret_cast<float2*>(red + (tl.wn * BM + ml) * 4) = float2{s1[0], s2[0]};
     }
   }
   __syncthreads();
@@ -397,10 +392,10 @@ __device__ __forceinline__ void conv16_epilogue_bnfused(const Conv16Args& p, con
     float cn = 0.f, cmean = 0.f, cm2 = 0.f;
 #pragma unroll
     for (int w = 0; w < NWN; ++w) {
-      const float4 rv = *reinterpret_cast<const float4*>(red + (w * BM + tl.t) * 4);
+      const float2 rv = *reinterpret_cast<const float2*>(red + (w * BM + tl.t) * 4);
       const float nw = (float)wcnt[w];
       if (nw > 0.f) {
-        const float mw = rv.z + rv.x / nw, m2w = fmaxf(rv.y - rv.x * rv.x / nw, 0.f);
+        const float mw = bias_t + rv.x / nw, m2w = fmaxf(rv.y - rv.x * rv.x / nw, 0.f);
         const float tot = cn + nw, dl = mw - cmean;
         cmean += dl * (nw / tot);
         cm2 += m2w + dl * dl * (cn * nw / tot);

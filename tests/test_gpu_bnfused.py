@@ -205,9 +205,9 @@ def test_unsafe_channel_blocks_keep_y_raw():
 
 
 def test_channel_with_mean_far_above_sigma_keeps_its_variance():
-  """A channel whose mean is 1000 sigma (a large bias): the tile partials are sums about a pivot, published as (mean, M2, count)
-  and combined by Chan's rule -- sum x^2 - (sum x)^2 / n in fp32 would lose the variance entirely.  Reference: the same 16-bit
-  operands in float64."""
+  """A channel whose mean is 1000 sigma because of its bias: the tile partials are sums of the bias-free accumulators, published
+  as (mean = bias + sum / n, M2, count) and combined in fp64 -- fp32 sum x^2 - (sum x)^2 / n over x = acc + bias would lose the
+  variance entirely.  Reference: the same 16-bit operands in float64."""
   from mix_stage_amd import ops16
   nd, B, cin, cout, groups, k, s, p, H, W, in_mode = GEOMS[0][1:]
   ch = 517

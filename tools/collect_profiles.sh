@@ -1,16 +1,16 @@
 #!/bin/bash
 # GPU box: the round's measurement artifacts -> gpurun_out/final_<tag>/ (copy the summaries into profiles/ afterwards)
 set -eu
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/final_$TAG
 mkdir -p "$OUT"
 # HBM traffic (FETCH_SIZE / WRITE_SIZE in separate passes) and SQ counters of the north-star launch, every arithmetic mode --
 # first, and into profiles/ of this copy of the tree, so that the bench lines below carry roofline.traffic
-cd "$R" && bash tools/pmc_decoder.sh fp32 bf16x6 bf16 > "$OUT/pmc_decoder.log" 2>&1
+cd "$R" && bash tools/pmc_chain.sh fp32 bf16 > "$OUT/pmc_decoder.log" 2>&1
 cp gpurun_out/pmc_decoder.json "$OUT/pmc_decoder.json"; cp gpurun_out/sq_counters.json "$OUT/sq_counters.json"
-cp gpurun_out/pmc_decoder.json profiles/r03_pmc_decoder.json
-rm -rf gpurun_out/pmcdec
+cp gpurun_out/pmc_decoder.json profiles/${TAG}_pmc_decoder.json
+rm -rf gpurun_out/pmcchain
 cd "$R" && python bench.py > "$OUT/bench_full.log" 2>&1
 grep -o '{"metric.*' "$OUT/bench_full.log" > "$OUT/bench.json"
 python bench.py --precision bf16 --no-cpu-baseline > "$OUT/bench_bf16_full.log" 2>&1
@@ -32,6 +32,9 @@ for c in c2 c4 c5; do
   python bench.py --config $c > "$OUT/bench_${c}_full.log" 2>&1
   grep -o '{"metric.*' "$OUT/bench_${c}_full.log" > "$OUT/bench_$c.json"
 done
+# roofline-vs-size diagnostic: the same workload at B = 32 .. 256 clips per GPU (M = 8, T = 64), fp32 and bf16 (the chained launch
+# serves B*M <= 256 workgroups; larger batches run the blocks one by one)
+python tools/frac_vs_batch.py > "$OUT/frac_vs_batch.json" 2> "$OUT/frac_vs_batch.log" || true
 # per-kernel timeline of one captured bf16 G-step (rocprofv3 kernel trace of a replay, tools/trace_summary.py)
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr16 -- python3 "$R/tools/trace_step.py" bf16 G 12 > "$OUT/trace16.log" 2>&1
