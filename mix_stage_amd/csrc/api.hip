@@ -5,6 +5,7 @@
 #include "conv16.h"
 
 namespace ms {
+extern int g_clip32;
 
 static int validate(const ms_conv_desc* d, const char* who) {
   if (!d) return set_error("%s: null descriptor", who);
@@ -91,7 +92,7 @@ size_t ms_conv_block_bwd_workspace(const ms_conv_desc* d) {
   size_t bytes = 0;
   bytes += align_up((size_t)ctot_of(d) * nchunk * 2 * sizeof(float), 256);  // bn partials
   bytes += align_up((size_t)ctot_of(d) * nchunk * sizeof(float), 256);      // colsum partials
-  bytes += align_up(std::max(dgrad_weight_elems(d->groups, d->Cout, d->Cin, d->KH, d->KW, d->SH, d->SW), clip32_dgrad_weight_floats(d)) * sizeof(float), 256);
+  bytes += align_up(std::max(dgrad_weight_elems(d->groups, d->Cout, d->Cin, d->KH, d->KW, d->SH, d->SW), std::max(clip32_dgrad_weight_floats(d), gdgrad32_weight_floats(d))) * sizeof(float), 256);
   bytes += align_up(wsize_of(d) * sizeof(float) * (splits > 1 ? splits : 0), 256);
   {
     const bool bc = d->in_mode == MS_IN_BCAST;
@@ -265,6 +266,10 @@ static DgradWeights dgrad_weights_of(const ms_conv_desc* d, const float* w) {
     r.need = 2; r.flip = 1; r.tg = 1; r.tcog = d->Cout; r.p6 = 0; r.elems = clip32_dgrad_weight_floats(d);
     return r;
   }
+  if (g_precision == 0 && g_clip32 && gdgrad32_ok(d)) {   // grouped decoder blocks: the clip-stationary data-gradient kernel's streams
+    r.need = 3; r.flip = 1; r.tg = d->groups; r.tcog = d->Cout; r.p6 = 0; r.elems = gdgrad32_weight_floats(d);
+    return r;
+  }
   r.tg = bcast ? 1 : d->groups;
   r.tcog = bcast ? d->groups * d->Cout : d->Cout;
   const int jh = cdiv(d->KH, d->SH), jw = cdiv(d->KW, d->SW);
@@ -378,6 +383,11 @@ int ms_dgrad_weights_prepare(int n, const ms_conv_desc* descs, const float* cons
       if (rc) return rc;
       continue;
     }
+    if (dw.need == 3) {
+      rc = gdgrad32_prepare(d, w[i], wt[i], (hipStream_t)stream);
+      if (rc) return rc;
+      continue;
+    }
     TransposeJob jb = {w[i], wt[i], dw.tg, dw.tcog, d->Cin, d->KH, d->KW, d->SH, d->SW, d->PH, d->PW, dw.flip, 0};
     tb.job[tb.n++] = jb;
     if (tb.n == TRANSPOSE_BATCH_MAX) {
@@ -474,7 +484,7 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
   char* wsp = (char*)workspace;
   float* bn_part = (float*)wsp; wsp += align_up((size_t)C * nchunk * 2 * sizeof(float), 256);
   float* colpart = (float*)wsp; wsp += align_up((size_t)C * nchunk * sizeof(float), 256);
-  float* wt = (float*)wsp; wsp += align_up(std::max(dgrad_weight_elems(d->groups, d->Cout, d->Cin, d->KH, d->KW, d->SH, d->SW), clip32_dgrad_weight_floats(d)) * sizeof(float), 256);
+  float* wt = (float*)wsp; wsp += align_up(std::max(dgrad_weight_elems(d->groups, d->Cout, d->Cin, d->KH, d->KW, d->SH, d->SW), std::max(clip32_dgrad_weight_floats(d), gdgrad32_weight_floats(d))) * sizeof(float), 256);
   float* wg_part = (float*)wsp;
   {
     const int sp = wgrad_total_splits(d);
@@ -532,6 +542,18 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
     if (rc && rc != -2) return rc;
     dx_done = rc == 0;
     rc = 0;
+  }
+  if (dx && !dx_done && g_precision == 0 && g_clip32 && gdgrad32_ok(d)) {
+    // grouped decoder blocks: one clip of one group per workgroup, all 256 rows, weights streamed into registers (chain32.hip)
+    const float* wp = wt_prepared;
+    if (!wp) {
+      rc = gdgrad32_prepare(d, w, wt, s);
+      if (rc) return rc;
+      wp = wt;
+    }
+    rc = gdgrad32_launch(d, g, wp, dx, s);
+    if (rc) return rc;
+    dx_done = true;
   }
   if (dx && !dx_done) {
     const int tg = bcast ? 1 : d->groups;          // broadcast input: all groups sum into the same channels

@@ -504,6 +504,180 @@ __global__ __launch_bounds__(256, 1) void chain32_kernel(const Chain32Args p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// One grouped k3 s1 p1 conv, 256 -> 256 channels per group, T = 64, bias-free, with the same recipe (a workgroup = one clip of one
+// group, all 256 output rows; input image resident in LDS; weights streamed into registers; no barrier in the K loop): the DATA
+// GRADIENT of decoder.1-3 (what autograd derives for layers.py:78 / JL:69-77: dx = conv(dy_raw, w transposed, taps reversed)).
+// Independent workgroups: no meeting, any batch size.
+constexpr int GD_NBLK = 16;
+constexpr size_t GD_WAVE_STREAM = (size_t)(GD_NBLK + 2) * CH_BLK * 2 * 256;      // floats per (group, wave): 16 blocks + 2 of slack
+struct Gconv32Args {
+  const float* x;      // (B, M*256, 64)
+  const float* wp;     // [M][4][GD_WAVE_STREAM]
+  float* y;            // (B, M*256, 64)
+  int B, M;
+};
+
+__global__ __launch_bounds__(256, 1) void gconv32_kernel(const Gconv32Args p) {
+  extern __shared__ float smem[];
+  float* img = smem;                         // [32 groups][2][68][4]
+  float* oimg = img + CH_BUF1;               // the output tile in the same layout
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, n0 = lane & 31, h = lane >> 5;
+  const int g = blockIdx.x % p.M, b = blockIdx.x / p.M;
+  const int C = p.M * CH_C;
+  const size_t gbase = ((size_t)b * C + (size_t)g * CH_C) * CH_T;
+  // input image: every load first, then the weight ring's first fill behind them
+  constexpr int NPL = 16;                    // planes per wave (64 planes, a wave takes every 4th)
+  float xv[NPL][4];
+  {
+    const float* xb = p.x + gbase + lane;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xv[i][j] = xb[(size_t)(4 * (w + 4 * i) + j) * CH_T];
+  }
+  const float4* ws = reinterpret_cast<const float4*>(p.wp + ((size_t)g * 4 + w) * GD_WAVE_STREAM) + lane;
+  float4 ra0[CH_BLK][2], ra1[CH_BLK][2];
+#pragma unroll
+  for (int u = 0; u < CH_BLK; ++u)
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      ra0[u][mb] = ld_global_f4(ws + ((0 * CH_BLK + u) * 2 + mb) * 64);
+      ra1[u][mb] = ld_global_f4(ws + ((1 * CH_BLK + u) * 2 + mb) * 64);
+    }
+  for (int e = t; e < 64 * 4; e += 256) {
+    const int plane = e >> 2, sl = e & 3;
+    *reinterpret_cast<float4*>(img + plane * CH_PLANE + (sl == 0 ? 0 : 64 + sl) * 4) = float4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int i = 0; i < NPL; ++i)
+    *reinterpret_cast<float4*>(img + (w + 4 * i) * CH_PLANE + (1 + lane) * 4) = float4{xv[i][0], xv[i][1], xv[i][2], xv[i][3]};
+  __syncthreads();
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[mb][nb][q] = 0.f;
+  auto run_block = [&](float4 (&ra)[CH_BLK][2], const float* bb, size_t refill) {
+    float4 bf[2][2];
+    auto fetch_b = [&](int u, float4 (&dst)[2]) {
+      const int k8s = u / 3, tap = u - 3 * k8s;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+        dst[nb] = *reinterpret_cast<const float4*>(bb + (k8s * 2 + h) * CH_PLANE + (32 * nb + n0 + tap) * 4);
+    };
+    fetch_b(0, bf[0]);
+#pragma unroll
+    for (int u = 0; u < CH_BLK; ++u) {
+      if (u + 1 < CH_BLK) fetch_b(u + 1, bf[(u + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(ra[u][mb], j), f4e(bf[u & 1][nb], j), acc[mb][nb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) ra[u][mb] = ld_global_f4(ws + ((refill * CH_BLK + u) * 2 + mb) * 64);
+    }
+  };
+  {
+    const float* bb = img;
+    size_t blk = 0;
+    for (int d = 0; d < GD_NBLK / 2; ++d) {
+      run_block(ra0, bb, blk + 2);
+      run_block(ra1, bb + 4 * CH_PLANE, blk + 3);
+      blk += 2; bb += 8 * CH_PLANE;
+    }
+  }
+  // output through LDS: whole 16-byte vectors along the frames (thread = 4 channels x 16 frames, as in the chained kernel)
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const int c0 = 64 * w + 32 * mb + 8 * rq + 4 * h;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+        *reinterpret_cast<float4*>(oimg + ((c0 >> 3) * 2 + h) * CH_PLANE + (1 + 32 * nb + n0) * 4) =
+            float4{acc[mb][nb][4 * rq], acc[mb][nb][4 * rq + 1], acc[mb][nb][4 * rq + 2], acc[mb][nb][4 * rq + 3]};
+    }
+  __syncthreads();
+  const int pl = t >> 2, pq = t & 3;
+  const float* src = oimg + pl * CH_PLANE + (1 + 4 * pq) * 4;
+  float* dst = p.y + gbase + (size_t)(4 * pl) * CH_T + 4 * pq;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float4 v[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) v[f] = *reinterpret_cast<const float4*>(src + (16 * k + f) * 4);
+    *reinterpret_cast<float4*>(dst + 16 * k) = float4{v[0].x, v[1].x, v[2].x, v[3].x};
+    *reinterpret_cast<float4*>(dst + CH_T + 16 * k) = float4{v[0].y, v[1].y, v[2].y, v[3].y};
+    *reinterpret_cast<float4*>(dst + 2 * CH_T + 16 * k) = float4{v[0].z, v[1].z, v[2].z, v[3].z};
+    *reinterpret_cast<float4*>(dst + 3 * CH_T + 16 * k) = float4{v[0].w, v[1].w, v[2].w, v[3].w};
+  }
+}
+
+// transposed stream: rows = input channels ci of the group, reduction over (co, tap) with the taps reversed:
+// A(ci, (co, tap)) = w[g*256 + co][ci][2 - tap].  One workgroup per (group, wave, row block, half of the co range): per co the 32
+// rows x 3 taps are 96 contiguous floats of the weight tensor.
+__global__ __launch_bounds__(256) void gconv32_prep_kernel(const float* w, float* out, int M) {
+  __shared__ float lds[128 * 97];
+  const int t = threadIdx.x;
+  int id = blockIdx.x;
+  const int kh = id & 1; id >>= 1;
+  const int mb = id & 1; id >>= 1;
+  const int wv = id & 3; id >>= 2;
+  const int g = id;
+  const int ci0 = 64 * wv + 32 * mb;
+  for (int e = t; e < 128 * 96; e += 256) {
+    const int col = e / 96, k = e - col * 96;
+    lds[col * 97 + k] = w[((size_t)(g * CH_C + 128 * kh + col) * CH_C + ci0) * 3 + k];
+  }
+  __syncthreads();
+  float4* dst = reinterpret_cast<float4*>(out) + ((size_t)g * 4 + wv) * (GD_WAVE_STREAM / 4);
+  const int lane = t & 63, rr = lane & 31, h = lane >> 5;
+  for (int qi = t >> 6; qi < 16 * 3; qi += 4) {
+    const int k8l = qi / 3, tap = qi - 3 * k8l, k8 = 16 * kh + k8l;
+    float vv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vv[j] = lds[(8 * k8l + 4 * h + j) * 97 + rr * 3 + (2 - tap)];
+    dst[((size_t)((k8 >> 1) * CH_BLK + (k8 & 1) * 3 + tap) * 2 + mb) * 64 + lane] = float4{vv[0], vv[1], vv[2], vv[3]};
+  }
+}
+
+bool gdgrad32_ok(const ms_conv_desc* d) {
+  return (d->dtype & 0xff) == 0 && d->H == 1 && d->KH == 1 && d->KW == 3 && d->SW == 1 && d->PW == 1 && d->W == CH_T && d->groups > 1 &&
+         d->Cin == CH_C && d->Cout == CH_C && d->in_mode == MS_IN_PLAIN;
+}
+size_t gdgrad32_weight_floats(const ms_conv_desc* d) { return gdgrad32_ok(d) ? (size_t)d->groups * 4 * GD_WAVE_STREAM : 0; }
+int gdgrad32_prepare(const ms_conv_desc* d, const float* w, float* out, hipStream_t s) {
+  TimingScope ts(s, 0, 0, "gconv32_prep_kernel|gdgrad_prep g%d", d->groups);
+  if (ts.skip()) return 0;
+  hipLaunchKernelGGL(gconv32_prep_kernel, dim3(d->groups * 4 * 2 * 2), dim3(256), 0, s, w, out, d->groups);
+  return check_launch("gconv32_prep_kernel");
+}
+int gdgrad32_launch(const ms_conv_desc* d, const float* g, const float* wp, float* dx, hipStream_t s) {
+  static int attr_done = 0;
+  const int lds = 2 * CH_BUF1 * (int)sizeof(float);
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gconv32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return set_error("gconv32: cannot raise the dynamic LDS limit");
+    attr_done = 1;
+  }
+  Gconv32Args a = {g, wp, dx, d->B, d->groups};
+  const double flops = 2.0 * CH_C * CH_C * 3.0 * d->B * CH_T * d->groups;
+  const double bytes = 4.0 * (2.0 * d->B * d->groups * CH_C * CH_T + (double)d->groups * CH_C * CH_C * 3);
+  TimingScope ts(s, flops, bytes, "gconv32_kernel|conv_dgrad_gclip k1x3 s1 g%d B%d", d->groups, d->B);
+  if (ts.skip()) return 0;
+  hipLaunchKernelGGL(gconv32_kernel, dim3(d->B * d->groups), dim3(256), lds, s, a);
+  return check_launch("gconv32_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------
 // weight streams.  One thread per 16-byte vector: [group][wave][stream position][row block][lane] = 4 consecutive reduction
 // channels 8*k8 + 4*(lane>>5) + 0..3 at one tap, of output row 64*wave + 32*mb + (lane & 31)
 struct ChainPrepArgs {

@@ -15,12 +15,22 @@
 
 namespace ms {
 
+// channels per K chunk of the 2-D kernels (tuning: -DMS_CK9=8 ...)
+#ifndef MS_CK9
+#define MS_CK9 4
+#endif
+#ifndef MS_CK16
+#define MS_CK16 4
+#endif
+#ifndef MS_CK24
+#define MS_CK24 2
+#endif
 template <int KH, int KW>
 struct PatchCfg {
   static constexpr int KHW = KH * KW;
   // channels per K-chunk: K_step = CK*KHW in [36, 64], multiple of 4
-  static constexpr int CK = KHW == 1 ? 32 : KHW == 2 ? 16 : KHW == 3 ? 16 : KHW == 4 ? 16 : KHW == 9 ? 4
-                            : KHW == 16 ? 4 : KHW == 24 ? 2 : 4;
+  static constexpr int CK = KHW == 1 ? 32 : KHW == 2 ? 16 : KHW == 3 ? 16 : KHW == 4 ? 16 : KHW == 9 ? MS_CK9
+                            : KHW == 16 ? MS_CK16 : KHW == 24 ? MS_CK24 : 4;
   static constexpr int KSTEP = CK * KHW;
 };
 
@@ -383,7 +393,7 @@ int g_precision = 0;
 int g_patch_intra = 1;          // tuning knob: intra-workgroup K split for small 1-D k3 layers
 int patch_chunk_channels(int KH, int KW) {
   const int khw = KH * KW;
-  return khw == 1 ? 32 : khw == 2 ? 16 : khw == 3 ? 16 : khw == 4 ? 16 : khw == 9 ? 4 : khw == 16 ? 4 : khw == 24 ? 2 : 4;
+  return khw == 1 ? 32 : khw == 2 ? 16 : khw == 3 ? 16 : khw == 4 ? 16 : khw == 9 ? MS_CK9 : khw == 16 ? MS_CK16 : khw == 24 ? MS_CK24 : 4;
 }
 
 PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH, int SW, int B, int OH, int OW, int zmul) {

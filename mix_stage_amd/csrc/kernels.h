@@ -164,6 +164,12 @@ int clip32_block_fwd(const ms_conv_desc* d, const float* x, const float* x2, con
                      int sync_words, hipStream_t s);
 int clip32_block_dgrad(const ms_conv_desc* d, const float* g, const float* wp, float* dx, float* dx2, hipStream_t s);
 
+// data gradient of the grouped decoder blocks (chain32.hip: gconv32_kernel)
+bool gdgrad32_ok(const ms_conv_desc* d);
+size_t gdgrad32_weight_floats(const ms_conv_desc* d);
+int gdgrad32_prepare(const ms_conv_desc* d, const float* w, float* out, hipStream_t s);
+int gdgrad32_launch(const ms_conv_desc* d, const float* g, const float* wp, float* dx, hipStream_t s);
+
 // ---- chained pose decoder (chain32.hip: fp32; chain16.hip: bf16 / fp16), behind ms_decoder_chain_*
 int chain32_supported(const ms_chain_desc* d);
 size_t chain32_prepared_bytes(const ms_chain_desc* d);
