@@ -214,6 +214,31 @@ def test_chain_keeps_the_variance_of_a_channel_with_a_huge_mean():
   assert abs(float(rv_a[300]) - float(rv_b[300])) <= 2e-2 * abs(float(rv_b[300]))
 
 
+def test_an_expired_meeting_is_reported_and_poisons_the_output():
+  """A counter that is out of step with the launch (set by hand here: one arrival too many on block 0's counter of group 0, what a
+  foreign launch on the same words would leave) makes ONE workgroup wait for arrivals that never come: the bounded spin expires
+  (~0.3 s), that clip's output is NaN, word 0 of the sync buffer names the meeting, MixStageTrainStep.check_health raises and
+  clears; the next launch (counters re-zeroed) is clean."""
+  from mix_stage_amd import ops, ops16
+  from mix_stage_amd.train_step import MixStageTrainStep
+  B, M, P = 8, 4, 104
+  blocks, logits = _build(M, P, 10, seed=21)
+  x, score = _inputs(B, M, 266, seed=21)
+  good = _run(blocks, logits, x, score, P, True, grad=False)
+  assert not ops16.bn_sync_error()
+  buf = ops16.chain_sync(torch.device(DEV), B, M, 1)
+  buf[ops.CHAIN_SYNC_FIRST_WORD] += 1
+  bad = _run(blocks, logits, x, score, P, True, grad=False)
+  assert not torch.isfinite(bad['out']).all()
+  assert ops16.bn_sync_error()
+  assert any(w[0] == 1 for w in ops16.bn_sync_words())          # code 1 = block 0's meeting
+  with pytest.raises(RuntimeError, match='meeting timed out'):
+    MixStageTrainStep.check_health(None)
+  assert not ops16.bn_sync_error()                               # cleared (all words: the counters start again from zero)
+  again = _run(blocks, logits, x, score, P, True, grad=False)
+  assert torch.equal(again['out'], good['out'])
+
+
 def test_shapes_outside_the_chain_fall_back():
   """T != 64, more workgroups than compute units, hooks on a block: decoder_chain declines and the caller runs the blocks."""
   from mix_stage_amd import ops
