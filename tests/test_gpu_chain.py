@@ -227,7 +227,9 @@ def test_an_expired_meeting_is_reported_and_poisons_the_output():
   good = _run(blocks, logits, x, score, P, True, grad=False)
   assert not ops16.bn_sync_error()
   buf = ops16.chain_sync(torch.device(DEV), B, M, 1)
-  buf[ops.CHAIN_SYNC_FIRST_WORD] += 1
+  first = ops.CHAIN_SYNC_FIRST_WORD + int((buf[ops.CHAIN_SYNC_FIRST_WORD:] != 0).nonzero()[0])    # block 0's counter of group 0
+  assert int(buf[first]) % B == 0 and int(buf[first]) > 0
+  buf[first] += 1
   bad = _run(blocks, logits, x, score, P, True, grad=False)
   assert not torch.isfinite(bad['out']).all()
   assert ops16.bn_sync_error()
