@@ -11,7 +11,11 @@
 //     partial batch statistics, ONE in-launch meeting of the workgroups that share the channel tile (BN_TRAIN), normalise,
 //     activate, store y_raw / y -- no statistics launch, no normalising launch.
 // Replaces, per block: patch conv (intra-workgroup split) or im2col-gather conv + split-K epilogue + bn_finalize_apply.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include <algorithm>
+#include <vector>
 
 #include "kernels.h"
 
@@ -40,7 +44,9 @@ struct Clip32Args {
   int cnt_base;
   int B, Cin, Cout, To, Ti, ep, k8w, npw, rows_valid, nct;      // Cout: output channels (addressing) = rows_valid; nct = ceil(Cout / 32)
   float slope, eps, momentum;
+  unsigned long long* stamps;   // diagnostics (MS_CLIP_DBG=32): [workgroup][8] s_memrealtime stamps (100 MHz)
 };
+#define CL_STAMP(k) do { if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
 __device__ __forceinline__ float cl_f4e(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
 
@@ -65,12 +71,18 @@ __device__ __forceinline__ float cl_sum8(float v) {
   return v;
 }
 
-// KW taps, stride S; NB = 32-frame blocks of output per workgroup (2, stride 2: 1); UP2: the input is nearest_up2(a) + r
-template <int KW, int S, int NB, bool UP2>
+// KW taps, stride S; NB = 32-frame blocks of output per workgroup (2, stride 2: 1); UP2: the input is nearest_up2(a) + r.
+// K8W > 0: the channel groups per wave are a compile-time constant (the K loop is ONE basic block: operand reads of a unit are
+// issued a unit ahead, no wait sits in front of an MFMA but the one for its own operands) and, where a clip's frames come in
+// fours, every wave stages exactly the planes its own K slice reads (16-byte loads, all in flight at once, no workgroup barrier
+// between staging and the K loop).  K8W = 0: any geometry (run-time trip counts, scalar staging).
+template <int KW, int S, int NB, bool UP2, int K8W>
 __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
   prefetch_kernargs<sizeof(Clip32Args)>();
   extern __shared__ float cl_smem[];
+  CL_STAMP(0);
   constexpr int NPX = 32 * NB;                       // output frames per workgroup
+  constexpr int NWR = (K8W ? K8W : CL_MAXK8W) * KW;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, n0 = lane & 31, h = lane >> 5;
   const int nct = p.nct;
   const int ct = blockIdx.x % nct, pw = blockIdx.x / nct;      // channel tile, pixel workgroup
@@ -79,23 +91,74 @@ __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
   const int b0 = pw * ncl;
   const int row = Ti + 2;                            // slots per clip: halo + Ti + halo
   const int pslots = (ncl * row + 3) & ~3;           // slots per plane
-  const int k8w = p.k8w, nk8 = 4 * k8w;              // channel groups per wave / staged in all (zero beyond Cin)
+  const int k8w = K8W ? K8W : p.k8w, nk8 = 4 * k8w;  // channel groups per wave / staged in all (zero beyond Cin)
 
-  // ---- this wave's weights: the whole slice in flight (k8w * KW loads of 16 B per lane)
-  float4 wr[CL_MAXK8W * KW];
-  {
-    const float4* ws = reinterpret_cast<const float4*>(p.wp) + ((size_t)(ct * 4 + w) * k8w * KW) * 64 + lane;
+  // ---- this wave's weights: the whole slice in flight (k8w * KW loads of 16 B per lane).  Where the wave stages its own planes
+  // the image loads go first: they are needed first, and the counter of outstanding loads retires in order
+  float4 wr[NWR];
+  const float4* ws = reinterpret_cast<const float4*>(p.wp) + ((size_t)(ct * 4 + w) * k8w * KW) * 64 + lane;
+  const bool own_planes = K8W > 0 && (Ti & 3) == 0;  // (uniform)
+  if (!own_planes) {
 #pragma unroll
-    for (int i = 0; i < CL_MAXK8W * KW; ++i) wr[i] = ws[(size_t)min(i, k8w * KW - 1) * 64];
+    for (int i = 0; i < NWR; ++i) wr[i] = ws[(size_t)min(i, k8w * KW - 1) * 64];
   }
 
   // ---- the clips' input image: plane (k8, hh) = channels 8*k8 + 4*hh + 0..3, slot = clip * row + 1 + frame.
-  // Positions (clip, frame) are spread over the lanes, 4 coalesced loads + one 16-byte LDS store per position and plane.
-  {
+  if (own_planes) {
+    // wave w stages planes [2*K8W*w, 2*K8W*(w+1)): item = (plane, quad of frames): four 16-byte loads (the plane's four
+    // channels) -> four 16-byte LDS stores (the quad's four slots); ceil(K8W / 2) items per lane, every load issued first
+    constexpr int NI = K8W ? (K8W + 1) / 2 : 1;
+    constexpr int NITEMS = 2 * K8W * 16;
+    const int plw0 = 2 * K8W * w;
+    for (int e = lane; e < ncl * 2 * 2 * K8W; e += 64) {         // halos of this wave's planes
+      const int pl = plw0 + e / (ncl * 2), r2 = e % (ncl * 2), cl = r2 >> 1, sl = (r2 & 1) ? Ti + 1 : 0;
+      *reinterpret_cast<float4*>(cl_smem + ((size_t)pl * pslots + cl * row + sl) * 4) = float4{0.f, 0.f, 0.f, 0.f};
+    }
+    float4 v[NI][4];
+    float2 va[NI][4];
+#pragma unroll
+    for (int q = 0; q < NI; ++q) {
+      const int it = min(lane + 64 * q, NITEMS - 1);
+      const int pl = plw0 + (it >> 4), pos = 4 * (it & 15);
+      const int cl = pos / Ti, ti = pos - cl * Ti;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = min(4 * pl + j, p.Cin - 1);
+        if (UP2) {
+          v[q][j] = *reinterpret_cast<const float4*>(p.x2 + ((size_t)(b0 + cl) * p.Cin + c) * Ti + ti);
+          va[q][j] = *reinterpret_cast<const float2*>(p.x + ((size_t)(b0 + cl) * p.Cin + c) * (Ti / 2) + ti / 2);
+        } else {
+          v[q][j] = *reinterpret_cast<const float4*>(p.x + ((size_t)(b0 + cl) * p.Cin + c) * Ti + ti);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NWR; ++i) wr[i] = ws[(size_t)i * 64];
+#pragma unroll
+    for (int q = 0; q < NI; ++q) {
+      const int it = lane + 64 * q;
+      if (it < NITEMS) {
+        const int pl = plw0 + (it >> 4), pos = 4 * (it & 15);
+        const int cl = pos / Ti, ti = pos - cl * Ti;
+        float o[4][4];                                 // [frame][channel]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool ok = 4 * pl + j < p.Cin;
+          float4 u = v[q][j];
+          if (UP2) { u.x += va[q][j].x; u.y += va[q][j].x; u.z += va[q][j].y; u.w += va[q][j].y; }
+          o[0][j] = ok ? u.x : 0.f; o[1][j] = ok ? u.y : 0.f; o[2][j] = ok ? u.z : 0.f; o[3][j] = ok ? u.w : 0.f;
+        }
+        float* dst = cl_smem + ((size_t)pl * pslots + cl * row + 1 + ti) * 4;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) *reinterpret_cast<float4*>(dst + 4 * f) = float4{o[f][0], o[f][1], o[f][2], o[f][3]};
+      }
+    }
+  } else {
+    // Positions (clip, frame) are spread over the lanes, 4 coalesced loads + one 16-byte LDS store per position and plane.
     const int npos = ncl * Ti;                       // input frames of this workgroup (64 at every depth)
     for (int e = t; e < ncl * 2; e += 256) {         // halos
-      const int cl = e >> 1, s = (e & 1) ? Ti + 1 : 0;
-      for (int pl = 0; pl < nk8 * 2; ++pl) *reinterpret_cast<float4*>(cl_smem + ((size_t)pl * pslots + cl * row + s) * 4) = float4{0.f, 0.f, 0.f, 0.f};
+      const int cl = e >> 1, sl = (e & 1) ? Ti + 1 : 0;
+      for (int pl = 0; pl < nk8 * 2; ++pl) *reinterpret_cast<float4*>(cl_smem + ((size_t)pl * pslots + cl * row + sl) * 4) = float4{0.f, 0.f, 0.f, 0.f};
     }
     const int pos = t % npos, pl0 = t / npos, pstep = 256 / npos;      // npos divides 256 (npos = 64)
     const int cl = pos / Ti, ti = pos - cl * Ti;
@@ -137,7 +200,16 @@ __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
   const float bias_c = p.bias ? p.bias[cgc] : 0.f;
   float gam = 1.f, bet = 0.f, rmo = 0.f, rvo = 1.f;
   if (p.ep == EP_RAW_STATS || p.ep == EP_BN_EVAL) { gam = p.gamma[cgc]; bet = p.beta[cgc]; rmo = p.rm[cgc]; rvo = p.rv[cgc]; }
-  __syncthreads();
+  CL_STAMP(1);
+  if (own_planes) {
+    // the wave reads what it stored itself: its LDS stores complete in order ahead of its reads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
+  CL_STAMP(2);
 
   // ---- K loop: this wave's channel groups x taps, no barrier
   f32x16 acc[NB];
@@ -153,24 +225,49 @@ __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
   }
   {
     const float* img = cl_smem + ((size_t)(w * k8w) * 2 + h) * pslots * 4;
+    if constexpr (K8W > 0) {
+      constexpr int NU = K8W * KW;                   // units (channel group, tap)
+      float4 bf[2][NB];
 #pragma unroll
-    for (int i = 0; i < CL_MAXK8W; ++i) {
-      if (i < k8w) {
+      for (int nb = 0; nb < NB; ++nb) bf[0][nb] = *reinterpret_cast<const float4*>(img + ((size_t)bbase[nb]) * 4);
 #pragma unroll
-        for (int tap = 0; tap < KW; ++tap) {
-          float4 bf[NB];
+      for (int u = 0; u < NU; ++u) {
+        if (u + 1 < NU) {
+          const int i1 = (u + 1) / KW, tap1 = (u + 1) % KW;
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) bf[nb] = *reinterpret_cast<const float4*>(img + ((size_t)i * 2 * pslots + bbase[nb] + tap) * 4);
+          for (int nb = 0; nb < NB; ++nb)
+            bf[(u + 1) & 1][nb] = *reinterpret_cast<const float4*>(img + ((size_t)i1 * 2 * pslots + bbase[nb] + tap1) * 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);           // keep the next unit's LDS reads ahead of these MFMAs
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-              acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(cl_f4e(wr[i * KW + tap], j), cl_f4e(bf[nb], j), acc[nb], 0, 0, 0);
+          for (int nb = 0; nb < NB; ++nb)
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(cl_f4e(wr[u], j), cl_f4e(bf[u & 1][nb], j), acc[nb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < CL_MAXK8W; ++i) {
+        if (i < k8w) {
+#pragma unroll
+          for (int tap = 0; tap < KW; ++tap) {
+            float4 bf[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) bf[nb] = *reinterpret_cast<const float4*>(img + ((size_t)i * 2 * pslots + bbase[nb] + tap) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int nb = 0; nb < NB; ++nb)
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(cl_f4e(wr[i * KW + tap], j), cl_f4e(bf[nb], j), acc[nb], 0, 0, 0);
+          }
         }
       }
     }
   }
+  CL_STAMP(3);
   __syncthreads();                                   // every wave is done with the image: it becomes the exchange buffer
+  CL_STAMP(4);
 
   // ---- the four partial tiles meet in LDS: red[wave][channel 32][frame NPX + 4]
   constexpr int RP = NPX + 4;
@@ -234,6 +331,7 @@ __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
                                               (int)(8u * (unsigned)((ct * p.npw + pw) * 32 + chl)), 0, 16);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      CL_STAMP(5);
       int* lflag = reinterpret_cast<int*>(cl_smem + 4 * 32 * RP);
       if (t == 0) {
         int* counter = p.sync + p.cnt_base + 32 * ct;
@@ -247,6 +345,7 @@ __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
         lflag[0] = bad;
       }
       __syncthreads();
+      CL_STAMP(6);
       // the channel's partials, every 8th one per lane (up to 4 in flight), in fp64: sum of means, sum of M2, then the spread
       // of the means about the mean (equal counts) -- lane sums in lane order, then the 8 lanes by a fixed tree
       float2 pv[4];
@@ -318,6 +417,7 @@ __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
     for (int k = 0; k < FPT; ++k) v[k] = lrelu(p.ep == EP_LRELU ? v[k] : fmaf(v[k], sc, sh), p.slope);
   }
   store_frames(p.y, v);
+  CL_STAMP(7);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -439,9 +539,9 @@ int clip32_prep_flush(hipStream_t s) {
 size_t clip32_part_bytes(int rows, int npw) { return align_up((size_t)cdiv(rows, 32) * npw * 32 * 2 * sizeof(float), 256); }
 int clip32_sync_words(int rows) { return 32 * (cdiv(rows, 32) + 1); }
 
-template <int KW, int S, int NB, bool UP2>
-static int clip32_launch_t(const Clip32Args& a, int nwg, int lds_bytes, hipStream_t s) {
-  auto fn = clip32_kernel<KW, S, NB, UP2>;
+template <int KW, int S, int NB, bool UP2, int K8W>
+static int clip32_launch_k(const Clip32Args& a, int nwg, int lds_bytes, hipStream_t s) {
+  auto fn = clip32_kernel<KW, S, NB, UP2, K8W>;
   static int attr_done = 0;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -450,6 +550,17 @@ static int clip32_launch_t(const Clip32Args& a, int nwg, int lds_bytes, hipStrea
   }
   hipLaunchKernelGGL(fn, dim3(nwg), dim3(256), lds_bytes, s, a);
   return check_launch("clip32_kernel");
+}
+// the channel-group counts of the path's layers (64, 104 / 128, 256, 266 channels in) have instances of their own
+template <int KW, int S, int NB, bool UP2>
+static int clip32_launch_t(const Clip32Args& a, int nwg, int lds_bytes, hipStream_t s) {
+  switch (a.k8w) {
+    case 2: return clip32_launch_k<KW, S, NB, UP2, 2>(a, nwg, lds_bytes, s);
+    case 4: return clip32_launch_k<KW, S, NB, UP2, 4>(a, nwg, lds_bytes, s);
+    case 8: return clip32_launch_k<KW, S, NB, UP2, 8>(a, nwg, lds_bytes, s);
+    case 9: return clip32_launch_k<KW, S, NB, UP2, 9>(a, nwg, lds_bytes, s);
+    default: return clip32_launch_k<KW, S, NB, UP2, 0>(a, nwg, lds_bytes, s);
+  }
 }
 
 // ep: EP_BARE / EP_LRELU / EP_BN_EVAL / EP_RAW_STATS (= BN_TRAIN, everything in this launch) / EP_DGRAD_UP2
@@ -475,8 +586,34 @@ int clip32_launch(Clip32Args a, int KW, int S, bool up2, const char* what, hipSt
   TimingScope ts(s, flops, bytes, "clip32_kernel<%d,%d,%d,%d>|conv_%s_clip k1x%d s%d rows%d red%d T%d B%d ep%d", KW, S, nb, up2 ? 1 : 0, what, KW,
                  S, a.rows_valid, a.Cin, a.To, a.B, a.ep);
   if (ts.skip()) return 0;
-  if (KW == 3 && S == 1) return up2 ? clip32_launch_t<3, 1, 2, true>(a, nwg, lds, s) : clip32_launch_t<3, 1, 2, false>(a, nwg, lds, s);
-  return clip32_launch_t<4, 2, 1, false>(a, nwg, lds, s);
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("MS_CLIP_DBG"); dbg = e ? atoi(e) : 0; }
+  static unsigned long long* g_stamps = nullptr;
+  if (dbg & 32) {                           // diagnostics only: stamps of every workgroup, printed after a synchronisation
+    if (!g_stamps && hipMalloc(&g_stamps, 4096 * 8 * 8) != hipSuccess) g_stamps = nullptr;
+    if (g_stamps) (void)hipMemsetAsync(g_stamps, 0, 4096 * 8 * 8, s);
+    a.stamps = nwg <= 4096 ? g_stamps : nullptr;
+  }
+  int rc;
+  if (KW == 3 && S == 1) rc = up2 ? clip32_launch_t<3, 1, 2, true>(a, nwg, lds, s) : clip32_launch_t<3, 1, 2, false>(a, nwg, lds, s);
+  else rc = clip32_launch_t<4, 2, 1, false>(a, nwg, lds, s);
+  if (a.stamps) {
+    std::vector<unsigned long long> h((size_t)nwg * 8);
+    if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h.data(), g_stamps, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+      unsigned long long t0 = ~0ull;
+      for (int i = 0; i < nwg; ++i) t0 = std::min(t0, h[(size_t)i * 8]);
+      fprintf(stderr, "clip32 %s k%d s%d rows%d red%d ep%d: stamps (us after the first workgroup's entry; min / median / max over %d workgroups)\n", what, KW, S,
+              a.rows_valid, a.Cin, a.ep, nwg);
+      for (int k = 0; k < 8; ++k) {
+        std::vector<double> v;
+        for (int i = 0; i < nwg; ++i) if (h[(size_t)i * 8 + k]) v.push_back((double)(h[(size_t)i * 8 + k] - t0) * 0.01);
+        if (v.empty()) continue;
+        std::sort(v.begin(), v.end());
+        fprintf(stderr, "  stamp %d: %7.2f %7.2f %7.2f\n", k, v.front(), v[v.size() / 2], v.back());
+      }
+    }
+  }
+  return rc;
 }
 
 int clip32_block_fwd(const ms_conv_desc* d, const float* x, const float* x2, const float* wp, const float* bias, const float* gamma,
