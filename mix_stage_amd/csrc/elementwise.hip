@@ -4,6 +4,8 @@
 // All reductions run in a fixed order (no float atomics) -> bitwise reproducible.
 #include <algorithm>
 
+#include <stdint.h>
+
 #include "kernels.h"
 
 namespace ms {
@@ -277,6 +279,106 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const float v = gi * (dz - m1 - xh * m2);
     dyr[off] = v;
     cs += v;
+  }
+  cs = block_sum_256(cs, red);
+  if (t == 0) {
+    colpart[(size_t)c * nchunk + ch] = cs;
+    if (ch == 0 && dgamma) { dgamma[c] = s2; dbeta[c] = s1; }
+  }
+}
+
+// The same two passes for rows of HW % 4 == 0 values: 16 bytes per lane and load, four pairs of loads in flight per thread (the
+// 2-D layers stream 70-330 MB through these two launches; one dword and two integer divisions per element ran at 3.5 TB/s).
+__global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(const float* __restrict__ dy, const float* __restrict__ y_raw,
+                                                             const float* __restrict__ save, float* __restrict__ partial,
+                                                             int B, int C, int HW, int b_per_chunk, float slope) {
+  prefetch_kernargs<128>();
+  __shared__ float red[4];
+  const int c = blockIdx.x, ch = blockIdx.y, t = threadIdx.x;
+  const int b0 = ch * b_per_chunk, nb = min(b_per_chunk, B - b0);
+  const float mean = save[c], invstd = save[C + c], sc = save[2 * C + c], sh = save[3 * C + c];
+  const int HW4 = HW >> 2, nv = nb * HW4;
+  const FastDiv fd(HW4, nv + 1024);
+  float s1 = 0.f, s2 = 0.f;
+  for (int e0 = t; e0 < nv; e0 += 1024) {
+    float4 yr[4], g[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = min(e0 + 256 * u, nv - 1);
+      const int b = fd.div(e), p4 = e - b * HW4;
+      const size_t off = ((size_t)(b0 + b) * C + c) * HW + 4 * p4;
+      yr[u] = *reinterpret_cast<const float4*>(y_raw + off);
+      g[u] = *reinterpret_cast<const float4*>(dy + off);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (e0 + 256 * u < nv) {
+        const float a[4] = {yr[u].x, yr[u].y, yr[u].z, yr[u].w}, d[4] = {g[u].x, g[u].y, g[u].z, g[u].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float z = fmaf(a[j], sc, sh);
+          const float dz = d[j] * (z > 0.f ? 1.f : slope);
+          s1 += dz;
+          s2 += dz * ((a[j] - mean) * invstd);
+        }
+      }
+    }
+  }
+  s1 = block_sum_256(s1, red);
+  s2 = block_sum_256(s2, red);
+  if (t == 0) {
+    partial[((size_t)c * gridDim.y + ch) * 2] = s1;
+    partial[((size_t)c * gridDim.y + ch) * 2 + 1] = s2;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restrict__ dy, const float* __restrict__ y_raw,
+                                                            const float* __restrict__ save, const float* __restrict__ gamma,
+                                                            const float* __restrict__ partial, float* __restrict__ dyr,
+                                                            float* __restrict__ colpart, float* dgamma, float* dbeta,
+                                                            int B, int C, int HW, int b_per_chunk, float slope) {
+  prefetch_kernargs<128>();
+  __shared__ float red[4];
+  const int c = blockIdx.x, ch = blockIdx.y, t = threadIdx.x, nchunk = gridDim.y;
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = 0; k < nchunk; ++k) {
+    s1 += partial[((size_t)c * nchunk + k) * 2];
+    s2 += partial[((size_t)c * nchunk + k) * 2 + 1];
+  }
+  const float invN = 1.0f / (float)((size_t)B * HW);
+  const float mean = save[c], invstd = save[C + c], sc = save[2 * C + c], sh = save[3 * C + c];
+  const float gi = gamma[c] * invstd, m1 = s1 * invN, m2 = s2 * invN;
+  const int b0 = ch * b_per_chunk, nb = min(b_per_chunk, B - b0);
+  const int HW4 = HW >> 2, nv = nb * HW4;
+  const FastDiv fd(HW4, nv + 1024);
+  float cs = 0.f;
+  for (int e0 = t; e0 < nv; e0 += 1024) {
+    float4 yr[4], g[4];
+    size_t off[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = min(e0 + 256 * u, nv - 1);
+      const int b = fd.div(e), p4 = e - b * HW4;
+      off[u] = ((size_t)(b0 + b) * C + c) * HW + 4 * p4;
+      yr[u] = *reinterpret_cast<const float4*>(y_raw + off[u]);
+      g[u] = *reinterpret_cast<const float4*>(dy + off[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (e0 + 256 * u < nv) {
+        const float a[4] = {yr[u].x, yr[u].y, yr[u].z, yr[u].w}, d[4] = {g[u].x, g[u].y, g[u].z, g[u].w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float z = fmaf(a[j], sc, sh);
+          const float dz = d[j] * (z > 0.f ? 1.f : slope);
+          const float xh = (a[j] - mean) * invstd;
+          o[j] = gi * (dz - m1 - xh * m2);
+          cs += o[j];
+        }
+        *reinterpret_cast<float4*>(dyr + off[u]) = float4{o[0], o[1], o[2], o[3]};
+      }
+    }
   }
   cs = block_sum_256(cs, red);
   if (t == 0) {
@@ -1082,11 +1184,15 @@ int launch_bn_bwd(const float* dy, const float* y_raw, const float* save, const 
   const int nchunk = bwd_chunks(B, C, &bpc);
   TimingScope ts(s, 0, 20.0 * B * C * HW, "bn_bwd(reduce+apply) C%d HW%d B%d", C, HW, B);
   if (ts.skip()) return 0;
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, nchunk), dim3(256), 0, s, dy, y_raw, save, partial, B, C, HW, bpc, slope);
+  const bool vec = (HW & 3) == 0 && (((uintptr_t)dy | (uintptr_t)y_raw | (uintptr_t)dyr) & 15) == 0;
+  if (vec) hipLaunchKernelGGL(bn_bwd_reduce4_kernel, dim3(C, nchunk), dim3(256), 0, s, dy, y_raw, save, partial, B, C, HW, bpc, slope);
+  else hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, nchunk), dim3(256), 0, s, dy, y_raw, save, partial, B, C, HW, bpc, slope);
   int rc = check_launch("bn_bwd_reduce_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(C, nchunk), dim3(256), 0, s, dy, y_raw, save, gamma, partial, dyr, colpart,
-                     dgamma, dbeta, B, C, HW, bpc, slope);
+  if (vec) hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3(C, nchunk), dim3(256), 0, s, dy, y_raw, save, gamma, partial, dyr, colpart,
+                              dgamma, dbeta, B, C, HW, bpc, slope);
+  else hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(C, nchunk), dim3(256), 0, s, dy, y_raw, save, gamma, partial, dyr, colpart,
+                          dgamma, dbeta, B, C, HW, bpc, slope);
   return check_launch("bn_bwd_apply_kernel");
 }
 
