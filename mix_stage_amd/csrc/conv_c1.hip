@@ -3,6 +3,12 @@
 // here one thread computes one output pixel for all 64 channels on the VALU (weights come in through scalar loads) and
 // the launch is bound by writing the 67 MB output.  BN statistics: each wave passes its 64 x 64 tile through LDS and one
 // lane per channel accumulates (sum, M2 about the tile mean) in a fixed order -- same partials as the patch kernels.
+// Rows of W % 4 == 0 pixels (the path's: 128 mel bins) take conv_c1_3x3_v4_kernel: a thread owns four consecutive pixels (16-byte
+// stores), a workgroup's 1024 pixels are one statistics tile (4x fewer partials for bn_finalize), both statistics passes are
+// constant-trip LDS reductions; the conv is recomputed for the second pass instead of keeping 256 values per thread.
+#include <stdint.h>
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace ms {
@@ -75,10 +81,117 @@ __global__ __launch_bounds__(256) void conv_c1_3x3_kernel(const float* __restric
   if (lane == 0) counts[tile_id] = (float)cnt;
 }
 
+
+// NT threads per workgroup = NT / 64 waves; the reduction tile holds 65 floats per (channel, wave) + 1 per channel
+template <int CO, int NT>
+__global__ __launch_bounds__(NT) void conv_c1_3x3_v4_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ out,
+                                                             const float* __restrict__ bn_g, const float* __restrict__ bn_b,
+                                                             const float* __restrict__ bn_m, const float* __restrict__ bn_v,
+                                                             float* __restrict__ stats, float* __restrict__ counts, int B, int H,
+                                                             int W, int ep, float slope, float eps) {
+  constexpr int NWV = NT / 64, C1V_PITCH = NWV * 65 + 1;
+  extern __shared__ float c1_smem[];
+  float* tl = c1_smem;                       // [CO][waves][65]
+  float* tmean = tl + CO * C1V_PITCH;        // [CO]
+  float* wsm = tmean + CO;                   // [CO][9] weights, [CO] bias: broadcast LDS reads (with one wave per SIMD the 576
+                                             // scalar loads of the weights were the kernel: nothing hides their latency)
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  for (int i = t; i < CO * 10; i += NT) wsm[i] = i < CO * 9 ? w[i] : (bias ? bias[i - CO * 9] : 0.f);
+  const int W4 = W >> 2, hw = H * W, rows4 = H * W4, nq = B * rows4;
+  const int q = blockIdx.x * NT + t;
+  const bool pv = q < nq;
+  const int qq = pv ? q : nq - 1;
+  const int b = qq / rows4, r = qq - b * rows4, oy = r / W4, ox = 4 * (r - oy * W4);
+  float xin[3][6];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int iy = oy + kh - 1;
+    const bool rok = (unsigned)iy < (unsigned)H;
+    const float* row = x + (size_t)b * hw + (size_t)(rok ? iy : 0) * W + ox;
+    const float4 m = *reinterpret_cast<const float4*>(row);
+    const float l = ox > 0 ? row[-1] : 0.f, rr = ox + 4 < W ? row[4] : 0.f;
+    xin[kh][0] = rok ? l : 0.f; xin[kh][1] = rok ? m.x : 0.f; xin[kh][2] = rok ? m.y : 0.f; xin[kh][3] = rok ? m.z : 0.f;
+    xin[kh][4] = rok ? m.w : 0.f; xin[kh][5] = rok ? rr : 0.f;
+  }
+  __syncthreads();
+  auto conv4 = [&](int c, float (&a)[4]) {
+    const float bs = wsm[CO * 9 + c];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = bs;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const float wk = wsm[c * 9 + kh * 3 + kw];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = fmaf(wk, xin[kh][j + kw], a[j]);
+      }
+  };
+  float* op = out + (size_t)b * CO * hw + (size_t)oy * W + ox;
+#pragma unroll 16
+  for (int c = 0; c < CO; ++c) {
+    float a[4];
+    conv4(c, a);
+    if (ep == EP_RAW_STATS) tl[c * C1V_PITCH + wv * 65 + lane] = pv ? (a[0] + a[1]) + (a[2] + a[3]) : 0.f;
+    if (ep == EP_BN_EVAL) {
+      const float sc = bn_g[c] * (1.0f / sqrtf(bn_v[c] + eps)), sh = bn_b[c] - bn_m[c] * sc;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = lrelu(fmaf(a[j], sc, sh), slope);
+    }
+    if (ep == EP_LRELU) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = lrelu(a[j], slope);
+    }
+    if (pv) *reinterpret_cast<float4*>(op + (size_t)c * hw) = float4{a[0], a[1], a[2], a[3]};
+  }
+  if (ep != EP_RAW_STATS) return;
+  // statistics of the workgroup's tile: thread (channel t >> 2, quarter t & 3) adds 64 per-thread sums, the quarters by DPP
+  const int cnt = 4 * min(NT, nq - (int)blockIdx.x * NT);
+  const int cc = t / NWV, part = t % NWV;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll 16
+  for (int i = 0; i < 64; ++i) s += tl[cc * C1V_PITCH + part * 65 + i];
+  if (NWV >= 2) s += dpp_rot<0xB1>(s);
+  if (NWV >= 4) s += dpp_rot<0x4E>(s);
+  if (part == 0) tmean[cc] = s / (float)cnt;
+  __syncthreads();
+#pragma unroll 8
+  for (int c = 0; c < CO; ++c) {
+    float a[4];
+    conv4(c, a);
+    const float mn = tmean[c];
+    float m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float d = a[j] - mn; m2 = fmaf(d, d, m2); }
+    tl[c * C1V_PITCH + wv * 65 + lane] = pv ? m2 : 0.f;
+  }
+  __syncthreads();
+  float m2s = 0.f;
+#pragma unroll 16
+  for (int i = 0; i < 64; ++i) m2s += tl[cc * C1V_PITCH + part * 65 + i];
+  if (NWV >= 2) m2s += dpp_rot<0xB1>(m2s);
+  if (NWV >= 4) m2s += dpp_rot<0x4E>(m2s);
+  if (part == 0) {
+    float* st = stats + ((size_t)blockIdx.x * CO + cc) * 2;
+    st[0] = s;
+    st[1] = m2s;
+  }
+  if (t == 0) counts[blockIdx.x] = (float)cnt;
+}
+
+static bool c1_v4(int W) { return (W & 3) == 0; }
+
 bool conv_c1_ok(int groups, int Cin, int Cout, int KH, int KW, int SH, int SW, int PH, int PW, int H, int in_plain) {
   return groups == 1 && Cin == 1 && Cout == 64 && KH == 3 && KW == 3 && SH == 1 && SW == 1 && PH == 1 && PW == 1 && H > 1 && in_plain;
 }
-int conv_c1_tiles(int B, int H, int W) { return cdiv(B * H * W, 256) * 4; }
+static int c1_nt() {
+  static int nt = 0;
+  if (!nt) { const char* e = getenv("MS_C1_NT"); nt = e ? atoi(e) : 256; if (nt != 64 && nt != 128 && nt != 256) nt = 256; }
+  return nt;
+}
+int conv_c1_tiles(int B, int H, int W) { return c1_v4(W) ? cdiv(B * H * (W >> 2), c1_nt()) : cdiv(B * H * W, 256) * 4; }
 
 int launch_conv_c1(const float* x, const float* w, const float* bias, float* out, const float* bn_g, const float* bn_b,
                    const float* bn_m, const float* bn_v, float* stats, float* counts, int B, int H, int W, int ep, float slope,
@@ -87,6 +200,24 @@ int launch_conv_c1(const float* x, const float* w, const float* bias, float* out
   TimingScope ts(s, 2.0 * npix * 64 * 9, 4.0 * npix * 65, "conv_c1_3x3_kernel<64>|conv_fwd_c1 k3x3 Cout64 N%.0f%s", npix,
                  ep == EP_RAW_STATS ? " +bnstats" : "");
   if (ts.skip()) return 0;
+  if (c1_v4(W) && (((uintptr_t)x | (uintptr_t)out) & 15) == 0) {
+    const int nt = c1_nt(), nq = B * H * (W >> 2);
+#define MS_C1V(NT)                                                                                                                 \
+    do {                                                                                                                           \
+      constexpr int lds = (64 * ((NT / 64) * 65 + 1) + 64 + 640) * 4;                                                                   \
+      static int attr_done = 0;                                                                                                    \
+      if (!attr_done) {                                                                                                            \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c1_3x3_v4_kernel<64, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) \
+          return set_error("conv_c1: cannot raise the dynamic LDS limit");                                                         \
+        attr_done = 1;                                                                                                             \
+      }                                                                                                                            \
+      hipLaunchKernelGGL((conv_c1_3x3_v4_kernel<64, NT>), dim3(cdiv(nq, NT)), dim3(NT), lds, s, x, w, bias, out, bn_g, bn_b, bn_m,   \
+                         bn_v, stats, counts, B, H, W, ep, slope, eps);                                                            \
+    } while (0)
+    if (nt == 64) MS_C1V(64); else if (nt == 128) MS_C1V(128); else MS_C1V(256);
+#undef MS_C1V
+    return check_launch("conv_c1_3x3_v4_kernel");
+  }
   hipLaunchKernelGGL(conv_c1_3x3_kernel<64>, dim3(cdiv(B * H * W, 256)), dim3(256), 0, s, x, w, bias, out, bn_g, bn_b, bn_m, bn_v,
                      stats, counts, B, H, W, ep, slope, eps);
   return check_launch("conv_c1_3x3_kernel");

@@ -443,6 +443,64 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const float* __restri
   }
 }
 
+// The same for rows of HW % 4 == 0 values: NV 16-byte vectors of dy and of y_raw per thread (channels of <= 1024 * NV values).
+template <int NV>
+__global__ __launch_bounds__(256) void bn_bwd_fused4_kernel(const float* __restrict__ dy, const float* __restrict__ y_raw,
+                                                            const float* __restrict__ save, const float* __restrict__ gamma,
+                                                            float* __restrict__ dyr, float* dbias, float* dgamma, float* dbeta,
+                                                            int B, int C, int HW, float slope) {
+  prefetch_kernargs<128>();
+  const int HW4 = HW >> 2, nv = B * HW4;
+  const FastDiv fd(HW4, nv + 256 * NV);
+  __shared__ float red[4];
+  const int c = blockIdx.x, t = threadIdx.x;
+  float4 ry[NV], rg[NV];
+  size_t ofs[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int e = min(t + i * 256, nv - 1);
+    const int b = fd.div(e), p4 = e - b * HW4;
+    ofs[i] = ((size_t)b * C + c) * HW + 4 * p4;
+    ry[i] = *reinterpret_cast<const float4*>(y_raw + ofs[i]);
+    rg[i] = *reinterpret_cast<const float4*>(dy + ofs[i]);
+  }
+  const float mean = save[c], invstd = save[C + c], sc = save[2 * C + c], sh = save[3 * C + c], gm = gamma[c];
+  float dz[NV][4], xh[NV][4];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const bool ok = t + i * 256 < nv;
+    const float a[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w}, g[4] = {rg[i].x, rg[i].y, rg[i].z, rg[i].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float z = fmaf(a[j], sc, sh);
+      dz[i][j] = ok ? g[j] * (z > 0.f ? 1.f : slope) : 0.f;
+      xh[i][j] = ok ? (a[j] - mean) * invstd : 0.f;
+      s1 += dz[i][j];
+      s2 += dz[i][j] * xh[i][j];
+    }
+  }
+  s1 = block_sum_256(s1, red);
+  s2 = block_sum_256(s2, red);
+  const float invN = 1.0f / (float)(B * HW);
+  const float gi = gm * invstd, m1 = s1 * invN, m2 = s2 * invN;
+  float cs = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (t + i * 256 < nv) {
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { o[j] = gi * (dz[i][j] - m1 - xh[i][j] * m2); cs += o[j]; }
+      *reinterpret_cast<float4*>(dyr + ofs[i]) = float4{o[0], o[1], o[2], o[3]};
+    }
+  }
+  cs = block_sum_256(cs, red);
+  if (t == 0) {
+    if (dbias) dbias[c] = cs;
+    if (dgamma) { dgamma[c] = s2; dbeta[c] = s1; }
+  }
+}
+
 // activation backward for blocks without BN: mode 1 (LRELU): dyr = dy * (y>0 ? 1 : slope); mode 0 (BARE): no
 // write (dyr == dy).  Always emits per-channel colsum partials (the bias gradient).
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
@@ -1171,7 +1229,14 @@ int launch_bn_bwd(const float* dy, const float* y_raw, const float* save, const 
   if (n <= 256 * 16) {
     TimingScope ts(s, 0, 12.0 * B * C * HW, "bn_bwd_fused C%d HW%d B%d", C, HW, B);
     if (ts.skip()) return 0;
-    if (n <= 256 * 4)
+    const bool vec4 = (HW & 3) == 0 && (((uintptr_t)dy | (uintptr_t)y_raw | (uintptr_t)dyr) & 15) == 0;
+    if (vec4 && n <= 1024)
+      hipLaunchKernelGGL(bn_bwd_fused4_kernel<1>, dim3(C), dim3(256), 0, s, dy, y_raw, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope);
+    else if (vec4 && n <= 2048)
+      hipLaunchKernelGGL(bn_bwd_fused4_kernel<2>, dim3(C), dim3(256), 0, s, dy, y_raw, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope);
+    else if (vec4)
+      hipLaunchKernelGGL(bn_bwd_fused4_kernel<4>, dim3(C), dim3(256), 0, s, dy, y_raw, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope);
+    else if (n <= 256 * 4)
       hipLaunchKernelGGL(bn_bwd_fused_kernel<4>, dim3(C), dim3(256), 0, s, dy, y_raw, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope);
     else if (n <= 256 * 8)
       hipLaunchKernelGGL(bn_bwd_fused_kernel<8>, dim3(C), dim3(256), 0, s, dy, y_raw, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope);

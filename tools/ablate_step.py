@@ -28,11 +28,11 @@ FAMILIES = {
              ('clip-resident data gradients (1-D blocks and grouped decoder)', 'conv_dgrad_clip;conv_dgrad_gclip'),
              ('conv fwd (all, chain excluded)', 'conv_fwd'), ('conv dgrad (all)', 'conv_dgrad'), ('conv wgrad', 'conv_wgrad'),
              ('split-K epilogues', 'splitk_'), ('wgrad slab reduce', 'reduce_splits;wgrad_reduce'), ('bn fwd', 'bn_finalize;bn_apply'),
-             ('bn bwd', 'bn_bwd;act_bwd'), ('weight prep', 'transpose_weight;split_weights;chain_prep;clip_prep;gdgrad_prep'),
+             ('bn bwd', 'bn_bwd'), ('activation bwd of the blocks without BN', 'act_bwd'), ('weight prep', 'transpose_weight;split_weights;chain_prep;clip_prep;gdgrad_prep'),
              ('losses, mixing, Adam, converters', 'ew_'), ('softmax mixture alone (fwd + bwd)', 'ew_softmax_mix'),
              ('everything labelled', 'conv_;decoder_chain;chain_prep;clip_prep;gdgrad_prep;reduce_splits;wgrad_reduce;bn_;act_bwd;transpose_weight;split_weights;splitk_;ew_')],
     'bf16': [('chained decoder (decoder.0-3 + logits + mixture, one launch)', 'decoder_chain'), ('conv fwd', 'conv_fwd'), ('conv dgrad', 'conv_dgrad'), ('conv wgrad', 'conv_wgrad'),
-             ('wgrad slab reduce', 'reduce_splits;wgrad_reduce'), ('bn fwd', 'bn_finalize;bn_apply'), ('bn bwd', 'bn_bwd;act_bwd'),
+             ('wgrad slab reduce', 'reduce_splits;wgrad_reduce'), ('bn fwd', 'bn_finalize;bn_apply'), ('bn bwd', 'bn_bwd'), ('activation bwd of the blocks without BN', 'act_bwd'),
              ('weight prep', 'prep16;chain_prep'), ('layout converters', 'cb8_'),
              ('losses, mixing, Adam', 'ew_'), ('softmax mixture alone (fwd + bwd)', 'ew_softmax_mix'),
              ('everything labelled', 'conv_;decoder_chain;chain_prep;reduce_splits;wgrad_reduce;bn_;act_bwd;prep16;cb8_;splitk_;ew_')],
