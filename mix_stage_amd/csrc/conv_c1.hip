@@ -98,6 +98,11 @@ __global__ __launch_bounds__(NT) void conv_c1_3x3_v4_kernel(const float* __restr
                                              // scalar loads of the weights were the kernel: nothing hides their latency)
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   for (int i = t; i < CO * 10; i += NT) wsm[i] = i < CO * 9 ? w[i] : (bias ? bias[i - CO * 9] : 0.f);
+  if (ep == EP_BN_EVAL && t < CO) {          // eval-mode scale / shift per channel, once
+    const float sc = bn_g[t] * (1.0f / sqrtf(bn_v[t] + eps));
+    wsm[CO * 10 + t] = sc;
+    wsm[CO * 11 + t] = bn_b[t] - bn_m[t] * sc;
+  }
   const int W4 = W >> 2, hw = H * W, rows4 = H * W4, nq = B * rows4;
   const int q = blockIdx.x * NT + t;
   const bool pv = q < nq;
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(NT) void conv_c1_3x3_v4_kernel(const float* __restr
     conv4(c, a);
     if (ep == EP_RAW_STATS) tl[c * C1V_PITCH + wv * 65 + lane] = pv ? (a[0] + a[1]) + (a[2] + a[3]) : 0.f;
     if (ep == EP_BN_EVAL) {
-      const float sc = bn_g[c] * (1.0f / sqrtf(bn_v[c] + eps)), sh = bn_b[c] - bn_m[c] * sc;
+      const float sc = wsm[CO * 10 + c], sh = wsm[CO * 11 + c];
 #pragma unroll
       for (int j = 0; j < 4; ++j) a[j] = lrelu(fmaf(a[j], sc, sh), slope);
     }
@@ -204,7 +209,7 @@ int launch_conv_c1(const float* x, const float* w, const float* bias, float* out
     const int nt = c1_nt(), nq = B * H * (W >> 2);
 #define MS_C1V(NT)                                                                                                                 \
     do {                                                                                                                           \
-      constexpr int lds = (64 * ((NT / 64) * 65 + 1) + 64 + 640) * 4;                                                                   \
+      constexpr int lds = (64 * ((NT / 64) * 65 + 1) + 64 + 768) * 4;                                                                   \
       static int attr_done = 0;                                                                                                    \
       if (!attr_done) {                                                                                                            \
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c1_3x3_v4_kernel<64, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) \

@@ -313,18 +313,37 @@ void conv_patch_kernel(const PatchArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) bias_r[r] = 0.f;
   }
+  // eval-mode BatchNorm: the rows' (gamma, beta, mean, var) eight rows per round trip -- fetched next to their use they were 16
+  // dependent rounds of four loads at the end of every eval-mode launch (the D-step's generator pass: +13..16 us per 2-D layer)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
+  for (int rh = 0; rh < 16; rh += 8) {
+  float sc_r[8], sh_r[8];
+  if (ep == EP_BN_EVAL) {
+    float gq[8], bq[8], mq[8], vq[8];
+#pragma unroll
+    for (int r8 = 0; r8 < 8; ++r8) {
+      const int r = rh + r8;
+      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      const int chn = g * p.Mg + (m < p.Mg ? m : 0);
+      gq[r8] = p.bn_g[chn]; bq[r8] = p.bn_b[chn]; mq[r8] = p.bn_m[chn]; vq[r8] = p.bn_v[chn];
+    }
+#pragma unroll
+    for (int r8 = 0; r8 < 8; ++r8) {
+      const float inv = 1.0f / sqrtf(vq[r8] + p.eps);
+      sc_r[r8] = gq[r8] * inv;
+      sh_r[r8] = bq[r8] - mq[r8] * sc_r[r8];
+    }
+  } else {
+#pragma unroll
+    for (int r8 = 0; r8 < 8; ++r8) { sc_r[r8] = 1.f; sh_r[r8] = 0.f; }
+  }
+#pragma unroll
+  for (int r = rh; r < rh + 8; ++r) {
     const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
     const bool mval = m < p.Mg;
     const int chn = g * p.Mg + (mval ? m : 0);
     const float bsv = bias_r[r];
-    float sc = 1.f, sh = 0.f;
-    if (ep == EP_BN_EVAL) {
-      const float inv = 1.0f / sqrtf(p.bn_v[chn] + p.eps);
-      sc = p.bn_g[chn] * inv;
-      sh = p.bn_b[chn] - p.bn_m[chn] * sc;
-    }
+    const float sc = sc_r[r - rh], sh = sh_r[r - rh];
     float v = acc[r] + bsv;
     if (ep == EP_RAW_STATS) acc[r] = v;
     if (ep == EP_BN_EVAL) v = lrelu(fmaf(v, sc, sh), p.slope);
@@ -340,6 +359,7 @@ void conv_patch_kernel(const PatchArgs p) {
     } else if (mval && cval) {
       p.out[(size_t)ooff + (size_t)chn * p.o_chan] = v;
     }
+  }
   }
 
   if (ep == EP_RAW_STATS) {
