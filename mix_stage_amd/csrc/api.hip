@@ -379,7 +379,7 @@ int ms_dgrad_weights_prepare(int n, const ms_conv_desc* descs, const float* cons
     if (!dw.need) continue;
     if (!wt[i]) return set_error("ms_dgrad_weights_prepare: block %d needs a buffer of ms_dgrad_weights_elems floats", i);
     if (dw.need == 2) {
-      rc = clip32_prep_queue(w[i], wt[i], d->Cin, d->Cout, 3, 1, d->Cin, (hipStream_t)stream);
+      rc = clip32_prep_queue(w[i], wt[i], d->Cin, d->Cout, d->KW, d->KW == 4 ? 2 : 1, d->Cin, (hipStream_t)stream);
       if (rc) return rc;
       continue;
     }
@@ -400,7 +400,7 @@ int ms_dgrad_weights_prepare(int n, const ms_conv_desc* descs, const float* cons
     const int rc = launch_transpose_weight_multi(tb, (hipStream_t)stream);
     if (rc) return rc;
   }
-  { const int rcq = clip32_prep_flush((hipStream_t)stream); if (rcq) return rcq; }
+  { int rcq = clip32_prep_flush((hipStream_t)stream); if (!rcq) rcq = gdgrad32_prep_flush((hipStream_t)stream); if (rcq) return rcq; }
   // bf16x6 mode: the planes of the fp32 copies just built, behind them
   SplitBatch sb;
   sb.n = 0;
@@ -533,7 +533,7 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
     // k3 s1 blocks whose reduction fits a workgroup: one launch of the clip-resident kernel (clip32.hip), no split-K slab
     const float* wp = wt_prepared;
     if (!wp) {
-      rc = clip32_prep_queue(w, wt, d->Cin, d->Cout, 3, 1, d->Cin, s);
+      rc = clip32_prep_queue(w, wt, d->Cin, d->Cout, d->KW, d->KW == 4 ? 2 : 1, d->Cin, s);
       if (!rc) rc = clip32_prep_flush(s);
       if (rc) return rc;
       wp = wt;
@@ -548,6 +548,7 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
     const float* wp = wt_prepared;
     if (!wp) {
       rc = gdgrad32_prepare(d, w, wt, s);
+      if (!rc) rc = gdgrad32_prep_flush(s);
       if (rc) return rc;
       wp = wt;
     }

@@ -624,8 +624,12 @@ __global__ __launch_bounds__(256, 1) void gconv32_kernel(const Gconv32Args p) {
 // transposed stream: rows = input channels ci of the group, reduction over (co, tap) with the taps reversed:
 // A(ci, (co, tap)) = w[g*256 + co][ci][2 - tap].  One workgroup per (group, wave, row block, half of the co range): per co the 32
 // rows x 3 taps are 96 contiguous floats of the weight tensor.
-__global__ __launch_bounds__(256) void gconv32_prep_kernel(const float* w, float* out, int M) {
+enum { GD_PREP_MAX = 8 };
+struct GdPrepBatch { int n; const float* w[GD_PREP_MAX]; float* out[GD_PREP_MAX]; };
+__global__ __launch_bounds__(256) void gconv32_prep_kernel(const GdPrepBatch pb, int M) {
   __shared__ float lds[128 * 97];
+  const float* w = pb.w[blockIdx.y];
+  float* out = pb.out[blockIdx.y];
   const int t = threadIdx.x;
   int id = blockIdx.x;
   const int kh = id & 1; id >>= 1;
@@ -654,11 +658,26 @@ bool gdgrad32_ok(const ms_conv_desc* d) {
          d->Cin == CH_C && d->Cout == CH_C && d->in_mode == MS_IN_PLAIN;
 }
 size_t gdgrad32_weight_floats(const ms_conv_desc* d) { return gdgrad32_ok(d) ? (size_t)d->groups * 4 * GD_WAVE_STREAM : 0; }
-int gdgrad32_prepare(const ms_conv_desc* d, const float* w, float* out, hipStream_t s) {
-  TimingScope ts(s, 0, 0, "gconv32_prep_kernel|gdgrad_prep g%d", d->groups);
+// queued: the blocks of one ms_dgrad_weights_prepare call (equal group counts) share a launch
+static GdPrepBatch g_gd_prep;
+static int g_gd_prep_groups = 0;
+int gdgrad32_prep_flush(hipStream_t s) {
+  if (!g_gd_prep.n) return 0;
+  const GdPrepBatch pb = g_gd_prep;
+  const int groups = g_gd_prep_groups;
+  g_gd_prep.n = 0;
+  TimingScope ts(s, 0, 0, "gconv32_prep_kernel|gdgrad_prep g%d jobs%d", groups, pb.n);
   if (ts.skip()) return 0;
-  hipLaunchKernelGGL(gconv32_prep_kernel, dim3(d->groups * 4 * 2 * 2), dim3(256), 0, s, w, out, d->groups);
+  hipLaunchKernelGGL(gconv32_prep_kernel, dim3(groups * 4 * 2 * 2, pb.n), dim3(256), 0, s, pb, groups);
   return check_launch("gconv32_prep_kernel");
+}
+int gdgrad32_prepare(const ms_conv_desc* d, const float* w, float* out, hipStream_t s) {
+  if (g_gd_prep.n && (g_gd_prep.n == GD_PREP_MAX || g_gd_prep_groups != d->groups)) { const int rc = gdgrad32_prep_flush(s); if (rc) return rc; }
+  g_gd_prep_groups = d->groups;
+  g_gd_prep.w[g_gd_prep.n] = w;
+  g_gd_prep.out[g_gd_prep.n] = out;
+  ++g_gd_prep.n;
+  return 0;
 }
 int gdgrad32_launch(const ms_conv_desc* d, const float* g, const float* wp, float* dx, hipStream_t s) {
   static int attr_done = 0;

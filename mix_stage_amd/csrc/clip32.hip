@@ -76,7 +76,10 @@ __device__ __forceinline__ float cl_sum8(float v) {
 // issued a unit ahead, no wait sits in front of an MFMA but the one for its own operands) and, where a clip's frames come in
 // fours, every wave stages exactly the planes its own K slice reads (16-byte loads, all in flight at once, no workgroup barrier
 // between staging and the K loop).  K8W = 0: any geometry (run-time trip counts, scalar staging).
-template <int KW, int S, int NB, bool UP2, int K8W>
+// DG2: data gradient of a k4 s2 p1 block (KW = 4, S = 1, NB = 2): the image holds the Ti = To / 2 frames of dy_raw per clip, output
+// frame 2m is taps (1, 3) at frames (m, m - 1), frame 2m + 1 taps (0, 2) at (m + 1, m): one accumulator per parity, every unit
+// (channel group, tap) feeds the one its tap belongs to -- no zero-stuffed operand, half the matrix work of a k4 s1 conv.
+template <int KW, int S, int NB, bool UP2, int K8W, bool DG2 = false>
 __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
   prefetch_kernargs<sizeof(Clip32Args)>();
   extern __shared__ float cl_smem[];
@@ -107,8 +110,9 @@ __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
   if (own_planes) {
     // wave w stages planes [2*K8W*w, 2*K8W*(w+1)): item = (plane, quad of frames): four 16-byte loads (the plane's four
     // channels) -> four 16-byte LDS stores (the quad's four slots); ceil(K8W / 2) items per lane, every load issued first
-    constexpr int NI = K8W ? (K8W + 1) / 2 : 1;
-    constexpr int NITEMS = 2 * K8W * 16;
+    constexpr int NQ = DG2 ? 8 : 16;                 // quads of input frames per plane (64 frames; DG2: 32)
+    constexpr int NITEMS = 2 * K8W * NQ;
+    constexpr int NI = K8W ? (NITEMS + 63) / 64 : 1;
     const int plw0 = 2 * K8W * w;
     for (int e = lane; e < ncl * 2 * 2 * K8W; e += 64) {         // halos of this wave's planes
       const int pl = plw0 + e / (ncl * 2), r2 = e % (ncl * 2), cl = r2 >> 1, sl = (r2 & 1) ? Ti + 1 : 0;
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
 #pragma unroll
     for (int q = 0; q < NI; ++q) {
       const int it = min(lane + 64 * q, NITEMS - 1);
-      const int pl = plw0 + (it >> 4), pos = 4 * (it & 15);
+      const int pl = plw0 + it / NQ, pos = 4 * (it % NQ);
       const int cl = pos / Ti, ti = pos - cl * Ti;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
     for (int q = 0; q < NI; ++q) {
       const int it = lane + 64 * q;
       if (it < NITEMS) {
-        const int pl = plw0 + (it >> 4), pos = 4 * (it & 15);
+        const int pl = plw0 + it / NQ, pos = 4 * (it % NQ);
         const int cl = pos / Ti, ti = pos - cl * Ti;
         float o[4][4];                                 // [frame][channel]
 #pragma unroll
@@ -220,12 +224,34 @@ __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
   int bbase[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
-    const int n = 32 * nb + n0, cl = n / To, tt = n - cl * To;
-    bbase[nb] = cl * row + tt * S;
+    if (DG2) {                                       // lane n0 = input frame m of the workgroup's 32: both parities read around it
+      const int cl = n0 / Ti, tt = n0 - cl * Ti;
+      bbase[nb] = cl * row + tt;
+    } else {
+      const int n = 32 * nb + n0, cl = n / To, tt = n - cl * To;
+      bbase[nb] = cl * row + tt * S;
+    }
   }
   {
     const float* img = cl_smem + ((size_t)(w * k8w) * 2 + h) * pslots * 4;
-    if constexpr (K8W > 0) {
+    if constexpr (K8W > 0 && DG2) {
+      constexpr int NU = K8W * 4;                    // units (channel group, tap k): slot offset (4 - k) >> 1, parity (k + 1) & 1
+      float4 bf[2];
+      bf[0] = *reinterpret_cast<const float4*>(img + ((size_t)bbase[0] + 2) * 4);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        if (u + 1 < NU) {
+          const int i1 = (u + 1) / 4, k1 = (u + 1) % 4;
+          bf[(u + 1) & 1] = *reinterpret_cast<const float4*>(img + ((size_t)i1 * 2 * pslots + bbase[0] + ((4 - k1) >> 1)) * 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int par = ((u % 4) + 1) & 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[par] = __builtin_amdgcn_mfma_f32_32x32x2f32(cl_f4e(wr[u], j), cl_f4e(bf[u & 1], j), acc[par], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if constexpr (K8W > 0) {
       constexpr int NU = K8W * KW;                   // units (channel group, tap)
       float4 bf[2][NB];
 #pragma unroll
@@ -252,6 +278,13 @@ __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
         if (i < k8w) {
 #pragma unroll
           for (int tap = 0; tap < KW; ++tap) {
+            if constexpr (DG2) {
+              const float4 b1 = *reinterpret_cast<const float4*>(img + ((size_t)i * 2 * pslots + bbase[0] + ((4 - tap) >> 1)) * 4);
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                acc[(tap + 1) & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cl_f4e(wr[i * KW + tap], j), cl_f4e(b1, j), acc[(tap + 1) & 1], 0, 0, 0);
+              continue;
+            }
             float4 bf[NB];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) bf[nb] = *reinterpret_cast<const float4*>(img + ((size_t)i * 2 * pslots + bbase[nb] + tap) * 4);
@@ -275,7 +308,7 @@ __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) red[(w * 32 + 8 * (q >> 2) + 4 * h + (q & 3)) * RP + 32 * nb + n0] = acc[nb][q];
+    for (int q = 0; q < 16; ++q) red[(w * 32 + 8 * (q >> 2) + 4 * h + (q & 3)) * RP + (DG2 ? 2 * n0 + nb : 32 * nb + n0)] = acc[nb][q];
   __syncthreads();
 
   // ---- thread (channel, slice of NPX / 8 frames): sum of the waves in wave order + bias
@@ -471,7 +504,7 @@ __global__ __launch_bounds__(256) void clip32_prep_kernel(const ClipPrepBatch pb
     for (int q = 0; q < 4; ++q) {
       const int cl = 8 * k8l + 4 * h + q;
       float val = 0.f;
-      if (rr < nr && cl < nc) val = jb.transposed ? lds[cl * pitch + rr * KW + (KW - 1 - tap)] : lds[rr * pitch + cl * KW + tap];
+      if (rr < nr && cl < nc) val = jb.transposed ? lds[cl * pitch + rr * KW + (jb.transposed == 1 ? KW - 1 - tap : tap)] : lds[rr * pitch + cl * KW + tap];
       vv[q] = val;
     }
     dst[(size_t)u * 64 + lane] = float4{vv[0], vv[1], vv[2], vv[3]};
@@ -504,16 +537,19 @@ bool clip32_fwd_ok(const ms_conv_desc* d) {
 }
 
 // data gradient of a k3 s1 p1 block as a k3 s1 conv of dy_raw with the transposed, tap-reversed weights
+// ... and of a k4 s2 p1 block as two 2-tap convs, one per output parity, in the same launch (DG2)
 bool clip32_dgrad_ok(const ms_conv_desc* d) {
   if ((d->dtype & 0xff) != 0) return false;
-  if (!(d->H == 1 && d->KH == 1 && d->PW == 1 && d->KW == 3 && d->SW == 1 && d->in_mode != MS_IN_BCAST)) return false;
+  if (!(d->H == 1 && d->KH == 1 && d->PW == 1 && d->in_mode != MS_IN_BCAST)) return false;
+  if (d->KW == 4 && d->SW == 2) return d->in_mode == 0 && 2 * d->OW == d->W && d->W >= 4 && clip_geom_ok(d->B, d->Cin, d->Cout, d->W, 4, 2, d->groups, 2);
+  if (!(d->KW == 3 && d->SW == 1)) return false;
   return clip_geom_ok(d->B, d->Cin, d->Cout, d->W, 3, 1, d->groups, 2);
 }
 
 size_t clip32_weight_floats(int rows, int red, int KW) { return (size_t)cdiv(rows, 32) * 4 * clip_k8w(red) * KW * 256; }
 
 size_t clip32_fwd_weight_bytes(const ms_conv_desc* d) { return clip32_fwd_ok(d) ? clip32_weight_floats(d->Cout, d->Cin, d->KW) * 4 : 0; }
-size_t clip32_dgrad_weight_floats(const ms_conv_desc* d) { return clip32_dgrad_ok(d) ? clip32_weight_floats(d->Cin, d->Cout, 3) : 0; }
+size_t clip32_dgrad_weight_floats(const ms_conv_desc* d) { return clip32_dgrad_ok(d) ? clip32_weight_floats(d->Cin, d->Cout, d->KW) : 0; }
 
 static ClipPrepBatch g_prep;
 static int g_prep_blocks = 0;
@@ -539,9 +575,9 @@ int clip32_prep_flush(hipStream_t s) {
 size_t clip32_part_bytes(int rows, int npw) { return align_up((size_t)cdiv(rows, 32) * npw * 32 * 2 * sizeof(float), 256); }
 int clip32_sync_words(int rows) { return 32 * (cdiv(rows, 32) + 1); }
 
-template <int KW, int S, int NB, bool UP2, int K8W>
+template <int KW, int S, int NB, bool UP2, int K8W, bool DG2 = false>
 static int clip32_launch_k(const Clip32Args& a, int nwg, int lds_bytes, hipStream_t s) {
-  auto fn = clip32_kernel<KW, S, NB, UP2, K8W>;
+  auto fn = clip32_kernel<KW, S, NB, UP2, K8W, DG2>;
   static int attr_done = 0;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -552,20 +588,20 @@ static int clip32_launch_k(const Clip32Args& a, int nwg, int lds_bytes, hipStrea
   return check_launch("clip32_kernel");
 }
 // the channel-group counts of the path's layers (64, 104 / 128, 256, 266 channels in) have instances of their own
-template <int KW, int S, int NB, bool UP2>
+template <int KW, int S, int NB, bool UP2, bool DG2 = false>
 static int clip32_launch_t(const Clip32Args& a, int nwg, int lds_bytes, hipStream_t s) {
   switch (a.k8w) {
-    case 2: return clip32_launch_k<KW, S, NB, UP2, 2>(a, nwg, lds_bytes, s);
-    case 4: return clip32_launch_k<KW, S, NB, UP2, 4>(a, nwg, lds_bytes, s);
-    case 8: return clip32_launch_k<KW, S, NB, UP2, 8>(a, nwg, lds_bytes, s);
-    case 9: return clip32_launch_k<KW, S, NB, UP2, 9>(a, nwg, lds_bytes, s);
-    default: return clip32_launch_k<KW, S, NB, UP2, 0>(a, nwg, lds_bytes, s);
+    case 2: return clip32_launch_k<KW, S, NB, UP2, 2, DG2>(a, nwg, lds_bytes, s);
+    case 4: return clip32_launch_k<KW, S, NB, UP2, 4, DG2>(a, nwg, lds_bytes, s);
+    case 8: return clip32_launch_k<KW, S, NB, UP2, 8, DG2>(a, nwg, lds_bytes, s);
+    case 9: return clip32_launch_k<KW, S, NB, UP2, 9, DG2>(a, nwg, lds_bytes, s);
+    default: return clip32_launch_k<KW, S, NB, UP2, 0, DG2>(a, nwg, lds_bytes, s);
   }
 }
 
 // ep: EP_BARE / EP_LRELU / EP_BN_EVAL / EP_RAW_STATS (= BN_TRAIN, everything in this launch) / EP_DGRAD_UP2
-int clip32_launch(Clip32Args a, int KW, int S, bool up2, const char* what, hipStream_t s) {
-  const int nb = S == 2 ? 1 : 2, npx = 32 * nb;
+int clip32_launch(Clip32Args a, int KW, int S, bool up2, const char* what, hipStream_t s, bool dg2 = false) {
+  const int nb = (S == 2 && !dg2) ? 1 : 2, npx = 32 * nb;
   a.k8w = clip_k8w(a.Cin);
   a.npw = a.B * a.To / npx;
   const int nct = cdiv(a.Cout, 32);
@@ -581,7 +617,7 @@ int clip32_launch(Clip32Args a, int KW, int S, bool up2, const char* what, hipSt
   // (one workgroup per CU is what every instance of the kernel is sure to get: LDS would allow two of the smaller images, the
   // register file of the upsample-add instance does not)
   if (a.ep == EP_RAW_STATS && a.npw > 1 && nwg > cus) return -2;      // caller falls back to the per-layer kernels
-  const double flops = 2.0 * a.rows_valid * a.Cin * KW * (double)a.B * a.To;
+  const double flops = 2.0 * a.rows_valid * a.Cin * (dg2 ? 2 : KW) * (double)a.B * a.To;
   const double bytes = 4.0 * ((double)a.rows_valid * a.Cin * KW + (double)a.B * a.Cin * a.Ti + (double)a.B * a.rows_valid * a.To);
   TimingScope ts(s, flops, bytes, "clip32_kernel<%d,%d,%d,%d>|conv_%s_clip k1x%d s%d rows%d red%d T%d B%d ep%d", KW, S, nb, up2 ? 1 : 0, what, KW,
                  S, a.rows_valid, a.Cin, a.To, a.B, a.ep);
@@ -595,7 +631,8 @@ int clip32_launch(Clip32Args a, int KW, int S, bool up2, const char* what, hipSt
     a.stamps = nwg <= 4096 ? g_stamps : nullptr;
   }
   int rc;
-  if (KW == 3 && S == 1) rc = up2 ? clip32_launch_t<3, 1, 2, true>(a, nwg, lds, s) : clip32_launch_t<3, 1, 2, false>(a, nwg, lds, s);
+  if (dg2) rc = clip32_launch_t<4, 1, 2, false, true>(a, nwg, lds, s);
+  else if (KW == 3 && S == 1) rc = up2 ? clip32_launch_t<3, 1, 2, true>(a, nwg, lds, s) : clip32_launch_t<3, 1, 2, false>(a, nwg, lds, s);
   else rc = clip32_launch_t<4, 2, 1, false>(a, nwg, lds, s);
   if (a.stamps) {
     std::vector<unsigned long long> h((size_t)nwg * 8);
@@ -636,6 +673,10 @@ int clip32_block_dgrad(const ms_conv_desc* d, const float* g, const float* wp, f
   a.y = dx; a.y2 = dx2;
   a.B = d->B; a.Cin = d->Cout; a.Cout = d->Cin; a.rows_valid = d->Cin; a.To = d->W; a.Ti = d->W;
   a.ep = up2 ? EP_DGRAD_UP2 : EP_BARE;
+  if (d->KW == 4) {                                  // k4 s2 block: the image is dy_raw at half the output's resolution
+    a.Ti = d->OW;
+    return clip32_launch(a, 4, 2, false, "dgrad", s, true);
+  }
   return clip32_launch(a, 3, 1, false, "dgrad", s);
 }
 

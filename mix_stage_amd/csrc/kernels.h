@@ -167,7 +167,8 @@ int clip32_block_dgrad(const ms_conv_desc* d, const float* g, const float* wp, f
 // data gradient of the grouped decoder blocks (chain32.hip: gconv32_kernel)
 bool gdgrad32_ok(const ms_conv_desc* d);
 size_t gdgrad32_weight_floats(const ms_conv_desc* d);
-int gdgrad32_prepare(const ms_conv_desc* d, const float* w, float* out, hipStream_t s);
+int gdgrad32_prepare(const ms_conv_desc* d, const float* w, float* out, hipStream_t s);      // queued ...
+int gdgrad32_prep_flush(hipStream_t s);                                                       // ... until this
 int gdgrad32_launch(const ms_conv_desc* d, const float* g, const float* wp, float* dx, hipStream_t s);
 
 // ---- chained pose decoder (chain32.hip: fp32; chain16.hip: bf16 / fp16), behind ms_decoder_chain_*
