@@ -531,7 +531,6 @@ bool clip32_fwd_ok(const ms_conv_desc* d) {
   if (!(d->H == 1 && d->KH == 1 && d->PW == 1 && d->in_mode != MS_IN_BCAST)) return false;
   const int nb = d->SW == 2 ? 1 : 2;
   if (d->in_mode == MS_IN_UP2ADD && !(d->KW == 3 && d->SW == 1)) return false;
-  if (d->Cout % 32) return false;
   if (d->OW * d->SW != d->W) return false;
   return clip_geom_ok(d->B, d->Cout, d->Cin, d->OW, d->KW, d->SW, d->groups, nb);
 }
@@ -541,7 +540,7 @@ bool clip32_fwd_ok(const ms_conv_desc* d) {
 bool clip32_dgrad_ok(const ms_conv_desc* d) {
   if ((d->dtype & 0xff) != 0) return false;
   if (!(d->H == 1 && d->KH == 1 && d->PW == 1 && d->in_mode != MS_IN_BCAST)) return false;
-  if (d->KW == 4 && d->SW == 2) return d->in_mode == 0 && 2 * d->OW == d->W && d->W >= 4 && clip_geom_ok(d->B, d->Cin, d->Cout, d->W, 4, 2, d->groups, 2);
+  if (d->KW == 4 && d->SW == 2) return d->in_mode == 0 && 2 * d->OW == d->W && clip_geom_ok(d->B, d->Cin, d->Cout, d->W, 4, 2, d->groups, 2);
   if (!(d->KW == 3 && d->SW == 1)) return false;
   return clip_geom_ok(d->B, d->Cin, d->Cout, d->W, 3, 1, d->groups, 2);
 }
