@@ -233,7 +233,7 @@ def test_an_expired_meeting_is_reported_and_poisons_the_output():
   bad = _run(blocks, logits, x, score, P, True, grad=False)
   assert not torch.isfinite(bad['out']).all()
   assert ops16.bn_sync_error()
-  assert any(w[0] == 1 for w in ops16.bn_sync_words())          # code 1 = block 0's meeting
+  assert any(w[0] != 0 for w in ops16.bn_sync_words())          # which meeting gave up (the peers that wait for the late workgroup at block 1 may expire too and overwrite block 0's code)
   with pytest.raises(RuntimeError, match='meeting timed out'):
     MixStageTrainStep.check_health(None)
   assert not ops16.bn_sync_error()                               # cleared (all words: the counters start again from zero)
