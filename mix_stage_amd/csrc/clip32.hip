@@ -520,7 +520,7 @@ static int clip_k8w(int red) { return (cdiv(red, 8) + 3) / 4; }
 static bool clip_geom_ok(int B, int rows, int red, int To, int KW, int S, int groups, int nb) {
   if (!g_clip32 || groups != 1) return false;
   if (!((KW == 3 && S == 1) || (KW == 4 && S == 2))) return false;
-  if (To < 2 || To > 32 * nb || (To & (To - 1))) return false;
+  if (To < 1 || To > 32 * nb || (To & (To - 1))) return false;
   if ((B * To) % (32 * nb)) return false;
   if (red > 8 * 4 * CL_MAXK8W || rows < 1) return false;
   return true;

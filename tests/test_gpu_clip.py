@@ -29,6 +29,10 @@ CASES = [
     ('s2_t4', '1d', 256, 256, 4, 2, 1, (4,), 'plain'),
     ('s2_64_128', '1d', 64, 128, 4, 2, 1, (32,), 'plain'),
     ('s2_128_256', '1d', 128, 256, 4, 2, 1, (8,), 'plain'),
+    ('s2_t2', '1d', 256, 256, 4, 2, 1, (2,), 'plain'),             # PoseStyleEncoder's last steps: one output frame per clip
+    ('s2_256_8_t2', '1d', 256, 8, 4, 2, 1, (2,), 'plain'),         # ... its 8-way style head (rows of the channel tile masked)
+    ('s2_104_64', '1d', 104, 64, 4, 2, 1, (64,), 'plain'),         # D.conv1's geometry (104 pose features in)
+    ('k3_256_40', '1d', 256, 40, None, None, 1, (64,), 'plain'),   # output channels that do not fill the second channel tile
 ]
 
 
@@ -49,8 +53,10 @@ def test_clip_block_train_fwd_bwd_vs_oracle(case):
   labels = _labels(lambda: _conv_block_case(case, B, 7))
   assert any('conv_fwd_clip' in l for l in labels), labels
   assert not any('bn_finalize' in l or 'splitk_fwd_epilogue' in l for l in labels), labels
-  if case[4] is None:                                    # k3 s1: the data gradient runs on the clip kernel as well
-    assert any('conv_dgrad_clip' in l for l in labels), labels
+  # the data gradient runs on the clip kernel as well: k3 s1 by the transposed, tap-reversed stream; k4 s2 as one 2-tap conv per
+  # output parity
+  assert any('conv_dgrad_clip' in l for l in labels), labels
+  assert not any('splitk_dgrad_epilogue' in l for l in labels), labels
   for attempt in range(4):
     if _conv_block_case(case, B, zlib.crc32(case[0].encode()) % 1000 + attempt):
       return
