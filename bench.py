@@ -350,8 +350,8 @@ def chain_roofline(chain, rows, precision):
     roof['weight_stream_prep_us'] = round(prep[0]['total_ms'] / prep[0]['count'] * 1e3, 2)
   try:
     pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r04_pmc_decoder.json')))
-    ent = pmc.get(precision)
-    if ent and ent.get('src_hash') == source_hash() and M == 8 and B_PER_GPU * T == 2048:
+    ent = pmc.get(precision if M == 8 else '%s_m%d' % (precision, M))      # (the passes cover the headline and configs[1]: M = 8 / 4)
+    if ent and ent.get('src_hash') == source_hash() and B_PER_GPU * T == 2048:
       roof['traffic'] = ent['hbm_bytes_per_launch']
       roof['traffic_over_algorithmic'] = round(ent['hbm_bytes_per_launch'] / roof['algorithmic_bytes_per_launch'], 3)
       roof['traffic_note'] = 'HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, profiles/r04_pmc_decoder.json (same sources: %s)' % ent['src_hash']

@@ -105,7 +105,12 @@ typedef struct ms_fwd_options {
   /* 16-bit BN_TRAIN blocks: zero-initialised int32 words through which the workgroups of the launch meet for the batch statistics
    * (BatchNorm inside the conv launch).  Give every (device, stream) that runs such blocks concurrently a buffer of its own;
    * NULL = the process-wide buffer of ms_set_bn_sync_buffer.  Word 0 is raised when a workgroup gave up waiting (the block's
-   * output is then NaN, the running statistics are left alone). */
+   * output is then NaN, the running statistics are left alone).
+   * fp32 1-D BN_TRAIN blocks (MS_F32): the same words for the clip-resident one-launch form -- owned by ONE (device, stream, block
+   * shape): the counters are monotonic and launches of different shapes must not share them.  Blocks of at most 4096 values per
+   * channel that ran in this form have y_raw written only for the channels whose BatchNorm + LeakyReLU map does not invert safely
+   * from y (tiny gamma, beta dominating gamma, ReLU): ms_conv_block_bwd must then be handed y (it reads y_raw for exactly those
+   * channels; handing y is always allowed). */
   int32_t* bn_sync;
   int32_t bn_sync_words;
 } ms_fwd_options;
@@ -293,7 +298,7 @@ typedef struct ms_chain_desc {
   int32_t mode;             /* MS_BN_TRAIN | MS_BN_EVAL */
   int32_t dtype;            /* ms_dtype */
   int32_t sync_first_word;  /* first word of `sync` this launch may use (>= 32: word 0 is the error flag) */
-  int32_t keep_all_raw;     /* 16-bit modes, BN_TRAIN: y_raw for every channel block (0: only where ms_conv_block_bwd will read it --
+  int32_t keep_all_raw;     /* BN_TRAIN: y_raw for every channel / channel block (0: only where ms_conv_block_bwd, handed y, will read it --
                              * blocks whose BatchNorm + LeakyReLU map does not invert safely from y, see ms_set_bn_sync_buffer) */
   float slope, eps, momentum;
 } ms_chain_desc;

@@ -507,7 +507,7 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
   const float* g = dy;
   int bias_done = 0;
   if (d->mode == MS_BN_TRAIN) {
-    rc = launch_bn_bwd(dy, y_raw, save, gamma, bn_part, dyr, colpart, dbias, dgamma, dbeta, d->B, C, hw, d->slope, &bias_done, s);
+    rc = launch_bn_bwd(dy, y_raw, y, save, gamma, bn_part, dyr, colpart, dbias, dgamma, dbeta, d->B, C, hw, d->slope, &bias_done, s);
     g = dyr;
   } else if (d->mode == MS_LRELU) {
     rc = launch_act_bwd(dy, y, dyr, colpart, d->B, C, hw, 1, d->slope, s);

@@ -23,6 +23,7 @@
 #include <algorithm>
 
 #include "kernels.h"
+#include "conv16.h"
 
 namespace ms {
 
@@ -49,7 +50,7 @@ constexpr size_t CH_WAVE_STREAM = (size_t)CH_CONV_BLOCKS * CH_BLK * 2 * 256 + (s
 constexpr int CH_SPIN_LIMIT = 1 << 21;
 constexpr int CH_PPAD = 128;              // rows of the logits tile (P <= 128)
 constexpr int CH_MAXM = 32;               // groups (the softmax of a frame is formed in registers)
-constexpr int CH_LDS_FLOATS = CH_BUF0 + CH_BUF1 + 3 * CH_NL * 256 + 2 * 256 + 64 + 8;
+constexpr int CH_LDS_FLOATS = CH_BUF0 + CH_BUF1 + 3 * CH_NL * 256 + 2 * 256 + 64 + 8 + 2 * 256;
 
 struct Chain32Args {
   const float* x;             // (B, cin0, 64)
@@ -72,6 +73,7 @@ struct Chain32Args {
   int* sync;                  // word 0: error flag
   int cnt_base;               // first counter word: [NL][M] layer meetings, then [B] clip meetings (each on a line of its own: stride 32)
   int B, M, P, cin0, train;
+  int raw_all;                // train: y_raw for every channel (0: only where the backward pass cannot take x_hat from y: bn_inv_unsafe)
   float slope, eps, momentum;
 };
 
@@ -111,6 +113,8 @@ __global__ __launch_bounds__(256, 1) void chain32_kernel(const Chain32Args p) {
   float* psh = psc + 256;                   // [256] shift
   float* sg = psh + 256;                    // [64] this group's softmax weight per frame
   int* lflag = reinterpret_cast<int*>(sg + 64);   // [0]: a meeting expired
+  float* pmn = sg + 64 + 8;                 // [256] batch mean of the current block (train) ...
+  float* pin = pmn + 256;                   // [256] ... and 1 / std: what the y_raw test reads
 
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, r = lane & 31, h = lane >> 5;
   const int g = blockIdx.x % p.M, b = blockIdx.x / p.M;
@@ -321,6 +325,11 @@ __global__ __launch_bounds__(256, 1) void chain32_kernel(const Chain32Args p) {
         nt_store4(dst + 3 * CH_T + 16 * k, v[4 * k].w, v[4 * k + 1].w, v[4 * k + 2].w, v[4 * k + 3].w);
       }
     };
+    auto store_row = [&](float* dst_base, int j) {           // one channel (4*pl + j) of the plane
+      float* dst = dst_base + gbase + (size_t)(4 * pl + j) * CH_T + 4 * pq;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) nt_store4(dst + 16 * k, f4e(v[4 * k], j), f4e(v[4 * k + 1], j), f4e(v[4 * k + 2], j), f4e(v[4 * k + 3], j));
+    };
     if (p.train) {
       // statistics of this clip: two passes over registers (mean, then M2 about it), the 4 lanes of a plane combined by DPP
       {
@@ -354,10 +363,13 @@ __global__ __launch_bounds__(256, 1) void chain32_kernel(const Chain32Args p) {
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave: its partials have left
       __syncthreads();
-      if (yr && t != 0) store_rows(yr);                      // conv + bias for the backward pass: drains while the group meets
+      // conv + bias for the backward pass.  Layers whose backward is the one-launch form read the block's OUTPUT instead wherever
+      // the BatchNorm + LeakyReLU map inverts safely (elementwise.hip: bn_bwd_fused*): only the other channels' rows are kept
+      // (below, once the statistics are known).  Larger batches keep every row: stored now, draining while the group meets.
+      if (yr && p.raw_all && t != 0) store_rows(yr);
       if (t == 0) {
         if (!chain_meet(p.sync + p.cnt_base + 32 * (l * p.M + g), p.B, p.sync, 1 + l)) lflag[0] = 1;
-        if (yr) store_rows(yr);
+        if (yr && p.raw_all) store_rows(yr);
       }
       __syncthreads();
       {
@@ -403,8 +415,17 @@ __global__ __launch_bounds__(256, 1) void chain32_kernel(const Chain32Args p) {
         }
         psc[t] = sc;
         psh[t] = sh;
+        pmn[t] = fmean;
+        pin[t] = invstd;
       }
       __syncthreads();
+      if (yr && !p.raw_all) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int cj = 4 * pl + j;
+          if (bn_inv_unsafe(pmn[cj], pin[cj], psc[cj], psh[cj], p.slope)) store_row(yr, j);
+        }
+      }
     }
     // normalise + activate the 4 x 16 values in registers: into the image in place (the next block's input) and to HBM
     {
@@ -834,6 +855,7 @@ int chain32_fwd(const ms_chain_desc* d, const ms_chain_tensors* tn, void* worksp
   a.mixpart = (float*)((char*)workspace + align_up((size_t)CH_NL * d->M * d->B * CH_C * 2 * sizeof(float), 256));
   a.sync = tn->sync; a.cnt_base = d->sync_first_word + 32;
   a.B = d->B; a.M = d->M; a.P = d->P; a.cin0 = d->cin0; a.train = d->mode == MS_BN_TRAIN;
+  a.raw_all = (d->keep_all_raw || (long)d->B * CH_T > BN_BWD32_FUSED_MAX) ? 1 : 0;      // (its two-pass backward reads y_raw, not y)
   a.slope = d->slope; a.eps = d->eps; a.momentum = d->momentum;
   const double bt = (double)d->B * CH_T;
   const double flops = 2.0 * bt * d->M * (CH_C * 3.0 * (d->cin0 + 3.0 * CH_C) + (double)d->P * CH_C);

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "conv16.h"
 
 namespace ms {
 
@@ -44,6 +45,7 @@ struct Clip32Args {
   int cnt_base;
   int B, Cin, Cout, To, Ti, ep, k8w, npw, rows_valid, nct;      // Cout: output channels (addressing) = rows_valid; nct = ceil(Cout / 32)
   float slope, eps, momentum;
+  int raw_all;           // BN_TRAIN: y_raw for every channel (0: only for channels whose backward cannot take x_hat from y: conv16.h bn_inv_unsafe)
   unsigned long long* stamps;   // diagnostics (MS_CLIP_DBG=32): [workgroup][8] s_memrealtime stamps (100 MHz)
 };
 #define CL_STAMP(k) do { if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
       p.rm[cgl] = (1.f - p.momentum) * rmo + p.momentum * fmean;
       p.rv[cgl] = (1.f - p.momentum) * rvo + p.momentum * unbiased;
     }
-    if (p.y_raw && rowok) store_frames(p.y_raw, v);
+    if (p.y_raw && rowok && (p.raw_all || bn_inv_unsafe(fmean, invstd, sc, sh, p.slope))) store_frames(p.y_raw, v);
   } else if (p.ep == EP_BN_EVAL) {
     sc = gam * (1.0f / sqrtf(rvo + p.eps));
     sh = bet - rmo * sc;
@@ -662,6 +664,9 @@ int clip32_block_fwd(const ms_conv_desc* d, const float* x, const float* x2, con
   a.ep = d->mode == MS_BARE ? EP_BARE : d->mode == MS_LRELU ? EP_LRELU : d->mode == MS_BN_EVAL ? EP_BN_EVAL : EP_RAW_STATS;
   a.slope = d->slope; a.eps = d->eps; a.momentum = d->momentum;
   if (a.ep == EP_RAW_STATS && (!sync || sync_words < 32 + clip32_sync_words(d->Cout) || !part)) return -2;
+  // the one-launch BatchNorm backward (bn_bwd_fused*) reads the block's output where the map inverts; larger layers' two-pass
+  // backward reads y_raw everywhere
+  a.raw_all = (long)d->B * d->OW > BN_BWD32_FUSED_MAX ? 1 : 0;
   return clip32_launch(a, d->KW, d->SW, d->in_mode == MS_IN_UP2ADD, "fwd", s);
 }
 

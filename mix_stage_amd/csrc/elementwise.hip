@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #include "kernels.h"
+#include "conv16.h"
 
 namespace ms {
 
@@ -389,9 +390,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
 
 // Fused BatchNorm+LeakyReLU backward for channels with <= 256*NE values: one workgroup owns a channel, keeps dy / y_raw
 // in registers across the reduction, and writes dy_raw, dgamma, dbeta and the bias gradient in one launch.
+// `y` != NULL: the block's OUTPUT stands in for y_raw wherever the BatchNorm + LeakyReLU map inverts safely (conv16.h:
+// bn_inv_unsafe, evaluated on the channel's save values exactly as the forward kernels do): z = y > 0 ? y : y / slope, x_hat =
+// (z - beta) / gamma.  The in-launch forward forms (chain32 / clip32) then write y_raw only for the channels that fail the test.
 template <int NE>
 __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const float* __restrict__ dy, const float* __restrict__ y_raw,
-                                                           const float* __restrict__ save, const float* __restrict__ gamma,
+                                                           const float* __restrict__ y, const float* __restrict__ save,
+                                                           const float* __restrict__ gamma,
                                                            float* __restrict__ dyr, float* dbias, float* dgamma, float* dbeta,
                                                            int B, int C, int HW, float slope) {
   prefetch_kernargs<128>();
@@ -401,6 +406,9 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const float* __restri
   const int n = B * HW;
   // every load is issued before the first one is consumed (clamped indices instead of branches): the kernel pays one
   // memory round trip, not NE of them -- with one wave per SIMD nothing else hides that latency
+  const float mean = save[c], invstd = save[C + c], sc = save[2 * C + c], sh = save[3 * C + c], gm = gamma[c];
+  const bool from_y = y != nullptr && !bn_inv_unsafe(mean, invstd, sc, sh, slope);       // (uniform: one channel per workgroup)
+  const float* src = from_y ? y : y_raw;
   float ry[NE], rg[NE];
   size_t ofs[NE];
 #pragma unroll
@@ -408,18 +416,26 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const float* __restri
     const int e = min(t + i * 256, n - 1);
     const int b = fdHW.div(e), pix = e - b * HW;
     ofs[i] = ((size_t)b * C + c) * HW + pix;
-    ry[i] = y_raw[ofs[i]];
+    ry[i] = src[ofs[i]];
     rg[i] = dy[ofs[i]];
   }
-  const float mean = save[c], invstd = save[C + c], sc = save[2 * C + c], sh = save[3 * C + c], gm = gamma[c];
+  const float beta_c = fmaf(mean, sc, sh), inv_sl = 1.0f / slope, inv_g = invstd / sc;     // (from_y: slope, scale are not tiny)
   float dz[NE], xh[NE];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < NE; ++i) {
     const bool ok = t + i * 256 < n;
-    const float z = fmaf(ry[i], sc, sh);
-    dz[i] = ok ? rg[i] * (z > 0.f ? 1.f : slope) : 0.f;
-    xh[i] = ok ? (ry[i] - mean) * invstd : 0.f;
+    bool pos;
+    float xv;
+    if (from_y) {
+      pos = ry[i] > 0.f;
+      xv = ((pos ? ry[i] : ry[i] * inv_sl) - beta_c) * inv_g;
+    } else {
+      pos = fmaf(ry[i], sc, sh) > 0.f;
+      xv = (ry[i] - mean) * invstd;
+    }
+    dz[i] = ok ? rg[i] * (pos ? 1.f : slope) : 0.f;
+    xh[i] = ok ? xv : 0.f;
     s1 += dz[i];
     s2 += dz[i] * xh[i];
   }
@@ -446,7 +462,8 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const float* __restri
 // The same for rows of HW % 4 == 0 values: NV 16-byte vectors of dy and of y_raw per thread (channels of <= 1024 * NV values).
 template <int NV>
 __global__ __launch_bounds__(256) void bn_bwd_fused4_kernel(const float* __restrict__ dy, const float* __restrict__ y_raw,
-                                                            const float* __restrict__ save, const float* __restrict__ gamma,
+                                                            const float* __restrict__ y, const float* __restrict__ save,
+                                                            const float* __restrict__ gamma,
                                                             float* __restrict__ dyr, float* dbias, float* dgamma, float* dbeta,
                                                             int B, int C, int HW, float slope) {
   prefetch_kernargs<128>();
@@ -454,6 +471,9 @@ __global__ __launch_bounds__(256) void bn_bwd_fused4_kernel(const float* __restr
   const FastDiv fd(HW4, nv + 256 * NV);
   __shared__ float red[4];
   const int c = blockIdx.x, t = threadIdx.x;
+  const float mean = save[c], invstd = save[C + c], sc = save[2 * C + c], sh = save[3 * C + c], gm = gamma[c];
+  const bool from_y = y != nullptr && !bn_inv_unsafe(mean, invstd, sc, sh, slope);       // (uniform: one channel per workgroup)
+  const float* src = from_y ? y : y_raw;
   float4 ry[NV], rg[NV];
   size_t ofs[NV];
 #pragma unroll
@@ -461,10 +481,10 @@ __global__ __launch_bounds__(256) void bn_bwd_fused4_kernel(const float* __restr
     const int e = min(t + i * 256, nv - 1);
     const int b = fd.div(e), p4 = e - b * HW4;
     ofs[i] = ((size_t)b * C + c) * HW + 4 * p4;
-    ry[i] = *reinterpret_cast<const float4*>(y_raw + ofs[i]);
+    ry[i] = *reinterpret_cast<const float4*>(src + ofs[i]);
     rg[i] = *reinterpret_cast<const float4*>(dy + ofs[i]);
   }
-  const float mean = save[c], invstd = save[C + c], sc = save[2 * C + c], sh = save[3 * C + c], gm = gamma[c];
+  const float beta_c = fmaf(mean, sc, sh), inv_sl = 1.0f / slope, inv_g = invstd / sc;     // (from_y: slope, scale are not tiny)
   float dz[NV][4], xh[NV][4];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -473,9 +493,17 @@ __global__ __launch_bounds__(256) void bn_bwd_fused4_kernel(const float* __restr
     const float a[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w}, g[4] = {rg[i].x, rg[i].y, rg[i].z, rg[i].w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float z = fmaf(a[j], sc, sh);
-      dz[i][j] = ok ? g[j] * (z > 0.f ? 1.f : slope) : 0.f;
-      xh[i][j] = ok ? (a[j] - mean) * invstd : 0.f;
+      bool pos;
+      float xv;
+      if (from_y) {
+        pos = a[j] > 0.f;
+        xv = ((pos ? a[j] : a[j] * inv_sl) - beta_c) * inv_g;
+      } else {
+        pos = fmaf(a[j], sc, sh) > 0.f;
+        xv = (a[j] - mean) * invstd;
+      }
+      dz[i][j] = ok ? g[j] * (pos ? 1.f : slope) : 0.f;
+      xh[i][j] = ok ? xv : 0.f;
       s1 += dz[i][j];
       s2 += dz[i][j] * xh[i][j];
     }
@@ -1221,27 +1249,27 @@ int bwd_chunks(int B, int C, int* b_per_chunk) {
 }
 
 // returns 1 if the fused single-launch form was used (dbias already final, no colsum_finalize needed)
-int launch_bn_bwd(const float* dy, const float* y_raw, const float* save, const float* gamma, float* partial, float* dyr,
+int launch_bn_bwd(const float* dy, const float* y_raw, const float* y, const float* save, const float* gamma, float* partial, float* dyr,
                   float* colpart, float* dbias, float* dgamma, float* dbeta, int B, int C, int HW, float slope, int* fused,
                   hipStream_t s) {
   *fused = 0;
   const long n = (long)B * HW;
-  if (n <= 256 * 16) {
+  if (n <= BN_BWD32_FUSED_MAX) {
     TimingScope ts(s, 0, 12.0 * B * C * HW, "bn_bwd_fused C%d HW%d B%d", C, HW, B);
     if (ts.skip()) return 0;
-    const bool vec4 = (HW & 3) == 0 && (((uintptr_t)dy | (uintptr_t)y_raw | (uintptr_t)dyr) & 15) == 0;
+    const bool vec4 = (HW & 3) == 0 && (((uintptr_t)dy | (uintptr_t)y_raw | (uintptr_t)y | (uintptr_t)dyr) & 15) == 0;
     if (vec4 && n <= 1024)
-      hipLaunchKernelGGL(bn_bwd_fused4_kernel<1>, dim3(C), dim3(256), 0, s, dy, y_raw, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope);
+      hipLaunchKernelGGL(bn_bwd_fused4_kernel<1>, dim3(C), dim3(256), 0, s, dy, y_raw, y, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope);
     else if (vec4 && n <= 2048)
-      hipLaunchKernelGGL(bn_bwd_fused4_kernel<2>, dim3(C), dim3(256), 0, s, dy, y_raw, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope);
+      hipLaunchKernelGGL(bn_bwd_fused4_kernel<2>, dim3(C), dim3(256), 0, s, dy, y_raw, y, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope);
     else if (vec4)
-      hipLaunchKernelGGL(bn_bwd_fused4_kernel<4>, dim3(C), dim3(256), 0, s, dy, y_raw, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope);
+      hipLaunchKernelGGL(bn_bwd_fused4_kernel<4>, dim3(C), dim3(256), 0, s, dy, y_raw, y, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope);
     else if (n <= 256 * 4)
-      hipLaunchKernelGGL(bn_bwd_fused_kernel<4>, dim3(C), dim3(256), 0, s, dy, y_raw, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope);
+      hipLaunchKernelGGL(bn_bwd_fused_kernel<4>, dim3(C), dim3(256), 0, s, dy, y_raw, y, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope);
     else if (n <= 256 * 8)
-      hipLaunchKernelGGL(bn_bwd_fused_kernel<8>, dim3(C), dim3(256), 0, s, dy, y_raw, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope);
+      hipLaunchKernelGGL(bn_bwd_fused_kernel<8>, dim3(C), dim3(256), 0, s, dy, y_raw, y, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope);
     else
-      hipLaunchKernelGGL(bn_bwd_fused_kernel<16>, dim3(C), dim3(256), 0, s, dy, y_raw, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope);
+      hipLaunchKernelGGL(bn_bwd_fused_kernel<16>, dim3(C), dim3(256), 0, s, dy, y_raw, y, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope);
     *fused = 1;
     return check_launch("bn_bwd_fused_kernel");
   }

@@ -224,7 +224,10 @@ int launch_bn_finalize_apply(const float* stats, const float* counts, int n_tile
                              const float* beta, float* rm, float* rv, float* save, float eps, float momentum, const float* y_raw,
                              float* y, int B, int HW, float slope, hipStream_t s);
 int bwd_chunks(int B, int C, int* b_per_chunk);
-int launch_bn_bwd(const float* dy, const float* y_raw, const float* save, const float* gamma, float* partial, float* dyr,
+// values per channel (B * OH * OW) up to which BatchNorm backward is ONE launch that can take x_hat from the block's output y
+// (elementwise.hip: bn_bwd_fused*): the in-launch forward forms keep y_raw only where that inversion is unsafe
+constexpr int BN_BWD32_FUSED_MAX = 256 * 16;
+int launch_bn_bwd(const float* dy, const float* y_raw, const float* y, const float* save, const float* gamma, float* partial, float* dyr,
                   float* colpart, float* dbias, float* dgamma, float* dbeta, int B, int C, int HW, float slope, int* fused,
                   hipStream_t s);
 int launch_act_bwd(const float* dy, const float* y, float* dyr, float* colpart, int B, int C, int HW, int mode, float slope,

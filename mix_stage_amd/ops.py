@@ -412,7 +412,10 @@ class _ConvBlockFn(torch.autograd.Function):
     ctx.mode, ctx.in_mode = mode, in_mode
     ctx.has_bias = bias is not None
     ctx.params = (w, bias, gamma, beta)          # parameter objects (for their gradient slots)
-    ctx.save_for_backward(x, x2, w, gamma, y_raw, y if mode == MS_LRELU else None, save)
+    # BN_TRAIN: the block's output is saved too -- the one-launch BatchNorm backward takes x_hat and the activation mask from it
+    # wherever the map inverts safely, and the in-launch forward forms (chained decoder, clip-resident blocks) write y_raw only
+    # for the other channels (include/mixstage.h: ms_fwd_options.bn_sync)
+    ctx.save_for_backward(x, x2, w, gamma, y_raw, y if mode in (MS_LRELU, MS_BN_TRAIN) else None, save)
     return y
 
   @staticmethod

@@ -241,6 +241,37 @@ def test_an_expired_meeting_is_reported_and_poisons_the_output():
   assert torch.equal(again['out'], good['out'])
 
 
+def test_channels_that_do_not_invert_keep_y_raw_and_their_gradients():
+  """The backward pass of a chained block reads the block's OUTPUT where BatchNorm + LeakyReLU inverts safely; the chain keeps
+  y_raw only for the other channels (here: gamma = 1e-6, and beta = 10 gamma).  Gradients must equal the blocks run one by one
+  (whose launches keep y_raw everywhere) on those channels as on the rest."""
+  B, M, P = 8, 4, 104
+  blocks, logits = _build(M, P, 10, seed=31)
+  with torch.no_grad():
+    blocks[1].norm.weight[7] = 1e-6
+    blocks[2].norm.weight[300] = 0.05
+    blocks[2].norm.bias[300] = 0.6
+    blocks[0].norm.weight[1000] = -0.7                   # negative gamma inverts fine
+  x, score = _inputs(B, M, 266, seed=31)
+  g = torch.Generator().manual_seed(5)
+  dout = torch.randn(B, 64, P, generator=g).to(DEV)
+  a = _run(blocks, logits, x, score, P, True, dout=dout)
+  b = _run(blocks, logits, x, score, P, False, dout=dout)
+  _close(a['out'], b['out'], 2e-5, 'mixture')
+  _close_l2(a['dx'], b['dx'], 2e-3, 'dx')                  # (a few activations at the LeakyReLU kink take the other slope)
+  gmax = max(float(g.abs().max()) for g in b['grads'])
+  for i, (ga, gb) in enumerate(zip(a['grads'], b['grads'])):
+    if i % 4 == 1 and i < 16:                              # conv bias in front of a batch-statistics BatchNorm: rounding noise
+      assert float(ga.abs().max()) <= 1e-4 * gmax and float(gb.abs().max()) <= 1e-4 * gmax, i
+    else:
+      _close_l2(ga, gb, 2e-3, 'gradient of parameter %d' % i)
+  # the channels that fail the inversion test in particular: gamma / beta gradients of block 1 channel 7 and block 2 channel 300
+  for blk, ch in ((1, 7), (2, 300)):
+    for k in (2, 3):                                       # parameters per block: conv.weight, conv.bias, norm.weight, norm.bias
+      ga, gb = a['grads'][4 * blk + k][ch], b['grads'][4 * blk + k][ch]
+      assert abs(float(ga) - float(gb)) <= 2e-3 * max(abs(float(gb)), 1e-3 * gmax), (blk, ch, k, float(ga), float(gb))
+
+
 def test_shapes_outside_the_chain_fall_back():
   """T != 64, more workgroups than compute units, hooks on a block: decoder_chain declines and the caller runs the blocks."""
   from mix_stage_amd import ops

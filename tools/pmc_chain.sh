@@ -18,4 +18,9 @@ for prec in ${@:-fp32 bf16}; do
     rocprofv3 --kernel-trace --output-format csv --pmc $grp -d "$OUT/${prec}_sq$i" -- python3 "$R/tools/probe_chain_pmc.py" $prec > /dev/null 2>&1 || true
   done
 done
+# BASELINE configs[1] (M = S = 4, bf16): traffic passes only
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  rm -rf "$OUT/bf16_m4_$ctr"
+  rocprofv3 --kernel-trace --output-format csv --pmc $ctr -d "$OUT/bf16_m4_$ctr" -- python3 "$R/tools/probe_chain_pmc.py" bf16 20 4 > /dev/null 2>&1 || true
+done
 cd "$R" && python3 tools/pmc_chain_summary.py "$OUT" gpurun_out/pmc_decoder.json gpurun_out/sq_counters.json

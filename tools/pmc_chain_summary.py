@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 
 root, out_traffic, out_sq = sys.argv[1:4]
-NAMES = {'fp32': 'chain32_kernel', 'bf16': 'chain16_kernel'}
+NAMES = {'fp32': 'chain32_kernel', 'bf16': 'chain16_kernel', 'bf16_m4': 'chain16_kernel'}     # key -> kernel; 'bf16_m4' = configs[1] (M = 4)
 
 
 def per_kernel(d):
@@ -45,7 +45,7 @@ for prec, kname in NAMES.items():
       ent['avg_us_under_pmc'] = round(dur[k][1] / dur[k][0], 2)
   if 'fetch_size_kb_per_launch' in ent and 'write_size_kb_per_launch' in ent:
     ent['hbm_bytes_per_launch'] = int((2 * ent['fetch_size_kb_per_launch'] + ent['write_size_kb_per_launch']) * 1024)
-    ent['what'] = 'decoder.0-3 + logits + softmax mixture in one launch, train mode, y_raw / y / z kept for the backward pass (B=32, M=8)'
+    ent['what'] = 'decoder.0-3 + logits + softmax mixture in one launch, train mode, y_raw / y / z kept for the backward pass (B=32, M=%d)' % (4 if prec.endswith('_m4') else 8)
     ent['src_hash'] = bench.source_hash()
     traffic[prec] = ent
   for d in sorted(glob.glob(os.path.join(root, prec + '_sq*'))):
