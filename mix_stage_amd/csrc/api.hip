@@ -510,10 +510,10 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
     rc = launch_bn_bwd(dy, y_raw, y, save, gamma, bn_part, dyr, colpart, dbias, dgamma, dbeta, d->B, C, hw, d->slope, &bias_done, s);
     g = dyr;
   } else if (d->mode == MS_LRELU) {
-    rc = launch_act_bwd(dy, y, dyr, colpart, d->B, C, hw, 1, d->slope, s);
+    rc = launch_act_bwd(dy, y, dyr, colpart, dbias, d->B, C, hw, 1, d->slope, &bias_done, s);
     g = dyr;
   } else if (dbias) {
-    rc = launch_act_bwd(dy, nullptr, nullptr, colpart, d->B, C, hw, 0, 0.f, s);
+    rc = launch_act_bwd(dy, nullptr, nullptr, colpart, dbias, d->B, C, hw, 0, 0.f, &bias_done, s);
   }
   if (rc) return rc;
   if (dbias && !bias_done) {

@@ -554,6 +554,42 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
   if (t == 0) colpart[(size_t)c * nchunk + ch] = cs;
 }
 
+// The same for channels of <= 256 * NE values: one workgroup per channel, every load in flight at once, the bias gradient
+// written directly (no column-sum partials, no colsum_finalize launch).
+template <int NE>
+__global__ __launch_bounds__(256) void act_bwd_fused_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                            float* __restrict__ dyr, float* __restrict__ dbias, int B, int C,
+                                                            int HW, int mode, float slope) {
+  prefetch_kernargs<128>();
+  const FastDiv fdHW(HW, B * HW);
+  __shared__ float red[4];
+  const int c = blockIdx.x, t = threadIdx.x, n = B * HW;
+  float g[NE], yv[NE];
+  size_t ofs[NE];
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = min(t + i * 256, n - 1);
+    const int b = fdHW.div(e), pix = e - b * HW;
+    ofs[i] = ((size_t)b * C + c) * HW + pix;
+    g[i] = dy[ofs[i]];
+    yv[i] = mode == 1 ? y[ofs[i]] : 1.f;
+  }
+  float cs = 0.f;
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    if (t + i * 256 < n) {
+      float v = g[i];
+      if (mode == 1) {
+        v *= (yv[i] > 0.f ? 1.f : slope);
+        dyr[ofs[i]] = v;
+      }
+      cs += v;
+    }
+  }
+  cs = block_sum_256(cs, red);
+  if (t == 0 && dbias) dbias[c] = cs;
+}
+
 __global__ void colsum_finalize_kernel(const float* __restrict__ colpart, float* __restrict__ out, int C, int nchunk) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
@@ -1289,8 +1325,20 @@ int launch_bn_bwd(const float* dy, const float* y_raw, const float* y, const flo
   return check_launch("bn_bwd_apply_kernel");
 }
 
-int launch_act_bwd(const float* dy, const float* y, float* dyr, float* colpart, int B, int C, int HW, int mode, float slope,
-                   hipStream_t s) {
+// returns 1 in *fused when the bias gradient was written by this launch (no colsum_finalize needed)
+int launch_act_bwd(const float* dy, const float* y, float* dyr, float* colpart, float* dbias, int B, int C, int HW, int mode, float slope,
+                   int* fused, hipStream_t s) {
+  *fused = 0;
+  const long nn = (long)B * HW;
+  if (nn <= 256 * 16 && (mode == 1 || dbias)) {
+    TimingScope ts(s, 0, (mode == 1 ? 12.0 : 4.0) * B * C * HW, "act_bwd_fused C%d HW%d B%d mode%d", C, HW, B, mode);
+    *fused = 1;
+    if (ts.skip()) return 0;
+    if (nn <= 256 * 4) hipLaunchKernelGGL(act_bwd_fused_kernel<4>, dim3(C), dim3(256), 0, s, dy, y, dyr, dbias, B, C, HW, mode, slope);
+    else if (nn <= 256 * 8) hipLaunchKernelGGL(act_bwd_fused_kernel<8>, dim3(C), dim3(256), 0, s, dy, y, dyr, dbias, B, C, HW, mode, slope);
+    else hipLaunchKernelGGL(act_bwd_fused_kernel<16>, dim3(C), dim3(256), 0, s, dy, y, dyr, dbias, B, C, HW, mode, slope);
+    return check_launch("act_bwd_fused_kernel");
+  }
   int bpc;
   const int nchunk = bwd_chunks(B, C, &bpc);
   TimingScope ts(s, 0, (mode == 1 ? 12.0 : 4.0) * B * C * HW, "act_bwd C%d HW%d B%d mode%d", C, HW, B, mode);

@@ -230,7 +230,7 @@ constexpr int BN_BWD32_FUSED_MAX = 256 * 16;
 int launch_bn_bwd(const float* dy, const float* y_raw, const float* y, const float* save, const float* gamma, float* partial, float* dyr,
                   float* colpart, float* dbias, float* dgamma, float* dbeta, int B, int C, int HW, float slope, int* fused,
                   hipStream_t s);
-int launch_act_bwd(const float* dy, const float* y, float* dyr, float* colpart, int B, int C, int HW, int mode, float slope,
+int launch_act_bwd(const float* dy, const float* y, float* dyr, float* colpart, float* dbias, int B, int C, int HW, int mode, float slope, int* fused,
                    hipStream_t s);
 int launch_colsum_finalize(const float* colpart, float* out, int B, int C, hipStream_t s);
 
