@@ -192,6 +192,14 @@ def test_block16_bn_backward_reads_y_or_y_raw_per_channel_block(name, args):
   _case(nd, B, cin, cout, groups, k, s, p, H, W, BN_TRAIN, in_mode, slope=0.0, grad_tol=3e-2)
 
 
+def test_block16_first_audio_layer_eval_and_lrelu():
+  """1 -> 64 channels, 3x3 (AudioEncoder conv.0): eval-mode BatchNorm and plain LeakyReLU run on the vector-unit kernel
+  (conv16_c1.hip), train mode on the matrix-pipe kernel; both against exact math on the same 16-bit inputs."""
+  _case(2, 2, 1, 64, 1, 3, 1, 1, 16, 32, BN_EVAL)
+  _case(2, 3, 1, 64, 1, 3, 1, 1, 10, 12, LRELU)
+  _case(2, 2, 1, 64, 1, 3, 1, 1, 16, 32, BN_EVAL, dt=torch.float16)
+
+
 def test_block16_fp16_eval():
   _case(1, 4, 64, 64, 1, 3, 1, 1, 1, 64, BN_EVAL, dt=torch.float16)
   _case(1, 4, 128, 128, 2, 3, 1, 1, 1, 64, LRELU, dt=torch.float16)
