@@ -134,18 +134,14 @@ int block_fwd16(const ms_conv_desc* d, const void* x, const void* x2, const floa
   // the single-input-channel 3x3 block (AudioEncoder conv.0): vector-unit kernel, no operand preparation
   // (train mode stays on the matrix-pipe kernel: with the tile statistics the vector-unit kernel is the slower one, 46 vs 35 us;
   // eval mode -- the D-step's generator pass -- 41 -> 28.5 us)
-  if (conv16_c1_ok(d) && d->mode != MS_BN_TRAIN && !outf32 && !bn_folded_of(d) && conv16_c1_tiles(d) <= pl.n_tiles && w) {
-    const int ep = d->mode == MS_BARE ? EP_BARE : d->mode == MS_BN_TRAIN ? EP_RAW_STATS : d->mode == MS_LRELU ? EP_LRELU : EP_BN_EVAL;
-    const int nt = conv16_c1_tiles(d);
-    int rc = launch_conv16_c1(g.dt, x, w, bias, d->mode == MS_BN_TRAIN ? y_raw : y, gamma, beta, running_mean, running_var, stats, counts,
-                              d->B, d->H, d->W, ep, d->slope, d->eps, s);
-    if (rc || d->mode != MS_BN_TRAIN) return rc;
-    if (nt <= 64)
-      return launch_bn_finalize_apply16(g.dt, stats, counts, nt, g.npix, gamma, beta, running_mean, running_var, save, d->eps,
-                                        d->momentum, y_raw, y, nullptr, d->B, g.C, g.hw, d->slope, s);
-    rc = launch_bn_finalize(stats, counts, nt, 0, g.npix, g.C, gamma, beta, running_mean, running_var, save, d->eps, d->momentum, s);
-    if (rc) return rc;
-    return launch_bn_apply16(g.dt, y_raw, y, nullptr, save, d->B, g.C, g.hw, d->slope, s);
+  if (conv16_c1_ok(d) && d->mode != MS_BN_TRAIN && !outf32 && conv16_c1_tiles(d) <= pl.n_tiles && w && (!bn_folded_of(d) || w_prepared)) {
+    // inference with eval BatchNorm folded: the prepared buffer carries scale | bias' behind the operand stages (the same values the
+    // matrix-pipe path folds into its weights and adds in its epilogue); what is left of the block is the activation
+    const bool fold = bn_folded_of(d);
+    const float* fscale = fold ? (const float*)((const char*)w_prepared + align_up(fwd_a_bytes(d, pl), 256)) : nullptr;
+    const int ep = d->mode == MS_BARE ? EP_BARE : (d->mode == MS_LRELU || fold) ? EP_LRELU : EP_BN_EVAL;
+    return launch_conv16_c1(g.dt, x, w, fscale, fold ? fscale + g.C : bias, y, gamma, beta, running_mean, running_var, stats, counts,
+                            d->B, d->H, d->W, ep, d->slope, d->eps, s);
   }
   const size_t a_bytes = align_up(fwd_a_bytes(d, pl), 256);
   const void* A = w_prepared;

@@ -137,7 +137,7 @@ void wgrad16_discard();
 // single-input-channel 3x3 block on the vector unit (conv16_c1.hip)
 bool conv16_c1_ok(const ms_conv_desc* d);
 int conv16_c1_tiles(const ms_conv_desc* d);
-int launch_conv16_c1(int dt, const void* x, const float* w, const float* bias, void* out, const float* bn_g, const float* bn_b,
+int launch_conv16_c1(int dt, const void* x, const float* w, const float* wscale, const float* bias, void* out, const float* bn_g, const float* bn_b,
                      const float* bn_m, const float* bn_v, float* stats, float* counts, int B, int H, int W, int ep, float slope,
                      float eps, hipStream_t s);
 int launch_bn_apply16(int dt, const void* y_raw, void* y, float* y_f32, const float* save, int B, int C, int HW, float slope,

@@ -13,6 +13,7 @@ namespace ms {
 
 template <typename DT>
 __global__ __launch_bounds__(256) void conv16_c1_3x3_kernel(const u32x4* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ wscale,      // per-channel factor folded into the weights before rounding (inference: eval BatchNorm), or NULL
                                                             const float* __restrict__ bias, u32x4* __restrict__ out,
                                                             const float* __restrict__ bn_g, const float* __restrict__ bn_b,
                                                             const float* __restrict__ bn_m, const float* __restrict__ bn_v,
@@ -26,7 +27,7 @@ __global__ __launch_bounds__(256) void conv16_c1_3x3_kernel(const u32x4* __restr
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   for (int i = t; i < CO * 10; i += 256) {
     float v = i < CO * 9 ? w[i] : (bias ? bias[i - CO * 9] : 0.f);
-    if (i < CO * 9) v = DT::lo(DT::pack2(v, 0.f));
+    if (i < CO * 9) v = DT::lo(DT::pack2(wscale ? v * wscale[i / 9] : v, 0.f));
     wsm[i] = v;
   }
   if (ep == EP_BN_EVAL && t < CO) {
@@ -122,7 +123,7 @@ bool conv16_c1_ok(const ms_conv_desc* d) {
 }
 int conv16_c1_tiles(const ms_conv_desc* d) { return cdiv(d->B * d->H * d->W, 256); }
 
-int launch_conv16_c1(int dt, const void* x, const float* w, const float* bias, void* out, const float* bn_g, const float* bn_b,
+int launch_conv16_c1(int dt, const void* x, const float* w, const float* wscale, const float* bias, void* out, const float* bn_g, const float* bn_b,
                      const float* bn_m, const float* bn_v, float* stats, float* counts, int B, int H, int W, int ep, float slope,
                      float eps, hipStream_t s) {
   const double npix = (double)B * H * W;
@@ -139,10 +140,10 @@ int launch_conv16_c1(int dt, const void* x, const float* w, const float* bias, v
   }
   const dim3 grid(cdiv(B * H * W, 256));
   if (dt == DT_BF16)
-    hipLaunchKernelGGL(conv16_c1_3x3_kernel<BF16>, grid, dim3(256), lds, s, (const u32x4*)x, w, bias, (u32x4*)out, bn_g, bn_b, bn_m, bn_v,
+    hipLaunchKernelGGL(conv16_c1_3x3_kernel<BF16>, grid, dim3(256), lds, s, (const u32x4*)x, w, wscale, bias, (u32x4*)out, bn_g, bn_b, bn_m, bn_v,
                        stats, counts, B, H, W, ep, slope, eps);
   else
-    hipLaunchKernelGGL(conv16_c1_3x3_kernel<F16>, grid, dim3(256), lds, s, (const u32x4*)x, w, bias, (u32x4*)out, bn_g, bn_b, bn_m, bn_v,
+    hipLaunchKernelGGL(conv16_c1_3x3_kernel<F16>, grid, dim3(256), lds, s, (const u32x4*)x, w, wscale, bias, (u32x4*)out, bn_g, bn_b, bn_m, bn_v,
                        stats, counts, B, H, W, ep, slope, eps);
   return check_launch("conv16_c1_3x3_kernel");
 }
