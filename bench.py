@@ -613,7 +613,8 @@ def main():
     }
     if world > 1:
       out['dp_fallback'] = os.environ.get('MS_DP_FALLBACK') or False
-      out['config']['grad_exchange'] = 'captured in the step graph' if ts.capture_allreduce else ('eager RCCL all-reduce between two graphs' if not args.no_graphs else 'eager')
+      coll = 'RCCL' if args.dist_backend == 'nccl' else args.dist_backend
+      out['config']['grad_exchange'] = 'captured in the step graph' if ts.capture_allreduce else ('eager %s all-reduce between two graphs' % coll if not args.no_graphs else 'eager %s all-reduce' % coll)
     if per_kind:
       g_ms, d_ms = 1e3 * per_kind['G'], 1e3 * per_kind['D']
       peak = {'fp32': FP32_MFMA_PEAK_TFLOPS, 'bf16x6': FP32_MFMA_PEAK_TFLOPS, 'bf16': BF16_MFMA_PEAK_TFLOPS}[args.precision]
