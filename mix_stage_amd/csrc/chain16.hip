@@ -328,35 +328,40 @@ __global__ __launch_bounds__(256, 1) void chain16_kernel(const Chain16Args p) {
       __syncthreads();
       if (l == 0) C16_STAMP(14);
       {
-        const unsigned base = 8u * (unsigned)(((l * p.M + g) * p.B) * C16_C + t);
+        // (an opaque zero: what is derived from it is computed HERE in every block instead of being hoisted out of the block loop
+        // and kept alive -- spilled to scratch, as it turned out -- across the K loops, where the register file is full)
+        int opq = 0;
+        asm volatile("" : "+s"(opq));
+        const int Bq = p.B + opq;
+        const unsigned base = 8u * (unsigned)(((l * p.M + g) * Bq) * C16_C + t);
         // equal counts (64 frames per clip): mean = average of the clips' means, M2 = sum of their M2 + 64 * sum (mean_i - mean)^2
         // -- two passes over the partials in clip order, fp64, no division in the loops (Chan's update costs two fp64 divisions
         // per clip: 3 us of the meeting)
         double msum = 0.0, m2c = 0.0, dev = 0.0;
         float2 pv[32];
-        const int nb32 = min(p.B, 32);
+        const int nb32 = min(Bq, 32);
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
-          const int bb2 = min(i, p.B - 1);
+          const int bb2 = min(i, Bq - 1);
           pv[i] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsPart, (int)(base + 8u * (unsigned)(bb2 * C16_C)), 0, 16));
         }
 #pragma unroll
         for (int i = 0; i < 32; ++i)
           if (i < nb32) { msum += (double)pv[i].x; m2c += (double)pv[i].y; }
-        for (int bb2 = 32; bb2 < p.B; ++bb2) {              // (B > 32: the rest one by one)
+        for (int bb2 = 32; bb2 < Bq; ++bb2) {              // (B > 32: the rest one by one)
           const float2 q = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsPart, (int)(base + 8u * (unsigned)(bb2 * C16_C)), 0, 16));
           msum += (double)q.x; m2c += (double)q.y;
         }
-        const double n = (double)p.B * C16_T, mean_c = msum / (double)p.B;
+        const double n = (double)Bq * C16_T, mean_c = msum / (double)Bq;
 #pragma unroll
         for (int i = 0; i < 32; ++i)
           if (i < nb32) { const double dl = (double)pv[i].x - mean_c; dev += dl * dl; }
-        for (int bb2 = 32; bb2 < p.B; ++bb2) {
+        for (int bb2 = 32; bb2 < Bq; ++bb2) {
           const float2 q = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsPart, (int)(base + 8u * (unsigned)(bb2 * C16_C)), 0, 16));
           const double dl = (double)q.x - mean_c; dev += dl * dl;
         }
         m2c += (double)C16_T * dev;
-        const int cg = g * C16_C + t;
+        const int cg = g * C16_C + t + opq;
         const float var = (float)(m2c / n), fmean = (float)mean_c;
         const float invstd = 1.0f / sqrtf(var + p.eps);
         float sc = tb1[l * 256 + t] * invstd;
