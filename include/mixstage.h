@@ -227,6 +227,12 @@ int ms_dgrad_weights_prepare(int n, const ms_conv_desc* descs, const float* cons
  * kernel), so dw must hold zeros or the step's other contributions.
  *   ms_wgrad_partials_elems   floats of slab space for block d (0: dw is written directly), *splits = slab count */
 size_t ms_wgrad_partials_elems(const ms_conv_desc* d, int* splits);
+/* Planner hint: on = 1 when the caller queues the weight gradients of a backward pass (ms_bwd_options.defer_wgrad_launch) and
+ * launches them side by side with ms_wgrad_flush -- a layer then need not fill the chip alone, its workgroups take at least
+ * `tiles_per_workgroup` (<= 0: keep, default 16) 64-pixel tiles of the pixel reduction: fewer, longer workgroups and fewer partial
+ * slabs.  Changes ms_wgrad_partials_elems / workspace sizes (ms_tuning_epoch moves): set it before sizing buffers.  Returns the
+ * previous `on`.  (Reference: the weight gradients of loss.backward(), trainer.py:1139, have no consumer before the optimizer step.) */
+int ms_set_wgrad_batched(int on, int tiles_per_workgroup);
 /* Launches the weight gradients queued by ms_bwd_options.defer_wgrad_launch on `stream`; call it
  * before ms_wgrad_reduce_multi.  ms_wgrad_discard drops the queue (after a failed backward pass).  Returns 0 or an error. */
 int ms_wgrad_flush(void* stream);
@@ -433,7 +439,10 @@ int ms_write_floats(float* dst, const float* host_values, int n, void* stream);
  * clip_grad_norm_(., max_norm) folded into a fused Adam step (torch.optim.Adam defaults).
  *   norm_out[0] = ||g||_2 ; coef = min(1, max_norm/(norm+1e-6)) applied to g inside ms_adam_step. */
 int ms_sqnorm(const float* g, size_t n, float* norm_out, float* partials, void* stream);
-/* step_state: 4 int32 words on the device, word 0 = step count (starts at 0), words 1..3 scratch. */
+/* step_state: 4 int32 words on the device, word 0 = step count (starts at 0), words 1..3 scratch.
+ * A NON-FINITE gradient norm (NaN / Inf in any gradient: e.g. behind a launch whose in-launch meeting timed out) skips the
+ * update: p, m, v keep their values, the step count still advances.  ms_adam_step_segmented reports it: word 2 = 1 while the
+ * LAST step was skipped, word 3 = number of skipped steps so far. */
 int ms_adam_step(float* p, const float* g, float* m, float* v, size_t n, const float* norm, float max_norm,
                  float lr, float beta1, float beta2, float eps, int32_t* step_state, void* stream);
 /* Same with torch.optim.Adam's PER-PARAMETER step counts: the flat buffer is a sequence of segments (one per parameter,

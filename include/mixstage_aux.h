@@ -54,6 +54,9 @@ int ms_debug_set_conv16_ring(int nstg, int wide8);
 int ms_debug_set_wgrad16_target(int workgroups);
 int ms_debug_set_wgrad16_ring(int buffers);           /* LDS-DMA ring depth of the 16-bit weight gradient (2..8, default 2) */
 int ms_debug_set_wgrad_target(int workgroups);      /* the same for the fp32 patch-staged weight gradient (default 768) */
+/* Test / ablation aid: 0 = the fp32 weight gradient never takes the wave-pipelined kernel (wgrad_wave_multi_kernel: no workgroup
+ * barrier in the reduction loop), 1 = it does where the layer qualifies (default).  Returns the previous value. */
+int ms_debug_set_wgrad_wave(int on);
 /* Test / ablation aid: 0 = 16-bit BN_TRAIN blocks never take the in-launch BatchNorm form (ms_set_bn_sync_buffer), 1 = they do
  * when eligible (default).  Returns the previous value. */
 int ms_debug_set_bn_fused(int on);

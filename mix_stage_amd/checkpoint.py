@@ -88,3 +88,19 @@ def load_weights(model, source, strict=True, trusted=False):
       v = v.reshape(ref.shape)          # e.g. 0-dim vs 1-element num_batches_tracked
     cast[name] = v
   return model.load_state_dict(cast, strict=strict)
+
+
+def save_weights(model, path, train_step=None):
+  """Write `model.state_dict()` in the reference's container (a torch.save'd name -> CPU tensor mapping: what BookKeeper's
+  `*_weights.p` holds, README.md:124-141).  With a MixStageTrainStep the device is checked first (check_health: a refused step or
+  an expired in-launch meeting raises there), and a state that holds a non-finite value is never written."""
+  if train_step is not None:
+    train_step.check_health()
+  state = {k: v.detach().to('cpu') for k, v in model.state_dict().items()}
+  bad = [k for k, v in state.items() if v.is_floating_point() and not bool(torch.isfinite(v).all())]
+  if bad:
+    raise RuntimeError('refusing to save: %d tensors hold non-finite values (first: %s)' % (len(bad), bad[0]))
+  tmp = os.fspath(path) + '.tmp'
+  torch.save(state, tmp)
+  os.replace(tmp, os.fspath(path))
+  return path

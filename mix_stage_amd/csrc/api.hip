@@ -33,7 +33,7 @@ static int wgrad_total_splits(const ms_conv_desc* d) {
   const int npix = d->B * d->OH * d->OW;
   const bool one_d = d->H == 1 && d->KH == 1;
   const WgradPatchPlan wp = plan_wgrad_patch(one_d ? 1 : 2, d->Cout, d->Cin * d->KH * d->KW, d->groups, d->KH, d->KW, d->SH,
-                                             d->SW, d->B, d->OH, d->OW);
+                                             d->SW, d->B, d->OH, d->OW, d->W, d->in_mode == MS_IN_UP2ADD);
   return std::max(wp.ok ? wp.splits : 1, wgrad_splits(d->Cout, d->Cin * d->KH * d->KW, d->groups, npix));
 }
 
@@ -288,7 +288,7 @@ static DgradWeights dgrad_weights_of(const ms_conv_desc* d, const float* w) {
 static int wgrad_splits_used(const ms_conv_desc* d) {
   const bool one_d = d->H == 1 && d->KH == 1;
   const WgradPatchPlan wp = plan_wgrad_patch(one_d ? 1 : 2, d->Cout, d->Cin * d->KH * d->KW, d->groups, d->KH, d->KW, d->SH,
-                                             d->SW, d->B, d->OH, d->OW);
+                                             d->SW, d->B, d->OH, d->OW, d->W, d->in_mode == MS_IN_UP2ADD);
   return wp.ok ? wp.splits : wgrad_splits(d->Cout, d->Cin * d->KH * d->KW, d->groups, d->B * d->OH * d->OW);
 }
 
@@ -665,7 +665,7 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
   if (dw) {
     const bool one_d = d->H == 1 && d->KH == 1;
     const WgradPatchPlan wp = plan_wgrad_patch(one_d ? 1 : 2, d->Cout, d->Cin * khw, d->groups, d->KH, d->KW, d->SH, d->SW,
-                                               d->B, d->OH, d->OW);
+                                               d->B, d->OH, d->OW, d->W, up2);
     if (wp.ok) {
       const int cin_tot = bcast ? d->Cin : d->groups * d->Cin;
       WgradPatchArgs q = {};

@@ -61,6 +61,7 @@ struct Chain16Args {
 };
 
 __device__ __forceinline__ bool chain16_meet(int* counter, int members, int* err_word, int code) {
+  const int prior = __hip_atomic_load(err_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sticky error word: chain32.hip, chain_meet
   const unsigned old = (unsigned)__hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned target = (old / (unsigned)members + 1u) * (unsigned)members;
   int spins = 0;
@@ -72,7 +73,7 @@ __device__ __forceinline__ bool chain16_meet(int* counter, int members, int* err
       return false;
     }
   }
-  return true;
+  return prior == 0;
 }
 
 typedef float f32x4n __attribute__((ext_vector_type(4)));
@@ -371,8 +372,7 @@ __global__ __launch_bounds__(256, 1) void chain16_kernel(const Chain16Args p) {
         else if (b == 0) {
           if (p.save[l]) { float* sv = p.save[l]; sv[cg] = fmean; sv[C + cg] = invstd; sv[2 * C + cg] = sc; sv[3 * C + cg] = sh; }
           const float unbiased = n > 1.0 ? (float)(m2c / (n - 1.0)) : var;
-          p.rm[l][cg] = (1.f - p.momentum) * rm_old[l] + p.momentum * fmean;
-          p.rv[l][cg] = (1.f - p.momentum) * rv_old[l] + p.momentum * unbiased;
+          running_stats_update(&p.rm[l][cg], &p.rv[l][cg], rm_old[l], rv_old[l], p.momentum, fmean, unbiased);
         }
         psc[t] = sc;
         psh[t] = sh;

@@ -83,6 +83,10 @@ __device__ __forceinline__ float4 ld_global_f4(const float4* p) { return *p; }
 
 // one lane arrives for the workgroup and waits for `members` arrivals of this launch; returns false when the bound expired
 __device__ __forceinline__ bool chain_meet(int* counter, int members, int* err_word, int code) {
+  // a raised error word is STICKY: an expired launch may leave these counters out of step, so every later launch on them gives up
+  // too (NaN outputs, which the optimizer refuses: adam_prep_seg_kernel) until the host has cleared the buffer.  The load travels
+  // with the arrival: no extra round trip.
+  const int prior = __hip_atomic_load(err_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned old = (unsigned)__hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned target = (old / (unsigned)members + 1u) * (unsigned)members;
   int spins = 0;
@@ -96,7 +100,7 @@ __device__ __forceinline__ bool chain_meet(int* counter, int members, int* err_w
       return false;
     }
   }
-  return true;
+  return prior == 0;
 }
 
 __global__ __launch_bounds__(256, 1) void chain32_kernel(const Chain32Args p) {
@@ -410,8 +414,7 @@ __global__ __launch_bounds__(256, 1) void chain32_kernel(const Chain32Args p) {
         else if (b == 0) {
           if (p.save[l]) { float* sv = p.save[l]; sv[cg] = fmean; sv[C + cg] = invstd; sv[2 * C + cg] = sc; sv[3 * C + cg] = sh; }
           const float unbiased = n > 1.0 ? (float)(m2 / (n - 1.0)) : var;
-          p.rm[l][cg] = (1.f - p.momentum) * rm_old[l] + p.momentum * fmean;
-          p.rv[l][cg] = (1.f - p.momentum) * rv_old[l] + p.momentum * unbiased;
+          running_stats_update(&p.rm[l][cg], &p.rv[l][cg], rm_old[l], rv_old[l], p.momentum, fmean, unbiased);
         }
         psc[t] = sc;
         psh[t] = sh;

@@ -370,6 +370,7 @@ __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
       int* lflag = reinterpret_cast<int*>(cl_smem + 4 * 32 * RP);
       if (t == 0) {
         int* counter = p.sync + p.cnt_base + 32 * ct;
+        const int prior = __hip_atomic_load(p.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sticky error word: chain32.hip, chain_meet
         const unsigned old = (unsigned)__hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = (old / (unsigned)p.npw + 1u) * (unsigned)p.npw;
         int spins = 0, bad = 0;
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
           __builtin_amdgcn_s_sleep(2);
           if (++spins > CL_SPIN_LIMIT) { __hip_atomic_store(p.sync, 20, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); bad = 1; break; }
         }
-        lflag[0] = bad;
+        lflag[0] = bad | (prior != 0);
       }
       __syncthreads();
       CL_STAMP(6);
@@ -417,8 +418,7 @@ __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
     if (pw == 0 && pq == 0 && rowok && fmean == fmean) {
       if (p.save) { p.save[cgl] = fmean; p.save[p.Cout + cgl] = invstd; p.save[2 * p.Cout + cgl] = sc; p.save[3 * p.Cout + cgl] = sh; }
       const float unbiased = n > 1.0 ? (float)(m2 / (n - 1.0)) : var;
-      p.rm[cgl] = (1.f - p.momentum) * rmo + p.momentum * fmean;
-      p.rv[cgl] = (1.f - p.momentum) * rvo + p.momentum * unbiased;
+      running_stats_update(&p.rm[cgl], &p.rv[cgl], rmo, rvo, p.momentum, fmean, unbiased);
     }
     if (p.y_raw && rowok && (p.raw_all || bn_inv_unsafe(fmean, invstd, sc, sh, p.slope))) store_frames(p.y_raw, v);
   } else if (p.ep == EP_BN_EVAL) {

@@ -158,6 +158,17 @@ __device__ inline float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsi
   return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
 
+// Running BatchNorm statistics (layers.py:60-66, momentum 0.1): a batch whose statistics are not finite -- the output of a launch
+// whose in-launch meeting timed out is poisoned with NaN, and every block downstream of it sees NaN -- must not reach the running
+// buffers, which outlive the step (the optimizer skips such a step too: adam_prep*).  Bit-identical for finite statistics.
+__device__ inline void running_stats_update(float* rm, float* rv, float rm_old, float rv_old, float momentum, float mean, float unbiased) {
+  const float nm = (1.f - momentum) * rm_old + momentum * mean;
+  const float nv = (1.f - momentum) * rv_old + momentum * unbiased;
+  const bool ok = (fabsf(nm) <= 3.0e38f) && (fabsf(nv) <= 3.0e38f);
+  *rm = ok ? nm : rm_old;
+  *rv = ok ? nv : rv_old;
+}
+
 __device__ inline float lrelu(float z, float slope) { return z > 0.f ? z : z * slope; }
 
 }  // namespace ms

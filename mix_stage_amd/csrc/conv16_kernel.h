@@ -416,6 +416,8 @@ __device__ __forceinline__ void conv16_epilogue_bnfused(const Conv16Args& p, con
   __syncthreads();
   if (tl.t == 0 && !(p.dbg & 128)) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (tl.t == 0 && !(p.dbg & (32 | 128))) {
+    // (a raised error word is sticky until the host clears the buffer: chain32.hip, chain_meet)
+    if (__hip_atomic_load(p.bn_sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) wcnt[NWN] = 1;
     int spins = 0;
     while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.gx) {
       __builtin_amdgcn_s_sleep(2);
@@ -479,8 +481,7 @@ __device__ __forceinline__ void conv16_epilogue_bnfused(const Conv16Args& p, con
         const int ctot = p.groups * p.Mg;
         p.save[chn] = fmean; p.save[ctot + chn] = invstd; p.save[2 * ctot + chn] = sc; p.save[3 * ctot + chn] = shf;
         const float unbiased = n > 1.0 ? (float)(m2 / (n - 1.0)) : var;
-        p.bn_m[chn] = (1.f - p.momentum) * rmean + p.momentum * fmean;
-        p.bn_v[chn] = (1.f - p.momentum) * rvar + p.momentum * unbiased;
+        running_stats_update(&p.bn_m[chn], &p.bn_v[chn], rmean, rvar, p.momentum, fmean, unbiased);
       }
     }
     scsh[tl.t * 2] = sc; scsh[tl.t * 2 + 1] = shf;

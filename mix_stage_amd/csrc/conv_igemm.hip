@@ -732,8 +732,7 @@ __global__ __launch_bounds__(256) void splitk_fwd_epilogue_kernel(const float* _
     save[2 * C + c] = sc;
     save[3 * C + c] = sh;
     const float unbiased = N > 1 ? m2 / (float)(N - 1) : var;
-    rm[c] = (1.f - momentum) * rm[c] + momentum * mean;
-    rv[c] = (1.f - momentum) * rv[c] + momentum * unbiased;
+    running_stats_update(&rm[c], &rv[c], rm[c], rv[c], momentum, mean, unbiased);
   }
 #pragma unroll
   for (int i = 0; i < NE; ++i) {
@@ -797,8 +796,7 @@ __global__ __launch_bounds__(256) void splitk_fwd_epilogue_big_kernel(const floa
     save[2 * C + c] = sc;
     save[3 * C + c] = sh;
     const float unbiased = N > 1 ? m2 / (float)(N - 1) : var;
-    rm[c] = (1.f - momentum) * rm[c] + momentum * mean;
-    rv[c] = (1.f - momentum) * rv[c] + momentum * unbiased;
+    running_stats_update(&rm[c], &rv[c], rm[c], rv[c], momentum, mean, unbiased);
   }
   for (int e = t; e < N; e += 256) {
     const int b = e / HW, pix = e - b * HW;

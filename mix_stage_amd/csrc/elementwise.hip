@@ -51,8 +51,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     save[2 * C + c] = sc;
     save[3 * C + c] = beta[c] - fmean * sc;
     const float unbiased = N > 1 ? (float)(m2 / (double)(N - 1)) : var;
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * fmean;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    running_stats_update(&running_mean[c], &running_var[c], running_mean[c], running_var[c], momentum, fmean, unbiased);
   }
 }
 
@@ -117,8 +116,7 @@ __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(const float* __r
     save[2 * C + c] = sc;
     save[3 * C + c] = sh;
     const float unbiased = N > 1 ? (float)(m2 / (double)(N - 1)) : var;
-    running_mean[c] = (1.f - momentum) * rm + momentum * fmean;
-    running_var[c] = (1.f - momentum) * rv + momentum * unbiased;
+    running_stats_update(&running_mean[c], &running_var[c], rm, rv, momentum, fmean, unbiased);
   }
 #pragma unroll
   for (int q = 0; q < FA_PRE; ++q)
@@ -1150,7 +1148,7 @@ __global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ a
 }
 
 // Adam (torch.optim.Adam defaults: no amsgrad, no weight decay) with clip_grad_norm_ folded in.
-// state words: [0] step (int32), [1] clip coef, [2] step_size = lr/bc1, [3] sqrt(bc2)
+// state words: [0] step (int32), [1] clip coef (NaN: the gradient norm was not finite, the update is skipped), [2] step_size = lr/bc1, [3] sqrt(bc2)
 __global__ void adam_prep_kernel(int32_t* state, const float* norm, float max_norm, float lr, float beta1, float beta2) {
   const int step = state[0] + 1;
   state[0] = step;
@@ -1159,6 +1157,7 @@ __global__ void adam_prep_kernel(int32_t* state, const float* norm, float max_no
   if (norm) {
     coef = max_norm / (norm[0] + 1e-6f);
     if (coef > 1.f) coef = 1.f;
+    if (!(fabsf(norm[0]) <= 3.0e38f)) coef = __builtin_nanf("");   // non-finite gradient: adam_kernel leaves p, m, v untouched
   }
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
@@ -1172,6 +1171,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float beta1, float beta2, float eps) {
   const float* f = reinterpret_cast<const float*>(state);
   const float coef = f[1], step_size = f[2], bc2s = f[3];
+  if (coef != coef) return;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float gi = g[i] * coef;
     const float mi = m[i] + (1.f - beta1) * (gi - m[i]);
@@ -1206,6 +1206,13 @@ __global__ void adam_prep_seg_kernel(int32_t* state, const float* norm, float ma
     if (norm) {
       coef = max_norm / (norm[0] + 1e-6f);
       if (coef > 1.f) coef = 1.f;
+      // A non-finite gradient norm (a launch whose in-launch meeting timed out poisons its output with NaN, and the NaN reaches
+      // every gradient behind it) must not reach the weights or the moments: the update of this step is SKIPPED on the device --
+      // word 2 flags the step, word 3 counts such steps (MixStageTrainStep reads both with the losses); the step clocks advance
+      // as if the step had had a zero gradient and frozen moments.
+      const bool bad = !(fabsf(norm[0]) <= 3.0e38f);
+      state[2] = bad ? 1 : 0;
+      if (bad) state[3] += 1;
     }
     reinterpret_cast<float*>(state)[1] = coef;
   }
@@ -1217,6 +1224,7 @@ __global__ __launch_bounds__(256) void adam_seg_kernel(float* __restrict__ p, co
                                                        const float* __restrict__ seg_scratch, float beta1, float beta2,
                                                        float eps) {
   const float coef = reinterpret_cast<const float*>(state)[1];
+  if (state[2]) return;                        // non-finite gradient norm: no update (adam_prep_seg_kernel)
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const int sidx = seg_of_chunk[i >> 6];
     const float step_size = seg_scratch[2 * sidx], bc2s = seg_scratch[2 * sidx + 1];

@@ -132,8 +132,7 @@ __global__ __launch_bounds__(256) void bn_finalize_apply16_kernel(const float* _
         save[2 * C + c] = sc;
         save[3 * C + c] = shf;
         const float unbiased = N > 1 ? (float)(m2 / (double)(N - 1)) : var;
-        running_mean[c] = (1.f - momentum) * rm + momentum * fmean;
-        running_var[c] = (1.f - momentum) * rv + momentum * unbiased;
+        running_stats_update(&running_mean[c], &running_var[c], rm, rv, momentum, fmean, unbiased);
       }
     }
     scsh[j] = sc; scsh[8 + j] = shf;

@@ -125,10 +125,13 @@ struct WgradPatchArgs {
   int tiles_x, tiles_y, n_tiles, tiles_per_split, splits;
   int gx, gy, gz;      // logical grid (column tiles, channel tiles, groups*splits); launched 1-D, XCD-remapped
   int accumulate;      // splits == 1 only: out += result instead of out = result (queued launches, ms_wgrad_flush)
+  int n_steps, steps_per_split;   // lean kernel (wgrad_wave_body): the reduction counted in 16-pixel runs of one output row
+  int wave_kind;                  // ... its instance: stride * 2 + (tile == 64 x 256) ...
+  int KH, KW, w4, nx4, xrp, xcp, xbuf;   // ... and the shape's geometry: taps, 16-byte slots per window row / in all, LDS pitches of the x window (row, channel), its size
   int* counters;       // per (group, channel tile, column tile) arrival counters: the last split sums the slabs in-launch
   float* final_out;    // dw, written by the last arriver
 };
-struct WgradPatchPlan { int ok, tw, tiles_y, tiles_x, n_tiles, splits, tiles_per_split, p6; };
+struct WgradPatchPlan { int ok, tw, tiles_y, tiles_x, n_tiles, splits, tiles_per_split, p6, wave; };   // wave: lean kernel's tile (0: the 64 x 64 kernel, 1: 128 x 128, 2: 64 x 256)
 // queued launches: many blocks' weight gradients side by side in one multi-block launch per kernel instance
 constexpr int WGP_MAX_JOBS = 24;
 struct WgradPatchBatch {
@@ -142,7 +145,8 @@ void wgrad_patch_discard();
 bool wgrad6_supported(int KH, int KW, int S);
 int launch_wgrad_patch6(const WgradPatchArgs& a, const WgradPatchPlan& pl, int KH, int KW, int S, bool up2, double flops,
                         double bytes, hipStream_t s);
-WgradPatchPlan plan_wgrad_patch(int nd, int Cog, int Kg, int groups, int KH, int KW, int SH, int SW, int B, int OH, int OW);
+WgradPatchPlan plan_wgrad_patch(int nd, int Cog, int Kg, int groups, int KH, int KW, int SH, int SW, int B, int OH, int OW, int W = 0,
+                                bool up2 = false);   // W: input row length (0: unknown -> the 64 x 64 kernel)
 int launch_wgrad_patch(const WgradPatchArgs& a, const WgradPatchPlan& pl, int KH, int KW, int S, bool up2, double flops,
                        double bytes, hipStream_t s);
 int launch_reduce_splits(const float* part, float* out, int n, int splits, hipStream_t s);

@@ -213,6 +213,9 @@ DEFER_WGRAD_LAUNCH = os.environ.get('MS_DEFER_WGRAD_LAUNCH', '1') != '0'   # exp
 
 def enable_deferred_wgrad(on):
   _deferred['on'] = bool(on)
+  # planner hint (fp32 weight gradients): queued launches share the chip, so a layer's workgroups take long runs of the pixel
+  # reduction instead of splitting it until the layer fills the chip alone (MS_WGRAD_TPS: tiles per workgroup, experiments)
+  lib().ms_set_wgrad_batched(1 if (on and DEFER_WGRAD_LAUNCH) else 0, int(os.environ.get('MS_WGRAD_TPS', '0')))
   reset_deferred_wgrad()
   if not on:
     _deferred['bufs'].clear()

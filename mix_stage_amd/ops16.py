@@ -107,6 +107,16 @@ def bn_sync_clear():
     b.zero_()
 
 
+def check_meetings():
+  """Raises if any launch of this process whose workgroups meet inside the launch gave up waiting (its outputs were NaN), and
+  re-arms the counters.  Synchronises the device."""
+  if bn_sync_error():
+    words = bn_sync_words()
+    bn_sync_clear()
+    raise RuntimeError('(sync words %s) an in-launch BatchNorm meeting timed out (the launch did not have the GPU to itself): the launch produced '
+                       'NaN; see MixStageTrainStep.check_health' % (words,))
+
+
 # ------------------------------------------------------------------------------------------------
 # layout converters
 class _ToCb8Fn(torch.autograd.Function):

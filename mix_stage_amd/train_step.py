@@ -302,7 +302,19 @@ class MixStageTrainStep:
       if len(set(seen)) < len(seen):
         ops16.set_in_launch_meetings(False)
     self._capture_stream = torch.cuda.Stream()      # warm-up and capture of every step kind: its scratch / counters are the graphs'
-    self.health_every = 256                         # steps between check_health() calls (one device synchronisation each; 0: never)
+    # Health, every step and without a device synchronisation: the optimizer REFUSES a step whose gradient norm is not finite
+    # (ms_adam_step_segmented: weights and moments untouched; the kernels keep such a batch out of the running BatchNorm statistics
+    # too) and counts it in its state words; a raised meeting error word is sticky on the device (every later launch on those
+    # counters yields NaN, i.e. more refused steps).  The two counters travel to pinned host memory behind every step -- the same
+    # D2H path `losses` take when the caller reads them -- and are looked at when their copy has completed (at most
+    # `_HEALTH_LAG` steps later): on_bad_step = 'raise' (default) raises then, with the model state intact; 'skip' warns, re-arms
+    # the meeting counters and goes on.  health_every > 0 additionally forces the synchronising check_health() every so many steps.
+    self.on_bad_step = 'raise'
+    self.health_every = 0
+    self._health_pin = torch.zeros(2, dtype=torch.int32).pin_memory()
+    self._health_events = []
+    self._health_seen = 0
+    self.skipped_steps = 0
     self._steps = 0
     self._graphs = {}
     self._static = None
@@ -457,19 +469,64 @@ class MixStageTrainStep:
       if kind is not None:
         m.D_prob = saved
     self._steps += 1
+    self._post_health()
     if self.health_every and self._steps % self.health_every == 0:
       self.check_health()
     return k
 
-  def check_health(self):
-    """Raises if a launch whose workgroups meet inside the launch (in-launch BatchNorm, chained decoder) gave up waiting: its
-    outputs were poisoned with NaN.  Synchronises the device.  Causes: another process or a large kernel on another stream held
-    compute units the launch needed -- run one trainer per GPU, or switch the forms off (ops16.set_in_launch_meetings(False))."""
-    if ops16.bn_sync_error():
+  _HEALTH_LAG = 4          # steps the host may run ahead of the health words before it waits for the oldest copy
+
+  def _post_health(self):
+    """Behind every step: both optimizers' refused-step counters -> pinned host memory (two 4-byte asynchronous copies on the
+    step's stream, no synchronisation), then look at whatever has already arrived."""
+    self._health_pin[0:1].copy_(self.optim_G.step_state[3:4], non_blocking=True)
+    self._health_pin[1:2].copy_(self.optim_D.step_state[3:4], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    self._health_events.append(ev)
+    self._poll_health(len(self._health_events) > self._HEALTH_LAG)
+
+  def _poll_health(self, wait_oldest=False):
+    evs = self._health_events
+    if wait_oldest and evs:
+      evs[0].synchronize()
+    arrived = False
+    while evs and evs[0].query():
+      evs.pop(0)
+      arrived = True
+    if arrived:
+      count = int(self._health_pin[0]) + int(self._health_pin[1])      # (monotonic: a later step's copy only adds to it)
+      if count > self._health_seen:
+        self._bad_steps(count)
+
+  def _bad_steps(self, count):
+    new, self._health_seen = count - self._health_seen, count
+    self.skipped_steps += new
+    words = None
+    if ops16.bn_sync_error():               # (synchronises; we are off the fast path here)
       words = ops16.bn_sync_words()
-      ops16.bn_sync_clear()
-      raise RuntimeError('(sync words %s) an in-launch BatchNorm meeting timed out (the launch did not have the GPU to itself): the step produced '
-                         'NaN; see MixStageTrainStep.check_health' % (words,))
+      ops16.bn_sync_clear()                 # re-arm: counters and the sticky error word back to zero
+    why = ('an in-launch BatchNorm / decoder-chain meeting timed out (the launch did not have the GPU to itself; sync words %s)' % (words,)
+           if words is not None else 'a non-finite gradient norm')
+    msg = ('%d training step(s) were refused on the device: %s.  Weights, Adam moments and running BatchNorm statistics were left '
+           'untouched by those steps; the meeting counters are re-armed.  See MixStageTrainStep.check_health' % (new, why))
+    if self.on_bad_step == 'raise':
+      raise RuntimeError(msg)
+    import warnings
+    warnings.warn(msg)
+
+  def check_health(self):
+    """Synchronising form of the per-step health check (call it before saving a checkpoint and at the end of an epoch): raises
+    (on_bad_step='raise') if a step was refused since the last look -- a launch whose workgroups meet inside the launch (in-launch
+    BatchNorm, chained decoder) gave up waiting and poisoned its outputs with NaN, or a gradient was not finite.  Causes of the
+    former: another process or a large kernel on another stream held compute units the launch needed -- run one trainer per GPU, or
+    switch the forms off (ops16.set_in_launch_meetings(False))."""
+    torch.cuda.synchronize()
+    self._health_events = []
+    count = int(self.optim_G.step_state[3]) + int(self.optim_D.step_state[3])
+    if count > self._health_seen:
+      self._bad_steps(count)
+    ops16.check_meetings()                  # a meeting that expired outside a training step (e.g. an evaluation forward)
 
   def _graph_step(self, k, pose_branch, audio, labels, pose, style, inputs_unchanged=False):
     self.model._lambda_host_writes = False   # the captured loss kernels read the device tensor written below

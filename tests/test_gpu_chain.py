@@ -235,7 +235,7 @@ def test_an_expired_meeting_is_reported_and_poisons_the_output():
   assert ops16.bn_sync_error()
   assert any(w[0] != 0 for w in ops16.bn_sync_words())          # which meeting gave up (the peers that wait for the late workgroup at block 1 may expire too and overwrite block 0's code)
   with pytest.raises(RuntimeError, match='meeting timed out'):
-    MixStageTrainStep.check_health(None)
+    ops16.check_meetings()
   assert not ops16.bn_sync_error()                               # cleared (all words: the counters start again from zero)
   again = _run(blocks, logits, x, score, P, True, grad=False)
   assert torch.equal(again['out'], good['out'])

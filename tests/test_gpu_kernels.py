@@ -58,6 +58,9 @@ BLOCK_CASES = [
     ('ae1', '2d', 64, 64, 4, 2, 1, (32, 48), 'plain'),
     ('ae2', '2d', 64, 128, None, None, 1, (16, 24), 'plain'),
     ('ae5', '2d', 256, 256, 4, 2, 1, (16, 32), 'plain'),
+    ('ae2_w32', '2d', 64, 128, None, None, 1, (6, 32), 'plain'),     # 3x3 with whole 16-pixel runs (the wave-pipelined weight gradient)
+    ('ae1_w64', '2d', 64, 64, 4, 2, 1, (12, 64), 'plain'),
+    ('ae6_w16', '2d', 256, 256, None, None, 1, (8, 16), 'plain'),
     ('ae7', '2d', 256, 256, (3, 8), 1, 1, (8, 16), 'plain'),
     ('ragged2d', '2d', 3, 6, (3, 8), 1, 1, (5, 11), 'plain'),
     ('odd_s2_2d', '2d', 5, 7, 4, 2, 1, (9, 37), 'plain'),      # stride-2 parity classes of different extents
@@ -77,18 +80,22 @@ def _mk_block(mod, case, seed=0):
   return blk
 
 
-@pytest.fixture(params=['auto', 'patch', 'gather'])
+@pytest.fixture(params=['auto', 'patch', 'patch_nowave', 'gather'])
 def kernel_path(request):
   """'auto': the production dispatch (at these sizes mostly the one-workgroup-per-channel small-conv kernel); 'patch'
   forces the patch-staged MFMA kernels wherever their geometry allows (normally chosen for launches with >= 32
-  workgroups); 'gather' forces the im2col-gather MFMA kernels with split-K (normally the fallback)."""
+  workgroups); 'patch_nowave' the same with the weight gradient kept on the barrier-per-tile kernel (the wave-pipelined one takes
+  the layers with whole 16-pixel runs otherwise); 'gather' forces the im2col-gather MFMA kernels with split-K (normally the
+  fallback)."""
   from mix_stage_amd import _lib
-  old = _lib.lib().ms_debug_set_patch_min_workgroups({'patch': 0, 'gather': 1 << 30}.get(request.param, 32))
+  old = _lib.lib().ms_debug_set_patch_min_workgroups({'patch': 0, 'patch_nowave': 0, 'gather': 1 << 30}.get(request.param, 32))
+  old_wave = _lib.lib().ms_debug_set_wgrad_wave(0 if request.param == 'patch_nowave' else 1)
   # ('auto' also takes the clip-resident 1-D kernels where a block qualifies, tests/test_gpu_clip.py; the forced paths keep them off)
   old_clip = _lib.lib().ms_debug_set_clip32(1 if request.param == 'auto' else 0)
   yield request.param
   _lib.lib().ms_debug_set_patch_min_workgroups(old)
   _lib.lib().ms_debug_set_clip32(old_clip)
+  _lib.lib().ms_debug_set_wgrad_wave(old_wave)
 
 
 @pytest.mark.parametrize('case', BLOCK_CASES, ids=[c[0] for c in BLOCK_CASES])
@@ -156,7 +163,7 @@ def _conv_block_case(case, B, seed):
   return True
 
 
-@pytest.mark.parametrize('case', [BLOCK_CASES[1], BLOCK_CASES[3], BLOCK_CASES[16], BLOCK_CASES[19]],
+@pytest.mark.parametrize('case', [c for c in BLOCK_CASES if c[0] in ('dec1', 'unet_down64', 'ae1', 'ae7')],
                          ids=lambda c: c[0])
 def test_conv_block_eval_mode(case, kernel_path):
   import mix_stage_amd as A
