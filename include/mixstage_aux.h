@@ -57,6 +57,8 @@ int ms_debug_set_wgrad_target(int workgroups);      /* the same for the fp32 pat
 /* Test / ablation aid: 0 = the fp32 weight gradient never takes the wave-pipelined kernel (wgrad_wave_multi_kernel: no workgroup
  * barrier in the reduction loop), 1 = it does where the layer qualifies (default).  Returns the previous value. */
 int ms_debug_set_wgrad_wave(int on);
+/* ... and 0 = the fp32 2-D convs never take the lean 128 x 128-tile kernel (conv_tile_kernel).  Returns the previous value. */
+int ms_debug_set_conv_tile(int on);
 /* Test / ablation aid: 0 = 16-bit BN_TRAIN blocks never take the in-launch BatchNorm form (ms_set_bn_sync_buffer), 1 = they do
  * when eligible (default).  Returns the previous value. */
 int ms_debug_set_bn_fused(int on);

@@ -154,6 +154,7 @@ SIGNATURES = {
     'ms_debug_set_wgrad16_ring': (c_int, [c_int]),
     'ms_debug_set_wgrad_target': (c_int, [c_int]),
     'ms_debug_set_wgrad_wave': (c_int, [c_int]),
+    'ms_debug_set_conv_tile': (c_int, [c_int]),
     'ms_set_wgrad_batched': (c_int, [c_int, c_int]),
     'ms_selftest_mfma': (c_int, [_P, _P, _P, c_int, _P]),
 }
@@ -188,6 +189,8 @@ def lib():
       handle.ms_debug_set_bn_fused_min_workgroups(int(os.environ['MS_BN_FUSED_MIN_WGS']))
     if os.environ.get('MS_CLIP32'):             # ablations only: MS_CLIP32=0 keeps the per-layer patch / gather kernels
       handle.ms_debug_set_clip32(int(os.environ['MS_CLIP32']))
+    if os.environ.get('MS_CONV_TILE'):          # ablations only: MS_CONV_TILE=0 keeps the 2-D fp32 convs on conv_patch_kernel
+      handle.ms_debug_set_conv_tile(int(os.environ['MS_CONV_TILE']))
     if os.environ.get('MS_WGRAD_WAVE'):         # ablations only: MS_WGRAD_WAVE=0 keeps the barrier-per-tile fp32 weight gradient
       handle.ms_debug_set_wgrad_wave(int(os.environ['MS_WGRAD_WAVE']))
     if os.environ.get('MS_PATCH_MIN_WGS'):      # tuning experiments only (ms_debug_set_patch_min_workgroups)

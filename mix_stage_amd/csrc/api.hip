@@ -47,7 +47,7 @@ static GatherPlan dgrad_plan(const ms_conv_desc* d) {
 
 static PatchPlan fwd_patch_plan(const ms_conv_desc* d) {
   const int nd = (d->H == 1 && d->KH == 1) ? 1 : 2;
-  return plan_patch(nd, d->Cout, d->groups, d->Cin, d->KH, d->KW, d->SH, d->SW, d->B, d->OH, d->OW);
+  return plan_patch(nd, d->Cout, d->groups, d->Cin, d->KH, d->KW, d->SH, d->SW, d->B, d->OH, d->OW, 1, d->W);
 }
 
 static inline int ctot_of(const ms_conv_desc* d) { return d->groups * d->Cout; }
@@ -99,7 +99,7 @@ size_t ms_conv_block_bwd_workspace(const ms_conv_desc* d) {
     const int tg2 = bc ? 1 : d->groups, tcog2 = bc ? d->groups * d->Cout : d->Cout;
     const bool one_d2 = d->H == 1 && d->KH == 1;
     const PatchPlan pq = plan_patch(one_d2 ? 1 : 2, d->Cin, tg2, tcog2, cdiv(d->KH, d->SH), cdiv(d->KW, d->SW), 1, 1, d->B,
-                                    cdiv(d->H, d->SH), cdiv(d->W, d->SW), d->SH * d->SW);
+                                    cdiv(d->H, d->SH), cdiv(d->W, d->SW), d->SH * d->SW, d->OW);
     if (pq.ok && pq.splitk > 1) bytes += align_up((size_t)pq.splitk * d->B * tg2 * d->Cin * d->H * d->W * sizeof(float), 256);
     if (pq.ok && pq.p6)   // bf16x6 data gradient: split planes of the transposed weights
       bytes += align_up((size_t)3 * d->SH * d->SW * tg2 * d->Cin * patch6_row_elems(tcog2, cdiv(d->KH, d->SH), cdiv(d->KW, d->SW)) * 2, 256);
@@ -275,7 +275,7 @@ static DgradWeights dgrad_weights_of(const ms_conv_desc* d, const float* w) {
   const int jh = cdiv(d->KH, d->SH), jw = cdiv(d->KW, d->SW);
   const bool one_d = d->H == 1 && d->KH == 1;
   const PatchPlan pp0 = plan_patch(one_d ? 1 : 2, d->Cin, r.tg, r.tcog, jh, jw, 1, 1, d->B, cdiv(d->H, d->SH), cdiv(d->W, d->SW),
-                                   d->SH * d->SW);
+                                   d->SH * d->SW, d->OW);
   const bool direct = pp0.ok && !pp0.p6 && patch_dgrad_direct_ok(w, d->Cin, d->KH, d->KW, d->SH, d->SW, bcast);
   r.need = direct ? 0 : 1;
   r.flip = pp0.ok ? 1 : 0;
@@ -564,7 +564,7 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
     const int ncls = d->SH * d->SW;
     // patch-staged path: each output-parity class is a dense stride-1 forward conv of dy_raw with the class's taps
     // reversed (weights prepared by transpose_weight_kernel(flip=1)); outputs are scattered with stride (SH, SW)
-    const PatchPlan pp0 = plan_patch(one_d ? 1 : 2, d->Cin, tg, tcog, jh, jw, 1, 1, d->B, cdiv(d->H, d->SH), cdiv(d->W, d->SW), ncls);
+    const PatchPlan pp0 = plan_patch(one_d ? 1 : 2, d->Cin, tg, tcog, jh, jw, 1, 1, d->B, cdiv(d->H, d->SH), cdiv(d->W, d->SW), ncls, d->OW);
     // stride-1 convs with whole 64-channel tiles: the patch kernel reads w in place, no transposed copy
     const bool direct = pp0.ok && !pp0.p6 && patch_dgrad_direct_ok(w, d->Cin, d->KH, d->KW, d->SH, d->SW, bcast != 0);
     if (wt_prepared) {

@@ -416,8 +416,17 @@ int patch_chunk_channels(int KH, int KW) {
   return khw == 1 ? 32 : khw == 2 ? 16 : khw == 3 ? 16 : khw == 4 ? 16 : khw == 9 ? MS_CK9 : khw == 16 ? MS_CK16 : khw == 24 ? MS_CK24 : 4;
 }
 
-PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH, int SW, int B, int OH, int OW, int zmul) {
-  PatchPlan pl = {0, 1, 64, 0, 0, 0, 1, 1 << 30, 1, 2, 1, 0};
+static PatchPlan plan_patch_impl(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH, int SW, int B, int OH, int OW, int zmul, int in_w);
+int g_tile_min_wgs = 256;     // layers with fewer 128 x 128 (64 x 256) tiles than this stay on the 64 x 64 kernel: measured, round 5 -- the
+                              // mid layers (128 tiles) need split-K partials + an epilogue launch there, which costs what the tile kernel wins
+PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH, int SW, int B, int OH, int OW, int zmul, int in_w) {
+  PatchPlan pl = plan_patch_impl(nd, Mg, groups, Kc, KH, KW, SH, SW, B, OH, OW, zmul, in_w);
+  if (pl.tile && (long)pl.n_tiles * cdiv(Mg, 64 * pl.tm) * groups * zmul < g_tile_min_wgs)
+    pl = plan_patch_impl(nd, Mg, groups, Kc, KH, KW, SH, SW, B, OH, OW, zmul, 0);
+  return pl;
+}
+static PatchPlan plan_patch_impl(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH, int SW, int B, int OH, int OW, int zmul, int in_w) {
+  PatchPlan pl = {0, 1, 64, 0, 0, 0, 1, 1 << 30, 1, 2, 1, 0, 0};
   const int S = SW;
   if (nd == 2 && SH != SW) return pl;
   const bool known = (KH == 1 && KW == 2 && S == 1) || (KH == 2 && KW == 2 && S == 1) || (KH == 1 && KW == 3 && S == 1) ||
@@ -431,20 +440,24 @@ PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH,
   if (nd == 1) tw = OW > 32 ? 64 : OW > 16 ? 32 : 16;
   else tw = OW > 16 ? 32 : 16;
   const bool p6 = g_precision == 1 && patch6_supported(KH, KW, S);   // bf16x6 kernels: 64 x 128 tiles
-  const int tm = 1, tn = p6 ? 2 : 1;
+  // the lean kernel (conv_tile.hip: 128 x 128 or, for at most 64 output rows, 64 x 256 tiles): 2-D layers whose input rows are
+  // 16-byte aligned and whose weight rows are whole 16-byte runs
+  const int tile = (g_conv_tile && !p6 && nd == 2 && conv_tile_shape_ok(KH, KW, S) && in_w > 0 && (in_w & 3) == 0 && ((Kc * KH * KW) & 3) == 0 &&
+                    (Mg <= 64 || Mg % 128 == 0 || KH * KW == 4 || KH * KW == 16)) ? (Mg <= 64 ? 2 : 1) : 0;
+  const int tm = tile == 1 ? 2 : 1, tn = tile == 1 ? 2 : tile == 2 ? 4 : p6 ? 2 : 1;
   const int th = 64 * tn / tw;
-  pl.ok = 1; pl.tm = tm; pl.tw = tw; pl.tn = tn; pl.p6 = p6 ? 1 : 0;
+  pl.ok = 1; pl.tm = tm; pl.tw = tw; pl.tn = tn; pl.p6 = p6 ? 1 : 0; pl.tile = tile;
   pl.tiles_y = cdiv(rows, th); pl.tiles_x = cdiv(OW, tw);
   pl.n_tiles = imgs * pl.tiles_y * pl.tiles_x;
   const long base = (long)pl.n_tiles * cdiv(Mg, 64 * tm) * groups * zmul;   // zmul: parity classes sharing the launch
   // too few workgroups: the split-K im2col path spreads the weight stream better
   if (base * tn < g_patch_min_wgs) pl.ok = 0;   // (bf16x6: 128-pixel tiles, half as many workgroups for the same layer)
   // fewer workgroups than 1.5 per CU and a long reduction: slice the channel chunks over workgroups
-  const int nchunks = cdiv(Kc, p6 ? (KH * KW <= 4 ? 16 : 8) : patch_chunk_channels(KH, KW));   // (bf16x6: 16 / 8 channels)
+  const int nchunks = cdiv(Kc, tile ? (KH * KW == 4 ? 8 : KH * KW == 9 ? 4 : 2) : p6 ? (KH * KW <= 4 ? 16 : 8) : patch_chunk_channels(KH, KW));   // (bf16x6: 16 / 8 channels; lean kernel: TileCfg)
   if (pl.ok && g_patch_force_splitk > 0 && nchunks >= g_patch_force_splitk) {
     pl.chunks_per_split = cdiv(nchunks, g_patch_force_splitk);
     pl.splitk = cdiv(nchunks, pl.chunks_per_split);
-  } else if (pl.ok && base < (p6 ? 256 : 384) && nchunks >= 4) {   // (bf16x6: 128-pixel tiles, 2 workgroups per CU)
+  } else if (pl.ok && base < (p6 || tile ? 256 : 384) && nchunks >= 4) {   // (bf16x6 / lean kernel: larger tiles, fewer workgroups per CU)
     const long base32 = (long)pl.n_tiles * cdiv(Mg, 32) * groups * zmul;
     // (short reductions only: with a long K -- the 2048-channel data gradient of the first decoder layer -- slices over
     // workgroups keep more of the chip busy: 91 vs 152 us)
@@ -523,6 +536,11 @@ bool patch_dgrad_direct_ok(const float* w, int Cin_g, int KH, int KW, int SH, in
 
 int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S, bool up2, double flops, double bytes,
                  hipStream_t s) {
+  if (pl.tile) {
+    if (up2 || (a.a_vec != 2 && !(a.a_vec && ((uintptr_t)a.A & 15) == 0)) || ((uintptr_t)a.src & 15))
+      return set_error("conv: the lean kernel needs 16-byte-aligned operands (weights %p, input %p)", (const void*)a.A, (const void*)a.src);
+    return launch_tile(a, pl, KH, KW, S, flops, bytes, s);
+  }
   const int bm = 32 * pl.wm;
   PatchArgs b = a;
   if (a.ncls > 4) return set_error("patch conv: more than 4 parity classes");

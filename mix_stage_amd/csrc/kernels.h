@@ -83,8 +83,11 @@ struct PatchArgs {
   unsigned plane_stride;       // elements per plane
   int a_row_elems;
 };
-struct PatchPlan { int ok, tm, tw, tiles_y, tiles_x, n_tiles, splitk, chunks_per_split, tn, wm, ksi, p6; };   // wm: 32-row wave tiles per tile; ksi: intra-workgroup K split
-PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH, int SW, int B, int OH, int OW, int zmul = 1);
+struct PatchPlan { int ok, tm, tw, tiles_y, tiles_x, n_tiles, splitk, chunks_per_split, tn, wm, ksi, p6, tile; };   // wm: 32-row wave tiles per tile; ksi: intra-workgroup K split; tile: lean kernel (conv_tile.hip), 1 = 128 x 128, 2 = 64 x 256
+PatchPlan plan_patch(int nd, int Mg, int groups, int Kc, int KH, int KW, int SH, int SW, int B, int OH, int OW, int zmul = 1, int in_w = 0);   // in_w: row length of the conv's input (0: unknown -> never the lean kernel)
+extern int g_conv_tile;
+bool conv_tile_shape_ok(int KH, int KW, int S);
+int launch_tile(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S, double flops, double bytes, hipStream_t s);
 int patch_chunk_channels(int KH, int KW);
 bool patch_dgrad_direct_ok(const float* w, int Cin_g, int KH, int KW, int SH, int SW, bool up2_or_bcast);
 int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S, bool up2, double flops, double bytes,
