@@ -19,6 +19,9 @@
 
 #include "kernels.h"
 
+#ifndef MS_TILE_OCC
+#define MS_TILE_OCC 2
+#endif
 namespace ms {
 
 int g_conv_tile = 1;          // ms_debug_set_conv_tile: 0 keeps every layer on conv_patch_kernel
@@ -42,7 +45,7 @@ constexpr int tile_row_pitch(int win, int sv, int tw) {
 // AM 1: A rows [Mg][Kg], 16-byte loads.  AM 2: data gradient straight from the conv weight w[co][ci][tap] (stride-1 convs):
 // A(ci, (co, tap')) = w[co][ci][KHW-1-tap'], Mg = Cin_g, Kc = Cout_g.
 template <int KH, int KW, int S, int TW, int AM, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv_tile_kernel(const PatchArgs p) {
+__global__ __launch_bounds__(256, MS_TILE_OCC) void conv_tile_kernel(const PatchArgs p) {
   prefetch_kernargs<sizeof(PatchArgs)>();
   using Cfg = TileCfg<KH, KW>;
   static_assert(WM * WN == 4, "four waves");

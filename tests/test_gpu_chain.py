@@ -234,6 +234,12 @@ def test_an_expired_meeting_is_reported_and_poisons_the_output():
   assert not torch.isfinite(bad['out']).all()
   assert ops16.bn_sync_error()
   assert any(w[0] != 0 for w in ops16.bn_sync_words())          # which meeting gave up (the peers that wait for the late workgroup at block 1 may expire too and overwrite block 0's code)
+  # the raised error word is STICKY: with the counter repaired by hand the next launch meets normally, yet still gives up
+  # (NaN) -- an expired launch may leave counters out of step in ways nobody can see, so nothing is trusted until the host
+  # has cleared the buffer
+  buf[first] -= 1
+  still_bad = _run(blocks, logits, x, score, P, True, grad=False)
+  assert not torch.isfinite(still_bad['out']).all()
   with pytest.raises(RuntimeError, match='meeting timed out'):
     ops16.check_meetings()
   assert not ops16.bn_sync_error()                               # cleared (all words: the counters start again from zero)

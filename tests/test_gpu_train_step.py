@@ -332,3 +332,57 @@ def test_fp16_training_is_refused_and_bn_sync_is_per_trainer():
   assert ops._bn_sync['on'] is True           # ... but a's step runs with a's setting (one rank: same arithmetic as local)
   b.step(audio.to(DEV), labels.to(DEV), pose.to(DEV), style.to(DEV), kind='D')
   assert ops._bn_sync['on'] is False
+
+
+def test_a_step_with_non_finite_gradients_is_refused_on_the_device():
+  """A NaN anywhere in a step's gradients (here: a poisoned input; in production: the output of a launch whose in-launch meeting
+  timed out) must not reach the weights, the Adam moments or the running BatchNorm statistics: ms_adam_step_segmented skips the
+  update and counts it, the kernels keep the batch out of the running buffers, MixStageTrainStep reports it (per-step polling /
+  check_health) -- and the next clean step trains normally."""
+  import warnings
+  from mix_stage_amd.train_step import MixStageTrainStep
+  M = S = 2
+  for use_graphs in (False, True):
+    model = _hip(M, S)
+    ts = MixStageTrainStep(model, use_graphs=use_graphs)
+    ts.on_bad_step = 'skip'
+    good = [t.to(DEV) for t in O.synthetic_batch(3, M=M, S=S, seed=11)]
+    audio, pose, labels, style = good
+    for kind in ('G', 'D'):
+      ts.step(audio, labels, pose, style, kind=kind)
+    torch.cuda.synchronize()
+    ts.check_health()
+    assert ts.skipped_steps == 0
+    snap = dict(pG=ts.optim_G.flat_p.clone(), pD=ts.optim_D.flat_p.clone(), mG=ts.optim_G.exp_avg.clone(), vG=ts.optim_G.exp_avg_sq.clone(),
+                mD=ts.optim_D.exp_avg.clone(), bufs={n: b.clone() for n, b in model.named_buffers() if b.is_floating_point()})
+    bad_pose = pose.clone()
+    bad_pose[1, 5, 7] = float('nan')
+    bad_audio = audio.clone()
+    bad_audio[0, 3, 9] = float('nan')
+    with warnings.catch_warnings(record=True) as caught:
+      warnings.simplefilter('always')
+      ts.step(bad_audio, labels, bad_pose, style, kind='G')
+      ts.step(audio, labels, bad_pose, style, kind='D')
+      torch.cuda.synchronize()
+      ts.check_health()
+    assert ts.skipped_steps == 2, ts.skipped_steps
+    assert any('refused' in str(w.message) for w in caught)
+    assert torch.equal(ts.optim_G.flat_p, snap['pG']) and torch.equal(ts.optim_D.flat_p, snap['pD'])
+    assert torch.equal(ts.optim_G.exp_avg, snap['mG']) and torch.equal(ts.optim_G.exp_avg_sq, snap['vG']) and torch.equal(ts.optim_D.exp_avg, snap['mD'])
+    for n, b in model.named_buffers():
+      if b.is_floating_point():
+        assert torch.isfinite(b).all(), n
+        # running statistics: a poisoned batch leaves no trace.  (D's BatchNorm sees two batches per D-step, gan.py:120,126: the
+        # clean fake-pose pass of the refused D-step did update D's running statistics -- finite, valid statistics.)
+        if n.startswith('G.'):
+          assert torch.equal(b, snap['bufs'][n]), n
+    # on_bad_step = 'raise' (the default) raises instead of warning
+    ts.on_bad_step = 'raise'
+    ts.step(bad_audio, labels, bad_pose, style, kind='G')
+    with pytest.raises(RuntimeError, match='refused'):
+      ts.check_health()
+    # ... and training goes on from the intact state
+    ts.step(audio, labels, pose, style, kind='G')
+    torch.cuda.synchronize()
+    ts.check_health()
+    assert not torch.equal(ts.optim_G.flat_p, snap['pG']) and torch.isfinite(ts.optim_G.flat_p).all()
