@@ -169,6 +169,10 @@ __device__ inline void running_stats_update(float* rm, float* rv, float rm_old, 
   *rv = ok ? nv : rv_old;
 }
 
+__device__ inline float2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+}
+
 __device__ inline float lrelu(float z, float slope) { return z > 0.f ? z : z * slope; }
 
 }  // namespace ms

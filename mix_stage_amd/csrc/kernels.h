@@ -136,7 +136,7 @@ struct WgradPatchArgs {
 };
 struct WgradPatchPlan { int ok, tw, tiles_y, tiles_x, n_tiles, splits, tiles_per_split, p6, wave; };   // wave: lean kernel's tile (0: the 64 x 64 kernel, 1: 128 x 128, 2: 64 x 256)
 // queued launches: many blocks' weight gradients side by side in one multi-block launch per kernel instance
-constexpr int WGP_MAX_JOBS = 24;
+constexpr int WGP_MAX_JOBS = 48;    // (48 x 192 B of kernel arguments: every fp32 layer of the G-step in one launch)
 struct WgradPatchBatch {
   int n;
   int block_end[WGP_MAX_JOBS];

@@ -267,9 +267,12 @@ constexpr bool wave_banks_ok(int KH, int KW, int RP, int CP) {
   return true;
 }
 static_assert(wave_banks_ok(1, 3, 35, 35) && wave_banks_ok(3, 3, 35, 105) && wave_banks_ok(1, 4, 44, 44) && wave_banks_ok(4, 4, 44, 176) &&
-              wave_banks_ok(1, 1, 16, 17), "x window pitches put two columns of a read into one bank");
+              wave_banks_ok(1, 1, 16, 17) && wave_banks_ok(3, 8, 40, 120), "x window pitches put two columns of a read into one bank");
 
-template <int S, int WM, int WN>
+// MODE 0: plain.  1: dy rows are not 16-byte aligned / not whole 16-pixel runs (the (3, 8) layer: rows of 15) -- dy travels dword by
+// dword, pixels past the row end are zeros.  2: the input is nearest_up2(a) + r (UNet1D's up path, layers.py:148-151): a at half
+// resolution (p.src, 8-byte loads), r at full resolution (p.src2); the strides describe r.
+template <int S, int WM, int WN, int MODE = 0>
 __device__ __forceinline__ void wgrad_wave_body(const WgradPatchArgs& p, const int bid, float* smem) {
   static_assert(WM * WN == 4, "four waves");
   constexpr int LDA = WV_LDA, BM = 64 * WM, BN = 64 * WN, ABUF = BM * LDA;
@@ -288,7 +291,7 @@ __device__ __forceinline__ void wgrad_wave_body(const WgradPatchArgs& p, const i
   const int ci_first = n0 / KHW;
   const int cbase = (p.bcast ? 0 : g * p.Cig) + ci_first;
   const int PWA = (p.PW + 3) & ~3, shift = PWA - p.PW;
-  const int nseg = p.OUTW >> 4;
+  const int nseg = (p.OUTW + 15) >> 4;
 
   // ---- the workgroup's steps [sbeg, send); load cursor (scalar): the step whose loads are issued next
   const int sbeg = sp * p.steps_per_split, send = min(p.n_steps, sbeg + p.steps_per_split);
@@ -333,10 +336,12 @@ __device__ __forceinline__ void wgrad_wave_body(const WgradPatchArgs& p, const i
     xr[i] = r; xc4[i] = 4 * f;
     xlo[i] = e < NX4 ? c * CP + r * RP + 4 * f : XBUF - 4;
   }
-  const __amdgpu_buffer_rsrc_t rsD = buf_rsrc(p.dyr), rsS = buf_rsrc(p.src);
+  const __amdgpu_buffer_rsrc_t rsD = buf_rsrc(p.dyr), rsS = buf_rsrc(MODE == 2 ? p.src2 : p.src), rsH = buf_rsrc(p.src);
 
   // two register sets: the loads of step i + 3 are issued while step i computes and step i + 1 moves registers -> LDS
-  float4 rdd[2][WM], rxx[2][NXL];
+  constexpr int NSET = MODE == 0 ? 2 : 1;       // (the two rarer modes keep one set: their extra registers would spill at three workgroups per CU)
+  float4 rdd[NSET][WM], rxx[NSET][NXL];
+  float2 rhh[NSET][MODE == 2 ? NXL : 1];
   auto issue_loads = [&](const int set) {
     float4 (&rd)[WM] = rdd[set];
     float4 (&rx)[NXL] = rxx[set];
@@ -349,14 +354,27 @@ __device__ __forceinline__ void wgrad_wave_body(const WgradPatchArgs& p, const i
     }
     const bool valid = lidx < send;
     const unsigned dso = 4u * (unsigned)(limg * p.o_img + loy * p.o_row + lseg * 16);
+    if (MODE == 1) {
+      const int left = p.OUTW - lseg * 16 - 4 * (t & 3);          // valid pixels from this thread's first one on
 #pragma unroll
-    for (int i = 0; i < WM; ++i) rd[i] = buf_load4(rsD, valid ? dvo[i] : BUF_OOB, dso);
+      for (int i = 0; i < WM; ++i) {
+        const unsigned o = valid ? dvo[i] : BUF_OOB;
+        rd[i].x = buf_load(rsD, left > 0 ? o : BUF_OOB, dso);
+        rd[i].y = buf_load(rsD, left > 1 ? o + 4u : BUF_OOB, dso);
+        rd[i].z = buf_load(rsD, left > 2 ? o + 8u : BUF_OOB, dso);
+        rd[i].w = buf_load(rsD, left > 3 ? o + 12u : BUF_OOB, dso);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < WM; ++i) rd[i] = buf_load4(rsD, valid ? dvo[i] : BUF_OOB, dso);
+    }
     const int iy0 = loy * SV - p.PH, ix0 = lseg * 16 * S - PWA;
     const int xb = limg * p.s_img + cbase * p.s_chan + iy0 * p.s_row + ix0;
 #pragma unroll
     for (int i = 0; i < NXL; ++i) {
       const bool ok = valid & xok[i] & ((unsigned)(ix0 + xc4[i]) < (unsigned)p.SRCW) & ((unsigned)(iy0 + xr[i]) < (unsigned)p.SRCH);
       rx[i] = buf_load4(rsS, ok ? 4u * (unsigned)(xb + xinv[i]) : BUF_OOB, 0);
+      if (MODE == 2) rhh[set][i] = buf_load2(rsH, ok ? 4u * (unsigned)((xb + xinv[i]) >> 1) : BUF_OOB, 0);   // (all strides of r are even)
     }
   };
   float* const buf0 = smem;
@@ -371,7 +389,9 @@ __device__ __forceinline__ void wgrad_wave_body(const WgradPatchArgs& p, const i
     for (int i = 0; i < WM; ++i) *reinterpret_cast<float4*>(Ab + dlo + 64 * i * LDA) = rd[i];
 #pragma unroll
     for (int i = 0; i < NXL; ++i) {       // (dword stores: the bank-skewed pitches of the 3-tap shapes are odd)
-      Xb[xlo[i] + 0] = rx[i].x; Xb[xlo[i] + 1] = rx[i].y; Xb[xlo[i] + 2] = rx[i].z; Xb[xlo[i] + 3] = rx[i].w;
+      float4 v = rx[i];
+      if (MODE == 2) { const float2 h = rhh[set][i]; v.x += h.x; v.y += h.x; v.z += h.y; v.w += h.y; }
+      Xb[xlo[i] + 0] = v.x; Xb[xlo[i] + 1] = v.y; Xb[xlo[i] + 2] = v.z; Xb[xlo[i] + 3] = v.w;
     }
   };
 
@@ -431,8 +451,8 @@ __device__ __forceinline__ void wgrad_wave_body(const WgradPatchArgs& p, const i
   if (nst > 0) {
     issue_loads(0); advance();
     write_step(0, 0);
-    issue_loads(1); advance();                                // step 1 -> set 1
-    issue_loads(0); advance();                                // step 2 -> set 0
+    if (NSET == 2) { issue_loads(1); advance(); }             // step 1 -> set 1
+    issue_loads(0); advance();                                // step 2 -> set 0 (one set: step 1)
   }
   __syncthreads();
   if (nst > 0) {
@@ -440,8 +460,8 @@ __device__ __forceinline__ void wgrad_wave_body(const WgradPatchArgs& p, const i
     read_group(0, 1, 1);
   }
   auto body = [&](const int cur) {
-    write_step(cur ^ 1, cur ^ 1);                             // step i + 1: registers (loaded two steps ago) -> the other buffer
-    issue_loads(cur ^ 1); advance();                          // step i + 3 into the set just drained
+    write_step(cur ^ 1, (cur ^ 1) & (NSET - 1));              // step i + 1: registers (loaded two steps ago) -> the other buffer
+    issue_loads((cur ^ 1) & (NSET - 1)); advance();           // step i + 3 (one set: i + 2) into the set just drained
     __builtin_amdgcn_sched_barrier(0);
     mfma_rows(0, 0, 4);
     __builtin_amdgcn_sched_barrier(0);
@@ -497,11 +517,13 @@ __global__ __launch_bounds__(256, 3) void wgrad_wave_multi_kernel(const WgradPat
   prefetch_kernargs<sizeof(WgradPatchArgs)>((int)offsetof(WgradPatchBatch, job) + j * (int)sizeof(WgradPatchArgs));
   const WgradPatchArgs& p = b.job[j];
   const int bid = (int)blockIdx.x - b0;
-  switch (p.wave_kind) {            // stride * 2 + (tile == 64 x 256)
+  switch (p.wave_kind) {            // stride * 2 + (tile == 64 x 256); 6, 7: stride 1, 128 x 128, MODE 1 / 2
     case 2: wgrad_wave_body<1, 2, 2>(p, bid, wave_smem); break;
     case 3: wgrad_wave_body<1, 1, 4>(p, bid, wave_smem); break;
     case 4: wgrad_wave_body<2, 2, 2>(p, bid, wave_smem); break;
     case 5: wgrad_wave_body<2, 1, 4>(p, bid, wave_smem); break;
+    case 6: wgrad_wave_body<1, 2, 2, 1>(p, bid, wave_smem); break;     // ragged dy rows
+    case 7: wgrad_wave_body<1, 2, 2, 2>(p, bid, wave_smem); break;     // upsample-add input
     default: break;
   }
 }
@@ -510,16 +532,22 @@ int g_wgrad_wave = 1;          // ms_debug_set_wgrad_wave: 0 keeps every layer o
 
 // the wave-pipelined kernel takes whole 16-pixel runs and 16-byte-aligned rows
 static bool wgrad_wave_ok(const WgradPatchArgs& a, int KH, int KW, int S, bool up2) {
-  if (!g_wgrad_wave || up2 || a.counters) return false;
+  if (!g_wgrad_wave || a.counters) return false;
   const bool shape = (KH == 1 && KW == 3 && S == 1) || (KH == 1 && KW == 4 && S == 2) || (KH == 1 && KW == 1 && S == 1) ||
-                     (KH == 3 && KW == 3 && S == 1) || (KH == 4 && KW == 4 && S == 2);
+                     (KH == 3 && KW == 3 && S == 1) || (KH == 4 && KW == 4 && S == 2) || (KH == 3 && KW == 8 && S == 1);
   if (!shape) return false;
+  if (up2 && !(KH == 1 && KW == 3)) return false;
   if (KW == 1 && a.PW != 0) return false;
   if (a.PW < 0 || a.PW > 3 || a.PH < 0) return false;
-  const int al = a.OUTW | a.SRCW | a.s_img | a.s_chan | a.s_row | a.o_img | a.o_chan | a.o_row;
-  if ((a.OUTW & 15) || (al & 3)) return false;
-  if (((uintptr_t)a.dyr | (uintptr_t)a.src) & 15) return false;
+  if ((a.SRCW | a.s_img | a.s_chan | a.s_row) & 3) return false;                                  // x: 16-byte-aligned rows
+  if (((uintptr_t)a.src | (uintptr_t)(up2 ? a.src2 : a.src)) & 15) return false;
+  const bool dy_aligned = ((a.OUTW & 15) | ((a.o_img | a.o_chan | a.o_row) & 3) | (int)((uintptr_t)a.dyr & 15)) == 0;
+  if (!dy_aligned && (up2 || S != 1 || a.Cog <= 64)) return false;                             // ragged dy: MODE 1 exists for stride 1, 128 x 128 only
   return true;
+}
+static int wave_mode(const WgradPatchArgs& a, bool up2) {
+  if (up2) return 2;
+  return (((a.OUTW & 15) | ((a.o_img | a.o_chan | a.o_row) & 3) | (int)((uintptr_t)a.dyr & 15)) == 0) ? 0 : 1;
 }
 
 static int launch_wave(const WgradPatchBatch& b, hipStream_t s) {
@@ -542,15 +570,17 @@ static int launch_wave(const WgradPatchBatch& b, hipStream_t s) {
 }
 
 // grid and steps (16-pixel runs of one output row) of a layer on the lean kernel
-static int wave_setup(WgradPatchArgs& a, int wave, int KH, int KW, int S) {
+static int wave_setup(WgradPatchArgs& a, int wave, int KH, int KW, int S, bool up2) {
   const int bm = wave == 2 ? 64 : 128, bn = wave == 2 ? 256 : 128;
   const WaveGeo ge = wave_geo(KH, KW, S, bm, bn);
-  a.wave_kind = 2 * S + (wave == 2 ? 1 : 0);
+  const int mode = wave_mode(a, up2);
+  a.wave_kind = mode ? 5 + mode : 2 * S + (wave == 2 ? 1 : 0);
+  if (mode && (wave == 2 || S != 1)) return -1;
   a.KH = KH; a.KW = KW; a.w4 = ge.W4; a.nx4 = ge.NX4; a.xrp = ge.RP; a.xcp = ge.CP; a.xbuf = ge.XBUF;
   if (ge.NX4 > 256 * (wave == 2 ? 3 : 2)) return -1;        // (cannot happen for the shapes the planner sends)
   a.gx = cdiv(a.Kg, bn); a.gy = cdiv(a.Cog, bm); a.gz = a.groups * a.splits;
   const int imgs = a.n_tiles / std::max(1, a.tiles_y * a.tiles_x);
-  a.n_steps = imgs * a.OUTH * (a.OUTW / 16);
+  a.n_steps = imgs * a.OUTH * cdiv(a.OUTW, 16);
   a.steps_per_split = cdiv(a.n_steps, a.splits);
   return a.gx * a.gy * a.gz;
 }
@@ -577,11 +607,13 @@ WgradPatchPlan plan_wgrad_patch(int nd, int Cog, int Kg, int groups, int KH, int
   // ---- the lean kernel (wgrad_wave_multi_kernel) where the geometry allows: whole 16-pixel runs, 16-byte-aligned rows
   const bool wshape = (KH == 1 && KW == 3 && S == 1) || (KH == 1 && KW == 4 && S == 2) || (KH == 1 && KW == 1 && S == 1) ||
                       (KH == 3 && KW == 3 && S == 1) || (KH == 4 && KW == 4 && S == 2);
-  if (g_wgrad_wave && !pl.p6 && !up2 && wshape && W > 0 && (W & 3) == 0 && (OW & 15) == 0 && Kg >= 64 && (Cog > 64 || (Kg >= 256 && KH * KW > 1))) {
+  const bool wragged = (OW & 15) != 0;        // dy rows that are not whole 16-pixel runs: the kernel's dword path (stride 1, 128 x 128 tiles)
+  if (g_wgrad_wave && !pl.p6 && (wshape || (KH == 3 && KW == 8 && S == 1)) && W > 0 && (W & 3) == 0 && Kg >= 64 &&
+      (Cog > 64 || (Kg >= 256 && KH * KW > 1 && !up2 && !wragged)) && (!up2 || (KH == 1 && KW == 3)) && (!wragged || (S == 1 && !up2))) {
     pl.wave = Cog <= 64 ? 2 : 1;
     const int bm = pl.wave == 2 ? 64 : 128, bn = pl.wave == 2 ? 256 : 128;
     const long wbase = (long)cdiv(Cog, bm) * cdiv(Kg, bn) * groups;
-    const int n_steps = imgs * rows * (OW / 16);
+    const int n_steps = imgs * rows * cdiv(OW, 16);
     int sp;
     if (g_wgrad_batched) {
       // queued launches share the chip: a workgroup takes ~g_wgrad_steps_per_wg steps of the reduction (long enough to amortise
@@ -666,9 +698,9 @@ int queue_wgrad_patch(const WgradPatchArgs& a, const WgradPatchPlan& pl, int KH,
   pw.KH = KH; pw.KW = KW; pw.S = S; pw.tw = pl.tw; pw.up2 = up2 ? 1 : 0; pw.nwg = (int)nwg; pw.flops = flops; pw.bytes = bytes;
   pw.wave = (pl.wave && wgrad_wave_ok(pw.a, KH, KW, S, up2)) ? pl.wave : 0;
   if (pw.wave) {
-    pw.nwg = wave_setup(pw.a, pw.wave, KH, KW, S);
+    pw.nwg = wave_setup(pw.a, pw.wave, KH, KW, S, up2);
     if (pw.nwg < 0) return set_error("wgrad: x window does not fit the lean kernel's staging slots");
-    pw.KH = pw.KW = pw.S = 0;      // every shape shares the one launch
+    pw.KH = pw.KW = pw.S = 0; pw.up2 = 0;      // every shape shares the one launch
     pw.tw = 0;                       // one instance per kernel shape: the 16-pixel steps do not depend on the tile width
   }
   std::lock_guard<std::mutex> lk(g_pending_mu);
@@ -756,7 +788,8 @@ int launch_wgrad_patch(const WgradPatchArgs& a, const WgradPatchPlan& pl, int KH
     WgradPatchBatch wb;
     const int wave = pl.wave;
     wb.n = 1; wb.job[0] = b;
-    wb.block_end[0] = wave_setup(wb.job[0], wave, KH, KW, S);
+    wb.block_end[0] = wave_setup(wb.job[0], wave, KH, KW, S, up2);
+    if (wb.block_end[0] < 0) return set_error("wgrad: no lean-kernel instance for this layer");
     TimingScope ts(s, flops, bytes, "wgrad_wave_multi_kernel<%d,%d,%d,0,0>|conv_wgrad_wave k%dx%d s%d Cog%d Kg%d g%d steps%d splits%d",
                    KH, KW, S, KH, KW, S, a.Cog, a.Kg, a.groups, wb.job[0].n_steps, a.splits);
     if (ts.skip()) return 0;
