@@ -212,14 +212,14 @@ def usable_cores():
 
 def cpu_baseline(seed):
   """The oracle (pure PyTorch on the host cores) on a bounded sample of the same workload: fp32 G-steps and D-steps at
-  B=32 after one untimed step of each kind (2 timed steps per kind, 1 if a step takes longer than 8 s); plus ONE step of each
-  kind in fp64, the reference's own training dtype (trainer.py:138)."""
+  B=32 after one untimed step of each kind (5 timed steps per kind, the MEDIAN is reported; 1 if a step takes longer than 4 s);
+  plus 3 steps of each kind in fp64, the reference's own training dtype (trainer.py:138).  ~12 s of CPU work on 16 cores."""
   import torch
   from oracle import mixstage_oracle as O
   cores = min(usable_cores(), 32)       # oversubscribed intra-op threads make PyTorch CPU convs much slower
   torch.set_num_threads(cores)
   res = {}
-  for name, dtype, n_max in (('fp32', torch.float32, 2), ('fp64', torch.float64, 1)):
+  for name, dtype, n_max in (('fp32', torch.float32, 5), ('fp64', torch.float64, 3)):
     model = O.build_gan(M=M, S=S, T=T, P=P, dtype=dtype)
     og = torch.optim.Adam(model.G.parameters(), lr=1e-4)
     od = torch.optim.Adam(model.D.parameters(), lr=1e-4)
@@ -229,21 +229,55 @@ def cpu_baseline(seed):
       t0 = time.perf_counter()
       O.oracle_train_step(model, og, od, audio, pose, labels, style, kind, T=T)
       warm = time.perf_counter() - t0
-      n = n_max if warm < 8.0 else 1
-      t0 = time.perf_counter()
+      n = n_max if warm < 4.0 else 1
+      each = []
       for _ in range(n):
+        t0 = time.perf_counter()
         O.oracle_train_step(model, og, od, audio, pose, labels, style, kind, T=T)
-      times[kind], reps[kind] = (time.perf_counter() - t0) / n, n
+        each.append(time.perf_counter() - t0)
+      times[kind], reps[kind] = sorted(each)[len(each) // 2], n         # median of the timed steps
     res[name] = (times, reps)
   (t32, r32), (t64, r64) = res['fp32'], res['fp64']
   blend32 = 0.5 * (t32['G'] + t32['D'])       # D_prob = 0.5 (gan.py:27)
   blend64 = 0.5 * (t64['G'] + t64['D'])
   return dict(value=round(B_PER_GPU / blend32, 2), unit='clips/s', cores=cores, kind='port',
-              sample='oracle (PyTorch CPU fp32, %d threads): %d G-steps + %d D-steps at B=32 after 1 warm-up each; '
+              sample='oracle (PyTorch CPU fp32, %d threads): median of %d G-steps + %d D-steps at B=32 after 1 warm-up each; '
                      'G %.3f s, D %.3f s per step, 50/50 blend' % (cores, r32['G'], r32['D'], t32['G'], t32['D']),
               fp64=dict(value=round(B_PER_GPU / blend64, 2), unit='clips/s',
-                        sample='same oracle in float64 (the reference trains in fp64): %d G + %d D step(s) after 1 warm-up each; '
+                        sample='same oracle in float64 (the reference trains in fp64): median of %d G + %d D step(s) after 1 warm-up each; '
                                'G %.3f s, D %.3f s' % (r64['G'], r64['D'], t64['G'], t64['D'])))
+
+
+def measured_peaks(dev):
+  """On-box re-measurement of the three peaks the roofline fractions are quoted against: a bare MFMA loop on random
+  operands (ms_probe_peak: one wave per SIMD on every CU, operands in registers) in fp32 and bf16, and a 16-byte-per-lane copy of
+  1 GiB.  HIP events on the current stream, best of 3 after a warm-up."""
+  import ctypes
+  import torch
+  from mix_stage_amd import _lib
+  L = _lib.lib()
+  st = torch.cuda.current_stream(dev).cuda_stream
+  scratch = torch.zeros(16, dtype=torch.float32, device=dev)
+  n = 1 << 30
+  src = torch.empty(n // 4, dtype=torch.float32, device=dev).normal_()
+  dst = torch.empty_like(src)
+  out = {}
+  for name, kind, iters, a, b in (('fp32_mfma_tflops', 0, 4096, scratch, None), ('bf16_mfma_tflops', 1, 16384, scratch, None),
+                                  ('copy_gbs', 2, n, src, dst)):
+    best = 0.0
+    for rep in range(4):
+      work = ctypes.c_double(0)
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      e0.record()
+      _lib.check(L.ms_probe_peak(kind, iters, a.data_ptr(), b.data_ptr() if b is not None else None, ctypes.byref(work), st), 'ms_probe_peak')
+      e1.record()
+      torch.cuda.synchronize()
+      if rep:
+        best = max(best, work.value / (e0.elapsed_time(e1) * 1e-3))
+    out[name] = round(best / (1e9 if kind == 2 else 1e12), 1)
+  out['note'] = ('measured on this box by bench.py (ms_probe_peak): bare MFMA loops on random operands, one wave per SIMD; copy = read + written '
+                 'bytes of a 1 GiB float4 copy.  The fractions above use the SPEC peaks (157.3 TF / 2500 TF / 8000 GB/s).')
+  return out
 
 
 def source_hash():
@@ -636,6 +670,15 @@ def main():
       except Exception as e:  # noqa: BLE001
         roof = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
     out['roofline'] = roof
+    if isinstance(roof, dict) and 'error' not in roof:
+      try:
+        roof['measured_peaks'] = measured_peaks(dev)
+        mp = roof['measured_peaks']
+        meas = mp['bf16_mfma_tflops'] if args.precision == 'bf16' else mp['fp32_mfma_tflops']
+        if roof.get('achieved_tflops') and meas:
+          roof['frac_of_measured_mfma_peak'] = round(roof['achieved_tflops'] / meas, 4)
+      except Exception as e:  # noqa: BLE001
+        roof['measured_peaks'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
     out['kernel_table'] = [dict(label=r['label'].split('|')[-1], count=r['count'], avg_us=round(1e3 * r['total_ms'] / r['count'], 2),
                                 total_ms=round(r['total_ms'], 3),
                                 tflops=round(r['flops'] / (r['total_ms'] / r['count'] * 1e-3) / 1e12, 2))

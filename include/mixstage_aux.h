@@ -74,6 +74,10 @@ int ms_debug_set_clip32(int on);
 
 /* Self-test kernel: C(32x32) = A(32xK) * B(Kx32) through the fp32 MFMA path (checks fragment maps). */
 int ms_selftest_mfma(const float* A, const float* B, float* C, int K, void* stream);
+/* On-box peaks for bench.py's roofline: kind 0 / 1 = a bare fp32 / bf16 MFMA loop (operands in registers, `iters` rounds of 16 MFMAs per
+ * wave, one wave per SIMD on every CU; a = 4 bytes of device scratch), kind 2 = a 16-byte-per-lane copy of `iters` bytes from a to b.
+ * *work = FLOP (kinds 0, 1) or bytes read + written (kind 2) of the launch; time it with events on `stream`. */
+int ms_probe_peak(int kind, long iters, void* a, void* b, double* work, void* stream);
 
 #ifdef __cplusplus
 }

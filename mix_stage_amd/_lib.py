@@ -157,6 +157,7 @@ SIGNATURES = {
     'ms_debug_set_conv_tile': (c_int, [c_int]),
     'ms_set_wgrad_batched': (c_int, [c_int, c_int]),
     'ms_selftest_mfma': (c_int, [_P, _P, _P, c_int, _P]),
+    'ms_probe_peak': (c_int, [c_int, ctypes.c_long, _P, _P, ctypes.POINTER(ctypes.c_double), _P]),
 }
 
 _lib = None

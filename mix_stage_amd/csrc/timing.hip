@@ -96,3 +96,72 @@ extern "C" size_t ms_timing_report(char* buf, size_t cap) {
   }
   return out.size() + 1;
 }
+
+// ---- on-box peaks (bench.py prints them beside the spec peaks in `roofline`; SURVEY 8(d) asks for the re-measurement):
+// a bare MFMA loop on random operands held in registers, one wave per SIMD on every CU -- the matrix-pipe rate at the clock the
+// chip grants under that load -- and a 16-byte-per-lane copy for the HBM rate.
+namespace ms {
+typedef __attribute__((ext_vector_type(8))) __bf16 probe_bf16x8;
+template <int KIND>
+__global__ __launch_bounds__(256, 1) void probe_mfma_kernel(float* out, int iters) {
+  const int lane = threadIdx.x & 63;
+  f32x16 acc[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+  // operands: lane-dependent pseudo-random values in [-1, 1)
+  float fa[4], fb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    unsigned h = (unsigned)(lane * 2654435761u + (blockIdx.x + 1) * 40503u + j * 69069u + threadIdx.x);
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    fa[j] = (float)(h & 0xffff) / 32768.f - 1.f;
+    fb[j] = (float)(h >> 16) / 32768.f - 1.f;
+  }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (KIND == 0) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[(j + a) & 3], fb[j], acc[a], 0, 0, 0);
+      } else {
+        probe_bf16x8 va, vb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { va[e] = (__bf16)fa[(j + e) & 3]; vb[e] = (__bf16)fb[(j + e) & 3]; }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, vb, acc[a], 0, 0, 0);
+      }
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[a][r];
+  if (s == 12345.678f) out[0] = s;        // (keeps the loop alive)
+}
+__global__ __launch_bounds__(256) void probe_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+}  // namespace ms
+
+// kind 0: v_mfma_f32_32x32x2_f32, 1: v_mfma_f32_32x32x16_bf16 -- `iters` rounds of 16 MFMAs per wave on 256 x 4 waves; returns the FLOP
+// of the launch through *flops.  kind 2: copy of `iters` bytes (src -> dst, both at least that long), *flops = bytes moved (read + write).
+extern "C" int ms_probe_peak(int kind, long iters, void* a, void* b, double* flops, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (kind == 0 || kind == 1) {
+    if (!a || iters < 1 || iters > (1 << 24)) return ms::set_error("ms_probe_peak: bad argument");
+    if (kind == 0) hipLaunchKernelGGL(ms::probe_mfma_kernel<0>, dim3(256), dim3(256), 0, s, (float*)a, (int)iters);
+    else hipLaunchKernelGGL(ms::probe_mfma_kernel<1>, dim3(256), dim3(256), 0, s, (float*)a, (int)iters);
+    if (flops) *flops = 256.0 * 4 * (double)iters * 16 * (kind == 0 ? 4096.0 : 32768.0);
+    return ms::check_launch("probe_mfma_kernel");
+  }
+  if (kind == 2) {
+    if (!a || !b || iters < 16) return ms::set_error("ms_probe_peak: bad argument");
+    hipLaunchKernelGGL(ms::probe_copy_kernel, dim3(256 * 16), dim3(256), 0, s, (const float4*)a, (float4*)b, (size_t)iters / 16);
+    if (flops) *flops = 2.0 * (double)(iters / 16 * 16);
+    return ms::check_launch("probe_copy_kernel");
+  }
+  return ms::set_error("ms_probe_peak: kind %d", kind);
+}
