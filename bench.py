@@ -382,15 +382,20 @@ def chain_roofline(chain, rows, precision):
   prep = [r for r in rows if 'chain_prep' in r['label']]
   if prep:
     roof['weight_stream_prep_us'] = round(prep[0]['total_ms'] / prep[0]['count'] * 1e3, 2)
-  try:
-    pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r04_pmc_decoder.json')))
-    ent = pmc.get(precision if M == 8 else '%s_m%d' % (precision, M))      # (the passes cover the headline and configs[1]: M = 8 / 4)
-    if ent and ent.get('src_hash') == source_hash() and B_PER_GPU * T == 2048:
-      roof['traffic'] = ent['hbm_bytes_per_launch']
-      roof['traffic_over_algorithmic'] = round(ent['hbm_bytes_per_launch'] / roof['algorithmic_bytes_per_launch'], 3)
-      roof['traffic_note'] = 'HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, profiles/r04_pmc_decoder.json (same sources: %s)' % ent['src_hash']
-  except (OSError, ValueError, KeyError):
-    pass
+  # HBM traffic of the launch from the committed PMC passes (tools/pmc_chain.sh: rocprofv3 cannot run inside bench.py): the newest
+  # profiles/rNN_pmc_decoder.json whose `src_hash` equals the hash of the kernel sources being benchmarked, else null
+  import glob
+  for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_decoder.json')), reverse=True):
+    try:
+      pmc = json.load(open(path))
+      ent = pmc.get(precision if M == 8 else '%s_m%d' % (precision, M))      # (the passes cover the headline and configs[1]: M = 8 / 4)
+      if ent and 'hbm_bytes_per_launch' in ent and ent.get('src_hash') == source_hash() and B_PER_GPU * T == 2048:
+        roof['traffic'] = ent['hbm_bytes_per_launch']
+        roof['traffic_over_algorithmic'] = round(ent['hbm_bytes_per_launch'] / roof['algorithmic_bytes_per_launch'], 3)
+        roof['traffic_note'] = 'HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, profiles/%s (same sources: %s)' % (os.path.basename(path), ent['src_hash'])
+        break
+    except (OSError, ValueError, KeyError):
+      continue
   return roof
 
 

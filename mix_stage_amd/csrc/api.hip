@@ -342,6 +342,7 @@ size_t ms_fwd_weights_bytes(const ms_conv_desc* d) {
 
 int ms_fwd_weights_prepare(int n, const ms_conv_desc* descs, const float* const* w, void* const* planes, void* stream) {
   if (n < 0 || (n && (!descs || !w || !planes))) return set_error("ms_fwd_weights_prepare: null argument");
+  PrepQueueGuard queue_guard;          // (after the flush below the queues are empty: the guard only matters on error paths)
   SplitBatch sb;
   sb.n = 0;
   for (int i = 0; i < n; ++i) {
@@ -369,6 +370,7 @@ int ms_fwd_weights_prepare(int n, const ms_conv_desc* descs, const float* const*
 
 int ms_dgrad_weights_prepare(int n, const ms_conv_desc* descs, const float* const* w, float* const* wt, void* stream) {
   if (n < 0 || (n && (!descs || !w || !wt))) return set_error("ms_dgrad_weights_prepare: null argument");
+  PrepQueueGuard queue_guard;
   TransposeBatch tb;
   tb.n = 0;
   for (int i = 0; i < n; ++i) {

@@ -565,16 +565,15 @@ int chain16_sync_words(const ms_chain_desc* d) { return 32 * (C16_NL * d->M + d-
 
 int chain16_supported(const ms_chain_desc* d) {
   if (!chain16_shape_ok(d)) return 0;
-  static int cus = -1, lds_ok = -1;
-  if (cus < 0) {
-    hipDeviceProp_t prop;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    cus = prop.multiProcessorCount;
-    lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(chain16_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, C16_LDS_BYTES) == hipSuccess &&
-             hipFuncSetAttribute(reinterpret_cast<const void*>(chain16_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, C16_LDS_BYTES) == hipSuccess;
+  const int cus = current_device_cus();          // (per device, like the raised LDS limit: chain32_supported)
+  static unsigned long long lds_done = 0;
+  if (!cus) return 0;
+  if (first_time_on_device(lds_done)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(chain16_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, C16_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(chain16_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, C16_LDS_BYTES) != hipSuccess) return 0;
+    done_on_device(lds_done);
   }
-  return lds_ok && d->B * d->M <= cus;
+  return d->B * d->M <= cus;
 }
 
 int chain16_prepare(const ms_chain_desc* d, const float* const* w, const float* wl, void* prepared, hipStream_t s) {

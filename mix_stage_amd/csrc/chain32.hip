@@ -685,6 +685,7 @@ size_t gdgrad32_weight_floats(const ms_conv_desc* d) { return gdgrad32_ok(d) ? (
 // queued: the blocks of one ms_dgrad_weights_prepare call (equal group counts) share a launch
 static GdPrepBatch g_gd_prep;
 static int g_gd_prep_groups = 0;
+void gdgrad32_prep_discard() { g_gd_prep.n = 0; }
 int gdgrad32_prep_flush(hipStream_t s) {
   if (!g_gd_prep.n) return 0;
   const GdPrepBatch pb = g_gd_prep;
@@ -704,12 +705,12 @@ int gdgrad32_prepare(const ms_conv_desc* d, const float* w, float* out, hipStrea
   return 0;
 }
 int gdgrad32_launch(const ms_conv_desc* d, const float* g, const float* wp, float* dx, hipStream_t s) {
-  static int attr_done = 0;
+  static unsigned long long attr_done = 0;
   const int lds = 2 * CH_BUF1 * (int)sizeof(float);
-  if (!attr_done) {
+  if (first_time_on_device(attr_done)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gconv32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return set_error("gconv32: cannot raise the dynamic LDS limit");
-    attr_done = 1;
+    done_on_device(attr_done);
   }
   Gconv32Args a = {g, wp, dx, d->B, d->groups};
   const double flops = 2.0 * CH_C * CH_C * 3.0 * d->B * CH_T * d->groups;
@@ -810,16 +811,15 @@ int chain32_sync_words(const ms_chain_desc* d) { return 32 * (CH_NL * d->M + d->
 
 int chain32_supported(const ms_chain_desc* d) {
   if (!chain32_shape_ok(d)) return 0;
-  static int cus = -1, lds_ok = -1;
-  if (cus < 0) {
-    hipDeviceProp_t prop;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    cus = prop.multiProcessorCount;
-    lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(chain32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 CH_LDS_FLOATS * (int)sizeof(float)) == hipSuccess;
+  // (per device: the CU count and the raised LDS limit belong to the device that is current now)
+  const int cus = current_device_cus();
+  static unsigned long long lds_done = 0;
+  if (!cus) return 0;
+  if (first_time_on_device(lds_done)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(chain32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            CH_LDS_FLOATS * (int)sizeof(float)) != hipSuccess) return 0;
+    done_on_device(lds_done);
   }
-  if (!lds_ok) return 0;
   // train mode: the workgroups of a group meet inside the launch -- all of them must be resident at once (one per CU: 146 KB LDS)
   if (d->mode == MS_BN_TRAIN && d->B * d->M > cus) return 0;
   // (eval: the mixture's clip meeting has the same requirement)

@@ -562,6 +562,7 @@ int clip32_prep_queue(const float* w, float* out, int rows, int red, int KW, int
   g_prep.job[g_prep.n++] = jb;
   return 0;
 }
+void clip32_prep_discard() { g_prep.n = 0; g_prep_blocks = 0; }
 int clip32_prep_flush(hipStream_t s) {
   if (!g_prep.n) return 0;
   TimingScope ts(s, 0, 0, "clip32_prep_kernel|clip_prep jobs%d", g_prep.n);
@@ -579,11 +580,11 @@ int clip32_sync_words(int rows) { return 32 * (cdiv(rows, 32) + 1); }
 template <int KW, int S, int NB, bool UP2, int K8W, bool DG2 = false>
 static int clip32_launch_k(const Clip32Args& a, int nwg, int lds_bytes, hipStream_t s) {
   auto fn = clip32_kernel<KW, S, NB, UP2, K8W, DG2>;
-  static int attr_done = 0;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;          // (per device)
+  if (first_time_on_device(attr_done)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return set_error("clip32: cannot raise the dynamic LDS limit");
-    attr_done = 1;
+    done_on_device(attr_done);
   }
   hipLaunchKernelGGL(fn, dim3(nwg), dim3(256), lds_bytes, s, a);
   return check_launch("clip32_kernel");
@@ -614,7 +615,8 @@ int clip32_launch(Clip32Args a, int KW, int S, bool up2, const char* what, hipSt
   const int nwg = nct * a.npw;
   // the workgroups of a channel tile meet inside the launch (BN_TRAIN): all of them resident at once
   int cus = 256;
-  { static int ccus = -1; if (ccus < 0) { hipDeviceProp_t pr; int dv = 0; ccus = (hipGetDevice(&dv) == hipSuccess && hipGetDeviceProperties(&pr, dv) == hipSuccess) ? pr.multiProcessorCount : 256; } cus = ccus; }
+  cus = current_device_cus();
+  if (!cus) cus = 256;
   // (one workgroup per CU is what every instance of the kernel is sure to get: LDS would allow two of the smaller images, the
   // register file of the upsample-add instance does not)
   if (a.ep == EP_RAW_STATS && a.npw > 1 && nwg > cus) return -2;      // caller falls back to the per-layer kernels

@@ -23,3 +23,20 @@ extern "C" int ms_set_counter_buffer(int32_t* zeroed_counters, int n) {
   ms::g_counters_n = zeroed_counters ? n : 0;
   return 0;
 }
+
+namespace ms {
+int current_device_index() {
+  int dev = -1;
+  return hipGetDevice(&dev) == hipSuccess ? dev : -1;
+}
+int current_device_cus() {
+  static int cus[64] = {0};
+  const int dev = current_device_index();
+  if (dev < 0 || dev > 63) return 0;
+  if (!cus[dev]) {
+    hipDeviceProp_t prop;
+    cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : -1;
+  }
+  return cus[dev] > 0 ? cus[dev] : 0;
+}
+}  // namespace ms

@@ -29,6 +29,19 @@ inline int check_launch(const char* what) {
   return 0;
 }
 
+// One process may drive several devices (the launchers' residency decisions and hipFuncSetAttribute results are per device):
+// CU count of the CURRENT device, and "has this been done on the current device yet" for a per-call-site mask.
+int current_device_cus();
+int current_device_index();
+inline bool first_time_on_device(unsigned long long& mask) {
+  const int dev = current_device_index();
+  return dev < 0 || dev > 63 || !((mask >> dev) & 1ull);
+}
+inline void done_on_device(unsigned long long& mask) {
+  const int dev = current_device_index();
+  if (dev >= 0 && dev <= 63) mask |= 1ull << dev;
+}
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ inline int cdiv_dev(int a, int b) { return (a + b - 1) / b; }

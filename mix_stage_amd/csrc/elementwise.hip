@@ -1300,7 +1300,7 @@ int launch_bn_bwd(const float* dy, const float* y_raw, const float* y, const flo
   const long n = (long)B * HW;
   if (n <= BN_BWD32_FUSED_MAX) {
     TimingScope ts(s, 0, 12.0 * B * C * HW, "bn_bwd_fused C%d HW%d B%d", C, HW, B);
-    if (ts.skip()) return 0;
+    if (ts.skip()) { *fused = 1; return 0; }
     const bool vec4 = (HW & 3) == 0 && (((uintptr_t)dy | (uintptr_t)y_raw | (uintptr_t)y | (uintptr_t)dyr) & 15) == 0;
     if (vec4 && n <= 1024)
       hipLaunchKernelGGL(bn_bwd_fused4_kernel<1>, dim3(C), dim3(256), 0, s, dy, y_raw, y, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope);

@@ -163,6 +163,11 @@ size_t clip32_dgrad_weight_floats(const ms_conv_desc* d);
 size_t clip32_weight_floats(int rows, int red, int KW);
 int clip32_prep_queue(const float* w, float* out, int rows, int red, int KW, int transposed, int w_cols, hipStream_t s);
 int clip32_prep_flush(hipStream_t s);
+void clip32_prep_discard();
+void gdgrad32_prep_discard();
+// the weight-preparation entry points queue jobs in process-wide batches and launch them at their end: an early error return must not leave
+// queued jobs behind for the next, unrelated call to launch on its own stream against buffers that may be gone
+struct PrepQueueGuard { ~PrepQueueGuard() { clip32_prep_discard(); gdgrad32_prep_discard(); } };
 size_t clip32_part_bytes(int rows, int npw);
 int clip32_sync_words(int rows);
 // forward of block d (ep by mode) / data gradient of a k3 s1 block; -2: not resident at once, use the other kernels

@@ -551,9 +551,9 @@ static int wave_mode(const WgradPatchArgs& a, bool up2) {
 }
 
 static int launch_wave(const WgradPatchBatch& b, hipStream_t s) {
-  static bool attr = false;
+  static unsigned long long attr = 0;               // (per device)
   static int lds_bytes = 0;
-  if (!attr) {
+  if (first_time_on_device(attr)) {
     // the largest image of any shape: 64 x 256 tiles of the 4 x 4 stride-2 kernel
     for (int kind = 0; kind < 5; ++kind) {
       static const int khs[5] = {1, 1, 1, 3, 4}, kws[5] = {3, 4, 1, 3, 4}, ss[5] = {1, 2, 1, 1, 2};
@@ -563,7 +563,7 @@ static int launch_wave(const WgradPatchBatch& b, hipStream_t s) {
     if (e && atoi(e) > lds_bytes) lds_bytes = atoi(e);
     if (hipFuncSetAttribute((const void*)wgrad_wave_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
       return set_error("wgrad_wave_multi_kernel: cannot set the LDS size");
-    attr = true;
+    done_on_device(attr);
   }
   hipLaunchKernelGGL(wgrad_wave_multi_kernel, dim3(b.block_end[b.n - 1]), dim3(256), lds_bytes, s, b);
   return check_launch("wgrad_wave_multi_kernel");

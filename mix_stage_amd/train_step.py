@@ -295,11 +295,19 @@ class MixStageTrainStep:
       broadcast_from_rank0([self.optim_G.flat_p, self.optim_D.flat_p] + [b for b in model.buffers()], process_group)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
       # ranks that share a GPU (test set-ups): a launch whose workgroups wait for each other needs the device to itself
+      # (physical identity: launchers that set HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank make every rank see index 0)
       import socket
-      mine = (socket.gethostname(), torch.cuda.current_device())
+      props = torch.cuda.get_device_properties(torch.cuda.current_device())
+      ident = getattr(props, 'uuid', None)
+      ident = str(ident) if ident is not None else 'pci:%s:%s:%s' % (getattr(props, 'pci_domain_id', '?'), getattr(props, 'pci_bus_id', '?'),
+                                                                      getattr(props, 'pci_device_id', torch.cuda.current_device()))
+      mine = (socket.gethostname(), ident)
       seen = [None] * dist.get_world_size(process_group)
       dist.all_gather_object(seen, mine, group=process_group)
       if len(set(seen)) < len(seen):
+        import warnings
+        warnings.warn('mix_stage_amd: %d ranks share a GPU (%s): the in-launch forms (chained decoder, in-launch BatchNorm) need the device to '
+                      'themselves and are switched OFF for this process -- expect lower throughput than one rank per GPU' % (len(seen) - len(set(seen)) + 1, ident))
         ops16.set_in_launch_meetings(False)
     self._capture_stream = torch.cuda.Stream()      # warm-up and capture of every step kind: its scratch / counters are the graphs'
     # Health, every step and without a device synchronisation: the optimizer REFUSES a step whose gradient norm is not finite
