@@ -153,7 +153,26 @@ typedef struct ms_bwd_options {
                                  * dy / dyr and dw / wgrad_partials must stay valid until the flush; a queued kernel that
                                  * writes dw itself ADDS to it (dw holds zeros or the step's other contributions).  Blocks
                                  * whose kernel cannot be queued (bf16x6, im2col-gather path) launch at once as before. */
+  /* --- fusing the BatchNorm + LeakyReLU backward of the block that PRODUCED this block's input into this block's data-gradient
+   * launch (layers.py:77-78 under loss.backward(), trainer.py:1139; fp32 1-D blocks that ms_dgrad_fuses_prev_bn() accepts).
+   * prev_*: the producer's output y, y_raw, save vector, gamma and gradient slots (prev_dgamma / prev_dbeta / prev_dbias may be
+   * NULL).  dx then receives the gradient w.r.t. the producer's CONV output (its dy_raw) instead of the gradient w.r.t. y: the
+   * caller runs the producer's own backward with dy_is_dyr = 1 on it.  bn_sync: zeroed int32 counters as in ms_fwd_options. */
+  const float* prev_y;
+  const float* prev_y_raw;
+  const float* prev_save;
+  const float* prev_gamma;
+  float* prev_dgamma;
+  float* prev_dbeta;
+  float* prev_dbias;
+  float prev_slope;
+  int32_t* bn_sync;
+  int32_t bn_sync_words;
+  int dy_is_dyr;                /* this block's `dy` already is the gradient w.r.t. its conv output (a consumer's fused launch made it):
+                                 * no BatchNorm / activation backward here, dgamma / dbeta / dbias are not written, dyr is not used */
 } ms_bwd_options;
+/* 1 when block d's data-gradient launch can carry the BatchNorm backward of the producer of its input (see ms_bwd_options.prev_*). */
+int ms_dgrad_fuses_prev_bn(const ms_conv_desc* d);
 int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2, const float* w,
                          const float* gamma, const float* running_mean, const float* running_var,
                          const float* y_raw, const float* y, const float* save, const float* dy, float* dyr,

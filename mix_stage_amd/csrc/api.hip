@@ -90,6 +90,7 @@ size_t ms_conv_block_bwd_workspace(const ms_conv_desc* d) {
   const int npix = d->B * d->OH * d->OW;
   const int splits = wgrad_total_splits(d);
   size_t bytes = 0;
+  bytes += clip32_dgrad_bn_part_bytes(d);                                  // partials of a fused producer-BatchNorm backward (ms_bwd_options.prev_*)
   bytes += align_up((size_t)ctot_of(d) * nchunk * 2 * sizeof(float), 256);  // bn partials
   bytes += align_up((size_t)ctot_of(d) * nchunk * sizeof(float), 256);      // colsum partials
   bytes += align_up(std::max(dgrad_weight_elems(d->groups, d->Cout, d->Cin, d->KH, d->KW, d->SH, d->SW), std::max(clip32_dgrad_weight_floats(d), gdgrad32_weight_floats(d))) * sizeof(float), 256);
@@ -422,6 +423,11 @@ int ms_dgrad_weights_prepare(int n, const ms_conv_desc* descs, const float* cons
   return sb.n ? launch_split_weights_multi(sb, (hipStream_t)stream) : 0;
 }
 
+int ms_dgrad_fuses_prev_bn(const ms_conv_desc* d) {
+  if (!d || validate(d, "ms_dgrad_fuses_prev_bn")) return 0;
+  return (dt_of(d) == DT_F32 && g_precision == 0 && clip32_dgrad_bn_ok(d)) ? 1 : 0;
+}
+
 int ms_conv_block_bwd(const ms_conv_desc* d, const float* x, const float* x2, const float* w, const float* gamma,
                       const float* running_mean, const float* running_var, const float* y_raw, const float* y,
                       const float* save, const float* dy, float* dyr, float* dx, float* dx2, float* dw, float* dbias,
@@ -465,7 +471,8 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
   if (rc) return rc;
   if (d->mode == MS_BN_EVAL) return set_error("ms_conv_block_bwd: BN_EVAL blocks are never differentiated on the path");
   if (!dy || !w || !workspace) return set_error("ms_conv_block_bwd: null tensor");
-  if (d->mode == MS_BN_TRAIN && (!y_raw || !save || !gamma || !dyr)) return set_error("ms_conv_block_bwd: BN_TRAIN needs y_raw/save/gamma/dyr");
+  if (d->mode == MS_BN_TRAIN && !opt->dy_is_dyr && (!y_raw || !save || !gamma || !dyr)) return set_error("ms_conv_block_bwd: BN_TRAIN needs y_raw/save/gamma/dyr");
+  if ((opt->dy_is_dyr || opt->prev_y) && (dt_of(d) != DT_F32 || side_stream)) return set_error("ms_conv_block_bwd: the fused producer-BatchNorm backward is an fp32, single-stream form");
   if (d->mode == MS_LRELU && (!y || !dyr)) return set_error("ms_conv_block_bwd: LRELU needs y/dyr");
   if (dw && !x) return set_error("ms_conv_block_bwd: dw needs x");
   if (d->in_mode == MS_IN_UP2ADD && ((dw && !x2) || (dx && !dx2))) return set_error("ms_conv_block_bwd: UP2ADD needs x2/dx2");
@@ -484,6 +491,7 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
   int bpc;
   const int nchunk = bwd_chunks(d->B, C, &bpc);
   char* wsp = (char*)workspace;
+  float* fuse_part = (float*)wsp; wsp += clip32_dgrad_bn_part_bytes(d);
   float* bn_part = (float*)wsp; wsp += align_up((size_t)C * nchunk * 2 * sizeof(float), 256);
   float* colpart = (float*)wsp; wsp += align_up((size_t)C * nchunk * sizeof(float), 256);
   float* wt = (float*)wsp; wsp += align_up(std::max(dgrad_weight_elems(d->groups, d->Cout, d->Cin, d->KH, d->KW, d->SH, d->SW), std::max(clip32_dgrad_weight_floats(d), gdgrad32_weight_floats(d))) * sizeof(float), 256);
@@ -508,7 +516,14 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
   // 1. gradient wrt the raw conv output (+ per-channel column sums = bias gradient)
   const float* g = dy;
   int bias_done = 0;
-  if (d->mode == MS_BN_TRAIN) {
+  const bool have_prev = opt->prev_y != nullptr;
+  if (have_prev && !(dx && g_precision == 0 && clip32_dgrad_bn_ok(d)))
+    return set_error("ms_conv_block_bwd: this block's data gradient cannot carry the producer's BatchNorm backward (ms_dgrad_fuses_prev_bn)");
+  if (opt->dy_is_dyr) {
+    // a consumer's fused data-gradient launch already applied this block's BatchNorm + activation backward (and wrote dgamma / dbeta / dbias)
+    if (d->mode != MS_BN_TRAIN) return set_error("ms_conv_block_bwd: dy_is_dyr is the BN_TRAIN form");
+    bias_done = 1;
+  } else if (d->mode == MS_BN_TRAIN) {
     rc = launch_bn_bwd(dy, y_raw, y, save, gamma, bn_part, dyr, colpart, dbias, dgamma, dbeta, d->B, C, hw, d->slope, &bias_done, s);
     g = dyr;
   } else if (d->mode == MS_LRELU) {
@@ -518,7 +533,7 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
     rc = launch_act_bwd(dy, nullptr, nullptr, colpart, dbias, d->B, C, hw, 0, 0.f, &bias_done, s);
   }
   if (rc) return rc;
-  if (dbias && !bias_done) {
+  if (dbias && !bias_done && !opt->dy_is_dyr) {
     rc = launch_colsum_finalize(colpart, dbias, d->B, C, s);
     if (rc) return rc;
   }
@@ -540,7 +555,13 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
       if (rc) return rc;
       wp = wt;
     }
-    rc = clip32_block_dgrad(d, g, wp, dx, dx2, s);
+    if (have_prev) {
+      const Clip32PrevBN pv = {opt->prev_y, opt->prev_y_raw, opt->prev_save, opt->prev_gamma, opt->prev_dgamma, opt->prev_dbeta, opt->prev_dbias, opt->prev_slope};
+      rc = clip32_block_dgrad(d, g, wp, dx, dx2, s, &pv, fuse_part, opt->bn_sync, opt->bn_sync_words);
+      if (rc == -2) return set_error("ms_conv_block_bwd: the fused data gradient is not resident at once on this device");
+    } else {
+      rc = clip32_block_dgrad(d, g, wp, dx, dx2, s);
+    }
     if (rc && rc != -2) return rc;
     dx_done = rc == 0;
     rc = 0;

@@ -45,6 +45,9 @@ struct Clip32Args {
   int cnt_base;
   int B, Cin, Cout, To, Ti, ep, k8w, npw, rows_valid, nct;      // Cout: output channels (addressing) = rows_valid; nct = ceil(Cout / 32)
   float slope, eps, momentum;
+  // EP_DGRAD_BN: BatchNorm + LeakyReLU backward of the PRODUCER of this data gradient's rows, in the epilogue (y holds its dy_raw)
+  const float* pv_y; const float* pv_y_raw; const float* pv_save; const float* pv_gamma;
+  float* pv_dgamma; float* pv_dbeta; float* pv_dbias;
   int raw_all;           // BN_TRAIN: y_raw for every channel (0: only for channels whose backward cannot take x_hat from y: conv16.h bn_inv_unsafe)
   unsigned long long* stamps;   // diagnostics (MS_CLIP_DBG=32): [workgroup][8] s_memrealtime stamps (100 MHz)
 };
@@ -424,6 +427,101 @@ __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
   } else if (p.ep == EP_BN_EVAL) {
     sc = gam * (1.0f / sqrtf(rvo + p.eps));
     sh = bet - rmo * sc;
+  } else if (p.ep == EP_DGRAD_BN) {
+    // v = gradient w.r.t. the OUTPUT y_p of the block that produced this block's input (channel cgl, FPT frames).  Its BatchNorm +
+    // LeakyReLU backward (elementwise.hip: bn_bwd_fused_kernel, same arithmetic) needs the channel's sums of dz and dz * x_hat over
+    // the whole batch: the workgroups of the channel tile meet once, exactly like the forward statistics above.
+    const int C = p.Cout;
+    const float mean = p.pv_save[cgc], invstd = p.pv_save[C + cgc], scp = p.pv_save[2 * C + cgc], shp = p.pv_save[3 * C + cgc];
+    const float gm = p.pv_gamma[cgc];
+    const bool from_y = !bn_inv_unsafe(mean, invstd, scp, shp, p.slope);      // (per channel: the 8 threads of a channel agree)
+    const float* src = from_y ? p.pv_y : p.pv_y_raw;
+    float yv[FPT];
+    if (To >= FPT) {
+      const int cl = f0 / To, tt = f0 - cl * To;
+      const float* sp = src + ((size_t)(b0 + cl) * C + cgc) * To + tt;
+#pragma unroll
+      for (int k = 0; k < FPT; k += 4) {
+        const float4 u = *reinterpret_cast<const float4*>(sp + k);
+        yv[k] = u.x; yv[k + 1] = u.y; yv[k + 2] = u.z; yv[k + 3] = u.w;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < FPT; ++k) {
+        const int f = f0 + k, cl = f / To, tt = f - cl * To;
+        yv[k] = src[((size_t)(b0 + cl) * C + cgc) * To + tt];
+      }
+    }
+    const float beta_c = fmaf(mean, scp, shp), inv_sl = 1.0f / p.slope, inv_g = invstd / scp;     // (from_y: slope, scale are not tiny)
+    float dz[FPT], xh[FPT];
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int k = 0; k < FPT; ++k) {
+      bool pos;
+      float xv;
+      if (from_y) {
+        pos = yv[k] > 0.f;
+        xv = ((pos ? yv[k] : yv[k] * inv_sl) - beta_c) * inv_g;
+      } else {
+        pos = fmaf(yv[k], scp, shp) > 0.f;
+        xv = (yv[k] - mean) * invstd;
+      }
+      dz[k] = v[k] * (pos ? 1.f : p.slope);
+      xh[k] = xv;
+      s1 += dz[k];
+      s2 = fmaf(dz[k], xv, s2);
+      s3 += xv;
+    }
+    s1 = cl_sum8(s1); s2 = cl_sum8(s2); s3 = cl_sum8(s3);
+    double S1 = (double)s1, S2 = (double)s2, S3 = (double)s3;
+    if (p.npw > 1) {
+      const __amdgpu_buffer_rsrc_t rsPart = buf_rsrc(p.part);
+      if (pq == 0)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(cl_u32x4, float4{s1, s2, s3, 0.f}), rsPart,
+                                               (int)(16u * (unsigned)((ct * p.npw + pw) * 32 + chl)), 0, 16);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      int* lflag = reinterpret_cast<int*>(cl_smem + 4 * 32 * RP);
+      if (t == 0) {
+        int* counter = p.sync + p.cnt_base + 32 * ct;
+        const int prior = __hip_atomic_load(p.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sticky error word: chain32.hip, chain_meet
+        const unsigned old = (unsigned)__hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = (old / (unsigned)p.npw + 1u) * (unsigned)p.npw;
+        int spins = 0, bad = 0;
+        while ((int)((unsigned)__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > CL_SPIN_LIMIT) { __hip_atomic_store(p.sync, 21, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); bad = 1; break; }
+        }
+        lflag[0] = bad | (prior != 0);
+      }
+      __syncthreads();
+      // the channel's partials of every pixel workgroup, every 8th one per lane (4 in flight), summed in fp64 in a fixed order
+      const unsigned base = 16u * (unsigned)(ct * p.npw * 32 + chl);
+      double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      float4 pv4[4];
+      for (int i0 = pq; i0 < p.npw; i0 += 32) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = min(i0 + 8 * u, p.npw - 1);
+          pv4[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsPart, (int)(base + 16u * (unsigned)(i * 32)), 0, 16));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (i0 + 8 * u < p.npw) { a1 += (double)pv4[u].x; a2 += (double)pv4[u].y; a3 += (double)pv4[u].z; }
+      }
+      S1 = cl_sum8_d(a1); S2 = cl_sum8_d(a2); S3 = cl_sum8_d(a3);
+      if (lflag[0]) S1 = __builtin_nan("");
+    }
+    const double n = (double)p.npw * NPX;
+    const float m1 = (float)(S1 / n), m2 = (float)(S2 / n), gi = gm * invstd;
+#pragma unroll
+    for (int k = 0; k < FPT; ++k) v[k] = gi * (dz[k] - m1 - xh[k] * m2);
+    if (pw == 0 && pq == 0 && rowok) {
+      if (p.pv_dgamma) { p.pv_dgamma[cgl] = (float)S2; p.pv_dbeta[cgl] = (float)S1; }
+      if (p.pv_dbias) p.pv_dbias[cgl] = -gi * m2 * (float)S3;        // = the sum of dy_raw over the batch (zero but for rounding)
+    }
+    if (rowok) store_frames(p.y, v);
+    return;
   }
   if (!rowok) return;
   if (p.ep == EP_DGRAD_UP2) {
@@ -619,7 +717,7 @@ int clip32_launch(Clip32Args a, int KW, int S, bool up2, const char* what, hipSt
   if (!cus) cus = 256;
   // (one workgroup per CU is what every instance of the kernel is sure to get: LDS would allow two of the smaller images, the
   // register file of the upsample-add instance does not)
-  if (a.ep == EP_RAW_STATS && a.npw > 1 && nwg > cus) return -2;      // caller falls back to the per-layer kernels
+  if ((a.ep == EP_RAW_STATS || a.ep == EP_DGRAD_BN) && a.npw > 1 && nwg > cus) return -2;      // caller falls back to the per-layer kernels
   const double flops = 2.0 * a.rows_valid * a.Cin * (dg2 ? 2 : KW) * (double)a.B * a.To;
   const double bytes = 4.0 * ((double)a.rows_valid * a.Cin * KW + (double)a.B * a.Cin * a.Ti + (double)a.B * a.rows_valid * a.To);
   TimingScope ts(s, flops, bytes, "clip32_kernel<%d,%d,%d,%d>|conv_%s_clip k1x%d s%d rows%d red%d T%d B%d ep%d", KW, S, nb, up2 ? 1 : 0, what, KW,
@@ -672,13 +770,32 @@ int clip32_block_fwd(const ms_conv_desc* d, const float* x, const float* x2, con
   return clip32_launch(a, d->KW, d->SW, d->in_mode == MS_IN_UP2ADD, "fwd", s);
 }
 
-int clip32_block_dgrad(const ms_conv_desc* d, const float* g, const float* wp, float* dx, float* dx2, hipStream_t s) {
+// the fused form needs the plain-input data gradient (not the upsample-add one) and every workgroup of the launch resident at once
+bool clip32_dgrad_bn_ok(const ms_conv_desc* d) {
+  if (!clip32_dgrad_ok(d) || d->in_mode != MS_IN_PLAIN) return false;
+  const int cus = current_device_cus();
+  return cus > 0 && cdiv(d->Cin, 32) * (d->B * d->W / 64) <= cus;
+}
+size_t clip32_dgrad_bn_part_bytes(const ms_conv_desc* d) {
+  return clip32_dgrad_ok(d) && d->in_mode == MS_IN_PLAIN ? align_up((size_t)cdiv(d->Cin, 32) * (d->B * d->W / 64) * 32 * 4 * sizeof(float), 256) : 0;
+}
+
+int clip32_block_dgrad(const ms_conv_desc* d, const float* g, const float* wp, float* dx, float* dx2, hipStream_t s,
+                       const Clip32PrevBN* pv, float* part, int* sync, int sync_words) {
   Clip32Args a = {};
   const bool up2 = d->in_mode == MS_IN_UP2ADD;
   a.x = g; a.wp = wp;
   a.y = dx; a.y2 = dx2;
   a.B = d->B; a.Cin = d->Cout; a.Cout = d->Cin; a.rows_valid = d->Cin; a.To = d->W; a.Ti = d->W;
   a.ep = up2 ? EP_DGRAD_UP2 : EP_BARE;
+  if (pv) {
+    if (up2 || !part || !sync || sync_words < 32 + clip32_sync_words(d->Cin) || !pv->y || !pv->y_raw || !pv->save || !pv->gamma)
+      return set_error("clip32 data gradient with the producer's BatchNorm backward: missing buffer");
+    a.ep = EP_DGRAD_BN;
+    a.pv_y = pv->y; a.pv_y_raw = pv->y_raw; a.pv_save = pv->save; a.pv_gamma = pv->gamma;
+    a.pv_dgamma = pv->dgamma; a.pv_dbeta = pv->dbeta; a.pv_dbias = pv->dbias;
+    a.slope = pv->slope; a.part = part; a.sync = sync; a.cnt_base = 32;
+  }
   if (d->KW == 4) {                                  // k4 s2 block: the image is dy_raw at half the output's resolution
     a.Ti = d->OW;
     return clip32_launch(a, 4, 2, false, "dgrad", s, true);

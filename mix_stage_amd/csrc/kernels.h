@@ -4,7 +4,7 @@
 
 namespace ms {
 
-enum { EP_BARE = 0, EP_LRELU = 1, EP_BN_EVAL = 2, EP_RAW_STATS = 3, EP_DGRAD = 4, EP_DGRAD_UP2 = 5, EP_BN_FUSED = 6 };
+enum { EP_BARE = 0, EP_LRELU = 1, EP_BN_EVAL = 2, EP_RAW_STATS = 3, EP_DGRAD = 4, EP_DGRAD_UP2 = 5, EP_BN_FUSED = 6, EP_DGRAD_BN = 7 };
 
 struct GatherArgs {
   const float* A;     // [groups][Mg][Kg]
@@ -174,7 +174,13 @@ int clip32_sync_words(int rows);
 int clip32_block_fwd(const ms_conv_desc* d, const float* x, const float* x2, const float* wp, const float* bias, const float* gamma,
                      const float* beta, float* rm, float* rv, float* y_raw, float* y, float* save, float* part, int* sync,
                      int sync_words, hipStream_t s);
-int clip32_block_dgrad(const ms_conv_desc* d, const float* g, const float* wp, float* dx, float* dx2, hipStream_t s);
+// BatchNorm + LeakyReLU backward of the block that PRODUCED the input of block d (its output y / y_raw, save, gamma; gradient slots),
+// carried out in the epilogue of d's data-gradient launch (EP_DGRAD_BN): dx then holds dy_raw of the producer
+struct Clip32PrevBN { const float* y; const float* y_raw; const float* save; const float* gamma; float* dgamma; float* dbeta; float* dbias; float slope; };
+size_t clip32_dgrad_bn_part_bytes(const ms_conv_desc* d);
+bool clip32_dgrad_bn_ok(const ms_conv_desc* d);
+int clip32_block_dgrad(const ms_conv_desc* d, const float* g, const float* wp, float* dx, float* dx2, hipStream_t s,
+                       const Clip32PrevBN* pv = nullptr, float* part = nullptr, int* sync = nullptr, int sync_words = 0);
 
 // data gradient of the grouped decoder blocks (chain32.hip: gconv32_kernel)
 bool gdgrad32_ok(const ms_conv_desc* d);

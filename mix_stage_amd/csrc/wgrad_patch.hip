@@ -23,7 +23,7 @@ int g_wgrad_patch_target_wgs = 768;   // workgroups a layer's launch aims for th
 // made the slab reduction a 519 MB launch.
 int g_wgrad_batched = 0;
 int g_wgrad_tiles_per_wg = 16;
-int g_wgrad_min_wgs = 128;
+int g_wgrad_min_wgs = 48;       // (swept 16 / 48 / 128 on the headline G-step: 4.65 / 4.60 / 4.65 ms -- a lower floor means fewer partial slabs for the many small 1-D layers)
 int g_wgrad_steps_per_wg = 96;
 extern int g_wgrad_wave;
 
@@ -821,6 +821,7 @@ extern "C" int ms_debug_set_wgrad_wave(int on) {
 }
 
 extern "C" int ms_set_wgrad_batched(int on, int tiles_per_workgroup) {
+  if (const char* e = getenv("MS_WGRAD_MINWG")) { if (atoi(e) > 0) ms::g_wgrad_min_wgs = atoi(e); }      // experiments
   const int old = ms::g_wgrad_batched;
   if (old != (on ? 1 : 0) || (tiles_per_workgroup > 0 && tiles_per_workgroup != ms::g_wgrad_tiles_per_wg)) ms_debug_set_wgrad_target(ms::g_wgrad_patch_target_wgs);   // (bumps the tuning epoch: slab sizes change)
   ms::g_wgrad_batched = on ? 1 : 0;

@@ -155,7 +155,7 @@ class ConvNormRelu(nn.Module):
     if _train_tape is not None:
       _train_tape.append(self)
 
-  def _run(self, x, x2=None, in_mode=MS_IN_PLAIN, out_f32=False):
+  def _run(self, x, x2=None, in_mode=MS_IN_PLAIN, out_f32=False, chain_prev=False):
     if self._p and self.training:
       raise NotImplementedError('dropout p>0 is not on the Mix-StAGE path (p=0 everywhere, JL:26)')
     n = self.norm
@@ -190,7 +190,7 @@ class ConvNormRelu(nn.Module):
       y_raw = ops.conv_block(x, self.conv.weight, self.conv.bias, g, MS_BARE, x2=x2, in_mode=in_mode)
       return ops.sync_bn_act(y_raw, n.weight, n.bias, n.running_mean, n.running_var, g.slope, g.eps, g.momentum)
     return ops.conv_block(x, self.conv.weight, self.conv.bias, self._geometry(), mode, n.weight, n.bias,
-                          n.running_mean, n.running_var, x2=x2, in_mode=in_mode)
+                          n.running_mean, n.running_var, x2=x2, in_mode=in_mode, chain_prev=chain_prev and mode == MS_BN_TRAIN)
 
   def forward(self, x, **kwargs):
     # `_residual` / `_broadcast` / `_out_f32` select the fused forms below (package-internal; the reference's
@@ -201,7 +201,9 @@ class ConvNormRelu(nn.Module):
       return self._run(x, x2=residual, in_mode=MS_IN_UP2ADD, out_f32=out_f32)
     if kwargs.get('_broadcast'):
       return self._run(x, in_mode=MS_IN_BCAST, out_f32=out_f32)
-    return self._run(x, out_f32=out_f32)
+    # `_ms_chain`: set by the 1-D stacks of this file for every block but the first -- x is the previous block's output and feeds
+    # nothing else, so the backward pass may fuse that block's BatchNorm backward into this block's data gradient (ops.conv_block)
+    return self._run(x, out_f32=out_f32, chain_prev=bool(kwargs.get('_ms_chain')))
 
   def forward_upsample_add(self, a, residual):
     """== self(upsample_nearest2(a) + residual) without materialising the sum (layers.py:151)."""
@@ -241,8 +243,8 @@ class UNet1D(nn.Module):
     if was_plain:
       x = ops16.to_cb8(x, dt)
     channels = self.conv2[-1].conv.weight.shape[0]
-    for m in self.pre_downsampling_conv:
-      x = m(x)
+    for i, m in enumerate(self.pre_downsampling_conv):
+      x = m(x, _ms_chain=i > 0)
     residuals = [x]
     for i, down in enumerate(self.conv1):
       x = down(x)
@@ -306,8 +308,8 @@ class _TimeMajorStack(nn.Module):
         return mods[-1](x, _out_f32=True)
       return ops16.from_cb8(mods[-1](x), mods[-1].conv.weight.shape[0])
     x = ops.to_channel_major(x)
-    for m in self.conv:
-      x = m(x)
+    for i, m in enumerate(self.conv):
+      x = m(x, _ms_chain=i > 0)
     return x
 
 
@@ -380,8 +382,8 @@ class ClusterClassify(nn.Module):
     dt = getattr(self, '_ms_dt', 0)
     if dt and not ops16.is_cb8(x):
       x = ops16.to_cb8(x, dt)
-    for m in self.conv:
-      x = m(x)
+    for i, m in enumerate(self.conv):
+      x = m(x, _ms_chain=i > 0)
     return bare_conv(self.logits, x, out_f32=True)        # scores (B, M, T) are fp32 in every mode
 
 

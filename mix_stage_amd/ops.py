@@ -365,7 +365,7 @@ def _grad_slot(param, shape_like):
 
 class _ConvBlockFn(torch.autograd.Function):
   @staticmethod
-  def forward(ctx, x, x2, w, bias, gamma, beta, geom, mode, in_mode, stats, pre=None):
+  def forward(ctx, x, x2, w, bias, gamma, beta, geom, mode, in_mode, stats, pre=None, prev=None):
     rm, rv = stats if stats is not None else (None, None)
     _need_hip(x, x2, w, bias, gamma, beta, rm, rv)
     x = x.contiguous()
@@ -413,6 +413,17 @@ class _ConvBlockFn(torch.autograd.Function):
                                        _stream(), ctypes.byref(opt)), 'ms_conv_block_fwd_ex')
     ctx.geom_desc = d
     ctx.mode, ctx.in_mode = mode, in_mode
+    # `prev`: the autograd node of the BN_TRAIN block that produced x, handed over by a container that knows x has no other
+    # consumer (layers.py: the 1-D stacks).  If this block's data-gradient launch can carry that block's BatchNorm + LeakyReLU
+    # backward (ms_bwd_options.prev_*), the backward pass fuses the two: one launch and one pass over dy fewer per block.
+    ctx.prev = None
+    ctx.dy_is_dyr = False
+    if prev is not None and pre is None and in_mode == MS_IN_PLAIN and nd == 1 and getattr(prev, 'mode', None) == MS_BN_TRAIN \
+        and not bn_sync_active() and lib().ms_dgrad_fuses_prev_bn(ctypes.byref(d)):
+      from . import ops16
+      py = prev.saved_tensors[5]
+      if ops16.in_launch_meetings() and py is not None and py.data_ptr() == x.data_ptr() and tuple(py.shape) == tuple(x.shape):
+        ctx.prev = prev
     ctx.has_bias = bias is not None
     ctx.params = (w, bias, gamma, beta)          # parameter objects (for their gradient slots)
     # BN_TRAIN: the block's output is saved too -- the one-launch BatchNorm backward takes x_hat and the activation mask from it
@@ -431,7 +442,9 @@ class _ConvBlockFn(torch.autograd.Function):
     need_bn = mode == MS_BN_TRAIN and ctx.needs_input_grad[4]
     dy = dy.contiguous()
     dev = dy.device
-    dyr = torch.empty_like(dy) if mode != MS_BARE else None
+    is_dyr = bool(ctx.dy_is_dyr)          # a consumer's fused launch already ran this block's BatchNorm + activation backward
+    ctx.dy_is_dyr = False                 # (one backward pass: the consumer sets it again if the graph is walked once more)
+    dyr = torch.empty_like(dy) if (mode != MS_BARE and not is_dyr) else None
     up2 = in_mode == MS_IN_UP2ADD
     want_dx = need_x or (up2 and need_x2)
     dx = torch.empty_like(x) if want_dx else None
@@ -441,11 +454,29 @@ class _ConvBlockFn(torch.autograd.Function):
     direct_w = direct_b = direct_g = direct_be = False
     if need_w:
       dw, direct_w = _grad_slot(pw, w)
-      if ctx.has_bias:
+      if ctx.has_bias and not is_dyr:
         dbias, direct_b = _grad_slot(pbias, pbias)
-    if need_bn:
+    if need_bn and not is_dyr:
       dgamma, direct_g = _grad_slot(pgamma, gamma)
       dbeta, direct_be = _grad_slot(pbeta, gamma)
+    if is_dyr:
+      direct_b = direct_g = direct_be = True        # (written by the consumer's launch into the slots: autograd gets None)
+    # ---- fuse the producer's BatchNorm backward into this block's data gradient?
+    fuse = None
+    prev = ctx.prev
+    if prev is not None and want_dx and not up2 and _overlap['stream'] is None and not torch.is_grad_enabled():
+      ppw, ppbias, ppgamma, ppbeta = prev.params
+      p_need_w, p_need_bn = prev.needs_input_grad[2], prev.needs_input_grad[4]
+      wanted = ([ppbias] if (p_need_w and prev.has_bias) else []) + ([ppgamma, ppbeta] if p_need_bn else [])
+      if all(getattr(q, '_ms_grad_slot', None) is not None and (getattr(q, '_ms_grad_fresh', False) or _deferred['on']) for q in wanted):
+        _, _, _, pgam_t, py_raw, py, psave = prev.saved_tensors
+        if py_raw is not None and py is not None and psave is not None:
+          pdb = _grad_slot(ppbias, ppbias)[0] if (p_need_w and prev.has_bias) else None
+          pdg = _grad_slot(ppgamma, pgam_t)[0] if p_need_bn else None
+          pdbe = _grad_slot(ppbeta, pgam_t)[0] if p_need_bn else None
+          from . import ops16
+          sync = ops16.block_sync(dev, d, tag='dgrad_bn')     # (its own counters: the launch's member count is this block's pixel workgroups)
+          fuse = (py, py_raw, psave, pgam_t, pdg, pdbe, pdb, sync, float(prev.geom_desc.slope))
     ws = workspace(d._bwd_ws, dev)
     side = _overlap['stream']
     if side is not None and need_w and direct_w is not True:
@@ -470,9 +501,18 @@ class _ConvBlockFn(torch.autograd.Function):
       # the weight-gradient kernel itself is queued (ms_wgrad_flush at the end of the backward pass) when nothing downstream
       # reads dw: it lands in the flat gradient buffer
       defer_launch = bool(_deferred['on'] and direct_w is True and dw is not None and DEFER_WGRAD_LAUNCH)
-      if wt is not None or part is not None or defer_launch:
+      if wt is not None or part is not None or defer_launch or fuse is not None or is_dyr:
         opt = BwdOptions(None, None, 0, wt.data_ptr() if wt is not None else None,
                          part.data_ptr() if part is not None else None, 1 if defer_launch else 0)
+        if fuse is not None:
+          py, py_raw, psave, pgam_t, pdg, pdbe, pdb, sync, pslope = fuse
+          opt.prev_y, opt.prev_y_raw, opt.prev_save, opt.prev_gamma = py.data_ptr(), py_raw.data_ptr(), psave.data_ptr(), pgam_t.data_ptr()
+          opt.prev_dgamma = pdg.data_ptr() if pdg is not None else None
+          opt.prev_dbeta = pdbe.data_ptr() if pdbe is not None else None
+          opt.prev_dbias = pdb.data_ptr() if pdb is not None else None
+          opt.prev_slope, opt.bn_sync, opt.bn_sync_words = pslope, sync.data_ptr(), sync.numel()
+          prev.dy_is_dyr = True            # the producer's node runs after this one: its incoming gradient is dy_raw already
+        opt.dy_is_dyr = 1 if is_dyr else 0
         check(lib().ms_conv_block_bwd_ex(ctypes.byref(d), _ptr(x), _ptr(x2), _ptr(w), _ptr(gamma), None, None, _ptr(y_raw),
                                          _ptr(y), _ptr(save), _ptr(dy), _ptr(dyr), _ptr(dx), _ptr(dx2), _ptr(dw),
                                          _ptr(dbias), _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), _stream(),
@@ -490,7 +530,7 @@ class _ConvBlockFn(torch.autograd.Function):
                                       _ptr(dbias), _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), _stream()),
               'ms_conv_block_bwd')
     return (dx, dx2, None if direct_w else dw, None if direct_b else dbias, None if direct_g else dgamma,
-            None if direct_be else dbeta, None, None, None, None, None)
+            None if direct_be else dbeta, None, None, None, None, None, None)
 
 
 def _f32(t):
@@ -512,8 +552,19 @@ def _bridge64(fn):
   return wrapped
 
 
+# MS_CHAIN_BN=0 / enable_chain_fusion(False): the 1-D stacks keep every block's BatchNorm backward in its own launch (ablations;
+# the side-stream weight-gradient experiment, whose launches have no fused form)
+_chain_fusion = {'on': os.environ.get('MS_CHAIN_BN', '1') != '0'}
+
+
+def enable_chain_fusion(on):
+  old = _chain_fusion['on']
+  _chain_fusion['on'] = bool(on)
+  return old
+
+
 def conv_block(x, w, bias, geom, mode, gamma=None, beta=None, running_mean=None, running_var=None, x2=None,
-               in_mode=MS_IN_PLAIN):
+               in_mode=MS_IN_PLAIN, chain_prev=False):
   """One conv block of the path on the HIP kernels (see include/mixstage.h: ms_conv_block_fwd/bwd)."""
   if w.dtype == torch.float64 or x.dtype == torch.float64:
     # .double() model: fp32 shadows of the parameters (differentiable casts) and of the running statistics, which the
@@ -527,7 +578,9 @@ def conv_block(x, w, bias, geom, mode, gamma=None, beta=None, running_mean=None,
         running_var.copy_(rv32)
     return y.double()
   stats = (running_mean, running_var) if running_mean is not None else None
-  return _ConvBlockFn.apply(x, x2, w, bias, gamma, beta, geom, mode, in_mode, stats)
+  # chain_prev: the caller vouches that x -- the output of another conv block -- feeds nothing but this block
+  prev = x.grad_fn if (chain_prev and _chain_fusion['on'] and x.grad_fn is not None and type(x.grad_fn).__name__ == '_ConvBlockFnBackward') else None
+  return _ConvBlockFn.apply(x, x2, w, bias, gamma, beta, geom, mode, in_mode, stats, None, prev)
 
 
 # ------------------------------------------------------------------------------------------------

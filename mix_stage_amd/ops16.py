@@ -76,12 +76,12 @@ def chain_sync(device, B, M, words):
   return buf
 
 
-def block_sync(device, desc, words=1024):
+def block_sync(device, desc, words=1024, tag=''):
   """Meeting counters of ONE conv block (fp32 clip-resident kernels): a zeroed buffer per (device, stream, block descriptor) -- the
   counters are monotonic, so every launch that shares them must have the same member counts: one block, one shape."""
   if not _in_launch['on']:
     return None
-  key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream, 'block', id(desc))
+  key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream, 'block', id(desc), tag)
   buf = _bn_sync.get(key)
   if buf is None:
     buf = _bn_sync[key] = torch.zeros(words, dtype=torch.int32, device=device)

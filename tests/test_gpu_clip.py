@@ -120,3 +120,79 @@ def test_clip_block_is_bitwise_repeatable_and_replays_in_a_graph():
     torch.cuda.synchronize()
     assert torch.equal(yg, firsts[0][0])
   assert not ops16.bn_sync_error()
+
+
+@pytest.mark.parametrize('kind', ['classifier', 'style_encoder'])
+def test_stack_backward_fuses_the_producers_batchnorm_into_the_data_gradient(kind):
+  """Inside a 1-D stack (layers.py: ClusterClassify.conv 446-467, PoseStyleEncoder.conv 246-289) a block's output feeds the next
+  block only, so the backward pass lets the NEXT block's data-gradient launch carry this block's BatchNorm + LeakyReLU backward
+  (ms_bwd_options.prev_*: the workgroups of a channel tile meet inside the launch for the batch sums).  Gradients of every parameter
+  and of the input against the fp64 oracle stack, the launch list (one bn_bwd launch left: the last block's), and against the
+  unfused backward pass of the same modules."""
+  import mix_stage_amd as A
+  from mix_stage_amd import ops
+  from mix_stage_amd.train_step import FlatAdam
+  B = 8
+  gen = torch.Generator().manual_seed(3)
+  if kind == 'classifier':
+    ref = O.ClusterClassify(num_clusters=8, input_channels=266).double().train()
+    hip = A.ClusterClassify(num_clusters=8, input_channels=266)
+    x = torch.randn(B, 266, 64, generator=gen)
+    call = lambda m, t: m(t)
+    n_blocks = 6
+  else:
+    B = 32            # (the deepest levels hold B * T = 64 frames: one workgroup's worth only from 32 clips on)
+    ref = O.PoseStyleEncoder(input_channels=104, num_speakers=8).double().train()
+    hip = A.PoseStyleEncoder(input_channels=104, num_speakers=8)
+    x = torch.randn(B, 64, 104, generator=gen)
+    call = lambda m, t: m(t)
+    n_blocks = 7
+  sd = O.deterministic_state(ref.state_dict())
+  ref.load_state_dict(sd)
+  hip.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in sd.items()})
+  hip = hip.to(DEV).train()
+  opt = FlatAdam(hip.parameters())
+  x64 = x.double().requires_grad_()
+  y_ref = call(ref, x64)
+  gy = torch.randn(y_ref.shape, generator=gen)
+  y_ref.backward(gy.double())
+
+  def run(chain):
+    opt.zero_grad()
+    xh = x.to(DEV).requires_grad_()
+    if not chain:
+      mods = list(hip.conv)
+      saved = [m.forward for m in mods]
+      for m in mods:      # the same modules with the chain hint dropped
+        m.forward = (lambda mm: (lambda t, **kw: type(mm).forward(mm, t, **{k: v for k, v in kw.items() if k != '_ms_chain'})))(m)
+    try:
+      ops.timing_enable(True)
+      try:
+        call(hip, xh).backward(gy.to(DEV))
+        torch.cuda.synchronize()
+        lab = {r['label'].split('|')[-1]: r['count'] for r in ops.timing_report()}
+      finally:
+        ops.timing_enable(False)
+    finally:
+      if not chain:
+        for m, f in zip(mods, saved):
+          del m.forward
+    return xh.grad.clone(), opt.flat_g.clone(), lab
+
+  dx_f, g_f, lab_f = run(True)
+  dx_u, g_u, lab_u = run(False)
+  n_bn_f = sum(c for l, c in lab_f.items() if 'bn_bwd' in l)
+  n_bn_u = sum(c for l, c in lab_u.items() if 'bn_bwd' in l)
+  assert n_bn_u == n_blocks and n_bn_f == 1, (lab_f, lab_u)
+  assert sum(c for l, c in lab_f.items() if 'dgrad_clip' in l and 'ep7' in l) == n_blocks - 1
+  assert rel_err(dx_f, x64.grad) < 1e-4 and rel_err(dx_u, x64.grad) < 1e-4
+  for (n, p), o in zip(hip.named_parameters(), opt.offsets):
+    gref = dict(ref.named_parameters())[n].grad
+    gf = g_f[o:o + p.numel()].view_as(p)
+    gu = g_u[o:o + p.numel()].view_as(p)
+    if 'conv.bias' in n and not n.startswith('logits'):
+      # a conv bias in front of BatchNorm: the true gradient is 0, every side holds rounding noise
+      assert gf.abs().max().item() <= 1e-4 * max(1.0, gref.abs().max().item()), n
+      continue
+    assert rel_err(gf, gref) < 1e-4, (n, rel_err(gf, gref))
+    assert rel_err(gf, gu.double()) < 1e-5, (n, rel_err(gf, gu.double()))
