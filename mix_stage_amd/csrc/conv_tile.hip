@@ -20,7 +20,7 @@
 #include "kernels.h"
 
 #ifndef MS_TILE_OCC
-#define MS_TILE_OCC 2
+#define MS_TILE_OCC 3
 #endif
 namespace ms {
 
@@ -45,7 +45,9 @@ constexpr int tile_row_pitch(int win, int sv, int tw) {
 // AM 1: A rows [Mg][Kg], 16-byte loads.  AM 2: data gradient straight from the conv weight w[co][ci][tap] (stride-1 convs):
 // A(ci, (co, tap')) = w[co][ci][KHW-1-tap'], Mg = Cin_g, Kc = Cout_g.
 template <int KH, int KW, int S, int TW, int AM, int WM, int WN>
-__global__ __launch_bounds__(256, MS_TILE_OCC) void conv_tile_kernel(const PatchArgs p) {
+// (three workgroups per CU where the instance fits 168 registers: the 4 x 4 / 2 x 2 shapes and the 64 x 256 forms of the (3, .) shapes
+// with row-major weights; the 128 x 128 3 x 3 instances and the in-place-weight instances need ~200)
+__global__ __launch_bounds__(256, (KH * KW == 16 || KH * KW == 4 || (AM == 1 && WM == 1)) ? MS_TILE_OCC : 2) void conv_tile_kernel(const PatchArgs p) {
   prefetch_kernargs<sizeof(PatchArgs)>();
   using Cfg = TileCfg<KH, KW>;
   static_assert(WM * WN == 4, "four waves");
@@ -55,13 +57,18 @@ __global__ __launch_bounds__(256, MS_TILE_OCC) void conv_tile_kernel(const Patch
   constexpr int PR = (TH - 1) * SV + KH;
   constexpr int WIN = ((TW - 1) * S + KW + 3 + 3) / 4 * 4, W4 = WIN / 4;      // window start rounded down to a multiple of 4: shift <= 3
   constexpr int RP = tile_row_pitch(WIN, SV, TW), CP = PR * RP;
-  constexpr int LDA = BM + 1;
-  constexpr int ABUF = (KSTEP * LDA + 3) / 4 * 4;
-  constexpr int STAGE = ABUF + CK * CP + 3 * LDA + 8;                          // + pad words: idle staging slots (4 k-rows of a weight slot) land there
+  // weight slice in LDS: [row m][k], k contiguous as it lies in memory -- pitch = 4 * odd (mod 64): the 16 lanes of a ds_read_b128
+  // group (16 consecutive rows) cover the 64 banks.  The two halves of a wave take the two HALVES of the chunk's channels: lanes
+  // 0-31 k = kk, lanes 32-63 k = KSTEP / 2 + kk -- the same tap of a channel CK / 2 further on, i.e. ONE constant offset in the patch.
+  constexpr int KH2 = KSTEP / 2;                                               // k values per half = (CK / 2) * KHW
+  constexpr int AP = KSTEP % 8 == 4 ? KSTEP : KSTEP + 4;                       // 36 -> 36, 32 -> 36, 48 -> 52
+  constexpr int ABUF = BM * AP;
+  constexpr int STAGE = ABUF + CK * CP + 16;                                   // + pad words: idle staging slots land there
+  static_assert(CK % 2 == 0 && (AP / 4) % 2 == 1 && AP >= KSTEP, "bad weight-slice pitch");
   constexpr int NB4 = CK * PR * W4, NB = (NB4 + 255) / 256;                    // 16-byte slots of the patch
   constexpr int NAV = BM * (KSTEP / 4), NA = (NAV + 255) / 256;                // 16-byte slots of the weight slice
   constexpr int RUN4 = BM * KHW / 4;                                           // AM 2: 16-byte slots per output channel
-  static_assert(KSTEP % 4 == 0 && BN % TW == 0 && (BM * KHW) % 4 == 0, "bad tile configuration");
+  static_assert(KSTEP % 4 == 0 && BN % TW == 0 && (BM * KHW) % 4 == 0 && (KSTEP / 2) % 2 == 0, "bad tile configuration");
   static_assert(2 * STAGE >= 2 * WN * BM + 64, "statistics exchange does not fit the staging buffers");
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(256, MS_TILE_OCC) void conv_tile_kernel(const Patch
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int e = 4 * q4 + j, cil = e / KHW, tap = e - cil * KHW;
-        lsto[i][j] = idx < NAV ? (co * KHW + (KHW - 1 - tap)) * LDA + cil : ABUF + CK * CP + 4 + j;   // pad words
+        lsto[i][j] = idx < NAV ? cil * AP + co * KHW + (KHW - 1 - tap) : ABUF + CK * CP + 4 + j;   // pad words
       }
     } else {
       const int row = idx / (KSTEP / 4), kq = idx - row * (KSTEP / 4);
@@ -121,11 +128,13 @@ __global__ __launch_bounds__(256, MS_TILE_OCC) void conv_tile_kernel(const Patch
   const unsigned a_group = (unsigned)cls * p.cls_a_stride + (unsigned)g * p.Mg * Kg;
   const int img_base = img * p.s_img;
 
-  // two register sets: chunk c + 2 is in flight while chunk c + 1 moves registers -> LDS and chunk c computes
-  float4 raa[2][NA], rbb[2][NB];
+  // one register set: chunk c + 2 is requested right after chunk c + 1 moved registers -> LDS and has the whole of chunk c's MFMAs
+  // (72 per wave) to come back; a second set costs the third workgroup per CU
+  float4 raa[1][NA], rbb[1][NB];
   auto load_chunk = [&](int ci0, const int set) {
-    float4 (&ra)[NA] = raa[set];
-    float4 (&rb)[NB] = rbb[set];
+    float4 (&ra)[NA] = raa[0];
+    float4 (&rb)[NB] = rbb[0];
+    (void)set;
     const int k0 = ci0 * KHW;
     const unsigned sa = __builtin_amdgcn_readfirstlane(AM == 2 ? 4u * (a_group + (unsigned)(ci0 * p.Mg * KHW)) : 4u * (a_group + (unsigned)k0));
     const bool full_k = k0 + KSTEP <= Kg;               // uniform: only the last chunk can be partial
@@ -145,8 +154,9 @@ __global__ __launch_bounds__(256, MS_TILE_OCC) void conv_tile_kernel(const Patch
     for (int i = 0; i < NB; ++i) rb[i] = buf_load4(rsS, (full_c | (ci0 + gci[i] < p.Kc)) ? goff[i] : BUF_OOB, cb);
   };
   auto store_chunk = [&](int buf, const int set) {
-    const float4 (&ra)[NA] = raa[set];
-    const float4 (&rb)[NB] = rbb[set];
+    const float4 (&ra)[NA] = raa[0];
+    const float4 (&rb)[NB] = rbb[0];
+    (void)set;
     float* As = smem + buf * STAGE;
     float* Ps = As + ABUF;
 #pragma unroll
@@ -156,8 +166,7 @@ __global__ __launch_bounds__(256, MS_TILE_OCC) void conv_tile_kernel(const Patch
       } else {
         const int idx = t + i * 256;
         const int row = idx / (KSTEP / 4), kq = idx - row * (KSTEP / 4);
-        const int base = idx < NAV ? kq * 4 * LDA + row : ABUF + CK * CP + 4;   // out of range: the pad words
-        As[base + 0 * LDA] = ra[i].x; As[base + 1 * LDA] = ra[i].y; As[base + 2 * LDA] = ra[i].z; As[base + 3 * LDA] = ra[i].w;
+        *reinterpret_cast<float4*>(As + (idx < NAV ? row * AP + 4 * kq : ABUF + CK * CP + 8)) = ra[i];   // (out of range: the pad words)
       }
     }
 #pragma unroll
@@ -172,17 +181,14 @@ __global__ __launch_bounds__(256, MS_TILE_OCC) void conv_tile_kernel(const Patch
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  // ---- per-lane operand bases: k and k+1 of an MFMA pair sit in lanes 0-31 / 32-63
-  const int a_base = khalf * LDA + 64 * wm + l31;          // + 32 mi + k0 LDA
-  int b_same[2], b_row[2], b_chan[2];
+  // ---- per-lane operand bases: the two k values of an MFMA sit in lanes 0-31 / 32-63 = the two channel halves of the chunk
+  const int a_base = (64 * wm + l31) * AP + khalf * KH2;    // + 32 mi AP + kk
+  int b_base[2];
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     const int nloc = 64 * wn + 32 * ni + l31;
     const int ty = nloc / TW, tx = nloc - ty * TW;
-    const int base = ty * SV * RP + tx * S + shift;
-    b_same[ni] = base + khalf;                                         // k+1 = next tap in the same row
-    b_row[ni] = base + khalf * (RP - (KW - 1));                        // k+1 = first tap of the next kernel row
-    b_chan[ni] = base + khalf * (CP - (KH - 1) * RP - (KW - 1));       // k+1 = first tap of the next channel
+    b_base[ni] = ty * SV * RP + tx * S + shift + khalf * (CK / 2) * CP;
   }
 
   const int chunk_beg = ks * p.chunks_per_split;
@@ -190,23 +196,31 @@ __global__ __launch_bounds__(256, MS_TILE_OCC) void conv_tile_kernel(const Patch
   auto compute_chunk = [&](int cur) {
     const float* As = smem + cur * STAGE;
     const float* Ps = As + ABUF;
-    constexpr int NPAIR = KSTEP / 2, GP = 2, NG = (NPAIR + GP - 1) / GP;
-    float av[2][GP][2], bv[2][GP][2];
+    // groups of 4 k values per half (one ds_read_b128 per 32-row block; the 3 x 3 chunk ends with a group of 2): the next group's
+    // operands are read while the current group's MFMAs issue
+    constexpr int NG = (KH2 + 3) / 4;
+    float av[2][2][4], bv[2][4][2];
     auto read_group = [&](int gi, int slot) {
+      const int kk0 = 4 * gi;
+      constexpr int dummy = 0; (void)dummy;
 #pragma unroll
-      for (int q = 0; q < GP; ++q) {
-        const int jj = gi * GP + q;
-        if (jj < NPAIR) {
-          const int k0 = 2 * jj;
-          const int ci = k0 / KHW, rr = k0 - ci * KHW, kh = rr / KW, kw = rr - kh * KW;
+      for (int mi = 0; mi < 2; ++mi) {
+        if (kk0 + 4 <= KH2) {
+          const float4 v = *reinterpret_cast<const float4*>(As + a_base + 32 * mi * AP + kk0);
+          av[slot][mi][0] = v.x; av[slot][mi][1] = v.y; av[slot][mi][2] = v.z; av[slot][mi][3] = v.w;
+        } else {
+          const float2 v = *reinterpret_cast<const float2*>(As + a_base + 32 * mi * AP + kk0);
+          av[slot][mi][0] = v.x; av[slot][mi][1] = v.y;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kk = kk0 + r;
+        if (kk < KH2) {
+          const int ci = kk / KHW, rr = kk - ci * KHW, kh = rr / KW, kw = rr - kh * KW;
           const int offb = ci * CP + kh * RP + kw;
 #pragma unroll
-          for (int mi = 0; mi < 2; ++mi) av[slot][q][mi] = As[a_base + 32 * mi + k0 * LDA];
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni) {
-            const int base = (kw + 1 < KW) ? b_same[ni] : (kh + 1 < KH) ? b_row[ni] : b_chan[ni];
-            bv[slot][q][ni] = Ps[base + offb];
-          }
+          for (int ni = 0; ni < 2; ++ni) bv[slot][r][ni] = Ps[b_base[ni] + offb];
         }
       }
     };
@@ -216,13 +230,13 @@ __global__ __launch_bounds__(256, MS_TILE_OCC) void conv_tile_kernel(const Patch
       if (gi + 1 < NG) read_group(gi + 1, (gi + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);                  // keep the next group's LDS reads ahead of these MFMAs
 #pragma unroll
-      for (int q = 0; q < GP; ++q)
-        if (gi * GP + q < NPAIR) {
+      for (int r = 0; r < 4; ++r)
+        if (4 * gi + r < KH2) {
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[gi & 1][q][mi], bv[gi & 1][q][ni], acc[mi][ni], 0, 0, 0);
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[gi & 1][mi][r], bv[gi & 1][r][ni], acc[mi][ni], 0, 0, 0);
         }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -230,19 +244,18 @@ __global__ __launch_bounds__(256, MS_TILE_OCC) void conv_tile_kernel(const Patch
   // chunk i computes out of buffer i & 1 while chunk i + 1 moves registers -> the other buffer and chunk i + 3 is requested
   if (nchunks > 0) {
     load_chunk(chunk_beg * CK, 0);
-    if (nchunks > 1) load_chunk((chunk_beg + 1) * CK, 1);
     store_chunk(0, 0);
-    if (nchunks > 2) load_chunk((chunk_beg + 2) * CK, 0);
+    if (nchunks > 1) load_chunk((chunk_beg + 1) * CK, 0);
   }
   __syncthreads();
   for (int ch = 0; ch < nchunks; ch += 2) {
-    if (ch + 1 < nchunks) store_chunk(1, 1);
-    if (ch + 3 < nchunks) load_chunk((chunk_beg + ch + 3) * CK, 1);
+    if (ch + 1 < nchunks) store_chunk(1, 0);
+    if (ch + 2 < nchunks) load_chunk((chunk_beg + ch + 2) * CK, 0);
     compute_chunk(0);
     __syncthreads();
     if (ch + 1 >= nchunks) break;
     if (ch + 2 < nchunks) store_chunk(0, 0);
-    if (ch + 4 < nchunks) load_chunk((chunk_beg + ch + 4) * CK, 0);
+    if (ch + 3 < nchunks) load_chunk((chunk_beg + ch + 3) * CK, 0);
     compute_chunk(1);
     __syncthreads();
   }
@@ -272,23 +285,34 @@ __global__ __launch_bounds__(256, MS_TILE_OCC) void conv_tile_kernel(const Patch
         }
     return;
   }
-  float m2_keep[2][16];
-  float sum_keep[2][16];
+  // (register diet: this epilogue used to hold 112 registers of per-row temporaries next to the 64 accumulators and cost the kernel
+  // its third workgroup per CU.  Now: scale / folded shift of 16 rows at a time, and every row's statistics live in ONE lane --
+  // lane 16 mi + r of each half-wave keeps (sum, M2) of row (mi, r) after the half-wave reductions.)
+  const bool stats = ep == EP_RAW_STATS;
+  int cnt_w = 0;
+  if (stats) {
+    const int ty_lo = (64 * wn) / TW, ty_hi = (64 * wn + 63) / TW;               // this wave's rows of the tile (TW <= 64)
+    const int cols = min(TW, OUTWc - ox0);
+    cnt_w = max(0, min(ty_hi + 1, OUTHc - oy0) - ty_lo) * max(0, cols);
+  }
+  const float inv_cnt = cnt_w > 0 ? 1.0f / (float)cnt_w : 0.f;
+  float keep_s = 0.f, keep_m2 = 0.f;
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
-    // the 16 rows' parameters of this 32-row block in one round trip (clamped addresses, no branches between the loads)
-    float bias_r[16], sc_r[16], sh_r[16];
+    // the 16 rows' parameters of this 32-row block in one round trip (clamped addresses, no branches between the loads):
+    // v = acc * sc + sh with the bias folded into sh
+    float sc_r[16], sh_r[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + 64 * wm + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * khalf;
       const int chn = g * p.Mg + (m < p.Mg ? m : 0);
-      bias_r[r] = p.bias ? p.bias[chn] : 0.f;
+      const float bsv = p.bias ? p.bias[chn] : 0.f;
       if (ep == EP_BN_EVAL) {
         const float inv = 1.0f / sqrtf(p.bn_v[chn] + p.eps);
         sc_r[r] = p.bn_g[chn] * inv;
-        sh_r[r] = p.bn_b[chn] - p.bn_m[chn] * sc_r[r];
+        sh_r[r] = fmaf(bsv - p.bn_m[chn], sc_r[r], p.bn_b[chn]);
       } else {
-        sc_r[r] = 1.f; sh_r[r] = 0.f;
+        sc_r[r] = 1.f; sh_r[r] = bsv;
       }
     }
 #pragma unroll
@@ -296,56 +320,40 @@ __global__ __launch_bounds__(256, MS_TILE_OCC) void conv_tile_kernel(const Patch
       const int m = m0 + 64 * wm + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * khalf;
       const bool mval = m < p.Mg;
       const int chn = g * p.Mg + (mval ? m : 0);
-      float srow = 0.f;
+      float v[2], srow = 0.f;
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
-        float v = acc[mi][ni][r] + bias_r[r];
-        if (ep == EP_RAW_STATS) { acc[mi][ni][r] = v; srow += cval[ni] ? v : 0.f; }
-        if (ep == EP_BN_EVAL) v = lrelu(fmaf(v, sc_r[r], sh_r[r]), p.slope);
-        if (ep == EP_LRELU) v = lrelu(v, p.slope);
-        if (mval && cval[ni]) p.out[(size_t)ooff[ni] + (size_t)chn * p.o_chan] = v;
+        v[ni] = ep == EP_BN_EVAL ? fmaf(acc[mi][ni][r], sc_r[r], sh_r[r]) : acc[mi][ni][r] + sh_r[r];
+        if (stats) srow += cval[ni] ? v[ni] : 0.f;
+        float o = v[ni];
+        if (ep == EP_BN_EVAL || ep == EP_LRELU) o = lrelu(o, p.slope);
+        if (mval && cval[ni]) p.out[(size_t)ooff[ni] + (size_t)chn * p.o_chan] = o;
       }
-      sum_keep[mi][r] = srow;
-    }
-  }
-
-  if (ep == EP_RAW_STATS) {
-    // per-channel (sum, M2 about the tile's mean) over the tile's valid pixels, fixed order: each wave reduces its 64 pixels in
-    // registers (row sums over the 32 lanes of a half-wave), the WN waves that share the rows are combined Chan-style in wave order
-    const int ty_lo = (64 * wn) / TW, ty_hi = (64 * wn + 63) / TW;                  // this wave's rows of the tile (TW <= 64)
-    int cnt_w = 0;
-    {
-      const int cols = min(TW, OUTWc - ox0);
-      if (TW >= 64) cnt_w = (oy0 + ty_lo < OUTHc) ? max(0, min(64, cols - (64 * wn) % TW)) : 0;
-      else cnt_w = max(0, min(ty_hi + 1, OUTHc - oy0) - ty_lo) * max(0, cols);
-    }
-    const float inv_cnt = cnt_w > 0 ? 1.0f / (float)cnt_w : 0.f;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float s = half_wave_sum(sum_keep[mi][r]);
-        const float mean = s * inv_cnt;
+      if (stats) {
+        // per-channel (sum, M2 about this wave's mean) over the wave's valid pixels: row sums over the 32 lanes of a half-wave
+        const float sw = half_wave_sum(srow);
+        const float mean = sw * inv_cnt;
         float q = 0.f;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-          const float dlt = acc[mi][ni][r] - mean;
+          const float dlt = v[ni] - mean;
           q += cval[ni] ? dlt * dlt : 0.f;
         }
-        sum_keep[mi][r] = s;
-        m2_keep[mi][r] = half_wave_sum(q);
+        const float m2w = half_wave_sum(q);
+        if (l31 == 16 * mi + r) { keep_s = sw; keep_m2 = m2w; }
       }
+    }
+  }
+
+  if (stats) {
+    // the WN waves that share the rows are combined Chan-style in wave order (fixed order: bitwise reproducible)
     float* red = smem;                 // [wn][BM rows][2]
     __syncthreads();
-    if (l31 == 0) {
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ml = 64 * wm + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-          red[(wn * BM + ml) * 2 + 0] = sum_keep[mi][r];
-          red[(wn * BM + ml) * 2 + 1] = m2_keep[mi][r];
-        }
+    {
+      const int mi = l31 >> 4, r = l31 & 15;
+      const int ml = 64 * wm + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      red[(wn * BM + ml) * 2 + 0] = keep_s;
+      red[(wn * BM + ml) * 2 + 1] = keep_m2;
     }
     int* cnts = reinterpret_cast<int*>(red + 2 * WN * BM);
     if (lane == 0 && wm == 0) cnts[wn] = cnt_w;
