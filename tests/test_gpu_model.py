@@ -164,9 +164,23 @@ def test_golden_gradients_from_reference(golden_dir, name):
   z = np.load(os.path.join(golden_dir, name + '.npz'))
   B, T, M, S = [int(v) for v in z['meta']]
   batch = [torch.from_numpy(z[k]) for k in ('audio', 'pose', 'labels', 'style')]
-  for kind in ('G', 'D'):
-    hip = build_hip_gan(M, S)
-    _step(hip, batch, kind, DEV)
+  from mix_stage_amd import ops, _lib
+  for kind, forms in (('G', 'default'), ('D', 'default'), ('D', 'block by block')):
+    # 'block by block': the decoder blocks one by one and the per-layer conv kernels instead of the chained launch and the
+    # clip-resident blocks -- the generator's summation order closest to plain per-layer arithmetic.  D's gradient at these golden
+    # inputs is NOT a smooth function of the fake pose (an activation sits on its LeakyReLU kink: a 1e-7 perturbation of the pose
+    # moves D's gradients by 0.5-2 % in L2), so the default forms are held to a looser bar there and this pass to the strict one.
+    old_chain, old_clip = ops.USE_DECODER_CHAIN, None
+    if forms != 'default':
+      ops.USE_DECODER_CHAIN = False
+      old_clip = _lib.lib().ms_debug_set_clip32(0)
+    try:
+      hip = build_hip_gan(M, S)
+      _step(hip, batch, kind, DEV)
+    finally:
+      ops.USE_DECODER_CHAIN = old_chain
+      if old_clip is not None:
+        _lib.lib().ms_debug_set_clip32(old_clip)
     k = kind + '/'
     mod = hip.G if kind == 'G' else hip.D
     grads = {kind + '.' + n: p.grad.detach().double().reshape(-1).cpu() for n, p in mod.named_parameters()
@@ -188,10 +202,42 @@ def test_golden_gradients_from_reference(golden_dir, name):
       scale = gn / np.sqrt(g.numel()) + 1e-12            # rms of the gradient: the per-element yardstick
       assert abs(float(g.norm()) * coef - gn) <= 2e-3 * gn + 1e-9, (n, float(g.norm()) * coef, gn)
       worst = max(worst, float(np.abs(mine - gs).max() / scale))
-    # sampled elements within 5 % of the gradient's rms.  D-steps: the discriminator's gradient at these golden inputs is not a
-    # smooth function of the fake pose -- a 1e-7 perturbation of it moves D's gradients by 0.5-2 % in L2 (an activation sits on
-    # its LeakyReLU kink; tools/_dbg_sens2.py), so any change of the generator's summation order shows up there
-    assert worst <= (5e-2 if kind == 'G' else 2e-1), worst
+    # sampled elements within 5 % of the gradient's rms; the D-step through the chained / clip-resident generator forms: 20 % (see
+    # above; `test_d_step_gradients_do_not_depend_on_the_generator_forms_beyond_the_kink` bounds the forms against each other)
+    assert worst <= (2e-1 if (kind == 'D' and forms == 'default') else 5e-2), (kind, forms, worst)
+
+
+def test_d_step_gradients_do_not_depend_on_the_generator_forms_beyond_the_kink(golden_dir):
+  """The D-step's discriminator gradients with the generator's default forms (chained decoder, clip-resident blocks) against the
+  block-by-block forms, with the SAME fake pose fed to D in both: identical arithmetic in D then, so the gradients must agree to
+  fp32 rounding -- the 20 % bar of the golden D-step test is about the kink in D's input, not about D's own kernels."""
+  from mix_stage_amd import ops, _lib
+  z = np.load(os.path.join(golden_dir, 'c2r_fp32.npz'))
+  B, T, M, S = [int(v) for v in z['meta']]
+  batch = [torch.from_numpy(z[k]) for k in ('audio', 'pose', 'labels', 'style')]
+  hip = build_hip_gan(M, S)
+  fake, _ = _step(hip, batch, 'D', DEV)
+  fake = fake.detach()
+  g_default = {n: p.grad.detach().clone() for n, p in hip.D.named_parameters() if p.grad is not None}
+  # the same discriminator pass on that very fake pose, generator forms switched: only D's own launches matter now
+  old_chain = ops.USE_DECODER_CHAIN
+  old_clip = _lib.lib().ms_debug_set_clip32(0)
+  ops.USE_DECODER_CHAIN = False
+  try:
+    hip2 = build_hip_gan(M, S)
+    real_forward = hip2.G.forward
+    hip2.G.forward = lambda *a, **kw: (fake, real_forward(*a, **kw)[1])
+    _step(hip2, batch, 'D', DEV)
+  finally:
+    ops.USE_DECODER_CHAIN = old_chain
+    _lib.lib().ms_debug_set_clip32(old_clip)
+  for n, p in hip2.D.named_parameters():
+    if p.grad is None:
+      continue
+    a, b = g_default[n].double(), p.grad.detach().double()
+    if n.endswith('conv.bias') and 'conv1' not in n and 'logits' not in n:
+      continue                                         # conv bias in front of BN: rounding noise on both sides
+    assert (a - b).norm().item() <= 2e-4 * (b.norm().item() + 1e-12), (n, (a - b).norm().item(), b.norm().item())
 
 
 @pytest.mark.parametrize('name', ['c1_fp32', 'c2r_fp32', 'c3r_fp32'])
