@@ -59,6 +59,13 @@ enum ms_input_mode {
 enum ms_dtype { MS_F32 = 0, MS_BF16 = 1, MS_F16 = 2 };
 #define MS_DT_OUT_F32 0x100
 #define MS_DT_BN_FOLDED 0x200
+/* MS_DT_STAT_PAIR (flag, every arithmetic mode): the batch holds TWO passes of the module side by side -- clips [0, B/2) and
+ * [B/2, B) -- as gan.py:120,126 runs the discriminator on the fake and then on the real poses.  BN_TRAIN blocks take their batch
+ * statistics per half (save holds 2 x 4*C floats: the first half's vector, then the second half's), update the running statistics
+ * twice in that order, and their backward reduces per half; blocks without BatchNorm just see a batch of B.  Gradients of the
+ * weights are the sum over both halves, which is what two separate backward passes accumulate.  B must be even.
+ * ms_stat_pair_ok(d) says whether block d's kernels implement the flag. */
+#define MS_DT_STAT_PAIR 0x400
 
 /* Geometry of one conv block (1-D convs use H = KH = SH = 1, PH = 0). */
 typedef struct ms_conv_desc {
@@ -79,6 +86,9 @@ typedef struct ms_conv_desc {
 
 const char* ms_last_error(void);
 int ms_abi_version(void);
+/* 1 when forward and backward of block d (d->dtype carrying MS_DT_STAT_PAIR) are implemented for its geometry; 0: run the two
+ * passes one after the other. */
+int ms_stat_pair_ok(const ms_conv_desc* d);
 
 /* Bytes of scratch the forward / backward of this block needs. */
 size_t ms_conv_block_fwd_workspace(const ms_conv_desc* d);

@@ -67,6 +67,7 @@ class Prep16Item(ctypes.Structure):
 MS_BARE, MS_LRELU, MS_BN_TRAIN, MS_BN_EVAL = 0, 1, 2, 3
 MS_IN_PLAIN, MS_IN_BCAST, MS_IN_UP2ADD = 0, 1, 2
 MS_F32, MS_BF16, MS_F16, MS_DT_OUT_F32, MS_DT_BN_FOLDED = 0, 1, 2, 0x100, 0x200
+MS_DT_STAT_PAIR = 0x400      # BN_TRAIN statistics per half of the batch (two passes of a module side by side: include/mixstage.h)
 
 _P = c_void_p
 _DESC = ctypes.POINTER(ConvDesc)
@@ -160,6 +161,7 @@ SIGNATURES = {
     'ms_debug_set_conv_tile': (c_int, [c_int]),
     'ms_set_wgrad_batched': (c_int, [c_int, c_int]),
     'ms_dgrad_fuses_prev_bn': (c_int, [_P]),
+    'ms_stat_pair_ok': (c_int, [_P]),
     'ms_selftest_mfma': (c_int, [_P, _P, _P, c_int, _P]),
     'ms_probe_peak': (c_int, [c_int, ctypes.c_long, _P, _P, ctypes.POINTER(ctypes.c_double), _P]),
 }

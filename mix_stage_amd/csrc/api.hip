@@ -19,8 +19,9 @@ static int validate(const ms_conv_desc* d, const char* who) {
   if (d->in_mode < MS_IN_PLAIN || d->in_mode > MS_IN_UP2ADD) return set_error("%s: bad in_mode %d", who, d->in_mode);
   if (d->in_mode == MS_IN_UP2ADD && (d->H != 1 || d->KH != 1 || (d->W & 1)))
     return set_error("%s: UP2ADD needs a 1-D block with even W", who);
-  if (dt_of(d) > DT_F16 || (d->dtype & ~(0xff | MS_DT_OUT_F32 | MS_DT_BN_FOLDED))) return set_error("%s: bad dtype 0x%x", who, d->dtype);
-  if (dt_of(d) == DT_F32 && (d->dtype & ~0xff)) return set_error("%s: MS_DT_OUT_F32 is a flag of the 16-bit modes", who);
+  if (dt_of(d) > DT_F16 || (d->dtype & ~(0xff | MS_DT_OUT_F32 | MS_DT_BN_FOLDED | MS_DT_STAT_PAIR))) return set_error("%s: bad dtype 0x%x", who, d->dtype);
+  if (dt_of(d) == DT_F32 && (d->dtype & ~(0xff | MS_DT_STAT_PAIR))) return set_error("%s: MS_DT_OUT_F32 is a flag of the 16-bit modes", who);
+  if ((d->dtype & MS_DT_STAT_PAIR) && (d->B & 1)) return set_error("%s: MS_DT_STAT_PAIR needs an even batch", who);
   const double out_elems = (double)d->B * d->groups * d->Cout * d->OH * d->OW;
   const double in_elems = (double)d->B * d->groups * d->Cin * d->H * d->W;
   // the staging loads address a tensor with 32-bit BYTE offsets against one buffer descriptor: 2 GiB per tensor
@@ -51,6 +52,18 @@ static PatchPlan fwd_patch_plan(const ms_conv_desc* d) {
 }
 
 static inline int ctot_of(const ms_conv_desc* d) { return d->groups * d->Cout; }
+
+// MS_DT_STAT_PAIR, fp32 forward: the block ends in the register-resident split-K epilogue (one workgroup per channel walks the two
+// statistics groups) when the clip-resident launch does not take it -- the other BatchNorm finishes have no grouped form
+static bool stat_pair_fwd_epilogue_ok(const ms_conv_desc* d) {
+  if (d->mode != MS_BN_TRAIN) return true;
+  const long n_grp = (long)d->B / 2 * d->OH * d->OW;
+  if (n_grp > 4096) return false;
+  if (conv_c1_ok(d->groups, d->Cin, d->Cout, d->KH, d->KW, d->SH, d->SW, d->PH, d->PW, d->H, d->in_mode == MS_IN_PLAIN)) return false;
+  const PatchPlan pp = fwd_patch_plan(d);
+  if (pp.ok) return pp.splitk > 1 || pp.ksi > 1;
+  return plan_gather(d->Cout, d->B * d->OH * d->OW, d->groups, d->Cin * d->KH * d->KW).splitk > 1;
+}
 static inline size_t wsize_of(const ms_conv_desc* d) { return (size_t)d->groups * d->Cout * d->Cin * d->KH * d->KW; }
 
 }  // namespace ms
@@ -167,6 +180,9 @@ int ms_conv_block_fwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
   a.a_vec = (a.Kg % 4 == 0) && (((uintptr_t)w & 15) == 0);
   a.ep = d->mode == MS_BARE ? EP_BARE : d->mode == MS_LRELU ? EP_LRELU : d->mode == MS_BN_EVAL ? EP_BN_EVAL : EP_RAW_STATS;
   a.slope = d->slope; a.eps = d->eps;
+  const int sg = d->mode == MS_BN_TRAIN ? sg_of(d) : 1;
+  if (sg > 1 && !stat_pair_fwd_epilogue_ok(d))
+    return set_error("ms_conv_block_fwd: MS_DT_STAT_PAIR is not implemented for this block's kernels (ms_stat_pair_ok)");
   if (conv_c1_ok(d->groups, d->Cin, d->Cout, d->KH, d->KW, d->SH, d->SW, d->PH, d->PW, d->H, d->in_mode == MS_IN_PLAIN)) {
     // one input channel (the AudioEncoder's first block): VALU kernel bound by the output write
     const int nt = conv_c1_tiles(d->B, d->H, d->W);
@@ -230,7 +246,7 @@ int ms_conv_block_fwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
     if (rc) return rc;
     if (raw_out)
       return launch_splitk_fwd_epilogue(q.part, pp.splitk, q.part_stride, bias, gamma, beta, running_mean, running_var, y_raw,
-                                        y, save, d->B, C, hw, a.ep, d->slope, d->eps, d->momentum, s);
+                                        y, save, d->B, C, hw, a.ep, d->slope, d->eps, d->momentum, s, sg);
     if (d->mode == MS_BN_TRAIN) {
       rc = launch_bn_finalize_apply(q.stats, q.counts, pp.n_tiles, 0, npix, C, gamma, beta, running_mean, running_var, save, d->eps,
                                     d->momentum, y_raw, y, d->B, hw, d->slope, s);
@@ -247,7 +263,7 @@ int ms_conv_block_fwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
   if (pl.splitk > 1) {
     // few output pixels: K was sliced over workgroups; one launch sums the slices and finishes the block
     return launch_splitk_fwd_epilogue(a.part, pl.splitk, a.part_stride, bias, gamma, beta, running_mean, running_var, y_raw, y,
-                                      save, d->B, C, hw, a.ep, d->slope, d->eps, d->momentum, s);
+                                      save, d->B, C, hw, a.ep, d->slope, d->eps, d->momentum, s, sg);
   }
   if (d->mode == MS_BN_TRAIN) {
     rc = launch_bn_finalize_apply(a.stats, nullptr, pl.n_tiles, 64 * pl.tn, npix, C, gamma, beta, running_mean, running_var, save,
@@ -423,8 +439,23 @@ int ms_dgrad_weights_prepare(int n, const ms_conv_desc* descs, const float* cons
   return sb.n ? launch_split_weights_multi(sb, (hipStream_t)stream) : 0;
 }
 
+int ms_stat_pair_ok(const ms_conv_desc* d) {
+  if (!d || (d->B & 1) || validate(d, "ms_stat_pair_ok")) return 0;
+  if (d->mode != MS_BN_TRAIN) return 1;                 // no batch statistics: a batch of B
+  if (dt_of(d) != DT_F32) return stat_pair16_ok(d) ? 1 : 0;
+  if (g_precision != 0) return 0;
+  // backward: the one-launch BatchNorm backward walks the groups
+  if ((long)d->B / 2 * d->OH * d->OW > BN_BWD32_FUSED_MAX) return 0;
+  if (clip32_fwd_ok(d)) {
+    // the clip-resident launch: whole pixel workgroups per half, every workgroup resident at once (else the kernels below)
+    const int npx = d->SW == 2 ? 32 : 64, npw = d->B * d->OW / npx, cus = current_device_cus();
+    if (npw % 2 == 0 && cus > 0 && cdiv(d->Cout, 32) * npw <= cus) return 1;
+  }
+  return stat_pair_fwd_epilogue_ok(d) ? 1 : 0;
+}
+
 int ms_dgrad_fuses_prev_bn(const ms_conv_desc* d) {
-  if (!d || validate(d, "ms_dgrad_fuses_prev_bn")) return 0;
+  if (!d || validate(d, "ms_dgrad_fuses_prev_bn") || (d->dtype & MS_DT_STAT_PAIR)) return 0;
   return (dt_of(d) == DT_F32 && g_precision == 0 && clip32_dgrad_bn_ok(d)) ? 1 : 0;
 }
 
@@ -524,7 +555,7 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
     if (d->mode != MS_BN_TRAIN) return set_error("ms_conv_block_bwd: dy_is_dyr is the BN_TRAIN form");
     bias_done = 1;
   } else if (d->mode == MS_BN_TRAIN) {
-    rc = launch_bn_bwd(dy, y_raw, y, save, gamma, bn_part, dyr, colpart, dbias, dgamma, dbeta, d->B, C, hw, d->slope, &bias_done, s);
+    rc = launch_bn_bwd(dy, y_raw, y, save, gamma, bn_part, dyr, colpart, dbias, dgamma, dbeta, d->B, C, hw, d->slope, &bias_done, s, sg_of(d));
     g = dyr;
   } else if (d->mode == MS_LRELU) {
     rc = launch_act_bwd(dy, y, dyr, colpart, dbias, d->B, C, hw, 1, d->slope, &bias_done, s);

@@ -114,11 +114,16 @@ size_t block_bwd16_workspace(const ms_conv_desc* d) {
   return bytes;
 }
 
+// MS_DT_STAT_PAIR in the 16-bit modes: not offered yet (the trainer then runs the two passes one after the other)
+bool stat_pair16_ok(const ms_conv_desc* d) { (void)d; return false; }
+
 int block_fwd16(const ms_conv_desc* d, const void* x, const void* x2, const float* w, const float* bias, const float* gamma,
                 const float* beta, float* running_mean, float* running_var, void* y_raw, void* y, float* save, void* workspace,
                 size_t workspace_bytes, hipStream_t s, const void* w_prepared, int32_t* bn_sync, int bn_sync_words) {
   const Geo16 g = geo_of(d);
   if (g.dt != DT_BF16 && g.dt != DT_F16) return set_error("ms_conv_block_fwd: dtype %d", d->dtype);
+  if (d->mode == MS_BN_TRAIN && sg_of(d) > 1 && !stat_pair16_ok(d))
+    return set_error("ms_conv_block_fwd: MS_DT_STAT_PAIR is not implemented for this 16-bit block (ms_stat_pair_ok)");
   if (!bn_sync) { bn_sync = g_bn_sync; bn_sync_words = g_bn_sync_n; }      // (the process-wide buffer of ms_set_bn_sync_buffer)
   const Conv16Plan pl = fwd_plan16(d);
   if (!pl.ok) return set_error("ms_conv_block_fwd: no 16-bit kernel for a %dx%d stride (%d,%d) block", d->KH, d->KW, d->SH, d->SW);

@@ -48,6 +48,7 @@ struct Clip32Args {
   // EP_DGRAD_BN: BatchNorm + LeakyReLU backward of the PRODUCER of this data gradient's rows, in the epilogue (y holds its dy_raw)
   const float* pv_y; const float* pv_y_raw; const float* pv_save; const float* pv_gamma;
   float* pv_dgamma; float* pv_dbeta; float* pv_dbias;
+  int sg;                // BN_TRAIN: statistics groups along the batch (MS_DT_STAT_PAIR: 2), each npw / sg consecutive pixel workgroups
   int raw_all;           // BN_TRAIN: y_raw for every channel (0: only for channels whose backward cannot take x_hat from y: conv16.h bn_inv_unsafe)
   unsigned long long* stamps;   // diagnostics (MS_CLIP_DBG=32): [workgroup][8] s_memrealtime stamps (100 MHz)
 };
@@ -361,9 +362,43 @@ __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
     for (int k = 0; k < FPT; ++k) { const float d = v[k] - mean_w; q = fmaf(d, d, q); }
     const float m2_w = cl_sum8(q);
     double mean = (double)mean_w, m2 = (double)m2_w;
-    const double n = (double)p.npw * NPX;
+    // statistics group of this workgroup (MS_DT_STAT_PAIR: the batch holds two passes of the module side by side): npg consecutive
+    // pixel workgroups, first one pw0
+    const int npg = p.npw / p.sg, sgi = pw / npg, pw0 = sgi * npg;
+    const double n = (double)npg * NPX;
+    const __amdgpu_buffer_rsrc_t rsPart = buf_rsrc(p.part);
+    // (mean, M2) of the statistics group that starts at pixel workgroup `first`: the channel's partials, every 8th one per lane (up
+    // to 4 in flight), in fp64: sum of means, sum of M2, then the spread of the means about the mean (equal counts) -- lane sums
+    // in lane order, then the 8 lanes by a fixed tree
+    auto group_stats = [&](int first, double& gmean, double& gm2) {
+      float2 pv[4];
+      const unsigned base = 8u * (unsigned)((ct * p.npw + first) * 32 + chl);
+      double ms = 0.0, qs = 0.0, dv = 0.0;
+      for (int i0 = pq; i0 < npg; i0 += 32) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = min(i0 + 8 * u, npg - 1);
+          pv[u] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsPart, (int)(base + 8u * (unsigned)(i * 32)), 0, 16));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (i0 + 8 * u < npg) { ms += (double)pv[u].x; qs += (double)pv[u].y; }
+      }
+      gmean = cl_sum8_d(ms) / (double)npg;
+      for (int i0 = pq; i0 < npg; i0 += 32) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = min(i0 + 8 * u, npg - 1);
+          pv[u] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsPart, (int)(base + 8u * (unsigned)(i * 32)), 0, 16));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (i0 + 8 * u < npg) { const double dl = (double)pv[u].x - gmean; dv += dl * dl; }
+      }
+      gm2 = cl_sum8_d(qs) + (double)NPX * cl_sum8_d(dv);
+    };
+    bool expired = false;
     if (p.npw > 1) {
-      const __amdgpu_buffer_rsrc_t rsPart = buf_rsrc(p.part);
       if (pq == 0)
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cl_u32x2, float2{mean_w, m2_w}), rsPart,
                                               (int)(8u * (unsigned)((ct * p.npw + pw) * 32 + chl)), 0, 16);
@@ -385,43 +420,35 @@ __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
       }
       __syncthreads();
       CL_STAMP(6);
-      // the channel's partials, every 8th one per lane (up to 4 in flight), in fp64: sum of means, sum of M2, then the spread
-      // of the means about the mean (equal counts) -- lane sums in lane order, then the 8 lanes by a fixed tree
-      float2 pv[4];
-      const unsigned base = 8u * (unsigned)(ct * p.npw * 32 + chl);
-      double ms = 0.0, qs = 0.0, dv = 0.0;
-      for (int i0 = pq; i0 < p.npw; i0 += 32) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int i = min(i0 + 8 * u, p.npw - 1);
-          pv[u] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsPart, (int)(base + 8u * (unsigned)(i * 32)), 0, 16));
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (i0 + 8 * u < p.npw) { ms += (double)pv[u].x; qs += (double)pv[u].y; }
-      }
-      mean = cl_sum8_d(ms) / (double)p.npw;
-      for (int i0 = pq; i0 < p.npw; i0 += 32) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int i = min(i0 + 8 * u, p.npw - 1);
-          pv[u] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsPart, (int)(base + 8u * (unsigned)(i * 32)), 0, 16));
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (i0 + 8 * u < p.npw) { const double dl = (double)pv[u].x - mean; dv += dl * dl; }
-      }
-      m2 = cl_sum8_d(qs) + (double)NPX * cl_sum8_d(dv);
-      if (lflag[0]) { mean = __builtin_nan(""); }
+      group_stats(pw0, mean, m2);
+      expired = lflag[0] != 0;
+      if (expired) { mean = __builtin_nan(""); }
     }
     const float var = (float)(m2 / n), fmean = (float)mean;
     const float invstd = 1.0f / sqrtf(var + p.eps);
     sc = gam * invstd;
     sh = bet - fmean * sc;
-    if (pw == 0 && pq == 0 && rowok && fmean == fmean) {
-      if (p.save) { p.save[cgl] = fmean; p.save[p.Cout + cgl] = invstd; p.save[2 * p.Cout + cgl] = sc; p.save[3 * p.Cout + cgl] = sh; }
-      const float unbiased = n > 1.0 ? (float)(m2 / (n - 1.0)) : var;
-      running_stats_update(&p.rm[cgl], &p.rv[cgl], rmo, rvo, p.momentum, fmean, unbiased);
+    if (pw == pw0 && pq == 0 && rowok && fmean == fmean && p.save) {
+      float* sv = p.save + (size_t)sgi * 4 * p.Cout;
+      sv[cgl] = fmean; sv[p.Cout + cgl] = invstd; sv[2 * p.Cout + cgl] = sc; sv[3 * p.Cout + cgl] = sh;
+    }
+    if (pw == (p.sg - 1) * npg && !expired) {
+      // the running statistics move once per statistics group, in group order (two forward passes of the module, gan.py:120,126);
+      // the first workgroup of the LAST group applies all of them: the earlier groups' moments from their partials, then its own
+      float rmc = rmo, rvc = rvo;
+      for (int gi = 0; gi + 1 < p.sg; ++gi) {
+        double gmean, gm2;
+        group_stats(gi * npg, gmean, gm2);
+        if (pq == 0 && rowok) {
+          const float ub = n > 1.0 ? (float)(gm2 / (n - 1.0)) : (float)(gm2 / n);
+          running_stats_update(&p.rm[cgl], &p.rv[cgl], rmc, rvc, p.momentum, (float)gmean, ub);
+          rmc = p.rm[cgl]; rvc = p.rv[cgl];
+        }
+      }
+      if (pq == 0 && rowok && fmean == fmean) {
+        const float unbiased = n > 1.0 ? (float)(m2 / (n - 1.0)) : var;
+        running_stats_update(&p.rm[cgl], &p.rv[cgl], rmc, rvc, p.momentum, fmean, unbiased);
+      }
     }
     if (p.y_raw && rowok && (p.raw_all || bn_inv_unsafe(fmean, invstd, sc, sh, p.slope))) store_frames(p.y_raw, v);
   } else if (p.ep == EP_BN_EVAL) {
@@ -704,6 +731,8 @@ int clip32_launch(Clip32Args a, int KW, int S, bool up2, const char* what, hipSt
   const int nb = (S == 2 && !dg2) ? 1 : 2, npx = 32 * nb;
   a.k8w = clip_k8w(a.Cin);
   a.npw = a.B * a.To / npx;
+  if (a.sg < 1) a.sg = 1;
+  if (a.npw % a.sg) return -2;           // (a statistics group is whole pixel workgroups; else the per-layer kernels: ms_stat_pair_ok)
   const int nct = cdiv(a.Cout, 32);
   a.nct = nct;
   const int ncl = npx / a.To, pslots = (ncl * (a.Ti + 2) + 3) & ~3;
@@ -766,7 +795,8 @@ int clip32_block_fwd(const ms_conv_desc* d, const float* x, const float* x2, con
   if (a.ep == EP_RAW_STATS && (!sync || sync_words < 32 + clip32_sync_words(d->Cout) || !part)) return -2;
   // the one-launch BatchNorm backward (bn_bwd_fused*) reads the block's output where the map inverts; larger layers' two-pass
   // backward reads y_raw everywhere
-  a.raw_all = (long)d->B * d->OW > BN_BWD32_FUSED_MAX ? 1 : 0;
+  a.sg = a.ep == EP_RAW_STATS ? sg_of(d) : 1;
+  a.raw_all = (long)d->B / a.sg * d->OW > BN_BWD32_FUSED_MAX ? 1 : 0;
   return clip32_launch(a, d->KW, d->SW, d->in_mode == MS_IN_UP2ADD, "fwd", s);
 }
 

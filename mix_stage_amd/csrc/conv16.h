@@ -13,6 +13,10 @@ namespace ms {
 enum { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
 inline int dt_of(const ms_conv_desc* d) { return d->dtype & 0xff; }
 inline bool out_f32_of(const ms_conv_desc* d) { return (d->dtype & MS_DT_OUT_F32) != 0; }
+// statistics groups of a BN_TRAIN block along the batch axis (MS_DT_STAT_PAIR: the two passes of gan.py:120,126 side by side)
+inline int sg_of(const ms_conv_desc* d) { return (d->dtype & MS_DT_STAT_PAIR) ? 2 : 1; }
+// 16-bit BN_TRAIN blocks with MS_DT_STAT_PAIR (api16.hip)
+bool stat_pair16_ok(const ms_conv_desc* d);
 inline bool bn_folded_of(const ms_conv_desc* d) { return d->mode == MS_BN_EVAL && (d->dtype & MS_DT_BN_FOLDED) != 0; }
 inline int c8_of(int c) { return (c + 7) >> 3; }
 

@@ -660,7 +660,7 @@ __global__ __launch_bounds__(256) void splitk_fwd_epilogue_kernel(const float* _
                                                                   const float* __restrict__ beta, float* rm, float* rv,
                                                                   float* __restrict__ y_raw, float* __restrict__ y,
                                                                   float* __restrict__ save, int B, int C, int HW, int ep,
-                                                                  float slope, float eps, float momentum) {
+                                                                  float slope, float eps, float momentum, int sg) {
   prefetch_kernargs<192>();
   const FastDiv fdHW(HW, B * HW);
   // the channel's B*HW <= 256*NE values stay in registers between the passes
@@ -668,6 +668,10 @@ __global__ __launch_bounds__(256) void splitk_fwd_epilogue_kernel(const float* _
   const int c = blockIdx.x, t = threadIdx.x;
   const int N = B * HW;
   const float bsv = bias ? bias[c] : 0.f;
+  // (sg > 1, MS_DT_STAT_PAIR: B clips per statistics group, the groups one after the other -- the running statistics move twice,
+  // in group order, as two forward passes of the module move them)
+  for (int grp = 0; grp < sg; ++grp, part += (size_t)B * C * HW, y += (size_t)B * C * HW, y_raw = y_raw ? y_raw + (size_t)B * C * HW : y_raw,
+           save = save ? save + 4 * C : save) {
   float v[NE];
   size_t off[NE];
   float s1 = 0.f;
@@ -713,7 +717,7 @@ __global__ __launch_bounds__(256) void splitk_fwd_epilogue_kernel(const float* _
       if (ep == EP_LRELU) o = lrelu(o, slope);
       if (t + i * 256 < N) y[off[i]] = o;
     }
-    return;
+    continue;
   }
   const float mean = block_sum_256(s1, red) / (float)N;
   float q = 0.f;
@@ -740,6 +744,7 @@ __global__ __launch_bounds__(256) void splitk_fwd_epilogue_kernel(const float* _
       y_raw[off[i]] = v[i];
       y[off[i]] = lrelu(fmaf(v[i], sc, sh), slope);
     }
+  }
   }
 }
 
@@ -835,18 +840,22 @@ __global__ __launch_bounds__(256) void splitk_dgrad_epilogue_kernel(const float*
 
 int launch_splitk_fwd_epilogue(const float* part, int splitk, size_t part_stride, const float* bias, const float* gamma,
                                const float* beta, float* rm, float* rv, float* y_raw, float* y, float* save, int B, int C,
-                               int HW, int ep, float slope, float eps, float momentum, hipStream_t s) {
-  TimingScope ts(s, 0, 4.0 * B * C * HW * (splitk + 3), "splitk_fwd_epilogue C%d N%d splitk%d ep%d", C, B * HW, splitk, ep);
+                               int HW, int ep, float slope, float eps, float momentum, hipStream_t s, int sg) {
+  TimingScope ts(s, 0, 4.0 * B * C * HW * (splitk + 3), "splitk_fwd_epilogue C%d N%d splitk%d ep%d%s", C, B * HW, splitk, ep, sg > 1 ? " pair" : "");
   if (ts.skip()) return 0;
+  if (ep != EP_RAW_STATS) sg = 1;
+  if (sg > 1) B /= sg;                  // MS_DT_STAT_PAIR: clips per statistics group (the register-resident kernels only)
+  if (sg > 1 && (long)B * HW > 4096) return set_error("splitk_fwd_epilogue: statistics groups need <= 4096 values per channel and group");
 #define MS_SKE(K) hipLaunchKernelGGL(K, dim3(C), dim3(256), 0, s, part, splitk, part_stride, bias, gamma, beta, rm, rv, \
-                                     y_raw, y, save, B, C, HW, ep, slope, eps, momentum)
+                                     y_raw, y, save, B, C, HW, ep, slope, eps, momentum, sg)
   const long n = (long)B * HW;
   if (n <= 256) MS_SKE(splitk_fwd_epilogue_kernel<1>);
   else if (n <= 512) MS_SKE(splitk_fwd_epilogue_kernel<2>);
   else if (n <= 1024) MS_SKE(splitk_fwd_epilogue_kernel<4>);
   else if (n <= 2048) MS_SKE(splitk_fwd_epilogue_kernel<8>);
   else if (n <= 4096) MS_SKE(splitk_fwd_epilogue_kernel<16>);
-  else MS_SKE(splitk_fwd_epilogue_big_kernel);
+  else hipLaunchKernelGGL(splitk_fwd_epilogue_big_kernel, dim3(C), dim3(256), 0, s, part, splitk, part_stride, bias, gamma, beta, rm, rv,
+                          y_raw, y, save, B, C, HW, ep, slope, eps, momentum);
 #undef MS_SKE
   return check_launch("splitk_fwd_epilogue_kernel");
 }

@@ -396,12 +396,17 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const float* __restri
                                                            const float* __restrict__ y, const float* __restrict__ save,
                                                            const float* __restrict__ gamma,
                                                            float* __restrict__ dyr, float* dbias, float* dgamma, float* dbeta,
-                                                           int B, int C, int HW, float slope) {
+                                                           int B, int C, int HW, float slope, int sg) {
   prefetch_kernargs<128>();
   const FastDiv fdHW(HW, B * HW);
   __shared__ float red[4];
   const int c = blockIdx.x, t = threadIdx.x;
   const int n = B * HW;
+  // (sg > 1, MS_DT_STAT_PAIR: B clips per statistics group; the groups one after the other, the parameter gradients summed in
+  // group order -- what two backward passes accumulate)
+  float tot_cs = 0.f, tot_s1 = 0.f, tot_s2 = 0.f;
+  for (int grp = 0; grp < sg; ++grp, save += 4 * C, dy += (size_t)B * C * HW, dyr += (size_t)B * C * HW,
+           y_raw += (size_t)B * C * HW, y = y ? y + (size_t)B * C * HW : y) {
   // every load is issued before the first one is consumed (clamped indices instead of branches): the kernel pays one
   // memory round trip, not NE of them -- with one wave per SIMD nothing else hides that latency
   const float mean = save[c], invstd = save[C + c], sc = save[2 * C + c], sh = save[3 * C + c], gm = gamma[c];
@@ -451,9 +456,11 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const float* __restri
     }
   }
   cs = block_sum_256(cs, red);
+  tot_cs = grp ? tot_cs + cs : cs; tot_s1 = grp ? tot_s1 + s1 : s1; tot_s2 = grp ? tot_s2 + s2 : s2;
+  }
   if (t == 0) {
-    if (dbias) dbias[c] = cs;
-    if (dgamma) { dgamma[c] = s2; dbeta[c] = s1; }
+    if (dbias) dbias[c] = tot_cs;
+    if (dgamma) { dgamma[c] = tot_s2; dbeta[c] = tot_s1; }
   }
 }
 
@@ -463,12 +470,15 @@ __global__ __launch_bounds__(256) void bn_bwd_fused4_kernel(const float* __restr
                                                             const float* __restrict__ y, const float* __restrict__ save,
                                                             const float* __restrict__ gamma,
                                                             float* __restrict__ dyr, float* dbias, float* dgamma, float* dbeta,
-                                                            int B, int C, int HW, float slope) {
+                                                            int B, int C, int HW, float slope, int sg) {
   prefetch_kernargs<128>();
   const int HW4 = HW >> 2, nv = B * HW4;
   const FastDiv fd(HW4, nv + 256 * NV);
   __shared__ float red[4];
   const int c = blockIdx.x, t = threadIdx.x;
+  float tot_cs = 0.f, tot_s1 = 0.f, tot_s2 = 0.f;          // (sg statistics groups of B clips each: bn_bwd_fused_kernel)
+  for (int grp = 0; grp < sg; ++grp, save += 4 * C, dy += (size_t)B * C * HW, dyr += (size_t)B * C * HW,
+           y_raw += (size_t)B * C * HW, y = y ? y + (size_t)B * C * HW : y) {
   const float mean = save[c], invstd = save[C + c], sc = save[2 * C + c], sh = save[3 * C + c], gm = gamma[c];
   const bool from_y = y != nullptr && !bn_inv_unsafe(mean, invstd, sc, sh, slope);       // (uniform: one channel per workgroup)
   const float* src = from_y ? y : y_raw;
@@ -521,9 +531,11 @@ __global__ __launch_bounds__(256) void bn_bwd_fused4_kernel(const float* __restr
     }
   }
   cs = block_sum_256(cs, red);
+  tot_cs = grp ? tot_cs + cs : cs; tot_s1 = grp ? tot_s1 + s1 : s1; tot_s2 = grp ? tot_s2 + s2 : s2;
+  }
   if (t == 0) {
-    if (dbias) dbias[c] = cs;
-    if (dgamma) { dgamma[c] = s2; dbeta[c] = s1; }
+    if (dbias) dbias[c] = tot_cs;
+    if (dgamma) { dgamma[c] = tot_s2; dbeta[c] = tot_s1; }
   }
 }
 
@@ -1295,25 +1307,27 @@ int bwd_chunks(int B, int C, int* b_per_chunk) {
 // returns 1 if the fused single-launch form was used (dbias already final, no colsum_finalize needed)
 int launch_bn_bwd(const float* dy, const float* y_raw, const float* y, const float* save, const float* gamma, float* partial, float* dyr,
                   float* colpart, float* dbias, float* dgamma, float* dbeta, int B, int C, int HW, float slope, int* fused,
-                  hipStream_t s) {
+                  hipStream_t s, int sg) {
   *fused = 0;
+  if (sg > 1) B /= sg;                 // MS_DT_STAT_PAIR: clips per statistics group (the fused one-launch form only)
   const long n = (long)B * HW;
+  if (sg > 1 && n > BN_BWD32_FUSED_MAX) return set_error("bn_bwd: statistics groups need the one-launch form (%ld values per channel)", n);
   if (n <= BN_BWD32_FUSED_MAX) {
-    TimingScope ts(s, 0, 12.0 * B * C * HW, "bn_bwd_fused C%d HW%d B%d", C, HW, B);
+    TimingScope ts(s, 0, 12.0 * sg * B * C * HW, "bn_bwd_fused C%d HW%d B%d%s", C, HW, B * sg, sg > 1 ? " pair" : "");
     if (ts.skip()) { *fused = 1; return 0; }
     const bool vec4 = (HW & 3) == 0 && (((uintptr_t)dy | (uintptr_t)y_raw | (uintptr_t)y | (uintptr_t)dyr) & 15) == 0;
     if (vec4 && n <= 1024)
-      hipLaunchKernelGGL(bn_bwd_fused4_kernel<1>, dim3(C), dim3(256), 0, s, dy, y_raw, y, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope);
+      hipLaunchKernelGGL(bn_bwd_fused4_kernel<1>, dim3(C), dim3(256), 0, s, dy, y_raw, y, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope, sg);
     else if (vec4 && n <= 2048)
-      hipLaunchKernelGGL(bn_bwd_fused4_kernel<2>, dim3(C), dim3(256), 0, s, dy, y_raw, y, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope);
+      hipLaunchKernelGGL(bn_bwd_fused4_kernel<2>, dim3(C), dim3(256), 0, s, dy, y_raw, y, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope, sg);
     else if (vec4)
-      hipLaunchKernelGGL(bn_bwd_fused4_kernel<4>, dim3(C), dim3(256), 0, s, dy, y_raw, y, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope);
+      hipLaunchKernelGGL(bn_bwd_fused4_kernel<4>, dim3(C), dim3(256), 0, s, dy, y_raw, y, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope, sg);
     else if (n <= 256 * 4)
-      hipLaunchKernelGGL(bn_bwd_fused_kernel<4>, dim3(C), dim3(256), 0, s, dy, y_raw, y, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope);
+      hipLaunchKernelGGL(bn_bwd_fused_kernel<4>, dim3(C), dim3(256), 0, s, dy, y_raw, y, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope, sg);
     else if (n <= 256 * 8)
-      hipLaunchKernelGGL(bn_bwd_fused_kernel<8>, dim3(C), dim3(256), 0, s, dy, y_raw, y, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope);
+      hipLaunchKernelGGL(bn_bwd_fused_kernel<8>, dim3(C), dim3(256), 0, s, dy, y_raw, y, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope, sg);
     else
-      hipLaunchKernelGGL(bn_bwd_fused_kernel<16>, dim3(C), dim3(256), 0, s, dy, y_raw, y, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope);
+      hipLaunchKernelGGL(bn_bwd_fused_kernel<16>, dim3(C), dim3(256), 0, s, dy, y_raw, y, save, gamma, dyr, dbias, dgamma, dbeta, B, C, HW, slope, sg);
     *fused = 1;
     return check_launch("bn_bwd_fused_kernel");
   }

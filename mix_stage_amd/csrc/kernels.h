@@ -210,7 +210,7 @@ int launch_gather(GatherArgs a, bool transposed, bool up2, const GatherPlan& pla
 // sums the split-K partial tiles and applies the block epilogue; one workgroup per output channel
 int launch_splitk_fwd_epilogue(const float* part, int splitk, size_t part_stride, const float* bias, const float* gamma,
                                const float* beta, float* rm, float* rv, float* y_raw, float* y, float* save, int B, int C,
-                               int HW, int ep, float slope, float eps, float momentum, hipStream_t s);
+                               int HW, int ep, float slope, float eps, float momentum, hipStream_t s, int sg = 1);
 int launch_splitk_dgrad_epilogue(const float* part, int splitk, size_t part_stride, float* dx, float* dx2, size_t n, int W,
                                  int up2, hipStream_t s);
 int wgrad_splits(int Cog, int Kg, int groups, int Npix);
@@ -247,7 +247,7 @@ int bwd_chunks(int B, int C, int* b_per_chunk);
 constexpr int BN_BWD32_FUSED_MAX = 256 * 16;
 int launch_bn_bwd(const float* dy, const float* y_raw, const float* y, const float* save, const float* gamma, float* partial, float* dyr,
                   float* colpart, float* dbias, float* dgamma, float* dbeta, int B, int C, int HW, float slope, int* fused,
-                  hipStream_t s);
+                  hipStream_t s, int sg = 1);
 int launch_act_bwd(const float* dy, const float* y, float* dyr, float* colpart, float* dbias, int B, int C, int HW, int mode, float slope, int* fused,
                    hipStream_t s);
 int launch_colsum_finalize(const float* colpart, float* out, int B, int C, hipStream_t s);

@@ -2,6 +2,7 @@
 pose velocity, GAN + pose losses.  Same constructor (kwargs['input_modalities'] required),
 forward(x_audio, y_pose, **kwargs) -> (fake_pose, losses, {'W': W}), flags G_flag / fake_flag / D_prob."""
 import contextlib
+import os
 
 import torch
 import torch.nn as nn
@@ -90,6 +91,10 @@ class GAN(nn.Module):
     # In the G-step the reference also back-propagates into D's weights and then discards those gradients
     # (trainer.py:1104-1107,1140-1142).  Skipping that weight-gradient work changes no result.
     self.skip_D_weight_grads_in_G_step = True
+    # D-step: the discriminator sees the fake and the real velocities in one batch with two BatchNorm statistics groups (same
+    # results as gan.py:120,126's two passes; MS_PAIR_D=0 / False: the two passes one after the other)
+    self.pair_D_passes = os.environ.get('MS_PAIR_D', '1') != '0'
+    self._pair_probe = {}
 
   # API parity helpers -------------------------------------------------------------------------
   def get_velocity(self, x, x_audio=None):
@@ -161,6 +166,23 @@ class GAN(nn.Module):
       return self.D.forward_channel_major(v)[0]
     return self.D(ops.to_time_major(v))[0]
 
+  def _score_pair(self, first, second):
+    """D(get_velocity(first)), D(get_velocity(second)) from one pass over both (Speech2Gesture_D.forward_pair), or None when the
+    module or this batch has no paired form (16-bit modes, global BatchNorm statistics, unequal shapes, ...)."""
+    D = self.D
+    if not hasattr(D, 'forward_pair') or first.shape != second.shape or first.dtype != second.dtype or first.dim() != 3:
+      return None
+    if first.dtype != torch.float32 or not first.is_cuda:
+      return None
+    B, T, P = first.shape
+    probe = self._pair_probe.get((B, T, P, first.device))
+    if probe is None:
+      probe = self._pair_probe[(B, T, P, first.device)] = torch.empty(2 * B, P, T, device='meta')
+    if not D.pair_supported(probe):
+      return None
+    v = ops.velocity_cm(torch.cat([first, second], dim=0))
+    return D.forward_pair(v)
+
   def forward(self, x_audio, y_pose, **kwargs):
     internal_losses = []
     if 'confidence' in kwargs and not (isinstance(kwargs['confidence'], (int, float)) and kwargs['confidence'] == 1):
@@ -184,9 +206,16 @@ class GAN(nn.Module):
           args = args[0] if len(args) > 0 else {}
         self.G.train(self.training)
         self.fake_flag = True
-        fake_pose_score = self._score(fake_pose.detach())
-        fake_D_loss = self._loss(fake_pose_score, target=0.0, scale=lam_D)
-        real_pose_score = self._score(y_pose)
+        pair = self._score_pair(fake_pose.detach(), y_pose) if self.pair_D_passes else None
+        if pair is not None:
+          # D on the fake and on the real velocities as ONE batch of 2B clips with two BatchNorm statistics groups (include/mixstage.h:
+          # MS_DT_STAT_PAIR): the same values as the two passes below, half the launches
+          fake_pose_score, real_pose_score = pair
+          fake_D_loss = self._loss(fake_pose_score, target=0.0, scale=lam_D)
+        else:
+          fake_pose_score = self._score(fake_pose.detach())
+          fake_D_loss = self._loss(fake_pose_score, target=0.0, scale=lam_D)
+          real_pose_score = self._score(y_pose)
         real_D_loss = self._loss(real_pose_score, target=1.0)
         internal_losses.append(real_D_loss)
         internal_losses.append(fake_D_loss)

@@ -162,6 +162,8 @@ class ConvNormRelu(nn.Module):
     if self.training and n.track_running_stats:
       mode = MS_BN_TRAIN
       self._note_train_pass()
+      if ops.stat_pair_active():
+        self._note_train_pass()          # two passes side by side in this batch (ops.stat_pair): two tracked batches
     else:
       mode = MS_BN_EVAL
     dt = getattr(self, '_ms_dt', 0)

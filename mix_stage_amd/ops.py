@@ -4,13 +4,14 @@ PyTorch is plumbing here: it owns HBM allocations, the current HIP stream and th
 Every function below enqueues hand-written gfx950 kernels through the C-ABI with raw device
 pointers; there is no eager/CPU fallback -- a CPU tensor or a missing library raises.
 """
+import contextlib
 import ctypes
 import os
 
 import torch
 
 from . import _lib
-from ._lib import (BwdOptions, ConvDesc, FwdOptions, MS_BARE, MS_BN_EVAL, MS_BN_TRAIN, MS_IN_BCAST, MS_IN_PLAIN,
+from ._lib import (BwdOptions, ConvDesc, FwdOptions, MS_BARE, MS_BN_EVAL, MS_BN_TRAIN, MS_DT_STAT_PAIR, MS_IN_BCAST, MS_IN_PLAIN,
                    MS_IN_UP2ADD, MS_LRELU, check, lib)
 
 _vp = ctypes.c_void_p
@@ -339,6 +340,32 @@ class ConvGeom:
     return d
 
 
+# Two passes of a module side by side in one batch (gan.py:120,126: the discriminator on the fake, then on the real poses): inside
+# `stat_pair()` every conv block's descriptor carries MS_DT_STAT_PAIR -- BN_TRAIN blocks take their batch statistics per half of the
+# batch and move the running statistics twice, first half first (include/mixstage.h).
+_stat_pair = {'on': False}
+
+
+@contextlib.contextmanager
+def stat_pair():
+  old = _stat_pair['on']
+  _stat_pair['on'] = True
+  try:
+    yield
+  finally:
+    _stat_pair['on'] = old
+
+
+def stat_pair_active():
+  return _stat_pair['on']
+
+
+def stat_pair_ok(geom, B2, Cin_g, W, Cout_g, mode, dtype=0):
+  """Can the 1-D block of this geometry run a pair of passes (a batch of B2 = 2 B clips) -> (ok, output width)."""
+  d = geom.desc(B2, Cin_g, 1, W, Cout_g, mode, MS_IN_PLAIN, dtype | MS_DT_STAT_PAIR)
+  return bool(lib().ms_stat_pair_ok(ctypes.byref(d))), d.OW
+
+
 LATE = 'late'      # _grad_slot: truthy (autograd gets None for this gradient) but not the slot itself
 
 
@@ -384,7 +411,8 @@ class _ConvBlockFn(torch.autograd.Function):
       raise RuntimeError('conv block: expected %d input channels, got %d' % (exp_c, x.shape[1]))
     if in_mode == MS_IN_UP2ADD and (x.shape[2] * 2 != W or x2.shape[1] != exp_c):
       raise RuntimeError('UP2ADD: a %s and residual %s do not match' % (tuple(x.shape), tuple(x2.shape)))
-    d = geom.desc(B, Cin_g, H, W, Cout_g, mode, in_mode)
+    pair = MS_DT_STAT_PAIR if (_stat_pair['on'] and pre is None) else 0
+    d = geom.desc(B, Cin_g, H, W, Cout_g, mode, in_mode, pair)
     oshape = (B, ctot, d.OH, d.OW) if nd == 2 else (B, ctot, d.OW)
     if pre is not None:
       # the block's results were produced by a launch that chains several blocks (decoder_chain): nothing to run here, this
@@ -397,7 +425,7 @@ class _ConvBlockFn(torch.autograd.Function):
       y_raw = save = None
       if mode == MS_BN_TRAIN:
         y_raw = torch.empty_like(y)
-        save = torch.empty(4 * ctot, dtype=torch.float32, device=x.device)
+        save = torch.empty((8 if pair else 4) * ctot, dtype=torch.float32, device=x.device)     # (one vector per statistics group)
     ws = workspace(d._fwd_ws, x.device) if pre is None else None
     planes = _prepared_for(w, d, 'fwd') if pre is None else None
     if pre is None:
@@ -1009,6 +1037,24 @@ class _TransposeFn(torch.autograd.Function):
   @staticmethod
   def backward(ctx, dy):
     return _TransposeFn.apply(dy, not ctx.to_cm), None
+
+
+class _SplitHalvesFn(torch.autograd.Function):
+  """x (2B, ...) -> (x[:B], x[B:]) as views; the backward pass joins the two gradients with ONE copy launch (two slice nodes would
+  each fill a zero tensor of the whole batch and add)."""
+
+  @staticmethod
+  def forward(ctx, x):
+    h = x.shape[0] // 2
+    return x[:h], x[h:]
+
+  @staticmethod
+  def backward(ctx, g0, g1):
+    return torch.cat([g0, g1], dim=0)
+
+
+def split_halves(x):
+  return _SplitHalvesFn.apply(x)
 
 
 @_bridge64

@@ -40,6 +40,40 @@ class Speech2Gesture_D(nn.Module):
     x = bare_conv(self.logits, x, out_f32=True)                 # scores are fp32 in every mode
     return x.transpose(-1, -2).squeeze(dim=-1), []
 
+  def pair_supported(self, x):
+    """Can forward_pair run on x (2B, pose_feats, time) -- every block's kernels implement MS_DT_STAT_PAIR (ms_stat_pair_ok) for this
+    batch, train-mode BatchNorm with local statistics, the in-launch meetings available?  Cached per input shape and tuning epoch."""
+    from ._lib import MS_BARE, MS_BN_TRAIN, MS_LRELU
+    if not self.training or ops.bn_sync_active() or not ops16.in_launch_meetings() or getattr(self, '_ms_dt', 0):
+      return False
+    key = (tuple(x.shape), ops.lib().ms_tuning_epoch())
+    cache = self.__dict__.setdefault('_pair_ok', {})
+    if key not in cache:
+      ok, W = x.shape[0] % 2 == 0 and x.dim() == 3, x.shape[-1]
+      blocks = [(self.conv1[0], MS_LRELU, None)] + [(m.conv, MS_BN_TRAIN, m) for m in self.conv2] + \
+               [(self.conv3.conv, MS_BN_TRAIN, self.conv3), (self.logits, MS_BARE, None)]
+      for conv, mode, mod in blocks:
+        if not ok:
+          break
+        if mod is not None and (mod._p or not mod.norm.track_running_stats):
+          ok = False
+          break
+        geom = mod._geometry() if mod is not None else ops.ConvGeom(1, conv.groups, conv.kernel_size, conv.stride, conv.padding)
+        if W + 2 * geom.PW < geom.KW:
+          ok = False
+          break
+        ok, W = ops.stat_pair_ok(geom, x.shape[0], conv.weight.shape[1], W, conv.weight.shape[0] // conv.groups, mode)
+      cache[key] = bool(ok)
+    return cache[key]
+
+  def forward_pair(self, x):
+    """The discriminator on TWO inputs side by side, x = cat([first, second]) channel-major (2B, pose_feats, time) -> (scores of the
+    first, scores of the second).  Equal to forward_channel_major(first) followed by forward_channel_major(second) (gan.py:120,126):
+    BatchNorm statistics per half, the running statistics moved twice in that order -- in half the launches."""
+    with ops.stat_pair():
+      s = self.forward_channel_major(x)[0]
+    return ops.split_halves(s)
+
   def forward(self, x):
     dt = getattr(self, '_ms_dt', 0)
     if dt:

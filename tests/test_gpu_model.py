@@ -489,3 +489,73 @@ def test_reference_format_weight_file_on_the_device(tmp_path, dtype):
     kw_d = dict(kw); kw_d['style'] = kw['style'].to(DEV)
     y_hip, _, _ = hip([audio.to(DEV), labels.to(DEV)], pose.to(DEV), **kw_d)
   assert (y_hip.cpu().double() - y_ref.double()).abs().mean().item() <= 1e-4
+
+
+@pytest.mark.parametrize('B,T', [(32, 64), (4, 64), (6, 32)])
+def test_paired_discriminator_pass_equals_the_two_passes(B, T):
+  """Speech2Gesture_D.forward_pair (one batch of 2B clips, BatchNorm statistics per half: MS_DT_STAT_PAIR) against the two passes of
+  gan.py:120,126 one after the other: scores, every gradient, the running statistics after their two sequential updates and the
+  tracked batch counts.  Tolerances are fp32 summation order (the batch of 2B is tiled and split differently), not statistics."""
+  import copy
+  import mix_stage_amd as A
+  from mix_stage_amd import ops
+  torch.manual_seed(5)
+  D1 = A.Speech2Gesture_D(in_channels=104).to(DEV).train()
+  with torch.no_grad():
+    for m in D1.modules():
+      if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+        m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.3, 0.3)
+        m.running_mean.uniform_(-0.2, 0.2); m.running_var.uniform_(0.5, 1.5)
+  D2 = copy.deepcopy(D1)
+  fake = torch.randn(B, 104, T, device=DEV)
+  real = torch.randn(B, 104, T, device=DEV) * 1.7 + 0.4          # different statistics in the two halves
+  assert D2.pair_supported(torch.empty(2 * B, 104, T, device='meta')), 'the paired form is not offered at this shape'
+  s_f = D1.forward_channel_major(fake)[0]
+  s_r = D1.forward_channel_major(real)[0]
+  (ops.l1_mean(s_f, target=0.0, scale=0.7) + ops.l1_mean(s_r, target=1.0)).backward()
+  p_f, p_r = D2.forward_pair(torch.cat([fake, real], dim=0))
+  (ops.l1_mean(p_f, target=0.0, scale=0.7) + ops.l1_mean(p_r, target=1.0)).backward()
+  torch.cuda.synchronize()
+  assert torch.allclose(p_f, s_f, rtol=1e-4, atol=1e-5) and torch.allclose(p_r, s_r, rtol=1e-4, atol=1e-5)
+  for (n, a), (_, b) in zip(D1.named_parameters(), D2.named_parameters()):
+    if n.endswith('conv.bias'):
+      continue                           # a conv bias in front of BatchNorm: its true gradient is zero, both sides hold rounding noise
+    err = (a.grad - b.grad).norm().item()
+    assert err <= 2e-4 * (a.grad.norm().item() + 1e-8), (n, err, a.grad.norm().item())
+  sd1, sd2 = D1.state_dict(), D2.state_dict()
+  for k in sd1:
+    if 'running_' in k:
+      assert torch.allclose(sd1[k], sd2[k], rtol=1e-5, atol=1e-6), k
+    if 'num_batches_tracked' in k:
+      assert int(sd1[k]) == int(sd2[k]) == 2, (k, int(sd1[k]), int(sd2[k]))
+  # one half changed: the OTHER half's scores do not move (its statistics are its own)
+  D3 = copy.deepcopy(D2)
+  q_f, q_r = D3.forward_pair(torch.cat([fake, real * 3.0 - 1.0], dim=0))
+  d_f, d_r = D2.forward_pair(torch.cat([fake, real], dim=0))
+  # (D2 and D3 differ in running statistics only, which train-mode outputs do not read)
+  assert torch.equal(q_f, d_f) and not torch.allclose(q_r, d_r)
+
+
+def test_d_step_with_paired_passes_equals_the_step_with_two_passes(golden_dir):
+  """GAN.forward's D-step through the paired discriminator pass (the default) against the same step with the two passes one after the
+  other (pair_D_passes = False): losses, D's gradients, D's running statistics."""
+  z = np.load(os.path.join(golden_dir, 'c2r_fp32.npz'))
+  B, T, M, S = [int(v) for v in z['meta']]
+  batch = [torch.from_numpy(z[k]) for k in ('audio', 'pose', 'labels', 'style')]
+  out = []
+  for pair in (True, False):
+    hip = build_hip_gan(M, S)
+    hip.pair_D_passes = pair
+    torch.manual_seed(1)
+    _, losses = _step(hip, batch, 'D', DEV)
+    out.append((hip, [float(l.detach()) for l in losses]))
+  (h1, l1), (h2, l2) = out
+  assert np.allclose(l1, l2, rtol=1e-5, atol=1e-6), (l1, l2)
+  for (n, a), (_, b) in zip(h1.D.named_parameters(), h2.D.named_parameters()):
+    if n.endswith('conv.bias'):
+      continue
+    err = (a.grad - b.grad).norm().item()
+    assert err <= 2e-4 * (b.grad.norm().item() + 1e-8), (n, err, b.grad.norm().item())
+  for (n, a), (_, b) in zip(h1.D.named_buffers(), h2.D.named_buffers()):
+    if 'running_' in n:
+      assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), n
