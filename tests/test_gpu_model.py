@@ -53,7 +53,11 @@ FLIP_LOG = []
 def _count_kink_flips(rec_hip, rec_ref):
   flips = 0
   for name, outs in rec_ref.items():
-    for a, b in zip(rec_hip[name], outs):
+    outs_h = rec_hip[name]
+    if 2 * len(outs_h) == len(outs) and outs_h[0].shape[0] == 2 * outs[0].shape[0]:
+      # the D-step's paired discriminator pass: one call on the batch [fake; real] where the reference makes two calls
+      outs_h = [h for o in outs_h for h in (o[:o.shape[0] // 2], o[o.shape[0] // 2:])]
+    for a, b in zip(outs_h, outs):
       n = int(((a.cpu() > 0) != (b > 0)).sum())
       if n:
         bad = (a.cpu() > 0) != (b > 0)
