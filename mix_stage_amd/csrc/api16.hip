@@ -114,8 +114,18 @@ size_t block_bwd16_workspace(const ms_conv_desc* d) {
   return bytes;
 }
 
-// MS_DT_STAT_PAIR in the 16-bit modes: not offered yet (the trainer then runs the two passes one after the other)
-bool stat_pair16_ok(const ms_conv_desc* d) { (void)d; return false; }
+// MS_DT_STAT_PAIR in the 16-bit modes: the conv leaves its tile statistics (EP_RAW_STATS) and the normalising launch combines them
+// per half of the batch (bn_finalize_apply16_kernel) -- needs whole statistics tiles per half, at most 32 of them, a cb8 output,
+// and the one-launch BatchNorm backward
+bool stat_pair16_ok(const ms_conv_desc* d) {
+  if (d->mode != MS_BN_TRAIN) return true;
+  if ((d->B & 1) || out_f32_of(d)) return false;
+  const Geo16 g = geo_of(d);
+  const Conv16Plan pl = fwd_plan16(d);
+  if (!pl.ok || (pl.n_tiles & 1) || pl.n_tiles > 64) return false;
+  if (g.one_d && ((d->B / 2) % pl.th)) return false;          // (1-D: the batch is the row axis of one image; 2-D: tiles per image)
+  return (long)d->B / 2 * g.hw <= BN_BWD16_FUSED_MAX;
+}
 
 int block_fwd16(const ms_conv_desc* d, const void* x, const void* x2, const float* w, const float* bias, const float* gamma,
                 const float* beta, float* running_mean, float* running_var, void* y_raw, void* y, float* save, void* workspace,
@@ -196,7 +206,8 @@ int block_fwd16(const ms_conv_desc* d, const void* x, const void* x2, const floa
   // train-mode BatchNorm inside the conv launch (conv16_kernel.h, EP_BN_FUSED): the workgroups of a channel tile exchange
   // their partial statistics and normalise from registers -- taken when the whole grid is resident at once
   bool fused = false;
-  if (d->mode == MS_BN_TRAIN && !outf32 && g_bn_fused && bn_sync) {
+  const int sg = d->mode == MS_BN_TRAIN ? sg_of(d) : 1;
+  if (d->mode == MS_BN_TRAIN && !outf32 && g_bn_fused && bn_sync && sg == 1) {
     const int bm = 64 * pl.wm, gy = cdiv(d->Cout, bm), nwg = pl.n_tiles * gy * d->groups;
     const int scratch = (pl.nwn * bm * 4 + (128 * pl.nwn / bm) * bm * 3 * 2 + bm * 2 + bm / 8 + pl.nwn + 1) * 4;      // red | dred | scsh | rawflag | wcnt
     // (every workgroup reads its group's n_tiles partials: beyond 64 tiles per channel tile that traffic -- n_tiles^2 x 1 KB per
@@ -219,7 +230,7 @@ int block_fwd16(const ms_conv_desc* d, const void* x, const void* x2, const floa
   if (d->mode == MS_BN_TRAIN && pl.n_tiles <= 64)      // few statistics tiles: finalize inside the normalising launch
     return launch_bn_finalize_apply16(g.dt, stats, counts, pl.n_tiles, g.npix, gamma, beta, running_mean, running_var, save, d->eps,
                                       d->momentum, y_raw, outf32 ? nullptr : y, outf32 ? (float*)y : nullptr, d->B, g.C, g.hw,
-                                      d->slope, s);
+                                      d->slope, s, sg);
   if (d->mode == MS_BN_TRAIN) {
     rc = launch_bn_finalize(stats, counts, pl.n_tiles, 0, g.npix, g.C, gamma, beta, running_mean, running_var, save, d->eps,
                             d->momentum, s);
@@ -254,7 +265,7 @@ int block_bwd16(const ms_conv_desc* d, const void* x, const void* x2, const floa
   if (d->mode == MS_BN_TRAIN) {
     // (y: blocks with a cb8 output read x_hat and the activation mask from it wherever the map inverts safely -- conv16.h)
     rc = launch_bn_bwd16(g.dt, outf32 ? nullptr : dy, dyf, y_raw, outf32 ? nullptr : y, save, gamma, bn_part, dyr, colpart, dbias, dgamma, dbeta, d->B, g.C,
-                         g.hw, d->slope, &bias_done, s);
+                         g.hw, d->slope, &bias_done, s, sg_of(d));
     gsrc = dyr;
   } else if (d->mode == MS_LRELU) {
     rc = launch_act_bwd16(g.dt, dy, nullptr, y, dyr, colpart, d->B, g.C, g.hw, 1, d->slope, s);

@@ -149,14 +149,14 @@ int launch_bn_apply16(int dt, const void* y_raw, void* y, float* y_f32, const fl
 int bwd16_chunks(int B, int C8, int HW, int* b_per_chunk);
 int launch_bn_finalize_apply16(int dt, const float* stats, const float* counts, int n_tiles, int N, const float* gamma,
                                const float* beta, float* rm, float* rv, float* save, float eps, float momentum, const void* y_raw,
-                               void* y, float* y_f32, int B, int C, int HW, float slope, hipStream_t s);
+                               void* y, float* y_f32, int B, int C, int HW, float slope, hipStream_t s, int sg = 1);
 // dy: cb8, or plain fp32 (B,C,HW) when dy_f32 != NULL
 // y: the block's cb8 output, or NULL: x_hat and the activation mask always from y_raw (fp32-output blocks, callers without y).
 // Only the one-launch form (B*HW <= BN_BWD16_FUSED_MAX pixels) reads y; blocks with more pixels keep y_raw whole (block_fwd16)
 // and their two-pass backward reads it.
 int launch_bn_bwd16(int dt, const void* dy, const float* dy_f32, const void* y_raw, const void* y, const float* save, const float* gamma,
                     float* partial, void* dyr, float* colpart, float* dbias, float* dgamma, float* dbeta, int B, int C, int HW,
-                    float slope, int* bias_done, hipStream_t s);
+                    float slope, int* bias_done, hipStream_t s, int sg = 1);
 // mode 1: dyr = dy * lrelu'(y); mode 0: dyr = dy (written only when dy arrives as fp32); colsum partials always
 int launch_act_bwd16(int dt, const void* dy, const float* dy_f32, const void* y, void* dyr, float* colpart, int B, int C, int HW,
                      int mode, float slope, hipStream_t s);

@@ -73,20 +73,25 @@ __global__ __launch_bounds__(256) void bn_finalize_apply16_kernel(const float* _
                                                                   float* running_var, float* __restrict__ save, float eps,
                                                                   float momentum, const u32x4* __restrict__ y_raw,
                                                                   u32x4* __restrict__ y, float* __restrict__ y_f32, int B, int C,
-                                                                  int C8, int HW, int b_per_chunk, float slope) {
+                                                                  int C8, int HW, int b_per_chunk, float slope, int sg,
+                                                                  int chunks_per_grp) {
   prefetch_kernargs<192>();
   const FastDiv fdHW(HW, B * HW);
-  __shared__ double part[8][33];
+  __shared__ double part[2][8][33];
   __shared__ float scsh[16];
   const int cb = blockIdx.x, ch = blockIdx.y, t = threadIdx.x;
   const int j = t >> 5, i = t & 31, c = cb * 8 + j;
   const bool cv = c < C;
   const int cc = min(c, C - 1);
-  // chunk = b_per_chunk consecutive vectors of this channel block's flattened (batch item, pixel) space
-  const int e_base = ch * b_per_chunk, b0 = 0;
-  const int n = min(b_per_chunk, B * HW - e_base);
-  // statistics of tiles i and i + 32 (n_tiles <= 64) and the channel's parameters
-  const int k0 = min(i, n_tiles - 1), k1 = min(i + 32, n_tiles - 1);
+  // chunk = b_per_chunk consecutive vectors of this channel block's flattened (batch item, pixel) space.  sg == 2 (MS_DT_STAT_PAIR):
+  // the batch is two statistics groups of B / 2 clips; a chunk lies inside one of them (chunks_per_grp chunks each), the first
+  // half of the statistics tiles belongs to the first group
+  const int grp_vecs = B / sg * HW, my_grp = sg > 1 ? ch / chunks_per_grp : 0, chg = ch - my_grp * chunks_per_grp;
+  const int e_base = my_grp * grp_vecs + chg * b_per_chunk, b0 = 0;
+  const int n = min(b_per_chunk, grp_vecs - chg * b_per_chunk);
+  // statistics of tiles i and i + 32 (n_tiles <= 64) and the channel's parameters -- sg == 2: tile i of either group
+  const int ntg = n_tiles / sg;
+  const int k0 = sg > 1 ? min(i, ntg - 1) : min(i, n_tiles - 1), k1 = sg > 1 ? ntg + min(i, ntg - 1) : min(i + 32, n_tiles - 1);
   const float2 st0 = *(const float2*)(stats + ((size_t)k0 * C + cc) * 2), st1 = *(const float2*)(stats + ((size_t)k1 * C + cc) * 2);
   const float cnt0 = counts[k0], cnt1 = counts[k1];
   const float g = gamma[cc], bt = beta[cc], rm = running_mean[cc], rv = running_var[cc];
@@ -103,36 +108,51 @@ __global__ __launch_bounds__(256) void bn_finalize_apply16_kernel(const float* _
     raw[q] = y_raw[vofs[q]];
   }
   __builtin_amdgcn_sched_barrier(0);
-  const bool u0 = cv && i < n_tiles, u1 = cv && i + 32 < n_tiles;
-  part[j][i] = (u0 ? (double)st0.x : 0.0) + (u1 ? (double)st1.x : 0.0);
+  const bool u0 = cv && (sg > 1 ? i < ntg : i < n_tiles), u1 = cv && (sg > 1 ? i < ntg : i + 32 < n_tiles);
+  // sums of the tiles' sums: one total (sg == 1: both tiles of the thread belong to it) or one per group
+  part[0][j][i] = (u0 ? (double)st0.x : 0.0) + ((u1 && sg == 1) ? (double)st1.x : 0.0);
+  part[1][j][i] = (u1 && sg > 1) ? (double)st1.x : 0.0;
   __syncthreads();
-  double tot = 0.0;
+  double tot0 = 0.0, tot1 = 0.0;
 #pragma unroll 8
-  for (int k = 0; k < 32; ++k) tot += part[j][k];
-  const double mean = tot / (double)N;
+  for (int k = 0; k < 32; ++k) { tot0 += part[0][j][k]; tot1 += part[1][j][k]; }
+  const double Ng = (double)(N / sg);
+  const double mean0 = tot0 / Ng, mean1 = tot1 / Ng;
   __syncthreads();
-  double q2 = 0.0;
-  if (u0) { const double cn = (double)cnt0, dlt = (double)st0.x / cn - mean; q2 += (double)st0.y + cn * dlt * dlt; }
-  if (u1) { const double cn = (double)cnt1, dlt = (double)st1.x / cn - mean; q2 += (double)st1.y + cn * dlt * dlt; }
-  part[j][i] = q2;
+  double q0 = 0.0, q1 = 0.0;
+  if (u0) { const double cn = (double)cnt0, dlt = (double)st0.x / cn - mean0; q0 += (double)st0.y + cn * dlt * dlt; }
+  if (u1) {
+    const double cn = (double)cnt1, dlt = (double)st1.x / cn - (sg > 1 ? mean1 : mean0), q = (double)st1.y + cn * dlt * dlt;
+    if (sg > 1) q1 += q; else q0 += q;
+  }
+  part[0][j][i] = q0;
+  part[1][j][i] = q1;
   __syncthreads();
   if (i == 0) {
-    double m2 = 0.0;
-    for (int k = 0; k < 32; ++k) m2 += part[j][k];
+    double m2g[2] = {0.0, 0.0};
+    for (int k = 0; k < 32; ++k) { m2g[0] += part[0][j][k]; m2g[1] += part[1][j][k]; }
+    const double meang[2] = {mean0, mean1};
     float sc = 0.f, shf = 0.f;
     if (cv) {
-      const float var = (float)(m2 / (double)N);
-      const float invstd = 1.0f / sqrtf(var + eps);
-      const float fmean = (float)mean;
-      sc = g * invstd;
-      shf = bt - fmean * sc;
-      if (ch == 0) {
-        save[c] = fmean;
-        save[C + c] = invstd;
-        save[2 * C + c] = sc;
-        save[3 * C + c] = shf;
-        const float unbiased = N > 1 ? (float)(m2 / (double)(N - 1)) : var;
-        running_stats_update(&running_mean[c], &running_var[c], rm, rv, momentum, fmean, unbiased);
+      // chunk 0 of group 0 records every group's vector and moves the running statistics once per group, in group order
+      float rmc = rm, rvc = rv;
+      for (int gi = 0; gi < sg; ++gi) {
+        if (gi != my_grp && ch != 0) continue;
+        const float var = (float)(m2g[gi] / Ng);
+        const float invstd = 1.0f / sqrtf(var + eps);
+        const float fmean = (float)meang[gi];
+        const float scg = g * invstd, shg = bt - fmean * scg;
+        if (gi == my_grp) { sc = scg; shf = shg; }
+        if (ch == 0) {
+          float* sv = save + (size_t)gi * 4 * C;
+          sv[c] = fmean;
+          sv[C + c] = invstd;
+          sv[2 * C + c] = scg;
+          sv[3 * C + c] = shg;
+          const float unbiased = Ng > 1.0 ? (float)(m2g[gi] / (Ng - 1.0)) : var;
+          running_stats_update(&running_mean[c], &running_var[c], rmc, rvc, momentum, fmean, unbiased);
+          rmc = running_mean[c]; rvc = running_var[c];
+        }
       }
     }
     scsh[j] = sc; scsh[8 + j] = shf;
@@ -174,20 +194,22 @@ __global__ __launch_bounds__(256) void bn_finalize_apply16_kernel(const float* _
 
 int launch_bn_finalize_apply16(int dt, const float* stats, const float* counts, int n_tiles, int N, const float* gamma,
                                const float* beta, float* rm, float* rv, float* save, float eps, float momentum, const void* y_raw,
-                               void* y, float* y_f32, int B, int C, int HW, float slope, hipStream_t s) {
+                               void* y, float* y_f32, int B, int C, int HW, float slope, hipStream_t s, int sg) {
   const int C8 = c8_of(C);
   int bpc;
-  const int nchunk = bwd16_chunks(B, C8, HW, &bpc);
+  // (sg statistics groups of B / sg clips: whole chunks per group)
+  const int cpg = bwd16_chunks(B / sg, C8, HW, &bpc), nchunk = cpg * sg;
+  if (sg > 1 && (n_tiles % sg || n_tiles / sg > 32)) return set_error("bn_finalize_apply16: %d statistics tiles in %d groups", n_tiles, sg);
   const dim3 grid(C8, nchunk);
   TimingScope ts(s, 0, (y_f32 ? 6.0 : 4.0) * 8.0 * (double)B * C8 * HW, "bn_finalize_apply16_kernel|bn_finalize_apply16 C%d N%d tiles%d", C,
                  B * HW, n_tiles);
   if (ts.skip()) return 0;
   if (dt == DT_BF16)
     hipLaunchKernelGGL(bn_finalize_apply16_kernel<BF16>, grid, dim3(256), 0, s, stats, counts, n_tiles, N, gamma, beta, rm, rv, save, eps,
-                       momentum, (const u32x4*)y_raw, (u32x4*)y, y_f32, B, C, C8, HW, bpc, slope);
+                       momentum, (const u32x4*)y_raw, (u32x4*)y, y_f32, B, C, C8, HW, bpc, slope, sg, cpg);
   else
     hipLaunchKernelGGL(bn_finalize_apply16_kernel<F16>, grid, dim3(256), 0, s, stats, counts, n_tiles, N, gamma, beta, rm, rv, save, eps,
-                       momentum, (const u32x4*)y_raw, (u32x4*)y, y_f32, B, C, C8, HW, bpc, slope);
+                       momentum, (const u32x4*)y_raw, (u32x4*)y, y_f32, B, C, C8, HW, bpc, slope, sg, cpg);
   return check_launch("bn_finalize_apply16_kernel");
 }
 
@@ -467,12 +489,23 @@ __global__ __launch_bounds__(NT) void bn_bwd16_fused_kernel(const u32x4* __restr
                                                              const u32x4* __restrict__ y_raw, const u32x4* __restrict__ y_out,
                                                              const float* __restrict__ save,
                                                              const float* __restrict__ gamma, u32x4* __restrict__ dyr, float* dbias,
-                                                             float* dgamma, float* dbeta, int B, int C, int C8, int HW, float slope) {
+                                                             float* dgamma, float* dbeta, int B, int C, int C8, int HW, float slope,
+                                                             int sg) {
   prefetch_kernargs<192>();
   const FastDiv fdHW(HW, B * HW);
   __shared__ float red[(NT / 64) * 16];
   const int cb = blockIdx.x, t = threadIdx.x;
   const int n = B * HW;
+  // (sg > 1, MS_DT_STAT_PAIR: B clips per statistics group, the groups one after the other; parameter gradients summed in group order)
+  float tot_cs = 0.f, tot_s1 = 0.f, tot_s2 = 0.f;
+  for (int grp = 0; grp < sg; ++grp) {
+  if (grp) {
+    __syncthreads();
+    const size_t adv = (size_t)B * C8 * HW;
+    save += 4 * C; dyr += adv; y_raw += adv;
+    if (y_out) y_out += adv;
+    if (DYF32) dy_f32 += (size_t)B * C * HW; else dy += adv;
+  }
   // all loads first (clamped indices, no branches): one memory round trip for the whole kernel
   // (the 40 per-channel parameters travel through LDS: as scalar loads the compiler sinks them behind the data and waits
   // for them in four more round trips)
@@ -546,14 +579,18 @@ __global__ __launch_bounds__(NT) void bn_bwd16_fused_kernel(const u32x4* __restr
   }
   block_sum_n<8, NT / 64>(cs, red);
   if (t < 8) {
+    float csj = 0.f, s1j = 0.f, s2j = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (t == j) { csj = cs[j]; s1j = s12[j]; s2j = s12[8 + j]; }
+    tot_cs = grp ? tot_cs + csj : csj; tot_s1 = grp ? tot_s1 + s1j : s1j; tot_s2 = grp ? tot_s2 + s2j : s2j;
+  }
+  }
+  if (t < 8) {
     const int c = cb * 8 + t;
     if (c < C) {
-      float csj = 0.f, s1j = 0.f, s2j = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (t == j) { csj = cs[j]; s1j = s12[j]; s2j = s12[8 + j]; }
-      if (dbias) dbias[c] = csj;
-      if (dgamma) { dgamma[c] = s2j; dbeta[c] = s1j; }
+      if (dbias) dbias[c] = tot_cs;
+      if (dgamma) { dgamma[c] = tot_s2; dbeta[c] = tot_s1; }
     }
   }
 }
@@ -571,9 +608,11 @@ int bwd16_chunks(int B, int C8, int HW, int* b_per_chunk) {
 
 int launch_bn_bwd16(int dt, const void* dy, const float* dy_f32, const void* y_raw, const void* y, const float* save, const float* gamma,
                     float* partial, void* dyr, float* colpart, float* dbias, float* dgamma, float* dbeta, int B, int C, int HW,
-                    float slope, int* bias_done, hipStream_t s) {
+                    float slope, int* bias_done, hipStream_t s, int sg) {
   const int C8 = c8_of(C);
   *bias_done = 0;
+  if (sg > 1) B /= sg;                  // MS_DT_STAT_PAIR: clips per statistics group (the one-launch form only)
+  if (sg > 1 && (long)B * HW > BN_BWD16_FUSED_MAX) return set_error("bn_bwd16: statistics groups need the one-launch form");
   if ((long)B * HW <= BN_BWD16_FUSED_MAX) {
     *bias_done = 1;
     // 1024 threads per channel block when there is enough to share: few workgroups exist (C/8), so each one's latency counts
@@ -584,7 +623,7 @@ int launch_bn_bwd16(int dt, const void* dy, const float* dy_f32, const void* y_r
     if (ts.skip()) return 0;
 #define MS_BNF(DT, F, NE, NT)                                                                                                      \
     hipLaunchKernelGGL((bn_bwd16_fused_kernel<DT, F, NE, NT>), dim3(C8), dim3(NT), 0, s, (const u32x4*)dy, dy_f32, (const u32x4*)y_raw, \
-                       (const u32x4*)y, save, gamma, (u32x4*)dyr, dbias, dgamma, dbeta, B, C, C8, HW, slope)
+                       (const u32x4*)y, save, gamma, (u32x4*)dyr, dbias, dgamma, dbeta, B, C, C8, HW, slope, sg)
 #define MS_BNF_NE(DT, F) do { if (ne <= 1) MS_BNF(DT, F, 1, 256); else if (ne <= 2) MS_BNF(DT, F, 2, 256);                         \
                               else if (ne <= 4) MS_BNF(DT, F, 4, 256); else MS_BNF(DT, F, 8, 256); } while (0)
     if (dt == DT_BF16) { if (dy_f32) MS_BNF_NE(BF16, true); else MS_BNF_NE(BF16, false); }

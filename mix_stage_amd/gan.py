@@ -180,8 +180,9 @@ class GAN(nn.Module):
       probe = self._pair_probe[(B, T, P, first.device)] = torch.empty(2 * B, P, T, device='meta')
     if not D.pair_supported(probe):
       return None
-    v = ops.velocity_cm(torch.cat([first, second], dim=0))
-    return D.forward_pair(v)
+    both = torch.cat([first, second], dim=0)
+    dt = getattr(D, '_ms_dt', 0)
+    return D.forward_pair(ops16.btc_to_cb8(both, dt, velocity=True) if dt else ops.velocity_cm(both))
 
   def forward(self, x_audio, y_pose, **kwargs):
     internal_losses = []

@@ -10,7 +10,7 @@ import ctypes
 import torch
 
 from . import ops
-from ._lib import (BwdOptions, ConvDesc, FwdOptions, MS_BARE, MS_BF16, MS_BN_EVAL, MS_BN_TRAIN, MS_DT_BN_FOLDED, MS_DT_OUT_F32,
+from ._lib import (BwdOptions, ConvDesc, FwdOptions, MS_BARE, MS_BF16, MS_BN_EVAL, MS_BN_TRAIN, MS_DT_BN_FOLDED, MS_DT_OUT_F32, MS_DT_STAT_PAIR,
                    MS_F16, MS_IN_BCAST, MS_IN_PLAIN, MS_IN_UP2ADD, MS_LRELU, Prep16Item, check, lib)
 from .ops import _grad_slot, _ptr, _stream, workspace
 
@@ -296,7 +296,7 @@ class _ConvBlock16Fn(torch.autograd.Function):
       y_raw = save = None
       if mode == MS_BN_TRAIN:
         y_raw = torch.empty((B, c8) + sp + (8,), dtype=x.dtype, device=x.device)
-        save = torch.empty(4 * ctot, dtype=torch.float32, device=x.device)
+        save = torch.empty((8 if (dt_flags & MS_DT_STAT_PAIR) else 4) * ctot, dtype=torch.float32, device=x.device)
       ws = workspace(d._fwd_ws, x.device)
       sync = _ensure_bn_sync(x.device) if mode == MS_BN_TRAIN else None
       folded = mode == MS_BN_EVAL and bool(dt_flags & MS_DT_BN_FOLDED)
@@ -373,6 +373,8 @@ def conv_block16(x, w, bias, geom, mode, gamma=None, beta=None, running_mean=Non
   """One conv block in the 16-bit mode: x (and x2) cb8, result cb8 -- or plain fp32 (B, C, ...) with out_f32."""
   stats = (running_mean, running_var) if running_mean is not None else None
   flags = MS_DT[x.dtype] | (MS_DT_OUT_F32 if out_f32 else 0) | (MS_DT_BN_FOLDED if (bn_folded and mode == MS_BN_EVAL) else 0)
+  if ops.stat_pair_active():
+    flags |= MS_DT_STAT_PAIR            # two passes of the module side by side in this batch (ops.stat_pair)
   return _ConvBlock16Fn.apply(x, x2, w, bias, gamma, beta, geom, mode, in_mode, stats, flags)
 
 

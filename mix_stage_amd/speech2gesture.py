@@ -43,10 +43,11 @@ class Speech2Gesture_D(nn.Module):
   def pair_supported(self, x):
     """Can forward_pair run on x (2B, pose_feats, time) -- every block's kernels implement MS_DT_STAT_PAIR (ms_stat_pair_ok) for this
     batch, train-mode BatchNorm with local statistics, the in-launch meetings available?  Cached per input shape and tuning epoch."""
-    from ._lib import MS_BARE, MS_BN_TRAIN, MS_LRELU
-    if not self.training or ops.bn_sync_active() or not ops16.in_launch_meetings() or getattr(self, '_ms_dt', 0):
+    from ._lib import MS_BARE, MS_BN_TRAIN, MS_DT_OUT_F32, MS_LRELU
+    if not self.training or ops.bn_sync_active() or not ops16.in_launch_meetings():
       return False
-    key = (tuple(x.shape), ops.lib().ms_tuning_epoch())
+    dt = getattr(self, '_ms_dt', 0)
+    key = (tuple(x.shape), dt, ops.lib().ms_tuning_epoch())
     cache = self.__dict__.setdefault('_pair_ok', {})
     if key not in cache:
       ok, W = x.shape[0] % 2 == 0 and x.dim() == 3, x.shape[-1]
@@ -62,12 +63,14 @@ class Speech2Gesture_D(nn.Module):
         if W + 2 * geom.PW < geom.KW:
           ok = False
           break
-        ok, W = ops.stat_pair_ok(geom, x.shape[0], conv.weight.shape[1], W, conv.weight.shape[0] // conv.groups, mode)
+        flags = (dt | (MS_DT_OUT_F32 if conv is self.logits else 0)) if dt else 0
+        ok, W = ops.stat_pair_ok(geom, x.shape[0], conv.weight.shape[1], W, conv.weight.shape[0] // conv.groups, mode, flags)
       cache[key] = bool(ok)
     return cache[key]
 
   def forward_pair(self, x):
-    """The discriminator on TWO inputs side by side, x = cat([first, second]) channel-major (2B, pose_feats, time) -> (scores of the
+    """The discriminator on TWO inputs side by side, x = cat([first, second]) channel-major (2B, pose_feats, time; cb8 in the 16-bit
+    modes) -> (scores of the
     first, scores of the second).  Equal to forward_channel_major(first) followed by forward_channel_major(second) (gan.py:120,126):
     BatchNorm statistics per half, the running statistics moved twice in that order -- in half the launches."""
     with ops.stat_pair():
