@@ -456,6 +456,14 @@ int ms_lp_mean_fwd_ex(int squared, const float* a, const float* b, float target,
 int ms_lp_mean_bwd_ex(int squared, const float* a, const float* b, float target, const float* gscale, float* da, size_t n,
                       void* stream, const ms_loss_scale* ls);
 
+/* Two criterion terms of ONE tensor in one launch each way: halves [0, n) and [n, 2n) of `a` against the constants targets[0] /
+ * targets[1] with the weights ls[0] / ls[1] (NULL: 1) -> loss[0], loss[1] (gan.py:121,127: the D-step's fake and real terms on the
+ * paired discriminator pass, MS_DT_STAT_PAIR).  1 <= n <= 2048 per half; the same bits as two ms_lp_mean_*_ex calls.  Backward:
+ * da (2n) from the two incoming gradients (a NULL one leaves zeros in its half). */
+int ms_lp_mean_pair_fwd(int squared, const float* a, const float* targets, float* loss, size_t n, void* stream, const ms_loss_scale* ls);
+int ms_lp_mean_pair_bwd(int squared, const float* a, const float* targets, const float* gscale0, const float* gscale1, float* da, size_t n,
+                        void* stream, const ms_loss_scale* ls);
+
 /* n device-to-device copies (any sizes, any alignment) in one launch: the batch tensors of a step into the buffers a captured
  * step reads (the reference hands `batch` to the model directly, trainer.py:1077-1110; a HIP graph needs fixed addresses). */
 int ms_copy_multi(int n, const void* const* src, void* const* dst, const size_t* bytes, void* stream);

@@ -125,6 +125,8 @@ SIGNATURES = {
     'ms_cross_entropy_bwd_ex': (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [_P, _P]),
     'ms_lp_mean_fwd_ex': (c_int, [c_int, _P, _P, c_float, _P, _P, c_size_t, _P, _P]),
     'ms_lp_mean_bwd_ex': (c_int, [c_int, _P, _P, c_float, _P, _P, c_size_t, _P, _P]),
+    'ms_lp_mean_pair_fwd': (c_int, [c_int, _P, _P, _P, c_size_t, _P, _P]),
+    'ms_lp_mean_pair_bwd': (c_int, [c_int, _P, _P, _P, _P, _P, c_size_t, _P, _P]),
     'ms_velocity_fwd': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     'ms_velocity_bwd': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     'ms_transpose_btc': (c_int, [_P, _P, c_int, c_int, c_int, _P]),

@@ -1159,6 +1159,35 @@ __global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ a
   }
 }
 
+// Two criterion terms of ONE tensor in one launch each way: halves [0, n) and [n, 2n) of `a` against the constants target0 /
+// target1 with their own weights (gan.py:121,127: the D-step's fake and real terms on the paired discriminator pass).  n <= 2048
+// per half: the two-stage form above then has ONE partial per term, and this kernel forms it in the same order -- same bits.
+struct LossPair { float target[2], mul[2]; const float* mul_dev[2]; const float* gscale[2]; };
+template <int SQ>
+__global__ __launch_bounds__(256) void lp_pair_fwd_kernel(const float* __restrict__ a, float* __restrict__ loss, int n, const LossPair lp) {
+  __shared__ float red[4];
+  const int h = blockIdx.x;
+  const float* ah = a + (size_t)h * n;
+  const float target = lp.target[h];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float d = ah[i] - target;
+    s += SQ ? d * d : fabsf(d);
+  }
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) loss[h] = loss_weight((float)((double)s * (double)(1.0f / (float)n)), lp.mul[h], lp.mul_dev[h]);
+}
+template <int SQ>
+__global__ __launch_bounds__(256) void lp_pair_bwd_kernel(const float* __restrict__ a, float* __restrict__ da, int n, const LossPair lp) {
+  const int h = blockIdx.y;
+  const float g = lp.gscale[h] ? loss_weight(lp.gscale[h][0], lp.mul[h], lp.mul_dev[h]) / (float)n : 0.f;
+  const float target = lp.target[h];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float d = a[(size_t)h * n + i] - target;
+    da[(size_t)h * n + i] = SQ ? 2.f * g * d : (d > 0.f ? g : (d < 0.f ? -g : 0.f));
+  }
+}
+
 // Adam (torch.optim.Adam defaults: no amsgrad, no weight decay) with clip_grad_norm_ folded in.
 // state words: [0] step (int32), [1] clip coef (NaN: the gradient norm was not finite, the update is skipped), [2] step_size = lr/bc1, [3] sqrt(bc2)
 __global__ void adam_prep_kernel(int32_t* state, const float* norm, float max_norm, float lr, float beta1, float beta2) {
@@ -1674,6 +1703,29 @@ int ms_l2_mean_fwd(const float* a, const float* b, float target, float* loss, fl
 }
 int ms_l2_mean_bwd(const float* a, const float* b, float target, const float* gscale, float* da, size_t n, void* stream) {
   return lp_mean_bwd(1, a, b, target, gscale, da, n, stream, nullptr);
+}
+int ms_lp_mean_pair_fwd(int squared, const float* a, const float* targets, float* loss, size_t n, void* stream, const ms_loss_scale* ls) {
+  if (!a || !targets || !loss || n == 0 || n > 2048) return set_error("ms_lp_mean_pair_fwd: bad argument (1 <= n <= 2048 per half)");
+  TimingScope ts((hipStream_t)stream, 0, 0, squared ? "ew|ew_l2_mean_pair_fwd" : "ew|ew_l1_mean_pair_fwd");
+  if (ts.skip()) return 0;
+  LossPair lp = {};
+  for (int h = 0; h < 2; ++h) { lp.target[h] = targets[h]; lp.mul[h] = ls ? ls[h].scale : 1.0f; lp.mul_dev[h] = ls ? ls[h].scale_dev : nullptr; }
+  if (squared) hipLaunchKernelGGL(lp_pair_fwd_kernel<1>, dim3(2), dim3(256), 0, (hipStream_t)stream, a, loss, (int)n, lp);
+  else hipLaunchKernelGGL(lp_pair_fwd_kernel<0>, dim3(2), dim3(256), 0, (hipStream_t)stream, a, loss, (int)n, lp);
+  return check_launch("lp_pair_fwd_kernel");
+}
+int ms_lp_mean_pair_bwd(int squared, const float* a, const float* targets, const float* gscale0, const float* gscale1, float* da, size_t n,
+                        void* stream, const ms_loss_scale* ls) {
+  if (!a || !targets || !da || n == 0 || n > 2048) return set_error("ms_lp_mean_pair_bwd: bad argument (1 <= n <= 2048 per half)");
+  TimingScope ts((hipStream_t)stream, 0, 0, squared ? "ew|ew_l2_mean_pair_bwd" : "ew|ew_l1_mean_pair_bwd");
+  if (ts.skip()) return 0;
+  LossPair lp = {};
+  for (int h = 0; h < 2; ++h) { lp.target[h] = targets[h]; lp.mul[h] = ls ? ls[h].scale : 1.0f; lp.mul_dev[h] = ls ? ls[h].scale_dev : nullptr; }
+  lp.gscale[0] = gscale0; lp.gscale[1] = gscale1;
+  const dim3 grid((unsigned)((n + 255) / 256), 2);
+  if (squared) hipLaunchKernelGGL(lp_pair_bwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a, da, (int)n, lp);
+  else hipLaunchKernelGGL(lp_pair_bwd_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a, da, (int)n, lp);
+  return check_launch("lp_pair_bwd_kernel");
 }
 int ms_lp_mean_fwd_ex(int squared, const float* a, const float* b, float target, float* loss, float* partials, size_t n, void* stream,
                       const ms_loss_scale* ls) {

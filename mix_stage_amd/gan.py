@@ -167,7 +167,8 @@ class GAN(nn.Module):
     return self.D(ops.to_time_major(v))[0]
 
   def _score_pair(self, first, second):
-    """D(get_velocity(first)), D(get_velocity(second)) from one pass over both (Speech2Gesture_D.forward_pair), or None when the
+    """D(get_velocity(first)) and D(get_velocity(second)) as one (2B, *) score tensor from one pass over both
+    (Speech2Gesture_D.forward_pair), or None when the
     module or this batch has no paired form (16-bit modes, global BatchNorm statistics, unequal shapes, ...)."""
     D = self.D
     if not hasattr(D, 'forward_pair') or first.shape != second.shape or first.dtype != second.dtype or first.dim() != 3:
@@ -182,7 +183,7 @@ class GAN(nn.Module):
       return None
     both = torch.cat([first, second], dim=0)
     dt = getattr(D, '_ms_dt', 0)
-    return D.forward_pair(ops16.btc_to_cb8(both, dt, velocity=True) if dt else ops.velocity_cm(both))
+    return D.forward_pair(ops16.btc_to_cb8(both, dt, velocity=True) if dt else ops.velocity_cm(both), split=False)
 
   def forward(self, x_audio, y_pose, **kwargs):
     internal_losses = []
@@ -211,13 +212,18 @@ class GAN(nn.Module):
         if pair is not None:
           # D on the fake and on the real velocities as ONE batch of 2B clips with two BatchNorm statistics groups (include/mixstage.h:
           # MS_DT_STAT_PAIR): the same values as the two passes below, half the launches
-          fake_pose_score, real_pose_score = pair
-          fake_D_loss = self._loss(fake_pose_score, target=0.0, scale=lam_D)
+          if pair.dtype == torch.float32 and pair.numel() // 2 <= ops.LP_PAIR_MAX:
+            # both criterion terms in one launch each way (the same bits as the two calls below)
+            fake_D_loss, real_D_loss = ops.lp_mean_pair(pair, (0.0, 1.0), (lam_D, 1.0), squared=self.criterion_name == 'MSELoss')
+          else:
+            fake_pose_score, real_pose_score = ops.split_halves(pair)
+            fake_D_loss = self._loss(fake_pose_score, target=0.0, scale=lam_D)
+            real_D_loss = self._loss(real_pose_score, target=1.0)
         else:
           fake_pose_score = self._score(fake_pose.detach())
           fake_D_loss = self._loss(fake_pose_score, target=0.0, scale=lam_D)
           real_pose_score = self._score(y_pose)
-        real_D_loss = self._loss(real_pose_score, target=1.0)
+          real_D_loss = self._loss(real_pose_score, target=1.0)
         internal_losses.append(real_D_loss)
         internal_losses.append(fake_D_loss)
         internal_losses += partial_i_loss

@@ -1110,6 +1110,45 @@ def l2_mean(a, b=None, target=0.0, scale=1.0):
   return _L1MeanFn.apply(a, b, float(target), scale if torch.is_tensor(scale) else float(scale), True)
 
 
+LP_PAIR_MAX = 2048      # values per half up to which the paired criterion is one launch (include/mixstage.h: ms_lp_mean_pair_fwd)
+
+
+class _LpPairFn(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, a, t0, t1, s0, s1, squared):
+    _need_hip(a)
+    a = a.contiguous()
+    n = a.numel() // 2
+    out = torch.empty(2, dtype=torch.float32, device=a.device)
+    ls = (_lib.LossScale * 2)(_loss_scale(s0), _loss_scale(s1))
+    tg = (ctypes.c_float * 2)(t0, t1)
+    check(lib().ms_lp_mean_pair_fwd(1 if squared else 0, _ptr(a), tg, _ptr(out), n, _stream(), ls), 'ms_lp_mean_pair_fwd')
+    ctx.save_for_backward(a, s0 if torch.is_tensor(s0) else None, s1 if torch.is_tensor(s1) else None)
+    ctx.consts = (t0, t1, None if torch.is_tensor(s0) else s0, None if torch.is_tensor(s1) else s1, squared)
+    return out[0], out[1]
+
+  @staticmethod
+  def backward(ctx, g0, g1):
+    a, s0t, s1t = ctx.saved_tensors
+    t0, t1, s0, s1, squared = ctx.consts
+    da = torch.empty_like(a)
+    ls = (_lib.LossScale * 2)(_loss_scale(s0t if s0t is not None else s0), _loss_scale(s1t if s1t is not None else s1))
+    tg = (ctypes.c_float * 2)(t0, t1)
+    g0 = g0.contiguous() if g0 is not None else None
+    g1 = g1.contiguous() if g1 is not None else None
+    check(lib().ms_lp_mean_pair_bwd(1 if squared else 0, _ptr(a), tg, _ptr(g0), _ptr(g1), _ptr(da), a.numel() // 2, _stream(), ls),
+          'ms_lp_mean_pair_bwd')
+    return da, None, None, None, None, None
+
+
+def lp_mean_pair(a, targets, scales, squared=False):
+  """(scales[0] * mean|a[:B] - targets[0]|, scales[1] * mean|a[B:] - targets[1]|) (squared: the MSELoss form) of the two halves of a
+  fp32 tensor in one launch each way -- the same bits as two l1_mean / l2_mean calls on the halves (gan.py:121,127 on the paired
+  discriminator pass).  At most LP_PAIR_MAX values per half."""
+  s0, s1 = [s if torch.is_tensor(s) else float(s) for s in scales]
+  return _LpPairFn.apply(a, float(targets[0]), float(targets[1]), s0, s1, bool(squared))
+
+
 def copy_multi(pairs):
   """dst.copy_(src) for every (dst, src) pair of contiguous device tensors of equal size and dtype, in ONE launch."""
   pairs = [(d, s) for d, s in pairs if d.numel()]

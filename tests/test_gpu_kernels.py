@@ -344,6 +344,35 @@ def test_loss_weights_inside_the_kernels_equal_scaling_outside():
   assert abs(v2 / v1 - 2.0 / 0.37) < 1e-5
 
 
+@pytest.mark.parametrize('shape', [(64, 10), (4, 61), (2, 2048), (6, 1)])
+def test_paired_criterion_equals_the_two_calls_bit_for_bit(shape):
+  """ops.lp_mean_pair (ms_lp_mean_pair_fwd / _bwd: both criterion terms of the D-step's paired discriminator pass in one launch each
+  way) against l1_mean / l2_mean on the two halves: losses and gradients bit for bit, host and device weights, one term unused."""
+  from mix_stage_amd import ops
+  gen = torch.Generator().manual_seed(3)
+  a = torch.randn(*shape, generator=gen).to(DEV)
+  a[0, 0] = 1.0                                   # a score exactly on a target: sign(0) = 0 in the L1 gradient
+  lam = torch.tensor([0.37, 1.83], device=DEV)
+  h = shape[0] // 2
+  for squared in (False, True):
+    fn = ops.l2_mean if squared else ops.l1_mean
+    for scales in ((lam[0], 1.0), (0.5, lam[1])):
+      x = a.clone().requires_grad_()
+      r0 = fn(x[:h], target=0.0, scale=scales[0]); r1 = fn(x[h:], target=1.0, scale=scales[1])
+      (r0 * 1.0 + r1 * 1.0).backward()
+      y = a.clone().requires_grad_()
+      p0, p1 = ops.lp_mean_pair(y, (0.0, 1.0), scales, squared=squared)
+      (p0 * 1.0 + p1 * 1.0).backward()
+      assert torch.equal(p0.detach(), r0.detach()) and torch.equal(p1.detach(), r1.detach()), (squared, p0, r0, p1, r1)
+      assert torch.equal(y.grad, x.grad)
+    y = a.clone().requires_grad_()
+    p0, _ = ops.lp_mean_pair(y, (0.0, 1.0), (1.0, 1.0), squared=squared)
+    p0.backward()
+    x = a.clone().requires_grad_()
+    fn(x[:h], target=0.0).backward()
+    assert torch.equal(y.grad, x.grad) and not y.grad[h:].any()
+
+
 def test_copy_multi_any_sizes_and_dtypes():
   """ms_copy_multi: many device-to-device copies in one launch (more than the 8 a launch holds; odd byte counts; unaligned
   views; int64)."""
