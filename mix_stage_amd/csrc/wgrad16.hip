@@ -628,8 +628,13 @@ static int launch_wm(const Wgrad16Batch& b, int lds, hipStream_t s) {
   return 0;
 }
 
-// npxt: slots of input rows a thread keeps in registers (3, 5) or 0 = the per-tile loop (layers with a few pixels per row)
+// npxt: slots of input rows a thread keeps in registers (3, 5) or 0 = the per-tile loop (layers with a few pixels per row).
+// Queued jobs (wgrad16_flush) all take the 5-slot instance up to 5 slots: a slot beyond a job's rows is a wave-uniform skip, and
+// the jobs of a backward pass then share ONE launch per number of taps -- with 3- and 5-slot instances apart, a single
+// 192-workgroup job ran alone on a corner of the chip for 55 us.  (A universal kernel holding every instance behind a switch was
+// tried: the register allocator gives the cases disjoint accumulator ranges -- 168 VGPR + 128 AGPR, 3.7 KB of scratch.)
 inline int wg16_npxt(int npx) { return npx <= 3 ? 3 : npx <= 5 ? 5 : 0; }
+inline int wg16_npxt_queued(int npx) { return npx <= 5 ? 5 : 0; }
 
 template <typename DT, int TP>
 static int launch_np_multi(const Wgrad16Batch& b, int npxt, int lds, hipStream_t s) {
@@ -700,7 +705,7 @@ int queue_wgrad16(int dt, const Wgrad16Args& a, const Wgrad16Plan& pl, bool up2,
   // a queued kernel that writes dw itself (no pixel split) ADDS to it: by the time it runs, autograd may already have
   // accumulated the parameter's other uses of this step into the same slot (the slot starts the step zeroed)
   if (pl.splits == 1) pw.a.accumulate = 1;
-  pw.dt = dt; pw.tp = up2 ? 3 : pl.tp; pw.up2 = up2 ? 1 : 0; pw.npxt = up2 ? 0 : wg16_npxt(pl.npx); pw.lds = pl.lds_bytes; pw.nwg = (int)nwg; pw.flops = flops; pw.bytes = bytes;
+  pw.dt = dt; pw.tp = up2 ? 3 : pl.tp; pw.up2 = up2 ? 1 : 0; pw.npxt = up2 ? 0 : wg16_npxt_queued(pl.npx); pw.lds = pl.lds_bytes; pw.nwg = (int)nwg; pw.flops = flops; pw.bytes = bytes;
   std::lock_guard<std::mutex> lk(t_pending_mu);
   t_pending.push_back(pw);
   return 0;
