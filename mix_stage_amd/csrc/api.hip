@@ -30,7 +30,13 @@ static int validate(const ms_conv_desc* d, const char* who) {
   return 0;
 }
 
+static inline bool wgrad_c1_of(const ms_conv_desc* d) {
+  return dt_of(d) == DT_F32 && g_precision == 0 &&
+         wgrad_c1_ok(d->groups, d->Cin, d->Cout, d->KH, d->KW, d->SH, d->SW, d->PH, d->PW, d->H, d->W, d->in_mode == MS_IN_PLAIN);
+}
+
 static int wgrad_total_splits(const ms_conv_desc* d) {
+  if (wgrad_c1_of(d)) return wgrad_c1_splits(d->B, d->H);
   const int npix = d->B * d->OH * d->OW;
   const bool one_d = d->H == 1 && d->KH == 1;
   const WgradPatchPlan wp = plan_wgrad_patch(one_d ? 1 : 2, d->Cout, d->Cin * d->KH * d->KW, d->groups, d->KH, d->KW, d->SH,
@@ -303,6 +309,7 @@ static DgradWeights dgrad_weights_of(const ms_conv_desc* d, const float* w) {
 
 // Pixel splits of the block's weight gradient as the backward will run it (1: dw is written directly).
 static int wgrad_splits_used(const ms_conv_desc* d) {
+  if (wgrad_c1_of(d)) return wgrad_c1_splits(d->B, d->H);
   const bool one_d = d->H == 1 && d->KH == 1;
   const WgradPatchPlan wp = plan_wgrad_patch(one_d ? 1 : 2, d->Cout, d->Cin * d->KH * d->KW, d->groups, d->KH, d->KW, d->SH,
                                              d->SW, d->B, d->OH, d->OW, d->W, d->in_mode == MS_IN_UP2ADD);
@@ -716,6 +723,12 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
   }
 
   // 3. weight gradient
+  if (dw && wgrad_c1_of(d)) {
+    // the single-input-channel 3x3 block: a stream over dy_raw on the vector unit (conv_c1.hip), slabs reduced like any split
+    rc = launch_wgrad_c1(g, x, wg_part, d->B, d->H, d->W, ws_stream);
+    if (!rc && !defer_wgrad) rc = launch_reduce_splits(wg_part, dw, C * d->Cin * khw, wgrad_c1_splits(d->B, d->H), ws_stream);
+    return rc;
+  }
   if (dw) {
     const bool one_d = d->H == 1 && d->KH == 1;
     const WgradPatchPlan wp = plan_wgrad_patch(one_d ? 1 : 2, d->Cout, d->Cin * khw, d->groups, d->KH, d->KW, d->SH, d->SW,

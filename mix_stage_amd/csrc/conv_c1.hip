@@ -7,6 +7,7 @@
 // stores), a workgroup's 1024 pixels are one statistics tile (4x fewer partials for bn_finalize), both statistics passes are
 // constant-trip LDS reductions; the conv is recomputed for the second pass instead of keeping 256 values per thread.
 #include <stdint.h>
+#include <algorithm>
 #include <stdlib.h>
 
 #include "kernels.h"
@@ -226,6 +227,97 @@ int launch_conv_c1(const float* x, const float* w, const float* bias, float* out
   hipLaunchKernelGGL(conv_c1_3x3_kernel<64>, dim3(cdiv(B * H * W, 256)), dim3(256), 0, s, x, w, bias, out, bn_g, bn_b, bn_m, bn_v,
                      stats, counts, B, H, W, ep, slope, eps);
   return check_launch("conv_c1_3x3_kernel");
+}
+
+// ---- weight gradient of the same block: dw[c][kh][kw] = sum over (b, h, w) of dy_raw[b][c][h][w] * x[b][0][h + kh - 1][w + kw - 1].
+// 576 numbers reduced over every pixel: on the MFMA kernel a 64 x 64 x 9 tile whose input-channel side is 63/64 zeros (37 us, 8 TF).
+// Here it is a stream over dy_raw (67 MB at the headline size) on the vector unit: a workgroup owns `rows_per_wg` rows of the
+// flattened (image, row) space; thread (cs = t / 32, v = t % 32) takes the 16-byte column groups v, v + 32, ... of a row for the
+// 8 channels cs, cs + 8, ..., keeps the 3 x 6 input window of its four pixels in registers (shared by all channels) and 8 x 9
+// running sums.  Fixed-order finish: the 32 lanes of a channel set by xor-shuffles, one slab of 576 partial sums per workgroup,
+// summed across workgroups by the caller's slab reduction like every other split weight gradient (bit-reproducible).
+__global__ __launch_bounds__(256) void wgrad_c1_3x3_kernel(const float* __restrict__ dyr, const float* __restrict__ x,
+                                                           float* __restrict__ part, int B, int H, int W, int rows_per_wg) {
+  const int t = threadIdx.x, v = t & 31, cs = t >> 5;
+  const int W4 = W >> 2, rows = B * H;
+  const int r0 = blockIdx.x * rows_per_wg, r1 = min(rows, r0 + rows_per_wg);
+  float acc[8][9];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int q = 0; q < 9; ++q) acc[k][q] = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    const int b = r / H, h = r - b * H;
+    for (int v0 = v; v0 < W4; v0 += 32) {
+      // dy_raw of this thread's four pixels, 8 channels: all eight 16-byte loads go out before anything is consumed
+      float4 d[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        d[k] = *reinterpret_cast<const float4*>(dyr + (((size_t)b * 64 + cs + 8 * k) * H + h) * W + 4 * v0);
+      // input window: rows h-1 .. h+1, columns 4 v0 - 1 .. 4 v0 + 4 (zero padding)
+      float xw[3][6];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int hh = h + kh - 1;
+        const bool rv = (unsigned)hh < (unsigned)H;
+        const float* xr = x + ((size_t)b * H + (rv ? hh : h)) * W + 4 * v0;
+        const float4 m = *reinterpret_cast<const float4*>(xr);
+        const float lf = v0 > 0 ? xr[-1] : 0.f, rt = v0 + 1 < W4 ? xr[4] : 0.f;
+        xw[kh][0] = rv ? lf : 0.f; xw[kh][1] = rv ? m.x : 0.f; xw[kh][2] = rv ? m.y : 0.f;
+        xw[kh][3] = rv ? m.z : 0.f; xw[kh][4] = rv ? m.w : 0.f; xw[kh][5] = rv ? rt : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            float a = acc[k][kh * 3 + kw];
+            a = fmaf(d[k].x, xw[kh][kw], a);
+            a = fmaf(d[k].y, xw[kh][kw + 1], a);
+            a = fmaf(d[k].z, xw[kh][kw + 2], a);
+            a = fmaf(d[k].w, xw[kh][kw + 3], a);
+            acc[k][kh * 3 + kw] = a;
+          }
+    }
+  }
+  // the 32 lanes of a channel set (lane bits 0..4), fixed butterfly
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      float a = acc[k][q];
+#pragma unroll
+      for (int m = 1; m < 32; m <<= 1) a += __shfl_xor(a, m, 64);
+      acc[k][q] = a;
+    }
+  if (v == 0) {
+    float* o = part + (size_t)blockIdx.x * 576;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int q = 0; q < 9; ++q) o[(cs + 8 * k) * 9 + q] = acc[k][q];
+  }
+}
+
+bool wgrad_c1_ok(int groups, int Cin, int Cout, int KH, int KW, int SH, int SW, int PH, int PW, int H, int W, int in_plain) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("MS_WGRAD_C1"); on = e ? atoi(e) : 1; }
+  return on && conv_c1_ok(groups, Cin, Cout, KH, KW, SH, SW, PH, PW, H, in_plain) && (W & 3) == 0;
+}
+// slabs (= workgroups) of the launch: four rows per workgroup, at most 1024 slabs
+int wgrad_c1_splits(int B, int H) {
+  const int rows = B * H;
+  return std::max(2, std::min(1024, cdiv(rows, 4)));
+}
+int launch_wgrad_c1(const float* dyr, const float* x, float* part, int B, int H, int W, hipStream_t s) {
+  const int S = wgrad_c1_splits(B, H), rows_per_wg = cdiv(B * H, S);
+  const double npix = (double)B * H * W;
+  TimingScope ts(s, 2.0 * npix * 64 * 9, 4.0 * npix * 65, "wgrad_c1_3x3_kernel|conv_wgrad_c1 k3x3 Cout64 N%.0f slabs%d", npix, S);
+  if (ts.skip()) return 0;
+  if ((((uintptr_t)dyr | (uintptr_t)x) & 15) != 0) return set_error("wgrad_c1: unaligned tensors");
+  hipLaunchKernelGGL(wgrad_c1_3x3_kernel, dim3(S), dim3(256), 0, s, dyr, x, part, B, H, W, rows_per_wg);
+  return check_launch("wgrad_c1_3x3_kernel");
 }
 
 }  // namespace ms

@@ -96,6 +96,10 @@ int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S,
 // single-input-channel 3x3 conv on the VALU (conv_c1.hip)
 bool conv_c1_ok(int groups, int Cin, int Cout, int KH, int KW, int SH, int SW, int PH, int PW, int H, int in_plain);
 int conv_c1_tiles(int B, int H, int W);
+// ... and its weight gradient: wgrad_c1_splits slabs of 576 partial sums (the caller reduces them like any split weight gradient)
+bool wgrad_c1_ok(int groups, int Cin, int Cout, int KH, int KW, int SH, int SW, int PH, int PW, int H, int W, int in_plain);
+int wgrad_c1_splits(int B, int H);
+int launch_wgrad_c1(const float* dyr, const float* x, float* part, int B, int H, int W, hipStream_t s);
 int launch_conv_c1(const float* x, const float* w, const float* bias, float* out, const float* bn_g, const float* bn_b,
                    const float* bn_m, const float* bn_v, float* stats, float* counts, int B, int H, int W, int ep, float slope,
                    float eps, hipStream_t s);

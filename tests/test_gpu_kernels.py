@@ -55,6 +55,8 @@ BLOCK_CASES = [
     ('ragged_g3', '1d', 7, 5, 3, 1, 3, (37,), 'plain'),
     ('ragged_bcast', '1d', 10, 33, 3, 1, 3, (19,), 'bcast'),
     ('ae0', '2d', 1, 64, None, None, 1, (64, 128), 'plain'),
+    ('ae0_w20', '2d', 1, 64, None, None, 1, (7, 20), 'plain'),       # the single-input-channel weight gradient on ragged rows / a part-filled column group
+    ('ae0_w160', '2d', 1, 64, None, None, 1, (5, 160), 'plain'),     # ... and rows wider than one pass of the 32 column groups
     ('ae1', '2d', 64, 64, 4, 2, 1, (32, 48), 'plain'),
     ('ae2', '2d', 64, 128, None, None, 1, (16, 24), 'plain'),
     ('ae5', '2d', 256, 256, 4, 2, 1, (16, 32), 'plain'),

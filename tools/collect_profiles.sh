@@ -41,6 +41,13 @@ rocprofv3 --kernel-trace --output-format csv -d /tmp/tr16 -- python3 "$R/tools/t
 python3 "$R/tools/trace_summary.py" "$(ls /tmp/tr16/*/*kernel_trace.csv | head -1)" "$OUT/timeline_bf16_gstep.json" >> "$OUT/trace16.log" 2>&1
 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr32 -- python3 "$R/tools/trace_step.py" fp32 G 12 > "$OUT/trace32.log" 2>&1
 python3 "$R/tools/trace_summary.py" "$(ls /tmp/tr32/*/*kernel_trace.csv | head -1)" "$OUT/timeline_fp32_gstep.json" >> "$OUT/trace32.log" 2>&1
+for K in D; do for P in fp32 bf16; do
+rocprofv3 --kernel-trace --output-format csv -d /tmp/trd$P -- python3 "$R/tools/trace_step.py" $P $K 12 > /dev/null 2>&1
+python3 "$R/tools/trace_summary.py" "$(ls /tmp/trd$P/*/*kernel_trace.csv | head -1)" "$OUT/timeline_${P}_dstep.json" > /dev/null 2>&1
+done; done
 cd "$R"
+# SQ / TCC counters of every kernel of an eager fp32 G-step (the backward GEMMs: review item 1), and the residual of the captured steps
+bash tools/pmc_step.sh fp32 G "$OUT/sq_backward.json" 3 > "$OUT/pmc_step.log" 2>&1 || true
+bash tools/residual.sh "$OUT/residual.json" > "$OUT/residual.log" 2>&1 || true
 python -m pytest tests/test_gpu_model16.py -q -m gpu > "$OUT/precision_tests.log" 2>&1; cp gpurun_out/precision_report.json "$OUT/precision_report.json"
 cut -c1-300 "$OUT/bench.json"; cut -c1-300 "$OUT/bench_bf16.json"
