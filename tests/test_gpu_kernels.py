@@ -442,3 +442,69 @@ def test_bf16x6_mode_matches_fp32_accuracy():
   finally:
     L.ms_set_precision(0)
     L.ms_debug_set_patch_min_workgroups(old_wg)
+
+
+PAIR_CASES = [
+    # (name, cin, cout, kernel, stride, T, B per pass): the discriminator's two BatchNorm blocks and other 1-D shapes of the path
+    ('d_conv2', 64, 128, 4, 2, 32, 32),          # clip-resident launch, 128 workgroups
+    ('d_conv3', 128, 256, 4, 1, 16, 32),         # split-K / register-resident epilogue
+    ('d_conv2_b2', 64, 128, 4, 2, 32, 2),
+    ('d_conv3_t64', 128, 256, 4, 1, 64, 2),      # T = 256 clips of configs[3] after the two stride-2 blocks
+    ('k3_256', 256, 256, None, None, 64, 4),     # a k3 s1 block of the 1-D stacks
+    ('cls_266', 266, 256, None, None, 64, 4),
+    ('odd_ch', 24, 40, 4, 2, 16, 6),
+]
+
+
+@pytest.mark.parametrize('case', PAIR_CASES, ids=[c[0] for c in PAIR_CASES])
+def test_stat_pair_block_equals_two_blocks(case):
+  """One ConvNormRelu block on a batch of 2B clips under MS_DT_STAT_PAIR (ops.stat_pair: BatchNorm statistics per half, running
+  statistics moved twice, first half first) against the same block applied to the two halves one after the other -- outputs, input
+  gradients, parameter gradients, running statistics, and both against the fp64 oracle block doing the two passes."""
+  import copy
+  import mix_stage_amd as A
+  from mix_stage_amd import ops
+  name, cin, cout, k, s, T, B = case
+  blk_case = (name, '1d', cin, cout, k, s, 1, (T,), 'plain')
+  ref = _mk_block(O, blk_case).double().train()
+  hip2 = _mk_block(A, blk_case).to(DEV).train()
+  hipp = copy.deepcopy(hip2)
+  gen = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
+  x1 = torch.randn(B, cin, T, generator=gen)
+  x2 = torch.randn(B, cin, T, generator=gen) * 1.6 + 0.3
+  # is the paired form offered for this block at all?  (else nothing to compare: the trainer would run two passes)
+  g = hipp._geometry()
+  from mix_stage_amd._lib import MS_BN_TRAIN
+  ok, _ = ops.stat_pair_ok(g, 2 * B, cin, T, cout, MS_BN_TRAIN)
+  if not ok:
+    pytest.skip('ms_stat_pair_ok says no for this geometry')
+  # fp64 oracle, two passes
+  a64, b64 = x1.double().requires_grad_(), x2.double().requires_grad_()
+  y1r, y2r = ref(a64), ref(b64)
+  gy1 = torch.randn(y1r.shape, generator=gen); gy2 = torch.randn(y2r.shape, generator=gen)
+  (y1r * gy1.double()).sum().backward(); (y2r * gy2.double()).sum().backward()
+  # HIP, two passes
+  a, b = x1.to(DEV).requires_grad_(), x2.to(DEV).requires_grad_()
+  y1, y2 = hip2(a), hip2(b)
+  ((y1 * gy1.to(DEV)).sum() + (y2 * gy2.to(DEV)).sum()).backward()
+  # HIP, paired
+  xp = torch.cat([x1, x2]).to(DEV).requires_grad_()
+  with ops.stat_pair():
+    yp = hipp(xp)
+  (yp * torch.cat([gy1, gy2]).to(DEV)).sum().backward()
+  torch.cuda.synchronize()
+  y2pass = torch.cat([y1, y2])
+  errs = {'y vs two passes': (rel_err(yp, y2pass), 2e-6), 'y vs fp64': (rel_err(yp, torch.cat([y1r, y2r])), 2e-5),
+          'dx vs two passes': (rel_err(xp.grad, torch.cat([a.grad, b.grad])), 2e-5),
+          'dx vs fp64': (rel_err(xp.grad, torch.cat([a64.grad, b64.grad])), 1e-4),
+          'dw vs two passes': (rel_err(hipp.conv.weight.grad, hip2.conv.weight.grad), 2e-5),
+          'dw vs fp64': (rel_err(hipp.conv.weight.grad, ref.conv.weight.grad), 1e-4),
+          'dgamma vs fp64': (rel_err(hipp.norm.weight.grad, ref.norm.weight.grad), 1e-4),
+          'dbeta vs fp64': (rel_err(hipp.norm.bias.grad, ref.norm.bias.grad), 1e-4),
+          'running_mean vs fp64': (rel_err(hipp.norm.running_mean, ref.norm.running_mean), 1e-5),
+          'running_var vs fp64': (rel_err(hipp.norm.running_var, ref.norm.running_var), 1e-5),
+          'running_mean vs two passes': (rel_err(hipp.norm.running_mean, hip2.norm.running_mean), 1e-6),
+          'running_var vs two passes': (rel_err(hipp.norm.running_var, hip2.norm.running_var), 1e-6)}
+  bad = {kk: v for kk, v in errs.items() if not v[0] <= v[1]}
+  assert not bad, 'errors (value, bar): %s | all: %s' % (bad, {kk: '%.2e' % v[0] for kk, v in errs.items()})
+  assert int(hipp.state_dict()['norm.num_batches_tracked']) == int(hip2.state_dict()['norm.num_batches_tracked']) == 2
