@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define MS_ABI_VERSION 2
+/* 3: ms_bwd_options grew (prev_*, bn_sync, dy_is_dyr), MS_DT_STAT_PAIR (save holds two vectors), ms_lp_mean_pair_*, Adam state words 2 / 3 */
+#define MS_ABI_VERSION 3
 
 /* epilogue of a conv block */
 enum ms_block_mode {
