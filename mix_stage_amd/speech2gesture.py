@@ -46,6 +46,9 @@ class Speech2Gesture_D(nn.Module):
     from ._lib import MS_BARE, MS_BN_TRAIN, MS_DT_OUT_F32, MS_LRELU
     if not self.training or ops.bn_sync_active() or not ops16.in_launch_meetings():
       return False
+    # a caller that hooked a block expects the reference's two calls per D-step, each on a batch of B
+    if any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, '_backward_pre_hooks', None) for m in self.modules()):
+      return False
     dt = getattr(self, '_ms_dt', 0)
     key = (tuple(x.shape), dt, ops.lib().ms_tuning_epoch())
     cache = self.__dict__.setdefault('_pair_ok', {})

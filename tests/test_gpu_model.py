@@ -563,3 +563,16 @@ def test_d_step_with_paired_passes_equals_the_step_with_two_passes(golden_dir):
   for (n, a), (_, b) in zip(h1.D.named_buffers(), h2.D.named_buffers()):
     if 'running_' in n:
       assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), n
+
+
+def test_paired_pass_steps_aside_for_hooked_modules():
+  """A forward hook on one of D's blocks expects the reference's two calls per D-step on batches of B: the paired pass declines."""
+  import mix_stage_amd as A
+  D = A.Speech2Gesture_D(in_channels=104).to(DEV).train()
+  probe = torch.empty(64, 104, 64, device='meta')
+  assert D.pair_supported(probe)
+  calls = []
+  h = D.conv3.register_forward_hook(lambda m, i, o: calls.append(o.shape[0]))
+  assert not D.pair_supported(probe)
+  h.remove()
+  assert D.pair_supported(probe)
