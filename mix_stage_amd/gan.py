@@ -168,8 +168,8 @@ class GAN(nn.Module):
 
   def _score_pair(self, first, second):
     """D(get_velocity(first)) and D(get_velocity(second)) as one (2B, *) score tensor from one pass over both
-    (Speech2Gesture_D.forward_pair), or None when the
-    module or this batch has no paired form (16-bit modes, global BatchNorm statistics, unequal shapes, ...)."""
+    (Speech2Gesture_D.forward_pair), or None when the module or this batch has no paired form (hooked modules, global BatchNorm
+    statistics, float64 or CPU poses, unequal shapes, a geometry ms_stat_pair_ok declines): the caller then makes the two passes."""
     D = self.D
     if not hasattr(D, 'forward_pair') or first.shape != second.shape or first.dtype != second.dtype or first.dim() != 3:
       return None

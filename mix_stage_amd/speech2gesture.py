@@ -73,9 +73,9 @@ class Speech2Gesture_D(nn.Module):
 
   def forward_pair(self, x, split=True):
     """The discriminator on TWO inputs side by side, x = cat([first, second]) channel-major (2B, pose_feats, time; cb8 in the 16-bit
-    modes) -> (scores of the
-    first, scores of the second).  Equal to forward_channel_major(first) followed by forward_channel_major(second) (gan.py:120,126):
-    BatchNorm statistics per half, the running statistics moved twice in that order -- in half the launches."""
+    modes) -> (scores of the first, scores of the second).  Equal to forward_channel_major(first) followed by
+    forward_channel_major(second) (gan.py:120,126): BatchNorm statistics per half, the running statistics moved twice in that
+    order -- in half the launches.  Call only where pair_supported(x) holds."""
     with ops.stat_pair():
       s = self.forward_channel_major(x)[0]
     return ops.split_halves(s) if split else s              # (split=False: the scores of both, (2B, *), first half first)
