@@ -100,7 +100,17 @@ def save_weights(model, path, train_step=None):
   bad = [k for k, v in state.items() if v.is_floating_point() and not bool(torch.isfinite(v).all())]
   if bad:
     raise RuntimeError('refusing to save: %d tensors hold non-finite values (first: %s)' % (len(bad), bad[0]))
-  tmp = os.fspath(path) + '.tmp'
-  torch.save(state, tmp)
-  os.replace(tmp, os.fspath(path))
+  # written beside the target under a name of its own (process id + random suffix), then renamed over it: concurrent savers -- the
+  # ranks of a data-parallel job pointed at one path; save from rank 0 only -- never see or replace each other's partial file
+  import tempfile
+  target = os.fspath(path)
+  fd, tmp = tempfile.mkstemp(prefix=os.path.basename(target) + '.', suffix='.%d.tmp' % os.getpid(), dir=os.path.dirname(target) or '.')
+  try:
+    with os.fdopen(fd, 'wb') as f:
+      torch.save(state, f)
+    os.replace(tmp, target)
+  except BaseException:
+    if os.path.exists(tmp):
+      os.unlink(tmp)
+    raise
   return path

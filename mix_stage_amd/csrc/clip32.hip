@@ -50,9 +50,18 @@ struct Clip32Args {
   float* pv_dgamma; float* pv_dbeta; float* pv_dbias;
   int sg;                // BN_TRAIN: statistics groups along the batch (MS_DT_STAT_PAIR: 2), each npw / sg consecutive pixel workgroups
   int raw_all;           // BN_TRAIN: y_raw for every channel (0: only for channels whose backward cannot take x_hat from y: conv16.h bn_inv_unsafe)
+  int cx, px;            // placement over the 8 XCDs (workgroup id % 8 = XCD): XCD (xc, xp) of a cx x px grid owns nct / cx channel tiles
+                         // x npw / px pixel workgroups, so that what its L2 fetches (weight slices + clip images) is smallest; cx = 0: linear
   unsigned long long* stamps;   // diagnostics (MS_CLIP_DBG=32): [workgroup][8] s_memrealtime stamps (100 MHz)
 };
 #define CL_STAMP(k) do { if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+
+__host__ __device__ constexpr int cl_pslots(int n) { return (n + 3) & ~3; }      // slots per plane
+// position of slot s (0 = left halo, 1 + frame, Ti + 1 = right halo) inside a clip's row.  Stride-2 forward: even and odd slots
+// apart ([row / 2 even slots][row / 2 odd slots]), so that the lanes of a K-loop read (output frame tt, tap k -> slot 2 tt + k) are
+// one slot apart instead of two (two slots apart is a 2-way conflict of every ds_read_b128: 16 lanes cover 32 slots of the 16-slot row).
+template <bool SPLIT>
+__device__ __forceinline__ int cl_pos(int s, int half) { return SPLIT ? (s & 1) * half + (s >> 1) : s; }
 
 __device__ __forceinline__ float cl_f4e(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
 
@@ -94,12 +103,20 @@ __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
   constexpr int NWR = (K8W ? K8W : CL_MAXK8W) * KW;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, n0 = lane & 31, h = lane >> 5;
   const int nct = p.nct;
-  const int ct = blockIdx.x % nct, pw = blockIdx.x / nct;      // channel tile, pixel workgroup
+  int ct = blockIdx.x % nct, pw = blockIdx.x / nct;  // channel tile, pixel workgroup
+  if (p.cx) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, tpx = nct / p.cx, ppx = p.npw / p.px;
+    const int xc = xcd % p.cx, xp = xcd / p.cx, jp = j / tpx;
+    ct = xc * tpx + (j - jp * tpx);
+    pw = xp * ppx + jp;
+  }
   const int To = p.To, Ti = p.Ti;
   const int ncl = NPX / To;                          // clips per workgroup (To <= NPX, a power of two)
   const int b0 = pw * ncl;
   const int row = Ti + 2;                            // slots per clip: halo + Ti + halo
-  const int pslots = (ncl * row + 3) & ~3;           // slots per plane
+  const int pslots = cl_pslots(ncl * row);           // slots per plane
+  constexpr bool SPLIT = S == 2 && !DG2;             // (stride-2 forward: even / odd slots apart, cl_pos)
+  const int half = row >> 1;
   const int k8w = K8W ? K8W : p.k8w, nk8 = 4 * k8w;  // channel groups per wave / staged in all (zero beyond Cin)
 
   // ---- this wave's weights: the whole slice in flight (k8w * KW loads of 16 B per lane).  Where the wave stages its own planes
@@ -150,6 +167,12 @@ __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
       if (it < NITEMS) {
         const int pl = plw0 + it / NQ, pos = 4 * (it % NQ);
         const int cl = pos / Ti, ti = pos - cl * Ti;
+        // (Neighbouring lanes hold neighbouring quads of frames -- a load instruction reads 256 contiguous bytes of a channel row -- so
+        // the 8 lanes of a ds_write_b128 group store 64 bytes apart: a 4-way bank conflict on each of these 16 stores, and all of the
+        // kernel's SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.51.  Measured in round 6 and left alone: two conflict-free forms
+        // (neighbouring lanes = neighbouring planes; each lane pair starting one frame on, components rotated by selects) brought
+        // the ratio to 0.12 and the block from 19.4 to 21.1 / 22.0 us -- the LDS is busy for 5 % of the launch, and the loads' shape
+        // or 32 selects per item cost more than the conflicts.  DESIGN.md 4h.)
         float o[4][4];                                 // [frame][channel]
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -158,9 +181,9 @@ __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
           if (UP2) { u.x += va[q][j].x; u.y += va[q][j].x; u.z += va[q][j].y; u.w += va[q][j].y; }
           o[0][j] = ok ? u.x : 0.f; o[1][j] = ok ? u.y : 0.f; o[2][j] = ok ? u.z : 0.f; o[3][j] = ok ? u.w : 0.f;
         }
-        float* dst = cl_smem + ((size_t)pl * pslots + cl * row + 1 + ti) * 4;
+        float* dst = cl_smem + ((size_t)pl * pslots + cl * row) * 4;
 #pragma unroll
-        for (int f = 0; f < 4; ++f) *reinterpret_cast<float4*>(dst + 4 * f) = float4{o[f][0], o[f][1], o[f][2], o[f][3]};
+        for (int f = 0; f < 4; ++f) *reinterpret_cast<float4*>(dst + 4 * cl_pos<SPLIT>(1 + ti + f, half)) = float4{o[f][0], o[f][1], o[f][2], o[f][3]};
       }
     }
   } else {
@@ -197,7 +220,7 @@ __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
           o.y = 4 * pl + 1 < p.Cin ? v[i][1] : 0.f;
           o.z = 4 * pl + 2 < p.Cin ? v[i][2] : 0.f;
           o.w = 4 * pl + 3 < p.Cin ? v[i][3] : 0.f;
-          *reinterpret_cast<float4*>(cl_smem + ((size_t)pl * pslots + cl * row + 1 + ti) * 4) = o;
+          *reinterpret_cast<float4*>(cl_smem + ((size_t)pl * pslots + cl * row + cl_pos<SPLIT>(1 + ti, half)) * 4) = o;
         }
       }
     }
@@ -235,7 +258,7 @@ __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
       bbase[nb] = cl * row + tt;
     } else {
       const int n = 32 * nb + n0, cl = n / To, tt = n - cl * To;
-      bbase[nb] = cl * row + tt * S;
+      bbase[nb] = cl * row + (SPLIT ? tt : tt * S);
     }
   }
   {
@@ -268,7 +291,7 @@ __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
           const int i1 = (u + 1) / KW, tap1 = (u + 1) % KW;
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
-            bf[(u + 1) & 1][nb] = *reinterpret_cast<const float4*>(img + ((size_t)i1 * 2 * pslots + bbase[nb] + tap1) * 4);
+            bf[(u + 1) & 1][nb] = *reinterpret_cast<const float4*>(img + ((size_t)i1 * 2 * pslots + bbase[nb] + cl_pos<SPLIT>(tap1, half)) * 4);
         }
         __builtin_amdgcn_sched_barrier(0);           // keep the next unit's LDS reads ahead of these MFMAs
 #pragma unroll
@@ -293,7 +316,7 @@ __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
             }
             float4 bf[NB];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) bf[nb] = *reinterpret_cast<const float4*>(img + ((size_t)i * 2 * pslots + bbase[nb] + tap) * 4);
+            for (int nb = 0; nb < NB; ++nb) bf[nb] = *reinterpret_cast<const float4*>(img + ((size_t)i * 2 * pslots + bbase[nb] + cl_pos<SPLIT>(tap, half)) * 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -735,12 +758,28 @@ int clip32_launch(Clip32Args a, int KW, int S, bool up2, const char* what, hipSt
   if (a.npw % a.sg) return -2;           // (a statistics group is whole pixel workgroups; else the per-layer kernels: ms_stat_pair_ok)
   const int nct = cdiv(a.Cout, 32);
   a.nct = nct;
-  const int ncl = npx / a.To, pslots = (ncl * (a.Ti + 2) + 3) & ~3;
+  const int ncl = npx / a.To, pslots = cl_pslots(ncl * (a.Ti + 2));
   const int img = 4 * a.k8w * 2 * pslots * 16, red = (4 * 32 * (npx + 4) + 4) * 4;
   const int lds = std::max(img, red);
   if (lds > 160 * 1024) return set_error("clip32: image of %d bytes", lds);
   const int nwg = nct * a.npw;
-  // the workgroups of a channel tile meet inside the launch (BN_TRAIN): all of them resident at once
+  // Placement over the XCDs (workgroups go to XCD id % 8, each XCD has its own L2): of the cx x px grids that divide the launch, the
+  // one whose XCD fetches the fewest bytes -- its share of the weight slices plus its share of the clip images.  The linear order
+  // (ct = id % nct) gives every XCD ONE channel tile and ALL images: 3.7x the algorithmic bytes at the fabric for a 256 -> 256
+  // block of 32 clips (profiles/r05_sq_backward.json); 4 tiles x 8 clips per XCD is 1.9x.  MS_CLIP_XCD=0: linear (A/B runs).
+  static int xcd_on = -1;
+  if (xcd_on < 0) { const char* e = getenv("MS_CLIP_XCD"); xcd_on = e ? atoi(e) : 1; }
+  a.cx = a.px = 0;
+  if (xcd_on && nwg % 8 == 0) {
+    const double wct = 32.0 * a.Cin * KW, imgb = (double)a.Cin * ncl * a.Ti * (up2 ? 1.5 : 1.0);
+    double best = nct % 8 == 0 ? wct * (nct / 8) + imgb * a.npw : 1e30;      // (linear order with nct % 8 == 0 is the 8 x 1 grid)
+    for (int cx = 4; cx >= 1; cx >>= 1) {
+      const int px = 8 / cx;
+      if (nct % cx || a.npw % px) continue;
+      const double cost = wct * (nct / cx) + imgb * (a.npw / px);
+      if (cost < best) { best = cost; a.cx = cx; a.px = px; }
+    }
+  }
   int cus = 256;
   cus = current_device_cus();
   if (!cus) cus = 256;

@@ -216,6 +216,27 @@ class ConvNormRelu(nn.Module):
     return self(x, _broadcast=True)
 
 
+def _hooked(*mods):
+  """Does anything outside this package get to see these modules' inputs, outputs or gradients?  Module hooks of any kind
+  (forward, forward-pre, full / legacy backward, backward-pre) or process-wide module hooks.  A hooked block keeps its
+  BatchNorm backward in its own launch: the fused form (ops.conv_block, chain_prev) hands the producer dy_raw in place of the
+  gradient of its output, which is only right while the output feeds exactly one consumer and nobody looks at its gradient."""
+  import torch.nn.modules.module as M
+  if (M._global_forward_hooks or M._global_forward_pre_hooks or M._global_backward_hooks or
+      getattr(M, '_global_backward_pre_hooks', None) or getattr(M, '_global_forward_hooks_always_called', None)):
+    return True
+  for m in mods:
+    if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, '_backward_pre_hooks', None):
+      return True
+  return False
+
+
+def _chain_ok(stack, i):
+  """Block i of a 1-D stack may fuse block i - 1's BatchNorm backward into its data gradient: i - 1's output is a local of the
+  stack's forward() that feeds block i only, unless a hook hands it to somebody else."""
+  return i > 0 and not _hooked(stack[i - 1], stack[i])
+
+
 class UNet1D(nn.Module):
   def __init__(self, input_channels, output_channels, max_depth=5, kernel_size=None, stride=None, p=0, groups=1):
     super(UNet1D, self).__init__()
@@ -246,7 +267,7 @@ class UNet1D(nn.Module):
       x = ops16.to_cb8(x, dt)
     channels = self.conv2[-1].conv.weight.shape[0]
     for i, m in enumerate(self.pre_downsampling_conv):
-      x = m(x, _ms_chain=i > 0)
+      x = m(x, _ms_chain=_chain_ok(self.pre_downsampling_conv, i))
     residuals = [x]
     for i, down in enumerate(self.conv1):
       x = down(x)
@@ -311,7 +332,7 @@ class _TimeMajorStack(nn.Module):
       return ops16.from_cb8(mods[-1](x), mods[-1].conv.weight.shape[0])
     x = ops.to_channel_major(x)
     for i, m in enumerate(self.conv):
-      x = m(x, _ms_chain=i > 0)
+      x = m(x, _ms_chain=_chain_ok(self.conv, i))
     return x
 
 
@@ -385,7 +406,7 @@ class ClusterClassify(nn.Module):
     if dt and not ops16.is_cb8(x):
       x = ops16.to_cb8(x, dt)
     for i, m in enumerate(self.conv):
-      x = m(x, _ms_chain=i > 0)
+      x = m(x, _ms_chain=_chain_ok(self.conv, i))
     return bare_conv(self.logits, x, out_f32=True)        # scores (B, M, T) are fp32 in every mode
 
 

@@ -450,7 +450,10 @@ class _ConvBlockFn(torch.autograd.Function):
         and not bn_sync_active() and lib().ms_dgrad_fuses_prev_bn(ctypes.byref(d)):
       from . import ops16
       py = prev.saved_tensors[5]
-      if ops16.in_launch_meetings() and py is not None and py.data_ptr() == x.data_ptr() and tuple(py.shape) == tuple(x.shape):
+      # (x must be an interior value nobody watches: a tensor hook or retain_grad() on it wants the gradient of the producer's
+      # OUTPUT, which the fused launch never forms -- it hands the producer dy_raw)
+      watched = bool(getattr(x, '_backward_hooks', None)) or bool(getattr(x, 'retains_grad', False))
+      if ops16.in_launch_meetings() and not watched and py is not None and py.data_ptr() == x.data_ptr() and tuple(py.shape) == tuple(x.shape):
         ctx.prev = prev
     ctx.has_bias = bias is not None
     ctx.params = (w, bias, gamma, beta)          # parameter objects (for their gradient slots)
@@ -499,12 +502,13 @@ class _ConvBlockFn(torch.autograd.Function):
       if all(getattr(q, '_ms_grad_slot', None) is not None and (getattr(q, '_ms_grad_fresh', False) or _deferred['on']) for q in wanted):
         _, _, _, pgam_t, py_raw, py, psave = prev.saved_tensors
         if py_raw is not None and py is not None and psave is not None:
-          pdb = _grad_slot(ppbias, ppbias)[0] if (p_need_w and prev.has_bias) else None
-          pdg = _grad_slot(ppgamma, pgam_t)[0] if p_need_bn else None
-          pdbe = _grad_slot(ppbeta, pgam_t)[0] if p_need_bn else None
           from . import ops16
           sync = ops16.block_sync(dev, d, tag='dgrad_bn')     # (its own counters: the launch's member count is this block's pixel workgroups)
-          fuse = (py, py_raw, psave, pgam_t, pdg, pdbe, pdb, sync, float(prev.geom_desc.slope))
+          if sync is not None:                # (None: in-launch meetings were switched off after the forward pass -- no fusion, and no slot taken yet)
+            pdb = _grad_slot(ppbias, ppbias)[0] if (p_need_w and prev.has_bias) else None
+            pdg = _grad_slot(ppgamma, pgam_t)[0] if p_need_bn else None
+            pdbe = _grad_slot(ppbeta, pgam_t)[0] if p_need_bn else None
+            fuse = (py, py_raw, psave, pgam_t, pdg, pdbe, pdb, sync, float(prev.geom_desc.slope))
     ws = workspace(d._bwd_ws, dev)
     side = _overlap['stream']
     if side is not None and need_w and direct_w is not True:

@@ -68,6 +68,11 @@ class StyleTransferSampler:
         st[k].copy_(src, non_blocking=True)
       entry['graph'].replay()
       results.append((name, entry['y_cap'].clone(), [l.clone() for l in entry['losses']]))
+    # an in-launch meeting that gave up (the launch did not have the GPU to itself) poisons its outputs with NaN: outside a
+    # training step nobody else looks at the error word, so every interval ends with the (synchronising) check -- the caller is
+    # about to read the poses anyway
+    from . import ops16
+    ops16.check_meetings()
     return results
 
   def _capture(self, key, audio, labels, pose, style):

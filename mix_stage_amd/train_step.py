@@ -311,8 +311,8 @@ class MixStageTrainStep:
         ops16.set_in_launch_meetings(False)
     self._capture_stream = torch.cuda.Stream()      # warm-up and capture of every step kind: its scratch / counters are the graphs'
     # Health, every step and without a device synchronisation: the optimizer REFUSES a step whose gradient norm is not finite
-    # (ms_adam_step_segmented: weights and moments untouched; the kernels keep such a batch out of the running BatchNorm statistics
-    # too) and counts it in its state words; a raised meeting error word is sticky on the device (every later launch on those
+    # (ms_adam_step_segmented: weights and moments untouched; a block whose OWN batch statistics are not finite does not write them
+    # into its running buffers -- blocks in front of the fault have moved theirs by then, as in any step) and counts it in its state words; a raised meeting error word is sticky on the device (every later launch on those
     # counters yields NaN, i.e. more refused steps).  The two counters travel to pinned host memory behind every step -- the same
     # D2H path `losses` take when the caller reads them -- and are looked at when their copy has completed (at most
     # `_HEALTH_LAG` steps later): on_bad_step = 'raise' (default) raises then, with the model state intact; 'skip' warns, re-arms
@@ -326,6 +326,7 @@ class MixStageTrainStep:
     self._steps = 0
     self._graphs = {}
     self._static = None
+    self._mods = None
     self._comm = torch.cuda.Stream() if (self.world > 1 and self.overlap_allreduce) else None
     self._early_done = False            # this step's first bucket went out at the backward-pass marker
     weakref.finalize(self, ops.drop_trainer_caches, [self.optim_G.flat_p.untyped_storage().data_ptr(),
@@ -446,6 +447,19 @@ class MixStageTrainStep:
     m.G_flag = kind == 'G'
     m.fake_flag = True
 
+  def _ensure_train_mode(self):
+    """model.train() (trainer.py:1104) without its cost: nn.Module.train() walks the module tree and re-assigns `training` through
+    Module.__setattr__ on each of the ~320 modules -- 0.4 ms of the 0.53 ms a replayed step used to cost on the host
+    (tools/prof_host.py).  The flags are read instead and train() runs only when one of them is off (an evaluation in between)."""
+    mods = self._mods
+    if mods is None:
+      mods = self._mods = list(self.model.modules())
+    for mod in mods:
+      if not mod.training:
+        self.model.train()
+        self._mods = None           # (re-list next time: whoever switched modes may also have edited the tree)
+        return
+
   # ---- public ----------------------------------------------------------------------------------------------
   def step(self, audio, labels, pose, style, kind=None, inputs_unchanged=False):
     """One training step.  kind=None follows the reference's coin flip (host generator); 'G'/'D' pins it.
@@ -453,7 +467,7 @@ class MixStageTrainStep:
     inputs_unchanged=True (graph mode only): the caller promises the four inputs hold the previous step's values, the
     copies into the captured step's static buffers are skipped."""
     m = self.model
-    m.train()
+    self._ensure_train_mode()
     # (module-level switch of the ops: another trainer built in this process may have set it differently)
     ops.set_bn_sync(self.bn_sync == 'global', self.process_group)
     if kind is not None:
@@ -506,6 +520,8 @@ class MixStageTrainStep:
       count = int(self._health_pin[0]) + int(self._health_pin[1])      # (monotonic: a later step's copy only adds to it)
       if count > self._health_seen:
         self._bad_steps(count)
+      elif count < self._health_seen:
+        self._health_seen = count       # the device counters were zeroed (FlatAdam.reset_state): count from there
 
   def _bad_steps(self, count):
     new, self._health_seen = count - self._health_seen, count
@@ -516,8 +532,10 @@ class MixStageTrainStep:
       ops16.bn_sync_clear()                 # re-arm: counters and the sticky error word back to zero
     why = ('an in-launch BatchNorm / decoder-chain meeting timed out (the launch did not have the GPU to itself; sync words %s)' % (words,)
            if words is not None else 'a non-finite gradient norm')
-    msg = ('%d training step(s) were refused on the device: %s.  Weights, Adam moments and running BatchNorm statistics were left '
-           'untouched by those steps; the meeting counters are re-armed.  See MixStageTrainStep.check_health' % (new, why))
+    msg = ('%d training step(s) were refused on the device: %s.  Weights and Adam moments were left untouched by those steps, and no '
+           'non-finite batch statistic was written into a running BatchNorm buffer -- but blocks in FRONT of the fault (and the clean '
+           'half of a refused discriminator step) did move their running statistics and batch counts as in any step.  The meeting '
+           'counters are re-armed.  See MixStageTrainStep.check_health' % (new, why))
     if self.on_bad_step == 'raise':
       raise RuntimeError(msg)
     import warnings
@@ -534,6 +552,8 @@ class MixStageTrainStep:
     count = int(self.optim_G.step_state[3]) + int(self.optim_D.step_state[3])
     if count > self._health_seen:
       self._bad_steps(count)
+    elif count < self._health_seen:
+      self._health_seen = count         # (counters zeroed by FlatAdam.reset_state since the last look)
     ops16.check_meetings()                  # a meeting that expired outside a training step (e.g. an evaluation forward)
 
   def _graph_step(self, k, pose_branch, audio, labels, pose, style, inputs_unchanged=False):

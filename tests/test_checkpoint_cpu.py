@@ -81,3 +81,30 @@ def test_weight_files_cannot_execute_code(tmp_path):
   assert torch.equal(got['G.eye'], torch.eye(2)) and torch.equal(got['n'], torch.ones(3))
   with pytest.raises(FileNotFoundError):
     read_weights(str(tmp_path / 'missing.p'))
+
+
+def test_save_weights_round_trip_and_refusal(tmp_path):
+  """save_weights -> load_weights gives the state back; a state with a non-finite value is refused and leaves neither the target
+  nor a temporary file behind; savers aimed at one path do not share a temporary name."""
+  import os
+  import pytest
+  from mix_stage_amd.checkpoint import load_weights, save_weights
+  ref = O.build_gan(M=2, S=2)
+  model = _hip_gan_cpu(2, 2)
+  load_weights(model, ref.state_dict())
+  path = tmp_path / 'exp_2_weights.p'
+  assert save_weights(model, str(path)) == str(path)
+  assert sorted(os.listdir(tmp_path)) == ['exp_2_weights.p']
+  back = _hip_gan_cpu(2, 2)
+  res = load_weights(back, str(path))
+  assert not res.missing_keys and not res.unexpected_keys
+  for (k, a), (_, b) in zip(back.state_dict().items(), model.state_dict().items()):
+    assert torch.equal(a, b), k
+  # an existing file survives a refused save untouched
+  before = path.read_bytes()
+  with torch.no_grad():
+    next(model.G.parameters()).view(-1)[0] = float('nan')
+  with pytest.raises(RuntimeError, match='non-finite'):
+    save_weights(model, str(path))
+  assert path.read_bytes() == before
+  assert sorted(os.listdir(tmp_path)) == ['exp_2_weights.p']

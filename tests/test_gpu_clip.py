@@ -196,3 +196,109 @@ def test_stack_backward_fuses_the_producers_batchnorm_into_the_data_gradient(kin
       continue
     assert rel_err(gf, gref) < 1e-4, (n, rel_err(gf, gref))
     assert rel_err(gf, gu.double()) < 1e-5, (n, rel_err(gf, gu.double()))
+
+
+@pytest.mark.parametrize('how', ['forward_hook_into_loss', 'tensor_hook', 'backward_hook'])
+def test_a_watched_intermediate_output_keeps_the_unfused_backward(how):
+  """The fused form hands the producing block dy_raw in place of the gradient of its OUTPUT, which is only right while that
+  output feeds the next block alone and nobody looks at its gradient (advisor, round 5).  A forward hook that puts an interior
+  block's output into the loss (a second consumer), a tensor hook on it, or a module backward hook must each see and produce the
+  gradients of the unfused backward pass: hooked blocks are left out of the fusion (layers._hooked, ops.conv_block)."""
+  import mix_stage_amd as A
+  from mix_stage_amd import ops
+  from mix_stage_amd.train_step import FlatAdam
+  B = 8
+  gen = torch.Generator().manual_seed(5)
+  ref = O.ClusterClassify(num_clusters=8, input_channels=266).double().train()
+  hip = A.ClusterClassify(num_clusters=8, input_channels=266)
+  sd = O.deterministic_state(ref.state_dict())
+  ref.load_state_dict(sd)
+  hip.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in sd.items()})
+  hip = hip.to(DEV).train()
+  opt = FlatAdam(hip.parameters())
+  x = torch.randn(B, 266, 64, generator=gen)
+  gy = torch.randn(B, 8, 64, generator=gen)
+  taps, seen = {}, {}
+
+  def attach(model, store):
+    blk = model.conv[2]
+    if how == 'forward_hook_into_loss':
+      return [blk.register_forward_hook(lambda m, i, o: store.__setitem__('y', o))]
+    if how == 'tensor_hook':
+      return [blk.register_forward_hook(lambda m, i, o: o.register_hook(lambda g: store.__setitem__('g', g.detach().clone())) and None)]
+    return [blk.register_full_backward_hook(lambda m, gi, go: store.__setitem__('g', go[0].detach().clone()))]
+
+  def loss_of(y, store, g):
+    l = (y * g).sum()
+    if how == 'forward_hook_into_loss':
+      l = l + 0.37 * (store['y'].double() if y.dtype == torch.float64 else store['y']).pow(2).sum()
+    return l
+
+  hs = attach(ref, taps)
+  x64 = x.double().requires_grad_()
+  loss_of(ref(x64), taps, gy.double()).backward()
+  for h in hs:
+    h.remove()
+  hs = attach(hip, seen)
+  opt.zero_grad()
+  xh = x.to(DEV).requires_grad_()
+  ops.timing_enable(True)
+  try:
+    loss_of(hip(xh), seen, gy.to(DEV)).backward()
+    torch.cuda.synchronize()
+    lab = {r['label'].split('|')[-1]: r['count'] for r in ops.timing_report()}
+  finally:
+    ops.timing_enable(False)
+    for h in hs:
+      h.remove()
+  # blocks 2 (hooked) and 3 (its consumer) stay out of the fusion: block 2's and block 1's BatchNorm backward run on their own
+  n_bn = sum(c for l, c in lab.items() if 'bn_bwd' in l)
+  assert n_bn >= 3, lab
+  assert rel_err(xh.grad, x64.grad) < 1e-4, rel_err(xh.grad, x64.grad)
+  if 'g' in taps:
+    assert rel_err(seen['g'], taps['g']) < 1e-4, rel_err(seen['g'], taps['g'])
+  for (n, p), o in zip(hip.named_parameters(), opt.offsets):
+    gref = dict(ref.named_parameters())[n].grad
+    gf = opt.flat_g[o:o + p.numel()].view_as(p)
+    if 'conv.bias' in n and not n.startswith('logits'):
+      continue
+    assert rel_err(gf, gref) < 1e-4, (n, rel_err(gf, gref))
+
+
+def test_fusion_is_dropped_when_meetings_are_switched_off_after_the_forward_pass():
+  """ops16.set_in_launch_meetings(False) between forward and backward (block_sync then returns None): the backward pass falls back
+  to the blocks' own BatchNorm backward instead of failing half-way (advisor, round 5)."""
+  import mix_stage_amd as A
+  from mix_stage_amd import ops16
+  from mix_stage_amd.train_step import FlatAdam
+  gen = torch.Generator().manual_seed(6)
+  ref = O.ClusterClassify(num_clusters=8, input_channels=266).double().train()
+  hip = A.ClusterClassify(num_clusters=8, input_channels=266)
+  sd = O.deterministic_state(ref.state_dict())
+  ref.load_state_dict(sd)
+  hip.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in sd.items()})
+  hip = hip.to(DEV).train()
+  opt = FlatAdam(hip.parameters())
+  x = torch.randn(8, 266, 64, generator=gen)
+  gy = torch.randn(8, 8, 64, generator=gen)
+  x64 = x.double().requires_grad_()
+  ref(x64).backward(gy.double())
+  def run(switch_off):
+    opt.zero_grad()
+    xh = x.to(DEV).requires_grad_()
+    y = hip(xh)
+    old = ops16.in_launch_meetings()
+    if switch_off:
+      ops16.set_in_launch_meetings(False)
+    try:
+      y.backward(gy.to(DEV))
+      torch.cuda.synchronize()
+    finally:
+      ops16.set_in_launch_meetings(old)
+    return xh.grad.clone(), opt.flat_g.clone()
+
+  dx_f, g_f = run(False)
+  dx_o, g_o = run(True)
+  assert rel_err(dx_f, x64.grad) < 1e-3 and rel_err(dx_o, x64.grad) < 1e-3
+  assert rel_err(dx_o, dx_f) < 1e-4, rel_err(dx_o, dx_f)
+  assert rel_err(g_o, g_f) < 1e-4, rel_err(g_o, g_f)
