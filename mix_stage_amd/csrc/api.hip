@@ -770,7 +770,7 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
       a.H = d->H; a.W = d->W; a.OH = d->OH; a.OW = d->OW; a.Npix = npix;
       a.KH = d->KH; a.KW = d->KW; a.SH = d->SH; a.SW = d->SW; a.PH = d->PH; a.PW = d->PW;
       a.bcast = bcast;
-      rc = launch_wgrad(a, up2, dw, wg_part, defer_wgrad, ws_stream);
+      rc = launch_wgrad(a, up2, dw, wg_part, defer_wgrad, ws_stream, opt->defer_wgrad_launch && ws_stream == s);
     }
   }
   return rc;

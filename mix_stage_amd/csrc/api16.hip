@@ -362,10 +362,11 @@ extern "C" {
 
 int ms_wgrad_flush(void* stream) {
   const int rc = wgrad_patch_flush((hipStream_t)stream);
+  const int rcg = wgrad_gather_flush((hipStream_t)stream);
   const int rc16 = wgrad16_flush((hipStream_t)stream);
-  return rc ? rc : rc16;
+  return rc ? rc : rcg ? rcg : rc16;
 }
-int ms_wgrad_discard(void) { wgrad_patch_discard(); wgrad16_discard(); return 0; }
+int ms_wgrad_discard(void) { wgrad_patch_discard(); wgrad_gather_discard(); wgrad16_discard(); return 0; }
 
 int ms_set_bn_sync_buffer(int32_t* zeroed_words, int n) {
   g_bn_sync = zeroed_words;

@@ -10,6 +10,8 @@
 // Replaces what ATen's convolution / convolution_backward compute for the reference's
 // ConvNormRelu / nn.Conv1d calls (layers.py:58-78, JL:83, S2G:50-63).
 #include <algorithm>
+#include <mutex>
+#include <vector>
 
 #include "kernels.h"
 
@@ -311,8 +313,9 @@ __global__ __launch_bounds__(256) void igemm_gather_kernel(const GatherArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// (bx, by, bz): the workgroup's place in the job's grid (Kg tiles, Cog tiles, groups x splits)
 template <int TM, int TN, int KH_, int KW_, bool UP2>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int bx_, const int by_, const int bz_) {
   constexpr int BM = 64 * TM, BN = 64 * TN, BR = 32;
   constexpr int LDA = BM + 1, LDB = BN + 1;
   constexpr int STAGE = BR * LDA + BR * LDB;
@@ -321,8 +324,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wm = wid >> 1, wn = wid & 1;
-  const int g = blockIdx.z / p.splits, sp = blockIdx.z - g * p.splits;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int g = bz_ / p.splits, sp = bz_ - g * p.splits;
+  const int m0 = by_ * BM, n0 = bx_ * BN;
   const int KH = KH_ ? KH_ : p.KH, KW = KW_ ? KW_ : p.KW, KHW = KH * KW;
   const int rl = t & 31, row0 = t >> 5;
   const int ohw = p.OH * p.OW;
@@ -422,9 +425,32 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int nc = n0 + wn * TN * 32 + j * 32 + (lane & 31);
-        if (m < p.Cog && nc < p.Kg) outp[(size_t)(g * p.Cog + m) * p.Kg + nc] = acc[i][j][r];
+        if (m < p.Cog && nc < p.Kg) {
+          float* o = outp + (size_t)(g * p.Cog + m) * p.Kg + nc;
+          *o = p.accumulate ? *o + acc[i][j][r] : acc[i][j][r];
+        }
       }
     }
+}
+
+template <int TM, int TN, int KH_, int KW_, bool UP2>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
+  wgrad_body<TM, TN, KH_, KW_, UP2>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Queued form (ms_bwd_options.defer_wgrad_launch / ms_wgrad_flush): the layers this kernel serves are the ones too short for the
+// patch kernels (1-D layers of fewer than 16 output frames: the deep UNet levels, the tails of the style encoder and of the
+// discriminator) -- 11 launches of 6-12 us each in the middle of the headline G-step's backward chain, which nothing downstream
+// reads.  They wait in a queue and run side by side in one launch per kernel shape at the end of the backward pass.
+template <int KH_, int KW_, bool UP2>
+__global__ __launch_bounds__(256) void wgrad_multi_kernel(const WgradBatch b) {
+  int j = 0;
+  while (j + 1 < b.n && (int)blockIdx.x >= b.block_end[j]) ++j;
+  const WgradArgs& p = b.job[j];
+  const int id = (int)blockIdx.x - (j ? b.block_end[j - 1] : 0);
+  const int gx = (p.Kg + 63) / 64, gy = (p.Cog + 63) / 64;
+  const int bz = id / (gx * gy), r = id - bz * gx * gy;
+  wgrad_body<1, 1, KH_, KW_, UP2>(p, r % gx, r / gx, bz);
 }
 
 // sum over the split slabs in ascending order (bitwise the same as the plain loop), 8 loads in flight at a time
@@ -928,18 +954,96 @@ int launch_reduce_splits_multi(ReduceBatch& rb, hipStream_t s) {
   return check_launch("reduce_splits_multi_kernel");
 }
 
-int launch_wgrad(WgradArgs a, bool up2, float* dw, float* partial_ws, bool defer_reduce, hipStream_t s) {
+struct PendingWgrad { WgradArgs a; int up2, nwg; double flops, bytes; };
+static std::vector<PendingWgrad> g_pending_wg;       // process-wide, like the patch kernels' queue (wgrad_patch.hip)
+static std::mutex g_pending_wg_mu;
+
+void wgrad_gather_discard() {
+  std::lock_guard<std::mutex> lk(g_pending_wg_mu);
+  g_pending_wg.clear();
+}
+
+template <int KH, int KW, bool UP2>
+static void launch_wgrad_multi(const WgradBatch& b, hipStream_t s) {
+  hipLaunchKernelGGL((wgrad_multi_kernel<KH, KW, UP2>), dim3(b.block_end[b.n - 1]), dim3(256), 0, s, b);
+}
+
+int wgrad_gather_flush(hipStream_t s) {
+  std::vector<PendingWgrad> q;
+  {
+    std::lock_guard<std::mutex> lk(g_pending_wg_mu);
+    q.swap(g_pending_wg);
+  }
+  // one launch per kernel shape: (1 x 4), (1 x 3), (1 x 3 on an upsample-add input), everything else through the run-time shape
+  auto shape_of = [](const PendingWgrad& w) {
+    if (w.a.KH == 1 && w.a.KW == 4 && !w.up2) return 0;
+    if (w.a.KH == 1 && w.a.KW == 3) return w.up2 ? 2 : 1;
+    return w.up2 ? 4 : 3;
+  };
+  for (int shape = 0; shape < 5; ++shape) {
+    WgradBatch b;
+    b.n = 0;
+    long blocks = 0;
+    double flops = 0, bytes = 0;
+    auto launch = [&]() -> int {
+      if (!b.n) return 0;
+      TimingScope ts(s, flops, bytes, "wgrad_multi_kernel<%d>|conv_wgrad_gather multi shape%d jobs%d wgs%ld", shape, shape, b.n, blocks);
+      int rc = 0;
+      if (!ts.skip()) {
+        switch (shape) {
+          case 0: launch_wgrad_multi<1, 4, false>(b, s); break;
+          case 1: launch_wgrad_multi<1, 3, false>(b, s); break;
+          case 2: launch_wgrad_multi<1, 3, true>(b, s); break;
+          case 3: launch_wgrad_multi<0, 0, false>(b, s); break;
+          default: launch_wgrad_multi<0, 0, true>(b, s); break;
+        }
+        rc = check_launch("wgrad_multi_kernel");
+      }
+      b.n = 0; blocks = 0; flops = bytes = 0;
+      return rc;
+    };
+    for (const PendingWgrad& w : q) {
+      if (shape_of(w) != shape) continue;
+      if (b.n == WG_MAX_JOBS) { const int rc = launch(); if (rc) return rc; }
+      blocks += w.nwg;
+      b.block_end[b.n] = (int)blocks;
+      b.job[b.n] = w.a;
+      ++b.n;
+      flops += w.flops; bytes += w.bytes;
+    }
+    const int rc = launch();
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+// queue = true: nothing of this call reads the result (dw written in place -- ADDED to, the slot may already hold the parameter's
+// other uses of the step -- or slabs left for the caller's reduction): the launch waits for wgrad_gather_flush
+int launch_wgrad(WgradArgs a, bool up2, float* dw, float* partial_ws, bool defer_reduce, hipStream_t s, bool queue) {
   const int ctot = a.groups * a.Cog;
   a.splits = wgrad_splits(a.Cog, a.Kg, a.groups, a.Npix);
   a.r_per_split = cdiv(cdiv(a.Npix, a.splits), 32) * 32;
   a.out = a.splits > 1 ? partial_ws : dw;
+  a.accumulate = 0;
   dim3 grid(cdiv(a.Kg, 64), cdiv(a.Cog, 64), a.groups * a.splits);
   if (grid.y > 65535 || grid.z > 65535) return set_error("wgrad grid too large");
+  const double batch = (double)a.Npix / ((double)a.OH * a.OW);
+  const double flops = 2.0 * a.Cog * a.Kg * (double)a.Npix * a.groups;
+  const double bytes = 4.0 * ((double)a.Npix * ctot + batch * a.src_ctotal * a.H * a.W + (double)ctot * a.Kg);
+  if (queue && (a.splits == 1 || defer_reduce)) {
+    PendingWgrad w;
+    w.a = a;
+    w.a.accumulate = a.splits == 1 ? 1 : 0;
+    w.up2 = up2 ? 1 : 0;
+    w.nwg = (int)(grid.x * grid.y * grid.z);
+    w.flops = flops; w.bytes = bytes;
+    std::lock_guard<std::mutex> lk(g_pending_wg_mu);
+    g_pending_wg.push_back(w);
+    return 0;
+  }
   int rc;
   {
-    const double batch = (double)a.Npix / ((double)a.OH * a.OW);
-    TimingScope ts(s, 2.0 * a.Cog * a.Kg * (double)a.Npix * a.groups,
-                   4.0 * ((double)a.Npix * ctot + batch * a.src_ctotal * a.H * a.W + (double)ctot * a.Kg),
+    TimingScope ts(s, flops, bytes,
                    "wgrad_kernel<1,1,%d,%d,%d>|conv_wgrad k%dx%d s%d Cog%d Kg%d g%d N%d splits%d", a.KH, a.KW, up2 ? 1 : 0, a.KH,
                    a.KW, a.SW, a.Cog, a.Kg, a.groups, a.Npix,
                    a.splits);

@@ -81,10 +81,16 @@ void conv_patch_kernel(const PatchArgs p) {
   // logical block id: channel tile fastest, then pixel tile, then (group, K slice); one contiguous range per XCD, so the
   // channel tiles that share an input patch sit behind the same L2
   const int vid = xcd_remap(blockIdx.x, p.gx * p.gy * p.gz);
-  const int by_ = vid % p.gy, bx_ = (vid / p.gy) % p.gx, bz_ = vid / (p.gy * p.gx);
+  // (strided data gradient with cls_fast: the output-parity class is the FASTEST index -- the 2 x 2 / 1 x 2 classes of a pixel tile
+  // read the same dy window and write interleaved pixels of the same dx lines; next to each other in one XCD's id range they
+  // share both in its L2.  Class-slowest gave every class to its own pair of XCDs: dy fetched once per class, 2.4x the
+  // algorithmic bytes at the fabric, L2 hit 0.54 -- profiles/r05_sq_backward.json)
+  const int cls_f = (p.ncls > 1 && p.cls_fast) ? vid % p.ncls : 0;
+  const int vid2 = (p.ncls > 1 && p.cls_fast) ? vid / p.ncls : vid;
+  const int by_ = vid2 % p.gy, bx_ = (vid2 / p.gy) % p.gx, bz_ = vid2 / (p.gy * p.gx);
   // (strided data gradient: the output-parity class comes first in z)
   const int zz = p.groups * p.splitk;
-  const int cls = p.ncls > 1 ? bz_ / zz : 0, bzc = bz_ - cls * zz;
+  const int cls = (p.ncls > 1 && !p.cls_fast) ? bz_ / zz : cls_f, bzc = (p.ncls > 1 && !p.cls_fast) ? bz_ - cls * zz : bz_;
   const int g = bzc / p.splitk, ks = bzc - g * p.splitk, m0 = by_ * BM;
   const int PHc = p.ncls > 1 ? p.cls_PH[cls] : p.PH, PWc = p.ncls > 1 ? p.cls_PW[cls] : p.PW;
   const int OUTHc = p.ncls > 1 ? p.cls_OUTH[cls] : p.OUTH, OUTWc = p.ncls > 1 ? p.cls_OUTW[cls] : p.OUTW;
@@ -545,6 +551,7 @@ int launch_patch(const PatchArgs& a, const PatchPlan& pl, int KH, int KW, int S,
   PatchArgs b = a;
   if (a.ncls > 4) return set_error("patch conv: more than 4 parity classes");
   b.gx = pl.n_tiles; b.gy = cdiv(a.Mg, bm); b.gz = a.groups * a.splitk * std::max(1, a.ncls);
+  { static int cf = -1; if (cf < 0) { const char* e = getenv("MS_CLS_FAST"); cf = e ? atoi(e) : 1; } b.cls_fast = cf; }   // (MS_CLS_FAST=0: class-slowest order, A/B runs)
   if ((double)b.gx * b.gy * b.gz > 2.0e9) return set_error("conv grid too large");
   dim3 grid(b.gx * b.gy * b.gz);
   if (a.splitk < 1 || (a.splitk > 1 && !a.part)) return set_error("patch conv: bad split-K setup");

@@ -36,6 +36,13 @@ struct WgradArgs {
   int Cog, Cig, Kg, groups, src_ctotal, H, W, OH, OW, Npix;
   int KH, KW, SH, SW, PH, PW;
   int bcast, splits, r_per_split;
+  int accumulate;     // splits == 1: add to `out` instead of overwriting it (queued launches: wgrad_gather_flush)
+};
+constexpr int WG_MAX_JOBS = 24;     // (24 x 120 B of kernel arguments)
+struct WgradBatch {
+  int n;
+  int block_end[WG_MAX_JOBS];
+  WgradArgs job[WG_MAX_JOBS];
 };
 
 // RAII pair of HIP events around a launch (no-op unless ms_timing_enable(1)); timing.hip
@@ -78,6 +85,7 @@ struct PatchArgs {
   // per class: padding, output extent, scatter phase; weights of class c start at A + c*cls_a_stride
   int ncls, cls_PH[4], cls_PW[4], cls_OUTH[4], cls_OUTW[4], cls_ry[4], cls_rx[4];
   unsigned cls_a_stride;
+  int cls_fast;       // the parity class is the fastest index of the logical workgroup id (conv_tile / conv_patch: shared dy window in L2)
   // bf16x6 kernels (conv_patch6.hip): pre-split weight planes [3][rows][a_row_elems] bf16; cls_a_stride counts ROWS there
   const unsigned short* Aplanes;
   unsigned plane_stride;       // elements per plane
@@ -218,7 +226,9 @@ int launch_splitk_fwd_epilogue(const float* part, int splitk, size_t part_stride
 int launch_splitk_dgrad_epilogue(const float* part, int splitk, size_t part_stride, float* dx, float* dx2, size_t n, int W,
                                  int up2, hipStream_t s);
 int wgrad_splits(int Cog, int Kg, int groups, int Npix);
-int launch_wgrad(WgradArgs a, bool up2, float* dw, float* partial_ws, bool defer_reduce, hipStream_t s);
+int launch_wgrad(WgradArgs a, bool up2, float* dw, float* partial_ws, bool defer_reduce, hipStream_t s, bool queue = false);
+int wgrad_gather_flush(hipStream_t s);
+void wgrad_gather_discard();
 struct ReduceJob {
   const float* part;   // [splits][n]
   float* out;          // [n], accumulated into

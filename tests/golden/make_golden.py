@@ -19,11 +19,16 @@ from oracle import mixstage_oracle as O   # noqa: E402
 from oracle import refload                # noqa: E402
 
 CONFIGS = {
-    # name: (B, T, M, S, dtype)
-    'c1_fp32': (4, 64, 1, 2, torch.float32),     # BASELINE configs[0] (S=2: S=1 crashes, SURVEY s.0 item 4)
-    'c1_fp64': (4, 64, 1, 2, torch.float64),
-    'c2r_fp32': (4, 64, 4, 4, torch.float32),    # BASELINE configs[1] at reduced batch
-    'c3r_fp32': (2, 64, 8, 8, torch.float32),    # headline M=S=8 at reduced batch
+    # name: (B, T, M, S, dtype, data seed)
+    'c1_fp32': (4, 64, 1, 2, torch.float32, 1234),     # BASELINE configs[0] (S=2: S=1 crashes, SURVEY s.0 item 4)
+    'c1_fp64': (4, 64, 1, 2, torch.float64, 1234),
+    # The data seeds of the two multi-speaker fixtures are SCREENED (tests/golden/screen_seed.py, seeds 2000-2159): the
+    # discriminator's gradients are not a smooth function of its input where a pre-activation sits on a LeakyReLU kink, and with
+    # seed 1234 the smallest |pre-activation| in D was 6.7e-6 (D-step) / 2.3e-6 (G-step) -- inside what two fp32 summation orders
+    # differ by.  The chosen seeds have the largest margin of the 160 screened (recorded below as `d_margin`); 1e-4 was not reached by
+    # any (D holds ~6e4 pre-activations per step with density ~1 around zero: the expected minimum is ~1e-5).
+    'c2r_fp32': (4, 64, 4, 4, torch.float32, 2089),    # BASELINE configs[1] at reduced batch; margins 2.4e-5 (D-step), 7.3e-5 (G-step)
+    'c3r_fp32': (2, 64, 8, 8, torch.float32, 2065),    # headline M=S=8 at reduced batch; margins 4.4e-5, 7.7e-5
 }
 BN_PROBES = ['G.decoder.0.norm', 'G.audio_encoder.conv.7.norm', 'D.conv3.norm']
 
@@ -50,10 +55,10 @@ def param_probe(model, which):
   return out
 
 
-def run(name, B, T, M, S, dtype):
-  audio, pose, labels, style = O.synthetic_batch(B, T=T, M=M, S=S, dtype=dtype)
+def run(name, B, T, M, S, dtype, seed=1234):
+  audio, pose, labels, style = O.synthetic_batch(B, T=T, M=M, S=S, dtype=dtype, seed=seed)
   rec = dict(audio=audio.numpy(), pose=pose.numpy(), labels=labels.numpy(), style=style.numpy(),
-             meta=np.array([B, T, M, S], dtype=np.int64))
+             meta=np.array([B, T, M, S], dtype=np.int64), data_seed=np.int64(seed))
   for kind in ('G', 'D'):
     ref = refload.build_ref_gan(M=M, S=S, T=T, dtype=None)
     ref.load_state_dict(O.deterministic_state(ref.state_dict()))
@@ -67,6 +72,9 @@ def run(name, B, T, M, S, dtype):
     def d_hook(m, i, o):
       dcalls.append(o[0].detach().clone())
 
+    dmin = []
+    hk = [m.register_forward_pre_hook(lambda mod, inp: dmin.append(float(inp[0].detach().abs().min())))
+          for m in ref.D.modules() if isinstance(m, torch.nn.LeakyReLU)]
     h1 = ref.G.pose_style_encoder.register_forward_hook(pse_hook)
     h2 = ref.D.register_forward_hook(d_hook)
     og = torch.optim.Adam(ref.G.parameters(), lr=1e-4)
@@ -75,7 +83,10 @@ def run(name, B, T, M, S, dtype):
     # forward/backward/clip/Adam through the trainer-step contract (model-agnostic driver)
     fake, losses, gnorm = O.oracle_train_step(ref, og, od, audio, pose, labels, style, kind, T=T)
     h1.remove(); h2.remove()
+    for h in hk:
+      h.remove()
     k = kind + '/'
+    rec[k + 'd_margin'] = np.float64(min(dmin))      # smallest |input| of any LeakyReLU of the discriminator in this step
     rec[k + 'pose'] = fake.numpy()
     rec[k + 'losses'] = np.array(losses, dtype=np.float64)
     rec[k + 'total_grad_norm'] = np.float64(gnorm)
@@ -190,7 +201,10 @@ if __name__ == '__main__':
   if len(sys.argv) > 1 and sys.argv[1] == 'evalacc':
     run_evalacc()
     sys.exit(0)
+  only = sys.argv[1:]
   for name, cfg in CONFIGS.items():
-    run(name, *cfg)
-  run_n1n3()
-  run_evalacc()
+    if not only or name in only:
+      run(name, *cfg)
+  if not only:
+    run_n1n3()
+    run_evalacc()

@@ -271,7 +271,7 @@ def test_fusion_is_dropped_when_meetings_are_switched_off_after_the_forward_pass
   import mix_stage_amd as A
   from mix_stage_amd import ops16
   from mix_stage_amd.train_step import FlatAdam
-  gen = torch.Generator().manual_seed(6)
+  gen = torch.Generator().manual_seed(3)       # (the draw of the stack test above: no activation within fp32 rounding of a LeakyReLU kink)
   ref = O.ClusterClassify(num_clusters=8, input_channels=266).double().train()
   hip = A.ClusterClassify(num_clusters=8, input_channels=266)
   sd = O.deterministic_state(ref.state_dict())

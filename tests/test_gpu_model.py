@@ -171,9 +171,10 @@ def test_golden_gradients_from_reference(golden_dir, name):
   from mix_stage_amd import ops, _lib
   for kind, forms in (('G', 'default'), ('D', 'default'), ('D', 'block by block')):
     # 'block by block': the decoder blocks one by one and the per-layer conv kernels instead of the chained launch and the
-    # clip-resident blocks -- the generator's summation order closest to plain per-layer arithmetic.  D's gradient at these golden
-    # inputs is NOT a smooth function of the fake pose (an activation sits on its LeakyReLU kink: a 1e-7 perturbation of the pose
-    # moves D's gradients by 0.5-2 % in L2), so the default forms are held to a looser bar there and this pass to the strict one.
+    # clip-resident blocks -- the generator's summation order closest to plain per-layer arithmetic.  Both forms are held to the
+    # same 5 % bar: the fixtures' data seeds are screened so that no pre-activation of D sits within 2e-5 of its LeakyReLU kink
+    # (tests/golden/screen_seed.py; with the unscreened seed of rounds 1-5 one sat at 6.7e-6, a 1e-7 perturbation of the fake pose
+    # moved D's gradients by 0.5-2 % in L2, and the default forms needed a 20 % bar).
     old_chain, old_clip = ops.USE_DECODER_CHAIN, None
     if forms != 'default':
       ops.USE_DECODER_CHAIN = False
@@ -206,15 +207,14 @@ def test_golden_gradients_from_reference(golden_dir, name):
       scale = gn / np.sqrt(g.numel()) + 1e-12            # rms of the gradient: the per-element yardstick
       assert abs(float(g.norm()) * coef - gn) <= 2e-3 * gn + 1e-9, (n, float(g.norm()) * coef, gn)
       worst = max(worst, float(np.abs(mine - gs).max() / scale))
-    # sampled elements within 5 % of the gradient's rms; the D-step through the chained / clip-resident generator forms: 20 % (see
-    # above; `test_d_step_gradients_do_not_depend_on_the_generator_forms_beyond_the_kink` bounds the forms against each other)
-    assert worst <= (2e-1 if (kind == 'D' and forms == 'default') else 5e-2), (kind, forms, worst)
+    # sampled elements within 5 % of the gradient's rms, production forms included
+    assert worst <= 5e-2, (kind, forms, worst)
 
 
 def test_d_step_gradients_do_not_depend_on_the_generator_forms_beyond_the_kink(golden_dir):
   """The D-step's discriminator gradients with the generator's default forms (chained decoder, clip-resident blocks) against the
   block-by-block forms, with the SAME fake pose fed to D in both: identical arithmetic in D then, so the gradients must agree to
-  fp32 rounding -- the 20 % bar of the golden D-step test is about the kink in D's input, not about D's own kernels."""
+  fp32 rounding (D's own kernels do not care which generator form produced their input)."""
   from mix_stage_amd import ops, _lib
   z = np.load(os.path.join(golden_dir, 'c2r_fp32.npz'))
   B, T, M, S = [int(v) for v in z['meta']]

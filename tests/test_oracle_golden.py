@@ -24,7 +24,8 @@ def test_train_step_matches_reference_vectors(golden_dir, name, dtype, tol, kind
   audio, pose = torch.from_numpy(z['audio']), torch.from_numpy(z['pose'])
   labels, style = torch.from_numpy(z['labels']), torch.from_numpy(z['style'])
   # the synthetic generator is part of the fixture contract
-  a2, p2, l2, s2 = O.synthetic_batch(B, T=T, M=M, S=S, dtype=dtype)
+  seed = int(z['data_seed']) if 'data_seed' in z.files else 1234       # (screened per fixture: tests/golden/make_golden.py)
+  a2, p2, l2, s2 = O.synthetic_batch(B, T=T, M=M, S=S, dtype=dtype, seed=seed)
   assert torch.equal(a2, audio) and torch.equal(p2, pose) and torch.equal(l2, labels) and torch.equal(s2, style)
 
   model = O.build_gan(M=M, S=S, T=T, dtype=dtype)
@@ -56,7 +57,8 @@ def test_train_step_matches_reference_vectors(golden_dir, name, dtype, tol, kind
 def test_eval_and_sample_forward(golden_dir, name, dtype, tol):
   z = _load(golden_dir, name)
   B, T, M, S = [int(v) for v in z['meta']]
-  audio, pose, labels, style = O.synthetic_batch(B, T=T, M=M, S=S, dtype=dtype)
+  seed = int(z['data_seed']) if 'data_seed' in z.files else 1234
+  audio, pose, labels, style = O.synthetic_batch(B, T=T, M=M, S=S, dtype=dtype, seed=seed)
   model = O.build_gan(M=M, S=S, T=T, dtype=dtype).eval()
   with torch.no_grad():
     fake, losses, _ = model([audio, labels], pose, **O.model_kwargs(style, T))
