@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 /* 3: ms_bwd_options grew (prev_*, bn_sync, dy_is_dyr), MS_DT_STAT_PAIR (save holds two vectors), ms_lp_mean_pair_*, Adam state words 2 / 3 */
-#define MS_ABI_VERSION 3
+#define MS_ABI_VERSION 4
 
 /* epilogue of a conv block */
 enum ms_block_mode {
@@ -181,7 +181,15 @@ typedef struct ms_bwd_options {
   int32_t bn_sync_words;
   int dy_is_dyr;                /* this block's `dy` already is the gradient w.r.t. its conv output (a consumer's fused launch made it):
                                  * no BatchNorm / activation backward here, dgamma / dbeta / dbias are not written, dyr is not used */
+  const float* dx_accum;        /* (ABI 4) same shape as dx: ADDED to the data gradient inside its launch -- the gradient that another
+                                 * consumer of this block's input has already produced (the UNet's residual uses every down-path
+                                 * output twice, layers.py:139-151: as the next block's input and as the up path's residual), so
+                                 * that dx leaves as the complete gradient of x and no separate accumulation launch runs.  Only for
+                                 * blocks ms_dgrad_takes_accum() accepts; composes with prev_*: the sum is what the producer's
+                                 * BatchNorm backward sees. */
 } ms_bwd_options;
+/* 1 when block d's data-gradient launch can add ms_bwd_options.dx_accum itself (fp32 clip-resident 1-D blocks, plain input). */
+int ms_dgrad_takes_accum(const ms_conv_desc* d);
 /* 1 when block d's data-gradient launch can carry the BatchNorm backward of the producer of its input (see ms_bwd_options.prev_*). */
 int ms_dgrad_fuses_prev_bn(const ms_conv_desc* d);
 int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2, const float* w,

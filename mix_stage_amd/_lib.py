@@ -23,7 +23,8 @@ class BwdOptions(ctypes.Structure):
               ('wt_prepared', ctypes.c_void_p), ('wgrad_partials', ctypes.c_void_p), ('defer_wgrad_launch', ctypes.c_int),
               ('prev_y', ctypes.c_void_p), ('prev_y_raw', ctypes.c_void_p), ('prev_save', ctypes.c_void_p), ('prev_gamma', ctypes.c_void_p),
               ('prev_dgamma', ctypes.c_void_p), ('prev_dbeta', ctypes.c_void_p), ('prev_dbias', ctypes.c_void_p), ('prev_slope', ctypes.c_float),
-              ('bn_sync', ctypes.c_void_p), ('bn_sync_words', ctypes.c_int32), ('dy_is_dyr', ctypes.c_int)]
+              ('bn_sync', ctypes.c_void_p), ('bn_sync_words', ctypes.c_int32), ('dy_is_dyr', ctypes.c_int),
+              ('dx_accum', ctypes.c_void_p)]
 
 
 class LossScale(ctypes.Structure):
@@ -163,6 +164,7 @@ SIGNATURES = {
     'ms_debug_set_conv_tile': (c_int, [c_int]),
     'ms_set_wgrad_batched': (c_int, [c_int, c_int]),
     'ms_dgrad_fuses_prev_bn': (c_int, [_P]),
+    'ms_dgrad_takes_accum': (c_int, [_P]),
     'ms_stat_pair_ok': (c_int, [_P]),
     'ms_selftest_mfma': (c_int, [_P, _P, _P, c_int, _P]),
     'ms_probe_peak': (c_int, [c_int, ctypes.c_long, _P, _P, ctypes.POINTER(ctypes.c_double), _P]),

@@ -466,6 +466,11 @@ int ms_dgrad_fuses_prev_bn(const ms_conv_desc* d) {
   return (dt_of(d) == DT_F32 && g_precision == 0 && clip32_dgrad_bn_ok(d)) ? 1 : 0;
 }
 
+int ms_dgrad_takes_accum(const ms_conv_desc* d) {
+  if (!d || validate(d, "ms_dgrad_takes_accum")) return 0;
+  return (dt_of(d) == DT_F32 && g_precision == 0 && d->in_mode == MS_IN_PLAIN && clip32_dgrad_ok(d)) ? 1 : 0;
+}
+
 int ms_conv_block_bwd(const ms_conv_desc* d, const float* x, const float* x2, const float* w, const float* gamma,
                       const float* running_mean, const float* running_var, const float* y_raw, const float* y,
                       const float* save, const float* dy, float* dyr, float* dx, float* dx2, float* dw, float* dbias,
@@ -513,6 +518,7 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
   if ((opt->dy_is_dyr || opt->prev_y) && (dt_of(d) != DT_F32 || side_stream)) return set_error("ms_conv_block_bwd: the fused producer-BatchNorm backward is an fp32, single-stream form");
   if (d->mode == MS_LRELU && (!y || !dyr)) return set_error("ms_conv_block_bwd: LRELU needs y/dyr");
   if (dw && !x) return set_error("ms_conv_block_bwd: dw needs x");
+  if (opt->dx_accum && !(dx && ms_dgrad_takes_accum(d))) return set_error("ms_conv_block_bwd: dx_accum on a block ms_dgrad_takes_accum() declines");
   if (d->in_mode == MS_IN_UP2ADD && ((dw && !x2) || (dx && !dx2))) return set_error("ms_conv_block_bwd: UP2ADD needs x2/dx2");
   if (dt_of(d) != DT_F32) {
     if (side_stream) return set_error("ms_conv_block_bwd: no side-stream form in the 16-bit modes");
@@ -595,10 +601,10 @@ int ms_conv_block_bwd_ex(const ms_conv_desc* d, const float* x, const float* x2,
     }
     if (have_prev) {
       const Clip32PrevBN pv = {opt->prev_y, opt->prev_y_raw, opt->prev_save, opt->prev_gamma, opt->prev_dgamma, opt->prev_dbeta, opt->prev_dbias, opt->prev_slope};
-      rc = clip32_block_dgrad(d, g, wp, dx, dx2, s, &pv, fuse_part, opt->bn_sync, opt->bn_sync_words);
+      rc = clip32_block_dgrad(d, g, wp, dx, dx2, s, &pv, fuse_part, opt->bn_sync, opt->bn_sync_words, opt->dx_accum);
       if (rc == -2) return set_error("ms_conv_block_bwd: the fused data gradient is not resident at once on this device");
     } else {
-      rc = clip32_block_dgrad(d, g, wp, dx, dx2, s);
+      rc = clip32_block_dgrad(d, g, wp, dx, dx2, s, nullptr, nullptr, nullptr, 0, opt->dx_accum);
     }
     if (rc && rc != -2) return rc;
     dx_done = rc == 0;

@@ -50,6 +50,7 @@ struct Clip32Args {
   float* pv_dgamma; float* pv_dbeta; float* pv_dbias;
   int sg;                // BN_TRAIN: statistics groups along the batch (MS_DT_STAT_PAIR: 2), each npw / sg consecutive pixel workgroups
   int raw_all;           // BN_TRAIN: y_raw for every channel (0: only for channels whose backward cannot take x_hat from y: conv16.h bn_inv_unsafe)
+  const float* acc;      // data gradient: (B, Cout, To) added to the result (ms_bwd_options.dx_accum: the input's other consumer's gradient)
   int cx, px;            // placement over the 8 XCDs (workgroup id % 8 = XCD): XCD (xc, xp) of a cx x px grid owns nct / cx channel tiles
                          // x npw / px pixel workgroups, so that what its L2 fetches (weight slices + clip images) is smallest; cx = 0: linear
   unsigned long long* stamps;   // diagnostics (MS_CLIP_DBG=32): [workgroup][8] s_memrealtime stamps (100 MHz)
@@ -233,6 +234,31 @@ __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
   const float bias_c = p.bias ? p.bias[cgc] : 0.f;
   float gam = 1.f, bet = 0.f, rmo = 0.f, rvo = 1.f;
   if (p.ep == EP_RAW_STATS || p.ep == EP_BN_EVAL) { gam = p.gamma[cgc]; bet = p.beta[cgc]; rmo = p.rm[cgc]; rvo = p.rv[cgc]; }
+  // (data gradient) what is added to this thread's frames, requested ahead of the K loop
+  constexpr int FPT_ = NPX / 8;
+  float av[UP2 ? 1 : FPT_];
+  if constexpr (!UP2) {
+#pragma unroll
+    for (int k = 0; k < FPT_; ++k) av[k] = 0.f;
+    if (p.acc && rowok) {
+      const int f0a = FPT_ * pq;
+      if (To >= FPT_) {
+        const int cl = f0a / To, tt = f0a - cl * To;
+        const float* sp = p.acc + ((size_t)(b0 + cl) * p.Cout + cgl) * To + tt;
+#pragma unroll
+        for (int k = 0; k < FPT_; k += 4) {
+          const float4 u = *reinterpret_cast<const float4*>(sp + k);
+          av[k] = u.x; av[k + 1] = u.y; av[k + 2] = u.z; av[k + 3] = u.w;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < FPT_; ++k) {
+          const int f = f0a + k, cl = f / To, tt = f - cl * To;
+          av[k] = p.acc[((size_t)(b0 + cl) * p.Cout + cgl) * To + tt];
+        }
+      }
+    }
+  }
   CL_STAMP(1);
   if (own_planes) {
     // the wave reads what it stored itself: its LDS stores complete in order ahead of its reads
@@ -354,6 +380,10 @@ __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
         s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w;
       }
       v[k] = s.x + bias_c; v[k + 1] = s.y + bias_c; v[k + 2] = s.z + bias_c; v[k + 3] = s.w + bias_c;
+    }
+    if constexpr (!UP2) {
+#pragma unroll
+      for (int k = 0; k < FPT; ++k) v[k] += av[k];
     }
   }
   // frame f = FPT * pq + k of the workgroup -> (clip, frame inside the clip); To >= FPT keeps a thread inside one clip
@@ -850,9 +880,11 @@ size_t clip32_dgrad_bn_part_bytes(const ms_conv_desc* d) {
 }
 
 int clip32_block_dgrad(const ms_conv_desc* d, const float* g, const float* wp, float* dx, float* dx2, hipStream_t s,
-                       const Clip32PrevBN* pv, float* part, int* sync, int sync_words) {
+                       const Clip32PrevBN* pv, float* part, int* sync, int sync_words, const float* accum) {
   Clip32Args a = {};
   const bool up2 = d->in_mode == MS_IN_UP2ADD;
+  if (accum && up2) return set_error("clip32 data gradient: dx_accum with an upsample-add input");
+  a.acc = accum;
   a.x = g; a.wp = wp;
   a.y = dx; a.y2 = dx2;
   a.B = d->B; a.Cin = d->Cout; a.Cout = d->Cin; a.rows_valid = d->Cin; a.To = d->W; a.Ti = d->W;

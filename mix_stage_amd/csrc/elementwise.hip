@@ -55,12 +55,15 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   }
 }
 
-// bn_finalize_kernel + bn_apply_kernel in ONE launch for layers with at most 64 statistics tiles (every 1-D layer): each
-// workgroup combines the per-tile partials of its channel itself -- the same operations in the same order as
-// bn_finalize_kernel, so the statistics are bit-identical -- chunk 0 records them, and every workgroup normalises its share of
-// the channel (grid (C, chunks of batch items)).  All loads (partials, parameters, FA_PRE data values per thread) are issued
-// before the first use.
+// bn_finalize_kernel + bn_apply_kernel in ONE launch for layers with at most 1024 statistics tiles (every 1-D layer and every 2-D
+// layer of the path but the first): each workgroup combines the per-tile partials of its channel itself -- the same operations in
+// the same order as bn_finalize_kernel (thread t takes tiles t, t + 256, ...), so the statistics are bit-identical -- chunk 0
+// records them, and every workgroup normalises its share of the channel (grid (C, chunks of batch items)).  All loads (partials,
+// parameters, FA_PRE data vectors per thread) are issued before the first use.  VEC = 4: 16-byte loads and stores (HW % 4 == 0):
+// the 2-D layers' 4-67 MB tensors move at the rate of the stand-alone bn_apply_kernel.
 constexpr int FA_PRE = 8;
+constexpr int FA_TILES = 4;          // partials per thread: n_tiles <= 1024
+template <int VEC>
 __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(const float* __restrict__ stats, const float* __restrict__ counts,
                                                                 int n_tiles, int tile_n, int N, int C,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -68,39 +71,51 @@ __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(const float* __r
                                                                 float eps, float momentum, const float* __restrict__ y_raw,
                                                                 float* __restrict__ y, int B, int HW, int b_per_chunk, float slope) {
   prefetch_kernargs<128>();
-  const FastDiv fdHW(HW, B * HW);
+  const int HWV = HW / VEC;
+  const FastDiv fdHW(HWV, B * HWV);
   __shared__ double red[4];
   const int c = blockIdx.x, ch = blockIdx.y, t = threadIdx.x;
   const int b0 = ch * b_per_chunk, nb = min(b_per_chunk, B - b0);
-  const int n = nb * HW;
-  const int tc = min(t, n_tiles - 1);
-  const float2 st = *(const float2*)(stats + ((size_t)tc * C + c) * 2);
-  const float cntf = counts ? counts[tc] : 0.f;
+  const int n = nb * HWV;                        // vectors of this workgroup
+  float2 st[FA_TILES];
+  float cntf[FA_TILES];
+#pragma unroll
+  for (int j = 0; j < FA_TILES; ++j) {
+    const int tc = min(t + 256 * j, n_tiles - 1);
+    st[j] = *(const float2*)(stats + ((size_t)tc * C + c) * 2);
+    cntf[j] = counts ? counts[tc] : 0.f;
+  }
   const float g = gamma[c], bt = beta[c], rm = running_mean[c], rv = running_var[c];
   __builtin_amdgcn_sched_barrier(0);
-  float v[FA_PRE];
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  vec_t v[FA_PRE];
   size_t ofs[FA_PRE];
 #pragma unroll
   for (int q = 0; q < FA_PRE; ++q) {
     const int e = min(t + q * 256, n - 1);
-    const int bl = fdHW.div(e), pix = e - bl * HW;
-    ofs[q] = ((size_t)(b0 + bl) * C + c) * HW + pix;
-    v[q] = y_raw[ofs[q]];
+    const int bl = fdHW.div(e), pix = e - bl * HWV;
+    ofs[q] = (((size_t)(b0 + bl) * C + c) * HWV + pix);
+    v[q] = reinterpret_cast<const vec_t*>(y_raw)[ofs[q]];
   }
   __builtin_amdgcn_sched_barrier(0);
-  const bool has = t < n_tiles;
-  double s = has ? (double)st.x : 0.0;
+  double s = 0.0;
+#pragma unroll
+  for (int j = 0; j < FA_TILES; ++j)
+    if (t + 256 * j < n_tiles) s += (double)st[j].x;
   s = wave_sum_d(s);
   if ((t & 63) == 0) red[t >> 6] = s;
   __syncthreads();
   const double mean = (red[0] + red[1] + red[2] + red[3]) / (double)N;
   __syncthreads();
   double q2 = 0.0;
-  if (has) {
-    const int cnt = counts ? (int)cntf : min(tile_n, N - t * tile_n);
-    const double d = (double)st.x / (double)cnt - mean;
-    q2 = (double)st.y + (double)cnt * d * d;
-  }
+#pragma unroll
+  for (int j = 0; j < FA_TILES; ++j)
+    if (t + 256 * j < n_tiles) {
+      const int i = t + 256 * j;
+      const int cnt = counts ? (int)cntf[j] : min(tile_n, N - i * tile_n);
+      const double d = (double)st[j].x / (double)cnt - mean;
+      q2 += (double)st[j].y + (double)cnt * d * d;
+    }
   q2 = wave_sum_d(q2);
   if ((t & 63) == 0) red[t >> 6] = q2;
   __syncthreads();
@@ -118,20 +133,25 @@ __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(const float* __r
     const float unbiased = N > 1 ? (float)(m2 / (double)(N - 1)) : var;
     running_stats_update(&running_mean[c], &running_var[c], rm, rv, momentum, fmean, unbiased);
   }
+  auto act = [&](vec_t u) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) u[k] = lrelu(fmaf(u[k], sc, sh), slope);
+    return u;
+  };
 #pragma unroll
   for (int q = 0; q < FA_PRE; ++q)
-    if (t + q * 256 < n) y[ofs[q]] = lrelu(fmaf(v[q], sc, sh), slope);
+    if (t + q * 256 < n) reinterpret_cast<vec_t*>(y)[ofs[q]] = act(v[q]);
   for (int e0 = t + FA_PRE * 256; e0 < n; e0 += FA_PRE * 256) {
 #pragma unroll
     for (int q = 0; q < FA_PRE; ++q) {
       const int e = min(e0 + q * 256, n - 1);
-      const int bl = fdHW.div(e), pix = e - bl * HW;
-      ofs[q] = ((size_t)(b0 + bl) * C + c) * HW + pix;
-      v[q] = y_raw[ofs[q]];
+      const int bl = fdHW.div(e), pix = e - bl * HWV;
+      ofs[q] = (((size_t)(b0 + bl) * C + c) * HWV + pix);
+      v[q] = reinterpret_cast<const vec_t*>(y_raw)[ofs[q]];
     }
 #pragma unroll
     for (int q = 0; q < FA_PRE; ++q)
-      if (e0 + q * 256 < n) y[ofs[q]] = lrelu(fmaf(v[q], sc, sh), slope);
+      if (e0 + q * 256 < n) reinterpret_cast<vec_t*>(y)[ofs[q]] = act(v[q]);
   }
 }
 
@@ -288,9 +308,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 
 // The same two passes for rows of HW % 4 == 0 values: 16 bytes per lane and load, four pairs of loads in flight per thread (the
 // 2-D layers stream 70-330 MB through these two launches; one dword and two integer divisions per element ran at 3.5 TB/s).
+// `xsum` (C x chunks): the chunk's sum of x_hat -- the bias gradient is the sum of dy_raw = -gamma invstd mean(dz x_hat) sum(x_hat)
+// (zero but for rounding: a conv bias in front of BatchNorm), which the apply pass then writes itself: no column-sum partials of
+// dy_raw and no finalize launch behind it.
 __global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(const float* __restrict__ dy, const float* __restrict__ y_raw,
                                                              const float* __restrict__ save, float* __restrict__ partial,
-                                                             int B, int C, int HW, int b_per_chunk, float slope) {
+                                                             float* __restrict__ xsum, int B, int C, int HW, int b_per_chunk, float slope) {
   prefetch_kernargs<128>();
   __shared__ float red[4];
   const int c = blockIdx.x, ch = blockIdx.y, t = threadIdx.x;
@@ -298,7 +321,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(const float* __rest
   const float mean = save[c], invstd = save[C + c], sc = save[2 * C + c], sh = save[3 * C + c];
   const int HW4 = HW >> 2, nv = nb * HW4;
   const FastDiv fd(HW4, nv + 1024);
-  float s1 = 0.f, s2 = 0.f;
+  float s1 = 0.f, s2 = 0.f, s3 = 0.f;
   for (int e0 = t; e0 < nv; e0 += 1024) {
     float4 yr[4], g[4];
 #pragma unroll
@@ -317,32 +340,36 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(const float* __rest
         for (int j = 0; j < 4; ++j) {
           const float z = fmaf(a[j], sc, sh);
           const float dz = d[j] * (z > 0.f ? 1.f : slope);
+          const float xh = (a[j] - mean) * invstd;
           s1 += dz;
-          s2 += dz * ((a[j] - mean) * invstd);
+          s2 += dz * xh;
+          s3 += xh;
         }
       }
     }
   }
   s1 = block_sum_256(s1, red);
   s2 = block_sum_256(s2, red);
+  s3 = block_sum_256(s3, red);
   if (t == 0) {
     partial[((size_t)c * gridDim.y + ch) * 2] = s1;
     partial[((size_t)c * gridDim.y + ch) * 2 + 1] = s2;
+    xsum[(size_t)c * gridDim.y + ch] = s3;
   }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restrict__ dy, const float* __restrict__ y_raw,
                                                             const float* __restrict__ save, const float* __restrict__ gamma,
                                                             const float* __restrict__ partial, float* __restrict__ dyr,
-                                                            float* __restrict__ colpart, float* dgamma, float* dbeta,
+                                                            const float* __restrict__ xsum, float* dbias, float* dgamma, float* dbeta,
                                                             int B, int C, int HW, int b_per_chunk, float slope) {
   prefetch_kernargs<128>();
-  __shared__ float red[4];
   const int c = blockIdx.x, ch = blockIdx.y, t = threadIdx.x, nchunk = gridDim.y;
-  float s1 = 0.f, s2 = 0.f;
+  float s1 = 0.f, s2 = 0.f, s3 = 0.f;
   for (int k = 0; k < nchunk; ++k) {
     s1 += partial[((size_t)c * nchunk + k) * 2];
     s2 += partial[((size_t)c * nchunk + k) * 2 + 1];
+    s3 += xsum[(size_t)c * nchunk + k];
   }
   const float invN = 1.0f / (float)((size_t)B * HW);
   const float mean = save[c], invstd = save[C + c], sc = save[2 * C + c], sh = save[3 * C + c];
@@ -350,7 +377,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
   const int b0 = ch * b_per_chunk, nb = min(b_per_chunk, B - b0);
   const int HW4 = HW >> 2, nv = nb * HW4;
   const FastDiv fd(HW4, nv + 1024);
-  float cs = 0.f;
   for (int e0 = t; e0 < nv; e0 += 1024) {
     float4 yr[4], g[4];
     size_t off[4];
@@ -373,16 +399,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restr
           const float dz = d[j] * (z > 0.f ? 1.f : slope);
           const float xh = (a[j] - mean) * invstd;
           o[j] = gi * (dz - m1 - xh * m2);
-          cs += o[j];
         }
         *reinterpret_cast<float4*>(dyr + off[u]) = float4{o[0], o[1], o[2], o[3]};
       }
     }
   }
-  cs = block_sum_256(cs, red);
-  if (t == 0) {
-    colpart[(size_t)c * nchunk + ch] = cs;
-    if (ch == 0 && dgamma) { dgamma[c] = s2; dbeta[c] = s1; }
+  if (t == 0 && ch == 0) {
+    if (dgamma) { dgamma[c] = s2; dbeta[c] = s1; }
+    if (dbias) dbias[c] = -gi * m2 * s3;             // = the sum of dy_raw over the batch (as the clip kernels' EP_DGRAD_BN writes it)
   }
 }
 
@@ -1300,17 +1324,30 @@ int launch_bn_finalize(const float* stats, const float* counts, int n_tiles, int
 int launch_bn_finalize_apply(const float* stats, const float* counts, int n_tiles, int tile_n, int N, int C, const float* gamma,
                              const float* beta, float* rm, float* rv, float* save, float eps, float momentum, const float* y_raw,
                              float* y, int B, int HW, float slope, hipStream_t s) {
-  if (n_tiles > 64 || n_tiles < 1) {
+  static int fa_max = -1;                        // MS_BN_FA_TILES: largest tile count of the one-launch form (A/B runs; 64 = round 5)
+  if (fa_max < 0) { const char* e = getenv("MS_BN_FA_TILES"); fa_max = e ? atoi(e) : 256 * FA_TILES; }
+  if (n_tiles > std::min(fa_max, 256 * FA_TILES) || n_tiles < 1) {
     const int rc = launch_bn_finalize(stats, counts, n_tiles, tile_n, N, C, gamma, beta, rm, rv, save, eps, momentum, s);
     if (rc) return rc;
     return launch_bn_apply(y_raw, y, save, C, HW, (size_t)N * C, slope, s);
   }
+  // chunks of batch items per channel: enough workgroups to fill the chip, and at most ~64 vectors per thread of one
   int bpc;
-  const int nchunk = bwd_chunks(B, C, &bpc);
+  int nchunk = bwd_chunks(B, C, &bpc);
+  const bool vec = (HW & 3) == 0 && (((size_t)y_raw | (size_t)y) & 15) == 0;
+  {
+    const long per_item = vec ? HW / 4 : HW;
+    const int want = (int)std::min<long>(B, std::max<long>(1, (per_item * B + 16383) / 16384));
+    if (want > nchunk) { nchunk = want; bpc = cdiv(B, nchunk); nchunk = cdiv(B, bpc); }
+  }
   TimingScope ts(s, 0, 8.0 * (double)N * C, "bn_finalize_apply C%d N%d tiles%d", C, N, n_tiles);
   if (ts.skip()) return 0;
-  hipLaunchKernelGGL(bn_finalize_apply_kernel, dim3(C, nchunk), dim3(256), 0, s, stats, counts, n_tiles, tile_n, N, C, gamma, beta, rm,
-                     rv, save, eps, momentum, y_raw, y, B, HW, bpc, slope);
+  if (vec)
+    hipLaunchKernelGGL(bn_finalize_apply_kernel<4>, dim3(C, nchunk), dim3(256), 0, s, stats, counts, n_tiles, tile_n, N, C, gamma, beta, rm,
+                       rv, save, eps, momentum, y_raw, y, B, HW, bpc, slope);
+  else
+    hipLaunchKernelGGL(bn_finalize_apply_kernel<1>, dim3(C, nchunk), dim3(256), 0, s, stats, counts, n_tiles, tile_n, N, C, gamma, beta, rm,
+                       rv, save, eps, momentum, y_raw, y, B, HW, bpc, slope);
   return check_launch("bn_finalize_apply_kernel");
 }
 
@@ -1365,14 +1402,19 @@ int launch_bn_bwd(const float* dy, const float* y_raw, const float* y, const flo
   TimingScope ts(s, 0, 20.0 * B * C * HW, "bn_bwd(reduce+apply) C%d HW%d B%d", C, HW, B);
   if (ts.skip()) return 0;
   const bool vec = (HW & 3) == 0 && (((uintptr_t)dy | (uintptr_t)y_raw | (uintptr_t)dyr) & 15) == 0;
-  if (vec) hipLaunchKernelGGL(bn_bwd_reduce4_kernel, dim3(C, nchunk), dim3(256), 0, s, dy, y_raw, save, partial, B, C, HW, bpc, slope);
+  if (vec) hipLaunchKernelGGL(bn_bwd_reduce4_kernel, dim3(C, nchunk), dim3(256), 0, s, dy, y_raw, save, partial, colpart, B, C, HW, bpc, slope);
   else hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, nchunk), dim3(256), 0, s, dy, y_raw, save, partial, B, C, HW, bpc, slope);
   int rc = check_launch("bn_bwd_reduce_kernel");
   if (rc) return rc;
-  if (vec) hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3(C, nchunk), dim3(256), 0, s, dy, y_raw, save, gamma, partial, dyr, colpart,
-                              dgamma, dbeta, B, C, HW, bpc, slope);
-  else hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(C, nchunk), dim3(256), 0, s, dy, y_raw, save, gamma, partial, dyr, colpart,
-                          dgamma, dbeta, B, C, HW, bpc, slope);
+  if (vec) {
+    // (the 16-byte form writes the bias gradient itself: *fused = 1 tells the caller that no colsum_finalize launch is needed)
+    hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3(C, nchunk), dim3(256), 0, s, dy, y_raw, save, gamma, partial, dyr, colpart, dbias,
+                       dgamma, dbeta, B, C, HW, bpc, slope);
+    *fused = 1;
+  } else {
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(C, nchunk), dim3(256), 0, s, dy, y_raw, save, gamma, partial, dyr, colpart,
+                       dgamma, dbeta, B, C, HW, bpc, slope);
+  }
   return check_launch("bn_bwd_apply_kernel");
 }
 

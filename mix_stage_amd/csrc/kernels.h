@@ -192,7 +192,8 @@ struct Clip32PrevBN { const float* y; const float* y_raw; const float* save; con
 size_t clip32_dgrad_bn_part_bytes(const ms_conv_desc* d);
 bool clip32_dgrad_bn_ok(const ms_conv_desc* d);
 int clip32_block_dgrad(const ms_conv_desc* d, const float* g, const float* wp, float* dx, float* dx2, hipStream_t s,
-                       const Clip32PrevBN* pv = nullptr, float* part = nullptr, int* sync = nullptr, int sync_words = 0);
+                       const Clip32PrevBN* pv = nullptr, float* part = nullptr, int* sync = nullptr, int sync_words = 0,
+                       const float* accum = nullptr);
 
 // data gradient of the grouped decoder blocks (chain32.hip: gconv32_kernel)
 bool gdgrad32_ok(const ms_conv_desc* d);

@@ -155,7 +155,7 @@ class ConvNormRelu(nn.Module):
     if _train_tape is not None:
       _train_tape.append(self)
 
-  def _run(self, x, x2=None, in_mode=MS_IN_PLAIN, out_f32=False, chain_prev=False):
+  def _run(self, x, x2=None, in_mode=MS_IN_PLAIN, out_f32=False, chain_prev=False, link=None):
     if self._p and self.training:
       raise NotImplementedError('dropout p>0 is not on the Mix-StAGE path (p=0 everywhere, JL:26)')
     n = self.norm
@@ -192,7 +192,8 @@ class ConvNormRelu(nn.Module):
       y_raw = ops.conv_block(x, self.conv.weight, self.conv.bias, g, MS_BARE, x2=x2, in_mode=in_mode)
       return ops.sync_bn_act(y_raw, n.weight, n.bias, n.running_mean, n.running_var, g.slope, g.eps, g.momentum)
     return ops.conv_block(x, self.conv.weight, self.conv.bias, self._geometry(), mode, n.weight, n.bias,
-                          n.running_mean, n.running_var, x2=x2, in_mode=in_mode, chain_prev=chain_prev and mode == MS_BN_TRAIN)
+                          n.running_mean, n.running_var, x2=x2, in_mode=in_mode, chain_prev=chain_prev and mode == MS_BN_TRAIN,
+                          link=link)
 
   def forward(self, x, **kwargs):
     # `_residual` / `_broadcast` / `_out_f32` select the fused forms below (package-internal; the reference's
@@ -200,16 +201,16 @@ class ConvNormRelu(nn.Module):
     residual = kwargs.get('_residual')
     out_f32 = bool(kwargs.get('_out_f32'))
     if residual is not None:
-      return self._run(x, x2=residual, in_mode=MS_IN_UP2ADD, out_f32=out_f32)
+      return self._run(x, x2=residual, in_mode=MS_IN_UP2ADD, out_f32=out_f32, link=kwargs.get('_ms_link'))
     if kwargs.get('_broadcast'):
       return self._run(x, in_mode=MS_IN_BCAST, out_f32=out_f32)
     # `_ms_chain`: set by the 1-D stacks of this file for every block but the first -- x is the previous block's output and feeds
     # nothing else, so the backward pass may fuse that block's BatchNorm backward into this block's data gradient (ops.conv_block)
-    return self._run(x, out_f32=out_f32, chain_prev=bool(kwargs.get('_ms_chain')))
+    return self._run(x, out_f32=out_f32, chain_prev=bool(kwargs.get('_ms_chain')), link=kwargs.get('_ms_link'))
 
-  def forward_upsample_add(self, a, residual):
+  def forward_upsample_add(self, a, residual, _ms_link=None):
     """== self(upsample_nearest2(a) + residual) without materialising the sum (layers.py:151)."""
-    return self(a, _residual=residual)
+    return self(a, _residual=residual, _ms_link=_ms_link)
 
   def forward_broadcast(self, x):
     """== self(torch.cat([x]*groups, dim=1)) without the replication (JL:190)."""
@@ -269,13 +270,21 @@ class UNet1D(nn.Module):
     for i, m in enumerate(self.pre_downsampling_conv):
       x = m(x, _ms_chain=_chain_ok(self.pre_downsampling_conv, i))
     residuals = [x]
+    # residuals[j] feeds conv1[j] AND, as the residual, conv2[max_depth - 1 - j]: the two gradients meet inside conv1[j]'s
+    # data-gradient launch (ops.ResidualLink) instead of in an accumulation launch per level -- unless a hook could be looking
+    links = []
     for i, down in enumerate(self.conv1):
-      x = down(x)
+      producer = self.conv1[i - 1] if i else self.pre_downsampling_conv[-1]
+      up = self.conv2[self.max_depth - 1 - i]
+      lk = ops.ResidualLink() if (not dt and torch.is_grad_enabled() and not _hooked(producer, down, up)) else None
+      links.append(lk)
+      x = down(x, _ms_link=(lk, 'consumer')) if lk is not None else down(x)
       if i < self.max_depth - 1:
         residuals.append(x)
     bn = x
     for i, up in enumerate(self.conv2):
-      x = up.forward_upsample_add(x, residuals[self.max_depth - i - 1])
+      lk = links[self.max_depth - i - 1]
+      x = up.forward_upsample_add(x, residuals[self.max_depth - i - 1], _ms_link=(lk, 'residual') if lk is not None else None)
     if was_plain:
       x, bn = ops16.from_cb8(x, channels), ops16.from_cb8(bn, channels)
     return (x, bn) if return_bottleneck else x

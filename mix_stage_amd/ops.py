@@ -390,9 +390,25 @@ def _grad_slot(param, shape_like):
   return torch.empty_like(shape_like), False
 
 
+_link_stats = {'in_launch': 0}       # data-gradient launches that took a residual gradient (tests)
+
+
+class ResidualLink:
+  """A tensor with TWO consumers inside one module whose gradients this package produces itself -- the UNet's down-path outputs
+  (layers.py:139-151 of the reference: input of the next down block AND residual of the up path).  Autograd would add the two
+  gradients with a launch of its own per level; instead the up-path block (role 'residual': it always runs first in the backward
+  pass, every deeper block depends on it) leaves its residual gradient here and reports None, and the down-path block (role
+  'consumer') hands it to its data-gradient launch as ms_bwd_options.dx_accum: dx leaves as the complete gradient.  `armed` is set
+  by the consumer's forward (it runs first) when its launch has that form; otherwise both ends behave as if the link were absent."""
+  __slots__ = ('armed', 'grad')
+
+  def __init__(self):
+    self.armed, self.grad = False, None
+
+
 class _ConvBlockFn(torch.autograd.Function):
   @staticmethod
-  def forward(ctx, x, x2, w, bias, gamma, beta, geom, mode, in_mode, stats, pre=None, prev=None):
+  def forward(ctx, x, x2, w, bias, gamma, beta, geom, mode, in_mode, stats, pre=None, prev=None, link=None):
     rm, rv = stats if stats is not None else (None, None)
     _need_hip(x, x2, w, bias, gamma, beta, rm, rv)
     x = x.contiguous()
@@ -455,6 +471,16 @@ class _ConvBlockFn(torch.autograd.Function):
       watched = bool(getattr(x, '_backward_hooks', None)) or bool(getattr(x, 'retains_grad', False))
       if ops16.in_launch_meetings() and not watched and py is not None and py.data_ptr() == x.data_ptr() and tuple(py.shape) == tuple(x.shape):
         ctx.prev = prev
+    # `link`: (ResidualLink, role) -- see ResidualLink
+    ctx.link = None
+    if link is not None and pre is None and nd == 1 and not bn_sync_active():
+      lk, role = link
+      if role == 'consumer' and in_mode == MS_IN_PLAIN and x.requires_grad and lib().ms_dgrad_takes_accum(ctypes.byref(d)) \
+          and not (getattr(x, '_backward_hooks', None) or getattr(x, 'retains_grad', False)):
+        lk.armed = True
+        ctx.link = link
+      elif role == 'residual' and in_mode == MS_IN_UP2ADD and lk.armed:
+        ctx.link = link
     ctx.has_bias = bias is not None
     ctx.params = (w, bias, gamma, beta)          # parameter objects (for their gradient slots)
     # BN_TRAIN: the block's output is saved too -- the one-launch BatchNorm backward takes x_hat and the activation mask from it
@@ -509,6 +535,14 @@ class _ConvBlockFn(torch.autograd.Function):
             pdg = _grad_slot(ppgamma, pgam_t)[0] if p_need_bn else None
             pdbe = _grad_slot(ppbeta, pgam_t)[0] if p_need_bn else None
             fuse = (py, py_raw, psave, pgam_t, pdg, pdbe, pdb, sync, float(prev.geom_desc.slope))
+    # ---- the gradient the input's other consumer left for this launch (ResidualLink)
+    acc = None
+    if ctx.link is not None and ctx.link[1] == 'consumer':
+      acc, ctx.link[0].grad = ctx.link[0].grad, None
+      if acc is not None and (not want_dx or tuple(acc.shape) != tuple(x.shape)):
+        raise RuntimeError('residual link: a residual gradient of shape %s arrived for an input of shape %s (needs grad: %s)' %
+                           (tuple(acc.shape), tuple(x.shape), want_dx))
+    acc_in_launch = False
     ws = workspace(d._bwd_ws, dev)
     side = _overlap['stream']
     if side is not None and need_w and direct_w is not True:
@@ -533,9 +567,14 @@ class _ConvBlockFn(torch.autograd.Function):
       # the weight-gradient kernel itself is queued (ms_wgrad_flush at the end of the backward pass) when nothing downstream
       # reads dw: it lands in the flat gradient buffer
       defer_launch = bool(_deferred['on'] and direct_w is True and dw is not None and DEFER_WGRAD_LAUNCH)
-      if wt is not None or part is not None or defer_launch or fuse is not None or is_dyr:
+      if wt is not None or part is not None or defer_launch or fuse is not None or is_dyr or acc is not None:
         opt = BwdOptions(None, None, 0, wt.data_ptr() if wt is not None else None,
                          part.data_ptr() if part is not None else None, 1 if defer_launch else 0)
+        if acc is not None:
+          acc = acc.contiguous()
+          opt.dx_accum = acc.data_ptr()
+          acc_in_launch = True
+          _link_stats['in_launch'] += 1
         if fuse is not None:
           py, py_raw, psave, pgam_t, pdg, pdbe, pdb, sync, pslope = fuse
           opt.prev_y, opt.prev_y_raw, opt.prev_save, opt.prev_gamma = py.data_ptr(), py_raw.data_ptr(), psave.data_ptr(), pgam_t.data_ptr()
@@ -561,8 +600,13 @@ class _ConvBlockFn(torch.autograd.Function):
                                       _ptr(y), _ptr(save), _ptr(dy), _ptr(dyr), _ptr(dx), _ptr(dx2), _ptr(dw),
                                       _ptr(dbias), _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), _stream()),
               'ms_conv_block_bwd')
+    if acc is not None and not acc_in_launch:
+      dx.add_(acc)                          # (side-stream experiment path: no options struct)
+    if ctx.link is not None and ctx.link[1] == 'residual' and dx2 is not None and ctx.needs_input_grad[1]:
+      ctx.link[0].grad = dx2                # the consumer's data-gradient launch adds it: autograd gets None for the residual
+      dx2 = None
     return (dx, dx2, None if direct_w else dw, None if direct_b else dbias, None if direct_g else dgamma,
-            None if direct_be else dbeta, None, None, None, None, None, None)
+            None if direct_be else dbeta, None, None, None, None, None, None, None)
 
 
 def _f32(t):
@@ -596,7 +640,7 @@ def enable_chain_fusion(on):
 
 
 def conv_block(x, w, bias, geom, mode, gamma=None, beta=None, running_mean=None, running_var=None, x2=None,
-               in_mode=MS_IN_PLAIN, chain_prev=False):
+               in_mode=MS_IN_PLAIN, chain_prev=False, link=None):
   """One conv block of the path on the HIP kernels (see include/mixstage.h: ms_conv_block_fwd/bwd)."""
   if w.dtype == torch.float64 or x.dtype == torch.float64:
     # .double() model: fp32 shadows of the parameters (differentiable casts) and of the running statistics, which the
@@ -612,7 +656,8 @@ def conv_block(x, w, bias, geom, mode, gamma=None, beta=None, running_mean=None,
   stats = (running_mean, running_var) if running_mean is not None else None
   # chain_prev: the caller vouches that x -- the output of another conv block -- feeds nothing but this block
   prev = x.grad_fn if (chain_prev and _chain_fusion['on'] and x.grad_fn is not None and type(x.grad_fn).__name__ == '_ConvBlockFnBackward') else None
-  return _ConvBlockFn.apply(x, x2, w, bias, gamma, beta, geom, mode, in_mode, stats, None, prev)
+  return _ConvBlockFn.apply(x, x2, w, bias, gamma, beta, geom, mode, in_mode, stats, None, prev,
+                            link if (link is not None and _chain_fusion['on'] and torch.is_grad_enabled()) else None)
 
 
 # ------------------------------------------------------------------------------------------------

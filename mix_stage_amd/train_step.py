@@ -496,11 +496,18 @@ class MixStageTrainStep:
       self.check_health()
     return k
 
-  _HEALTH_LAG = 4          # steps the host may run ahead of the health words before it waits for the oldest copy
+  _HEALTH_LAG = 4          # health copies the host may run ahead of before it waits for the oldest one
+  _HEALTH_EVERY = 8        # steps between two copies of the health words
 
   def _post_health(self):
-    """Behind every step: both optimizers' refused-step counters -> pinned host memory (two 4-byte asynchronous copies on the
-    step's stream, no synchronisation), then look at whatever has already arrived."""
+    """Behind every `_HEALTH_EVERY`-th step: both optimizers' refused-step counters -> pinned host memory (two 4-byte asynchronous
+    copies on the step's stream, no synchronisation), then look at whatever has already arrived.  The counters are monotonic, so a
+    refused step is seen at the next copy; every step would be 2 x (4.3 us + 4 us of launch gap) of the device's time per step
+    (profiles/r05_timeline_fp32_gstep.json: the two __amd_rocclr_copyBuffer launches in front of every replay)."""
+    if self._steps % self._HEALTH_EVERY:
+      if self._health_events:
+        self._poll_health(False)
+      return
     self._health_pin[0:1].copy_(self.optim_G.step_state[3:4], non_blocking=True)
     self._health_pin[1:2].copy_(self.optim_D.step_state[3:4], non_blocking=True)
     ev = torch.cuda.Event()

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
   assert 'ms_debug_' not in public and 'ms_conv_block_bwd_overlap' not in public and 'ms_set_counter_buffer' not in public
   assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
   L = _lib.lib()                                   # raises if the .so is missing or a symbol is absent
-  assert L.ms_abi_version() == 3
+  assert L.ms_abi_version() == 4
   d = _lib.ConvDesc(32, 256, 1, 64, 256, 8, 1, 3, 1, 1, 0, 1, 1, 64, _lib.MS_BN_TRAIN, _lib.MS_IN_PLAIN, 0.2, 1e-5,
                     0.1, 0)
   import ctypes

@@ -302,3 +302,53 @@ def test_fusion_is_dropped_when_meetings_are_switched_off_after_the_forward_pass
   assert rel_err(dx_f, x64.grad) < 1e-3 and rel_err(dx_o, x64.grad) < 1e-3
   assert rel_err(dx_o, dx_f) < 1e-4, rel_err(dx_o, dx_f)
   assert rel_err(g_o, g_f) < 1e-4, rel_err(g_o, g_f)
+
+
+@pytest.mark.parametrize('hooked', [False, True])
+def test_unet_residual_gradients_meet_inside_the_down_blocks_data_gradient(hooked):
+  """UNet1D (layers.py:80-157): every down-path output feeds the next down block and, as the residual, the up path.  The up block's
+  residual gradient is handed to the down block's data-gradient launch (ms_bwd_options.dx_accum, ops.ResidualLink) instead of being
+  added by an accumulation launch per level.  Input and parameter gradients against the fp64 oracle and against the same modules
+  with the links off; a hooked block keeps autograd's own accumulation."""
+  import mix_stage_amd as A
+  from mix_stage_amd import ops
+  from mix_stage_amd.train_step import FlatAdam
+  B = 32
+  gen = torch.Generator().manual_seed(11)
+  ref = O.UNet1D(256, 256).double().train()
+  hip = A.UNet1D(256, 256)
+  sd = O.deterministic_state(ref.state_dict())
+  ref.load_state_dict(sd)
+  hip.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in sd.items()})
+  hip = hip.to(DEV).train()
+  opt = FlatAdam(hip.parameters())
+  x = torch.randn(B, 256, 64, generator=gen)
+  gy = torch.randn(B, 256, 64, generator=gen)
+  x64 = x.double().requires_grad_()
+  ref(x64).backward(gy.double())
+  seen = []
+  h = hip.conv1[2].register_forward_hook(lambda m, i, o: seen.append(1)) if hooked else None
+
+  def run(links):
+    old = ops.enable_chain_fusion(links)
+    try:
+      opt.zero_grad()
+      xh = x.to(DEV).requires_grad_()
+      n0 = ops._link_stats['in_launch']
+      hip(xh).backward(gy.to(DEV))
+      torch.cuda.synchronize()
+      return xh.grad.clone(), opt.flat_g.clone(), ops._link_stats['in_launch'] - n0
+    finally:
+      ops.enable_chain_fusion(old)
+
+  try:
+    dx_l, g_l, n_l = run(True)
+    dx_u, g_u, n_u = run(False)
+  finally:
+    if h is not None:
+      h.remove()
+  # five levels; a hook on conv1[2] takes out the links in which it is producer (level 3) or consumer (level 2)
+  assert n_u == 0 and n_l == (3 if hooked else 5), (n_l, n_u)
+  assert rel_err(dx_l, x64.grad) < 1e-3 and rel_err(dx_u, x64.grad) < 1e-3, (rel_err(dx_l, x64.grad), rel_err(dx_u, x64.grad))
+  assert rel_err(dx_l, dx_u) < 2e-5, rel_err(dx_l, dx_u)
+  assert rel_err(g_l, g_u) < 2e-5, rel_err(g_l, g_u)

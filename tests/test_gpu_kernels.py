@@ -23,7 +23,7 @@ def rel_err(a, b):
 
 def test_library_loads_on_gpu_box():
   from mix_stage_amd import _lib
-  assert _lib.lib().ms_abi_version() == 3
+  assert _lib.lib().ms_abi_version() == 4
   assert torch.cuda.is_available()
 
 
