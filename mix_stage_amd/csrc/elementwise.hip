@@ -755,13 +755,23 @@ __global__ __launch_bounds__(256) void softmax_mix_bwd_kernel(const float* __res
   const float sw = tv ? soft[((size_t)b * T + tt) * M + m] : 0.f;
   const int fq = (P + 3) / 4, f0 = w * fq, f1 = min(P, f0 + fq);
   float ds = 0.f;
-  if (tv)
-    for (int f = f0; f < f1; ++f) {
-      const size_t off = ((size_t)b * M * P + (size_t)m * P + f) * T + tt;
-      const float g = tile[lane * (P + 1) + f];
-      ds += g * z[off];
-      dz[off] = sw * g;
+  if (tv) {
+    // 13 rows of z in flight per thread (one load after the other was a chain of 26 round trips: 18 us for 1.7 MB)
+    constexpr int U = 13;
+    for (int fb = f0; fb < f1; fb += U) {
+      float zz[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) zz[u] = z[((size_t)b * M * P + (size_t)m * P + min(fb + u, f1 - 1)) * T + tt];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (fb + u < f1) {
+          const int f = fb + u;
+          const float g = tile[lane * (P + 1) + f];
+          ds += g * zz[u];
+          dz[((size_t)b * M * P + (size_t)m * P + f) * T + tt] = sw * g;
+        }
     }
+  }
   dso[w * MIX_TT + lane] = ds;
   __syncthreads();
   if (w == 0 && tv)
@@ -1022,6 +1032,20 @@ __global__ __launch_bounds__(1024) void cross_entropy_fwd_kernel(const float* __
   for (int r = threadIdx.x; r < rows; r += 1024) {
     const int o = r / n_inner, i = r - o * n_inner;
     const float* sp = score + (size_t)o * so + (size_t)i * si;
+    if (C <= 8) {
+      // (the path's class counts: all of a row's scores and its target in flight at once, not one round trip per class)
+      float v[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v[c] = sp[(size_t)min(c, C - 1) * sc];
+      const int tg = (int)target[r];
+      float mx = -INFINITY, den = 0.f, vt = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) if (c < C) mx = fmaxf(mx, v[c]);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) if (c < C) { den += expf(v[c] - mx); vt = c == tg ? v[c] : vt; }
+      acc += (logf(den) + mx) - vt;
+      continue;
+    }
     float mx = -INFINITY;
     for (int c = 0; c < C; ++c) mx = fmaxf(mx, sp[(size_t)c * sc]);
     float den = 0.f;
@@ -1290,16 +1314,57 @@ __global__ __launch_bounds__(256) void adam_seg_kernel(float* __restrict__ p, co
                                                        float eps) {
   const float coef = reinterpret_cast<const float*>(state)[1];
   if (state[2]) return;                        // non-finite gradient norm: no update (adam_prep_seg_kernel)
+  // 16 bytes per lane and stream, two vectors per thread in flight (7 streams over the 60 MB of live parameters: dword accesses
+  // ran at 5.4 TB/s); a 64-element chunk belongs to one segment, so a vector does too.  n is a multiple of 64 (FlatAdam's layout);
+  // the buffers are 256-byte aligned
+  auto upd = [&](float pi, float gr, float mo, float vo, float step_size, float bc2s, float& mn, float& vn) {
+    const float gi = gr * coef;
+    mn = mo + (1.f - beta1) * (gi - mo);
+    vn = beta2 * vo + (1.f - beta2) * gi * gi;
+    return pi - step_size * (mn / (sqrtf(vn) / bc2s + eps));
+  };
+  if ((n & 3) == 0 && ((((size_t)p | (size_t)g | (size_t)m | (size_t)v) & 15) == 0)) {
+    const size_t n4 = n >> 2, stride = (size_t)gridDim.x * 256;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v);
+    for (size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 2 * stride) {
+      float4 pv[2], gv[2], mv[2], vv[2];
+      float ss[2], bc[2];
+      bool on[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const size_t i = i0 + u * stride;
+        on[u] = i < n4;
+        const int sidx = seg_of_chunk[min(i, n4 - 1) >> 4];
+        ss[u] = seg_scratch[2 * sidx]; bc[u] = seg_scratch[2 * sidx + 1];
+        on[u] = on[u] && bc[u] != 0.f;         // never received a gradient: torch.optim.Adam skips it
+        if (on[u]) { pv[u] = p4[i]; gv[u] = g4[i]; mv[u] = m4[i]; vv[u] = v4[i]; }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (!on[u]) continue;
+        const size_t i = i0 + u * stride;
+        float4 mn, vn, pn;
+        pn.x = upd(pv[u].x, gv[u].x, mv[u].x, vv[u].x, ss[u], bc[u], mn.x, vn.x);
+        pn.y = upd(pv[u].y, gv[u].y, mv[u].y, vv[u].y, ss[u], bc[u], mn.y, vn.y);
+        pn.z = upd(pv[u].z, gv[u].z, mv[u].z, vv[u].z, ss[u], bc[u], mn.z, vn.z);
+        pn.w = upd(pv[u].w, gv[u].w, mv[u].w, vv[u].w, ss[u], bc[u], mn.w, vn.w);
+        m4[i] = mn; v4[i] = vn; p4[i] = pn;
+      }
+    }
+    return;
+  }
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const int sidx = seg_of_chunk[i >> 6];
     const float step_size = seg_scratch[2 * sidx], bc2s = seg_scratch[2 * sidx + 1];
     if (bc2s == 0.f) continue;                 // never received a gradient: torch.optim.Adam skips it
-    const float gi = g[i] * coef;
-    const float mi = m[i] + (1.f - beta1) * (gi - m[i]);
-    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
-    p[i] -= step_size * (mi / (sqrtf(vi) / bc2s + eps));
+    float mn, vn;
+    const float pn = upd(p[i], g[i], m[i], v[i], step_size, bc2s, mn, vn);
+    m[i] = mn;
+    v[i] = vn;
+    p[i] = pn;
   }
 }
 

@@ -323,8 +323,10 @@ __device__ __forceinline__ bool bn_src_block(BnSrcShared& sh_, const float* __re
 template <typename DT, bool DYF32>
 __global__ __launch_bounds__(256) void bn_bwd16_reduce_kernel(const u32x4* __restrict__ dy, const float* __restrict__ dy_f32,
                                                               const u32x4* __restrict__ y_raw, const float* __restrict__ save,
-                                                              float* __restrict__ partial, int B, int C, int C8, int HW,
-                                                              int b_per_chunk, float slope) {
+                                                              float* __restrict__ partial, float* __restrict__ xsum, int B, int C, int C8,
+                                                              int HW, int b_per_chunk, float slope) {
+  // xsum[c][chunk] = sum of x_hat: the bias gradient (a conv bias in front of BatchNorm: zero but for rounding) is
+  // -gamma invstd mean(dz x_hat) sum(x_hat), written by the apply pass -- no column sums of dy_raw, no finalize launch
   prefetch_kernargs<192>();
   const FastDiv fdHW(HW, B * HW);
   __shared__ float red[32];
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(256) void bn_bwd16_reduce_kernel(const u32x4* __res
     const int c = min(cb * 8 + j, C - 1);
     mean[j] = save[c]; invstd[j] = save[C + c]; sc[j] = save[2 * C + c]; sh[j] = save[3 * C + c];
   }
-  float s1[8] = {}, s2[8] = {};
+  float s1[8] = {}, s2[8] = {}, s3[8] = {};
   const int n = min(b_per_chunk, B * HW - e_base);
   // 4 vectors per thread and step, all loads issued before the first use
   for (int e0 = t; e0 < n; e0 += 1024) {
@@ -370,14 +372,17 @@ __global__ __launch_bounds__(256) void bn_bwd16_reduce_kernel(const u32x4* __res
         for (int j = 0; j < 8; ++j) {
           const float z = fmaf(yr[j], sc[j], sh[j]);
           const float dz = g[j] * (z > 0.f ? 1.f : slope);
+          const float xh = (yr[j] - mean[j]) * invstd[j];
           s1[j] += dz;
-          s2[j] = fmaf(dz, (yr[j] - mean[j]) * invstd[j], s2[j]);
+          s2[j] = fmaf(dz, xh, s2[j]);
+          s3[j] += xh;
         }
       }
     }
   }
   block_sum8(s1, red);
   block_sum8(s2, red);
+  block_sum8(s3, red);
   if (t == 0) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -385,6 +390,7 @@ __global__ __launch_bounds__(256) void bn_bwd16_reduce_kernel(const u32x4* __res
       if (c < C) {
         partial[((size_t)c * nchunk + ch) * 2] = s1[j];
         partial[((size_t)c * nchunk + ch) * 2 + 1] = s2[j];
+        xsum[(size_t)c * nchunk + ch] = s3[j];
       }
     }
   }
@@ -395,28 +401,28 @@ template <typename DT, bool DYF32>
 __global__ __launch_bounds__(256) void bn_bwd16_apply_kernel(const u32x4* __restrict__ dy, const float* __restrict__ dy_f32,
                                                              const u32x4* __restrict__ y_raw, const float* __restrict__ save,
                                                              const float* __restrict__ gamma, const float* __restrict__ partial,
-                                                             u32x4* __restrict__ dyr, float* __restrict__ colpart, float* dgamma,
-                                                             float* dbeta, int B, int C, int C8, int HW, int b_per_chunk,
+                                                             u32x4* __restrict__ dyr, const float* __restrict__ xsum, float* dbias,
+                                                             float* dgamma, float* dbeta, int B, int C, int C8, int HW, int b_per_chunk,
                                                              float slope) {
   prefetch_kernargs<192>();
   const FastDiv fdHW(HW, B * HW);
-  __shared__ float red[32];
   const int cb = blockIdx.x, ch = blockIdx.y, t = threadIdx.x, nchunk = gridDim.y;
   const float invN = 1.0f / (float)((size_t)B * HW);
   // prologue in one memory round trip: a 32-lane group sums one channel's chunk partials, the 40 per-channel parameters
   // arrive through LDS
-  __shared__ float prm[56];
+  __shared__ float prm[64];
   {
     const int jj = t >> 5, ii = t & 31, cj = min(cb * 8 + jj, C - 1);
-    float a = 0.f, b2 = 0.f;
+    float a = 0.f, b2 = 0.f, c3 = 0.f;
     for (int k = ii; k < nchunk; k += 32) {
       const float2 pp = *(const float2*)(partial + ((size_t)cj * nchunk + k) * 2);
       a += pp.x; b2 += pp.y;
+      c3 += xsum[(size_t)cj * nchunk + k];
     }
     const int tp = min(t, 39);
     const float pv = (tp < 32 ? save + (size_t)(tp >> 3) * C : gamma)[min(cb * 8 + (tp & 7), C - 1)];
-    a = half_wave_sum(a); b2 = half_wave_sum(b2);
-    if (ii == 0) { prm[40 + jj] = a; prm[48 + jj] = b2; }
+    a = half_wave_sum(a); b2 = half_wave_sum(b2); c3 = half_wave_sum(c3);
+    if (ii == 0) { prm[40 + jj] = a; prm[48 + jj] = b2; prm[56 + jj] = c3; }
     if (t < 40) prm[t] = pv;
   }
   __syncthreads();
@@ -427,11 +433,13 @@ __global__ __launch_bounds__(256) void bn_bwd16_apply_kernel(const u32x4* __rest
     gi[j] = cb * 8 + j < C ? prm[32 + j] * invstd[j] : 0.f;
     m1[j] = prm[40 + j] * invN; m2[j] = prm[48 + j] * invN;
   }
-  if (t < 8 && ch == 0 && cb * 8 + t < C && dgamma) { dgamma[cb * 8 + t] = prm[48 + t]; dbeta[cb * 8 + t] = prm[40 + t]; }
+  if (t < 8 && ch == 0 && cb * 8 + t < C) {
+    if (dgamma) { dgamma[cb * 8 + t] = prm[48 + t]; dbeta[cb * 8 + t] = prm[40 + t]; }
+    if (dbias) dbias[cb * 8 + t] = -(prm[32 + t] * prm[8 + t]) * (prm[48 + t] * invN) * prm[56 + t];      // sum of dy_raw over the batch
+  }
   // chunk = b_per_chunk consecutive vectors of this channel block's flattened (batch item, pixel) space
   const int e_base = ch * b_per_chunk, b0 = 0;
   const int n = min(b_per_chunk, B * HW - e_base);
-  float cs[8] = {};
   for (int e0 = t; e0 < n; e0 += 1024) {
     u32x4 ry[4], rg[4];
     float gf[DYF32 ? 4 : 1][8];
@@ -467,17 +475,10 @@ __global__ __launch_bounds__(256) void bn_bwd16_apply_kernel(const u32x4* __rest
           const float dz = g[j] * (z > 0.f ? 1.f : slope);
           const float xh = (yr[j] - mean[j]) * invstd[j];
           o[j] = gi[j] * (dz - m1[j] - xh * m2[j]);
-          cs[j] += o[j];
         }
         dyr[vofs[q]] = pack8<DT>(o);
       }
     }
-  }
-  block_sum8(cs, red);
-  if (t == 0) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (cb * 8 + j < C) colpart[(size_t)(cb * 8 + j) * nchunk + ch] = cs[j];
   }
 }
 
@@ -641,13 +642,14 @@ int launch_bn_bwd16(int dt, const void* dy, const float* dy_f32, const void* y_r
 #define MS_BNB(DT, F)                                                                                                              \
   do {                                                                                                                             \
     hipLaunchKernelGGL((bn_bwd16_reduce_kernel<DT, F>), grid, dim3(256), 0, s, (const u32x4*)dy, dy_f32, (const u32x4*)y_raw, save,   \
-                       partial, B, C, C8, HW, bpc, slope);                                                                         \
+                       partial, colpart, B, C, C8, HW, bpc, slope);                                                                \
     hipLaunchKernelGGL((bn_bwd16_apply_kernel<DT, F>), grid, dim3(256), 0, s, (const u32x4*)dy, dy_f32, (const u32x4*)y_raw, save,    \
-                       gamma, partial, (u32x4*)dyr, colpart, dgamma, dbeta, B, C, C8, HW, bpc, slope);                             \
+                       gamma, partial, (u32x4*)dyr, colpart, dbias, dgamma, dbeta, B, C, C8, HW, bpc, slope);                      \
   } while (0)
   if (dt == DT_BF16) { if (dy_f32) MS_BNB(BF16, true); else MS_BNB(BF16, false); }
   else { if (dy_f32) MS_BNB(F16, true); else MS_BNB(F16, false); }
 #undef MS_BNB
+  *bias_done = 1;                       // (the apply pass wrote the bias gradient: no colsum16 launch behind it)
   return check_launch("bn_bwd16 kernels");
 }
 

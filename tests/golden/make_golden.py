@@ -22,13 +22,17 @@ CONFIGS = {
     # name: (B, T, M, S, dtype, data seed)
     'c1_fp32': (4, 64, 1, 2, torch.float32, 1234),     # BASELINE configs[0] (S=2: S=1 crashes, SURVEY s.0 item 4)
     'c1_fp64': (4, 64, 1, 2, torch.float64, 1234),
-    # The data seeds of the two multi-speaker fixtures are SCREENED (tests/golden/screen_seed.py, seeds 2000-2159): the
-    # discriminator's gradients are not a smooth function of its input where a pre-activation sits on a LeakyReLU kink, and with
-    # seed 1234 the smallest |pre-activation| in D was 6.7e-6 (D-step) / 2.3e-6 (G-step) -- inside what two fp32 summation orders
-    # differ by.  The chosen seeds have the largest margin of the 160 screened (recorded below as `d_margin`); 1e-4 was not reached by
-    # any (D holds ~6e4 pre-activations per step with density ~1 around zero: the expected minimum is ~1e-5).
-    'c2r_fp32': (4, 64, 4, 4, torch.float32, 2089),    # BASELINE configs[1] at reduced batch; margins 2.4e-5 (D-step), 7.3e-5 (G-step)
-    'c3r_fp32': (2, 64, 8, 8, torch.float32, 2065),    # headline M=S=8 at reduced batch; margins 4.4e-5, 7.7e-5
+    # The data seeds of the two multi-speaker fixtures are SCREENED (tests/golden/screen_seed.py, seeds 2000-2159), by two criteria.
+    # (1) The discriminator's gradients are not a smooth function of its input where a pre-activation sits on a LeakyReLU kink, and
+    # with seed 1234 the smallest |pre-activation| in D was 6.7e-6 (D-step) / 2.3e-6 (G-step) -- inside what two fp32 summation
+    # orders differ by.  The five seeds with the largest margin were kept (recorded below as `d_margin`); 1e-4 was not reached by any
+    # (D holds ~6e4 pre-activations per step with density ~1 around zero: the expected minimum is ~1e-5).  (2) The generator has
+    # ~1e7 activations, so SOME sit within fp32 rounding of a kink for every seed; what can be screened is how much that moves the
+    # gradients: among the five, the seed whose fp32 and fp64 reference G-steps agree best in every parameter's gradient norm
+    # (`screen_seed.py robust`: 1.2e-4 / 2.3e-4 for the seeds below; 7.2e-3 for the margin-best c3r seed 2065, which two fp32
+    # implementations cannot both match at the 2e-3 norm bar).
+    'c2r_fp32': (4, 64, 4, 4, torch.float32, 2069),    # BASELINE configs[1] at reduced batch; margins 2.1e-5 (D-step), 3.7e-5 (G-step)
+    'c3r_fp32': (2, 64, 8, 8, torch.float32, 2058),    # headline M=S=8 at reduced batch; margins 4.3e-5, 5.9e-5
 }
 BN_PROBES = ['G.decoder.0.norm', 'G.audio_encoder.conv.7.norm', 'D.conv3.norm']
 

@@ -1,6 +1,7 @@
 """Screens data seeds for the c2r / c3r fixtures (run in the build container only; imports the reference via oracle/refload.py):
 
-    python tests/golden/screen_seed.py c2r_fp32 [first_seed] [count]
+    python tests/golden/screen_seed.py c2r_fp32 [first_seed] [count]          # criterion 1: margin of D's pre-activations
+    python tests/golden/screen_seed.py robust c2r_fp32 seed [seed ...]         # criterion 2: fp32 vs fp64 gradient norms of a step
 
 For every seed: one D-step forward of the REFERENCE model on synthetic_batch(seed) and the smallest |input| over every LeakyReLU of
 the discriminator in that step (fake and real pass), plus the smallest top-2 margin of the pose-style-encoder scores.  The
@@ -43,9 +44,31 @@ def margins(B, T, M, S, dtype, seed, kinds=('D',)):
   return out
 
 
+def robustness(B, T, M, S, seed, kind):
+  """Largest relative difference of any parameter's gradient norm (conv biases in front of BatchNorm aside: exactly 0 in real
+  arithmetic) between an fp32 and an fp64 step of the oracle (== the reference, tests/test_oracle_vs_reference.py) on this seed's
+  batch: how much the activations that sit within fp32 rounding of a LeakyReLU kink move this draw's gradients."""
+  norms = {}
+  for dtype in (torch.float32, torch.float64):
+    audio, pose, labels, style = O.synthetic_batch(B, T=T, M=M, S=S, seed=seed, dtype=dtype)
+    model = O.build_gan(M=M, S=S, T=T, dtype=dtype)
+    og = torch.optim.Adam(model.G.parameters(), lr=1e-4)
+    od = torch.optim.Adam(model.D.parameters(), lr=1e-4)
+    torch.manual_seed(7)
+    O.oracle_train_step(model, og, od, audio, pose, labels, style, kind, T=T)
+    norms[dtype] = {n: p.grad.double().norm().item() for n, p in model.named_parameters()
+                    if p.grad is not None and not n.endswith('conv.bias')}
+  return max((abs(norms[torch.float32][n] - v) / (v + 1e-30), n) for n, v in norms[torch.float64].items())
+
+
 if __name__ == '__main__':
   sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
   from make_golden import CONFIGS
+  if sys.argv[1] == 'robust':
+    B, T, M, S = CONFIGS[sys.argv[2]][:4]
+    for seed in [int(v) for v in sys.argv[3:]]:
+      print(seed, 'G %.2e %s' % robustness(B, T, M, S, seed, 'G'), ' D %.2e %s' % robustness(B, T, M, S, seed, 'D'), flush=True)
+    sys.exit(0)
   name = sys.argv[1]
   first = int(sys.argv[2]) if len(sys.argv) > 2 else 1234
   count = int(sys.argv[3]) if len(sys.argv) > 3 else 200
