@@ -644,8 +644,11 @@ def main():
         'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
         'config': {'workload': 'Mix-StAGE GAN train step (reference D/G coin flip, seed %d: %d G + %d D steps), '
-                               'B=%d clips per GPU, T=%d, %d-mel, %d-dim pose, M=S=%d, audio branch pinned'
-                               % (args.seed, n_g, args.steps - n_g, B_PER_GPU, T, F_MEL, P, M),
+                               'B=%d clips per GPU, T=%d, %d-mel, %d-dim pose, M=S=%d, audio branch pinned; %s'
+                               % (args.seed, n_g, args.steps - n_g, B_PER_GPU, T, F_MEL, P, M,
+                                  {'fp32': 'fp32 arithmetic (the reference trains in fp64, trainer.py:138; held to it at 1e-4 pose L1)',
+                                   'bf16x6': 'fp32 products from bf16 splits (the reference trains in fp64)',
+                                   'bf16': 'bf16 arithmetic, fp32 accumulation and master weights (the reference trains in fp64)'}[args.precision]),
                    'global_batch': world * B_PER_GPU, 'parallelism': 'dp%d' % world, 'hip_graphs': not args.no_graphs,
                    'bn_sync': args.bn_sync},
         'last_losses': [round(l, 5) for l in losses], 'losses_finite': finite,
