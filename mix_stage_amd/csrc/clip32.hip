@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void clip32_kernel(const Clip32Args p) {
         // kernel's SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.51.  Measured in round 6 and left alone: two conflict-free forms
         // (neighbouring lanes = neighbouring planes; each lane pair starting one frame on, components rotated by selects) brought
         // the ratio to 0.12 and the block from 19.4 to 21.1 / 22.0 us -- the LDS is busy for 5 % of the launch, and the loads' shape
-        // or 32 selects per item cost more than the conflicts.  DESIGN.md 4h.)
+        // or 32 selects per item cost more than the conflicts.  DESIGN.md 4e.)
         float o[4][4];                                 // [frame][channel]
 #pragma unroll
         for (int j = 0; j < 4; ++j) {

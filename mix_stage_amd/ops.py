@@ -399,11 +399,13 @@ class ResidualLink:
   gradients with a launch of its own per level; instead the up-path block (role 'residual': it always runs first in the backward
   pass, every deeper block depends on it) leaves its residual gradient here and reports None, and the down-path block (role
   'consumer') hands it to its data-gradient launch as ms_bwd_options.dx_accum: dx leaves as the complete gradient.  `armed` is set
-  by the consumer's forward (it runs first) when its launch has that form; otherwise both ends behave as if the link were absent."""
-  __slots__ = ('armed', 'grad')
+  by the consumer's forward (it runs first) when its launch has that form; otherwise both ends behave as if the link were absent.
+  `taken`: the consumer's backward has run -- a residual gradient that arrives after it (an order the data dependencies of the UNet
+  rule out, kept safe anyway) goes to autograd like any other."""
+  __slots__ = ('armed', 'grad', 'taken')
 
   def __init__(self):
-    self.armed, self.grad = False, None
+    self.armed, self.grad, self.taken = False, None, False
 
 
 class _ConvBlockFn(torch.autograd.Function):
@@ -539,6 +541,7 @@ class _ConvBlockFn(torch.autograd.Function):
     acc = None
     if ctx.link is not None and ctx.link[1] == 'consumer':
       acc, ctx.link[0].grad = ctx.link[0].grad, None
+      ctx.link[0].taken = True
       if acc is not None and (not want_dx or tuple(acc.shape) != tuple(x.shape)):
         raise RuntimeError('residual link: a residual gradient of shape %s arrived for an input of shape %s (needs grad: %s)' %
                            (tuple(acc.shape), tuple(x.shape), want_dx))
@@ -602,7 +605,7 @@ class _ConvBlockFn(torch.autograd.Function):
               'ms_conv_block_bwd')
     if acc is not None and not acc_in_launch:
       dx.add_(acc)                          # (side-stream experiment path: no options struct)
-    if ctx.link is not None and ctx.link[1] == 'residual' and dx2 is not None and ctx.needs_input_grad[1]:
+    if ctx.link is not None and ctx.link[1] == 'residual' and dx2 is not None and ctx.needs_input_grad[1] and not ctx.link[0].taken:
       ctx.link[0].grad = dx2                # the consumer's data-gradient launch adds it: autograd gets None for the residual
       dx2 = None
     return (dx, dx2, None if direct_w else dw, None if direct_b else dbias, None if direct_g else dgamma,

@@ -316,8 +316,10 @@ class MixStageTrainStep:
     # counters yields NaN, i.e. more refused steps).  The two counters travel to pinned host memory behind every step -- the same
     # D2H path `losses` take when the caller reads them -- and are looked at when their copy has completed (at most
     # `_HEALTH_LAG` steps later): on_bad_step = 'raise' (default) raises then, with the model state intact; 'skip' warns, re-arms
-    # the meeting counters and goes on.  health_every > 0 additionally forces the synchronising check_health() every so many steps.
-    self.on_bad_step = 'raise'
+    # the meeting counters and goes on; 'degrade' does the same and, when the cause was a meeting that timed out (the launch did not
+    # have the device to itself), switches the in-launch meetings off so that the following steps run on the per-block kernels.  health_every > 0 additionally forces the synchronising check_health() every so many steps.
+    self.on_bad_step = 'raise'          # | 'skip' | 'degrade' (skip + switch the in-launch meetings off after a meeting timed out)
+    self.degraded = False
     self.health_every = 0
     self._health_pin = torch.zeros(2, dtype=torch.int32).pin_memory()
     self._health_events = []
@@ -546,6 +548,16 @@ class MixStageTrainStep:
     if self.on_bad_step == 'raise':
       raise RuntimeError(msg)
     import warnings
+    if self.on_bad_step == 'degrade' and words is not None and ops16.in_launch_meetings():
+      # The launches whose workgroups meet inside the launch (chained decoder, clip-resident blocks, in-launch BatchNorm) need every
+      # workgroup resident at once: 256 workgroups on 256 CUs for the headline decoder, zero margin.  Something else holds CUs on this
+      # device (a co-tenant, a profiler's kernels, another stream): instead of refusing every step from now on, fall back to the
+      # per-block forms -- same arithmetic to rounding, no meetings, slower -- and capture the steps again.
+      ops16.set_in_launch_meetings(False)
+      self._graphs = {}
+      self.degraded = True
+      msg += ('  on_bad_step="degrade": in-launch meetings are now OFF for this process (per-block kernels, lower throughput); the '
+              'captured steps are re-captured on their next use.')
     warnings.warn(msg)
 
   def check_health(self):

@@ -389,3 +389,46 @@ def test_a_step_with_non_finite_gradients_is_refused_on_the_device():
     torch.cuda.synchronize()
     ts.check_health()
     assert not torch.equal(ts.optim_G.flat_p, snap['pG']) and torch.isfinite(ts.optim_G.flat_p).all()
+
+
+def test_degrade_mode_switches_the_meetings_off_after_a_timeout_and_goes_on_training():
+  """on_bad_step='degrade': a meeting that times out (here: a decoder-chain counter put out of step by hand -- what a launch that did
+  not have the device to itself leaves behind) costs the steps it poisoned, then the trainer switches the in-launch meetings off,
+  re-captures its steps on the per-block kernels and goes on; weights stay finite and keep moving."""
+  import warnings
+  from mix_stage_amd import ops, ops16
+  from mix_stage_amd.train_step import MixStageTrainStep
+  M = S = 4
+  assert ops16.in_launch_meetings()
+  try:
+    model = _hip(M, S)
+    ts = MixStageTrainStep(model, use_graphs=True)
+    ts.on_bad_step = 'degrade'
+    batch = [t.to(DEV) for t in O.synthetic_batch(4, M=M, S=S, seed=13)]
+    audio, pose, labels, style = batch
+    for kind in ('G', 'D', 'G'):
+      ts.step(audio, labels, pose, style, kind=kind)
+    ts.check_health()
+    assert ts.skipped_steps == 0 and not ts.degraded
+    chains = [b for k, b in ops16._bn_sync.items() if 'chain' in k]
+    assert chains, 'the headline decoder runs as one chained launch'
+    for b in chains:                                   # one arrival too many on the first live counter of every chain buffer
+      nz = (b[ops.CHAIN_SYNC_FIRST_WORD:] != 0).nonzero()
+      if len(nz):
+        b[ops.CHAIN_SYNC_FIRST_WORD + int(nz[0])] += 1
+    before = ts.optim_G.flat_p.clone()
+    with warnings.catch_warnings(record=True) as caught:
+      warnings.simplefilter('always')
+      ts.step(audio, labels, pose, style, kind='G')    # a workgroup waits for an arrival that never comes: NaN, refused
+      ts.check_health()
+    assert ts.skipped_steps >= 1 and ts.degraded and not ops16.in_launch_meetings()
+    assert any('degrade' in str(w.message) for w in caught)
+    assert torch.equal(ts.optim_G.flat_p, before)      # the refused step did not touch the weights
+    for kind in ('G', 'D', 'G'):
+      ts.step(audio, labels, pose, style, kind=kind)
+    ts.check_health()
+    assert torch.isfinite(ts.optim_G.flat_p).all() and not torch.equal(ts.optim_G.flat_p, before)
+    assert all(float(l) == float(l) for l in ts.losses)
+  finally:
+    ops16.bn_sync_clear()
+    ops16.set_in_launch_meetings(True)
