@@ -659,19 +659,40 @@ __global__ __launch_bounds__(256) void clip32_prep_kernel(const ClipPrepBatch pb
   const int c_lo = wv * k8w * 8, nc = min(k8w * 8, max(0, jb.red - c_lo));       // reduction channels of this wave
   const int r_lo = 32 * ct, nr = min(32, jb.rows - r_lo);                          // rows of this tile
   int pitch;
+  // (every load of a batch is issued before the first LDS store: one at a time this kernel was a chain of 32 / 24 dependent round
+  // trips per thread -- 17 us per launch for 31 MB)
   if (!jb.transposed) {
     // source rows = output rows: w[(r_lo + rr) * w_cols + c_lo ..][tap], nc * KW contiguous floats each
     const int seg = nc * KW;
     pitch = (k8w * 8 * KW) | 1;
-    for (int k = t; k < seg; k += 256)
-      for (int rr = 0; rr < nr; ++rr) lds[rr * pitch + k] = jb.w[((size_t)(r_lo + rr) * jb.w_cols + c_lo) * KW + k];
+    for (int k = t; k < seg; k += 256) {
+      const float* src = jb.w + ((size_t)r_lo * jb.w_cols + c_lo) * KW + k;
+      const size_t rstride = (size_t)jb.w_cols * KW;
+      float v[32];
+#pragma unroll
+      for (int rr = 0; rr < 32; ++rr) v[rr] = src[(size_t)min(rr, nr - 1) * rstride];
+#pragma unroll
+      for (int rr = 0; rr < 32; ++rr)
+        if (rr < nr) lds[rr * pitch + k] = v[rr];
+    }
   } else {
     // source rows = reduction channels co: w[(c_lo + cc) * w_cols + r_lo ..][tap], nr * KW contiguous floats each
     const int seg = nr * KW;
     pitch = (32 * KW) | 1;
-    for (int e = t; e < nc * seg; e += 256) {
-      const int cc = e / seg, k = e - cc * seg;
-      lds[cc * pitch + k] = jb.w[((size_t)(c_lo + cc) * jb.w_cols + r_lo) * KW + k];
+    const int n = nc * seg;
+    for (int e0 = t; e0 < n; e0 += 8 * 256) {
+      float v[8];
+      int dst[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = min(e0 + 256 * u, n - 1);
+        const int cc = e / seg, k = e - cc * seg;
+        dst[u] = cc * pitch + k;
+        v[u] = jb.w[((size_t)(c_lo + cc) * jb.w_cols + r_lo) * KW + k];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (e0 + 256 * u < n) lds[dst[u]] = v[u];
     }
   }
   __syncthreads();
