@@ -103,6 +103,9 @@ size_t ms_conv_block_bwd_workspace(const ms_conv_desc* d);
  *   y_raw    BN_TRAIN only: conv+bias output kept for backward, same shape as y
  *   y        (B, groups*Cout, OH, OW) block output
  *   save     BN_TRAIN only: 4*groups*Cout floats = mean | invstd | scale | shift
+ * Alignment: every tensor starts on a 16-byte boundary (what any allocator of device memory returns; torch's are 256-byte aligned).
+ * The kernels load 16 bytes per lane wherever a row allows it; the 2-D layers with at least 256 output tiles have no other form, and a
+ * call that hands them an odd pointer (a sliced view with an element offset) returns an error that names it instead of computing.
  */
 int ms_conv_block_fwd(const ms_conv_desc* d, const float* x, const float* x2, const float* w,
                       const float* bias, const float* gamma, const float* beta, float* running_mean,
